@@ -1,0 +1,191 @@
+/*
+ * piet_metal_amd -- C ABI of the MI355X-native (gfx950) replacement for the
+ * compute path of linebender/piet-metal.
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the piet-metal repository).  No C++/torch types cross this boundary:
+ * plain pointers, sizes and status codes only.  Nothing here ever throws or
+ * unwinds; the reference's Rust panics / NSLog+nil become negative status codes.
+ *
+ * One pm_ctx = one GPU + one HIP stream.  A ctx is not thread-safe (the
+ * reference renderer is only ever driven from the main thread,
+ * TestApp/PietRenderer.m:59).  Multi-GPU = one process and one ctx per GPU,
+ * each rendering a band of tile rows (pm_set_band); the bands are gathered by
+ * the host layer over RCCL.
+ */
+#ifndef PIET_METAL_AMD_H
+#define PIET_METAL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <sys/types.h> /* ssize_t */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes --------------------------------------------------------- */
+#define PM_OK 0
+#define PM_ERR_INVALID (-1)   /* bad argument / encoder misuse (Rust assert!, src/lib.rs:147,152) */
+#define PM_ERR_NO_DEVICE (-2) /* no usable gfx950 device: the product has no CPU fallback */
+#define PM_ERR_HIP (-3)       /* HIP runtime error (see pm_last_error) */
+#define PM_ERR_CAPACITY (-4)  /* scene buffer / arena too small */
+#define PM_ERR_SCENE (-5)     /* malformed scene buffer */
+#define PM_ERR_PARSE (-6)     /* SVG / path-data syntax error */
+
+/* ---- constants kept from TestApp/PietShaderTypes.h:17-18 -------------------- */
+#define PM_TILE_W 16
+#define PM_TILE_H 16
+/* maxTilesWidth/Height (256) and tileBufSize (4096) of PietShaderTypes.h:27-32 are
+ * gone: the tile grid and the per-tile command storage are dynamic. */
+
+/* ==== 1. scene producer ====================================================== */
+
+/* Drop-in for include/piet_metal.h:3 (impl src/lib.rs:387-393): fills `buf`
+ * with the Ghostscript Tiger scene at scale 8, flattened ON DEVICE 0 and copied
+ * back.  Same signature, no status channel (errors leave buf untouched and are
+ * readable through pm_last_error()). */
+void init_test_scene(uint8_t *buf, ssize_t buf_size);
+
+/* Encoder, mirrors `impl Encoder` (src/lib.rs:103-254) method for method.
+ * Pure host code: it only writes bytes into the caller's buffer. */
+typedef struct pm_encoder pm_encoder;
+pm_encoder *pm_encoder_new(uint8_t *buf, size_t cap);                 /* Encoder::new      :104 */
+void pm_encoder_free(pm_encoder *e);
+size_t pm_encoder_alloc(pm_encoder *e, size_t size);                  /* Encoder::alloc    :114 */
+int pm_encoder_begin_group(pm_encoder *e, size_t n_items);            /* begin_group       :132 */
+int pm_encoder_end_group(pm_encoder *e);                              /* end_group         :146 */
+int pm_encoder_circle(pm_encoder *e, double cx, double cy, double r); /* circle            :167 */
+int pm_encoder_stroke_line(pm_encoder *e, double x0, double y0, double x1, double y1,
+                           float width, uint32_t rgba);               /* stroke_line       :177 */
+int pm_encoder_fill(pm_encoder *e, const double *pts_xy, size_t n_points,
+                    uint32_t rgba);                                   /* fill              :195 */
+int pm_encoder_polyline(pm_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba,
+                        float width);                                 /* polyline          :209 */
+size_t pm_encoder_bytes_used(const pm_encoder *e);                    /* free_space */
+
+/* The reference's two other test scenes (host only, no flattening involved).
+ * Return bytes written or a negative status. */
+int64_t pm_scene_cardioid(uint8_t *buf, size_t cap);  /* make_cardioid  src/lib.rs:257-270 */
+int64_t pm_scene_path_test(uint8_t *buf, size_t cap); /* make_path_test src/lib.rs:273-284 */
+
+/* ==== 2. SVG front-end (replaces roxmltree + kurbo::BezPath::from_svg as used
+ *         by make_tiger, src/lib.rs:286-328) ==================================== */
+
+#define PM_EL_MOVE 0
+#define PM_EL_LINE 1
+#define PM_EL_QUAD 2
+#define PM_EL_CURVE 3
+#define PM_EL_CLOSE 4
+
+typedef struct {
+    uint32_t tag; /* PM_EL_* (kurbo::PathEl) */
+    uint32_t pad;
+    double p[6];  /* up to three points, x then y */
+} pm_path_el;     /* 56 bytes */
+
+#define PM_PATH_FILL 1u
+#define PM_PATH_STROKE 2u
+
+typedef struct {
+    uint32_t el_begin, el_end; /* element range of this <path> */
+    uint32_t flags;            /* PM_PATH_FILL | PM_PATH_STROKE (attribute present) */
+    uint32_t fill_rgba;        /* 0xRRGGBBAA, parse_color src/lib.rs:375-385 */
+    uint32_t stroke_rgba;
+    float stroke_width;        /* user units (NOT yet scaled) */
+} pm_path;                     /* 24 bytes */
+
+#define PM_SVG_REJECT_ARC_PATHS 1 /* drop any path whose data holds A/a */
+
+typedef struct pm_svg pm_svg;
+pm_svg *pm_svg_parse(const char *text, size_t len, int flags, int *err);
+pm_svg *pm_svg_tiger(int flags, int *err); /* the embedded Ghostscript_Tiger.svg (src/lib.rs:288) */
+void pm_svg_free(pm_svg *s);
+size_t pm_svg_n_paths(const pm_svg *s);
+size_t pm_svg_n_els(const pm_svg *s);
+const pm_path *pm_svg_paths(const pm_svg *s);
+const pm_path_el *pm_svg_els(const pm_svg *s);
+uint32_t pm_parse_color(const char *s); /* parse_color src/lib.rs:375-385 */
+
+/* ==== 3. renderer (replaces PietRenderer, TestApp/PietRenderer.{h,m}) ========= */
+
+typedef struct pm_ctx pm_ctx;
+
+/* -initWithMetalKitView: (PietRenderer.m:23-57): device, pipelines, 16 MiB scene
+ * buffer.  Returns NULL and sets *err on failure (reference: NSLog + nil). */
+pm_ctx *pm_create(int device, int *err);
+void pm_destroy(pm_ctx *c);
+const char *pm_last_error(void);
+
+/* -mtkView:drawableSizeWillChange: (PietRenderer.m:105-146) minus the scene
+ * init: (re)allocates the framebuffer and the dynamic tile grid. */
+int pm_resize(pm_ctx *c, uint32_t width, uint32_t height);
+/* Render only tile rows [row0,row1) of the viewport (multi-GPU sharding). The
+ * framebuffer then holds just that band, row 0 = pixel row row0*16. */
+int pm_set_band(pm_ctx *c, uint32_t tile_row0, uint32_t tile_row1);
+
+/* _sceneBuf.contents (PietRenderer.m:52-53, :204): pinned host staging buffer the
+ * caller encodes into; pm_upload_scene makes `bytes` of it resident in HBM. */
+uint8_t *pm_scene_buffer(pm_ctx *c, size_t *cap);
+int pm_scene_reserve(pm_ctx *c, size_t cap);
+int pm_upload_scene(pm_ctx *c, size_t bytes);
+/* flatten.rs moved on-device: flatten + encode make_tiger-style paths directly
+ * into the device scene buffer (src/lib.rs:293-327, src/flatten.rs:10-47).
+ * affine = kurbo Affine coefficients [a b c d e f]; stroke widths are multiplied
+ * by `width_scale` in f32 (src/lib.rs:320).  On return the scene is resident. */
+int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths,
+                          const pm_path_el *els, size_t n_els, const double affine[6],
+                          float width_scale, size_t *scene_bytes, uint32_t *n_items);
+/* Copy the resident scene back (parity checks, init_test_scene). */
+int pm_download_scene(pm_ctx *c, uint8_t *dst, size_t cap, size_t *bytes);
+
+/* -drawInMTKView: (PietRenderer.m:59-103): enqueue one frame (binning + per-pixel
+ * kernels) on the ctx stream; asynchronous like [commandBuffer commit]. */
+int pm_render(pm_ctx *c);
+/* Same, into a caller-owned device buffer (e.g. a torch tensor) on a caller
+ * stream (hipStream_t; NULL = ctx stream).  stride in bytes, multiple of 4. */
+int pm_render_to(pm_ctx *c, void *dev_framebuffer, size_t stride_bytes, void *hip_stream);
+int pm_sync(pm_ctx *c);
+
+#define PM_FMT_RGBA8 0
+#define PM_FMT_BGRA8 1 /* the reference drawable's byte order, PietRenderer.m:29 */
+/* Read the (band of the) framebuffer back: height rows of width*4 bytes. */
+int pm_read_pixels(pm_ctx *c, uint8_t *dst, size_t dst_stride, int fmt);
+void *pm_framebuffer_device_ptr(pm_ctx *c, size_t *stride_bytes, uint32_t *rows);
+void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes);
+
+/* Time `iters` back-to-back frames with HIP events on the ctx stream.
+ * total_ms = whole batch; k1_ms/k2_ms = average per-launch duration of the
+ * binning and the per-tile kernels measured in separate event-bracketed passes
+ * (any pointer may be NULL). */
+int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *k1_ms, float *k2_ms);
+
+typedef struct {
+    uint32_t tiles_x, tiles_y;    /* tile grid of the viewport */
+    uint32_t band_row0, band_row1;
+    uint32_t n_items;             /* scene items */
+    uint32_t queued_tiles;        /* tiles handed to the per-tile kernel last frame */
+    uint32_t arena_used_dwords;   /* binning arena high-water mark last frame */
+    uint32_t arena_cap_dwords;
+    uint32_t overflow;            /* 1 if the last frame ran out of arena */
+    uint32_t scene_bytes;
+} pm_stats;
+int pm_get_stats(pm_ctx *c, pm_stats *out); /* synchronises */
+
+/* Debug/parity hook: re-run the last frame's per-tile kernel with command
+ * capture and return every tile's command list in the reference's 24-byte
+ * format (TestApp/GenTypes.h:430-495), including the trailing End / the lone
+ * Bail.  counts[tiles] and solid[tiles] are per tile (band-relative, row-major);
+ * cmds receives max_cmds_per_tile * tiles entries.  Lists longer than
+ * max_cmds_per_tile are truncated (count still reports the full length). */
+typedef struct {
+    uint32_t tag;
+    uint32_t body[5];
+} pm_cmd;
+int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *counts,
+                          uint32_t *solid, pm_cmd *cmds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIET_METAL_AMD_H */

@@ -1,0 +1,739 @@
+// Host runtime behind the C ABI: the MI355X replacement for PietRenderer
+// (TestApp/PietRenderer.{h,m}).  One context = one GPU + one HIP stream.
+//
+//   -initWithMetalKitView:               -> pm_create      (PietRenderer.m:23-57)
+//   -mtkView:drawableSizeWillChange:     -> pm_resize      (PietRenderer.m:105-146)
+//   init_test_scene(_sceneBuf.contents)  -> pm_scene_buffer / pm_upload_scene /
+//                                           pm_flatten_and_encode (PietRenderer.m:203-205)
+//   -drawInMTKView:                      -> pm_render      (PietRenderer.m:59-103)
+//
+// There is deliberately no CPU rendering path in this library: without a gfx950
+// device pm_create fails with PM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/piet_metal_amd.h"
+#include "pm_device.h"
+#include "pm_flatten.h"
+#include "pm_layout.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+void SetError(const std::string &s) { g_last_error = s; }
+
+int HipFail(hipError_t e, const char *what) {
+    SetError(std::string(what) + ": " + hipGetErrorString(e));
+    return PM_ERR_HIP;
+}
+
+#define PM_TRY(expr)                                         \
+    do {                                                     \
+        hipError_t e_ = (expr);                              \
+        if (e_ != hipSuccess) return HipFail(e_, #expr);     \
+    } while (0)
+
+// ---- binary16 helpers for the pinned lookup tables ----------------------------------------
+// (host-side only; the kernels use native _Float16)
+
+uint16_t HalfBitsFromDouble(double d) {  // one rounding, nearest-even
+    if (d != d) return 0x7e00;
+    uint16_t sign = 0;
+    if (std::signbit(d)) {
+        sign = 0x8000;
+        d = -d;
+    }
+    if (d == 0.0) return sign;
+    if (d >= 65520.0) return sign | 0x7c00;
+    int e;
+    const double m = std::frexp(d, &e);  // d = m * 2^e, m in [0.5, 1)
+    int E = e - 1;
+    if (E < -14) return sign | static_cast<uint16_t>(std::nearbyint(std::ldexp(d, 24)));
+    double q = std::nearbyint(std::ldexp(m, 11));  // [1024, 2048]
+    if (q == 2048.0) {
+        q = 1024.0;
+        E += 1;
+    }
+    return sign | static_cast<uint16_t>(((E + 15) << 10) | (static_cast<int>(q) - 1024));
+}
+
+float HalfBitsToFloat(uint16_t h) {
+    const int s = h >> 15, e = (h >> 10) & 31, m = h & 1023;
+    float v;
+    if (e == 0) v = std::ldexp(static_cast<float>(m), -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = std::ldexp(static_cast<float>(m + 1024), e - 25);
+    return s ? -v : v;
+}
+
+inline uint16_t RoundHalf(float f) { return HalfBitsFromDouble(static_cast<double>(f)); }
+
+struct Luts {
+    uint32_t srgb2lin[256];
+    uint32_t unorm2h[256];
+    uint8_t lin2srgb[65536];
+};
+
+// The three tables pin what Metal leaves to its half library:
+//   unpack_unorm4x8_srgb_to_half  : exact EOTF, rounded once to binary16
+//   final select(1.055*pow(rgb,1/2.4)-0.055, 12.92*rgb, rgb<0.0031308) on half3
+//   (PietRender.metal:563), constants and exponent taken in binary16, pow
+//   correctly rounded to binary16, then clamp*255 round-half-even to unorm8.
+void BuildLuts(Luts *l) {
+    for (int i = 0; i < 256; ++i) {
+        const double c = i / 255.0;
+        const double lin = (c <= 0.04045) ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
+        l->srgb2lin[i] = HalfBitsFromDouble(lin);
+        l->unorm2h[i] = HalfBitsFromDouble(c);
+    }
+    const float thr = HalfBitsToFloat(RoundHalf(0.0031308f));
+    const float k = HalfBitsToFloat(RoundHalf(12.92f));
+    const float s = HalfBitsToFloat(RoundHalf(1.055f));
+    const float o = HalfBitsToFloat(RoundHalf(0.055f));
+    const double ex = HalfBitsToFloat(RoundHalf(1.0f / 2.4f));
+    for (uint32_t h = 0; h < 65536; ++h) {
+        const float x = HalfBitsToFloat(static_cast<uint16_t>(h));
+        if (x != x) {
+            l->lin2srgb[h] = 0;
+            continue;
+        }
+        float y;
+        if (x < thr) {
+            y = HalfBitsToFloat(RoundHalf(k * x));
+        } else {
+            const float p = HalfBitsToFloat(HalfBitsFromDouble(std::pow(static_cast<double>(x), ex)));
+            const float sp = HalfBitsToFloat(RoundHalf(s * p));
+            y = HalfBitsToFloat(RoundHalf(sp - o));
+        }
+        const float cl = std::fmin(std::fmax(y, 0.0f), 1.0f);
+        l->lin2srgb[h] = static_cast<uint8_t>(std::rintf(cl * 255.0f));
+    }
+}
+
+}  // namespace
+
+struct pm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int n_cus = 0;
+
+    // scene
+    uint8_t *h_scene = nullptr;  // pinned staging
+    size_t scene_cap = 0;
+    uint8_t *d_scene = nullptr;
+    size_t scene_bytes = 0;
+    uint32_t n_items = 0;
+    std::vector<uint8_t> item_meta;  // copy of header + bboxes + items (arena sizing)
+
+    // viewport
+    uint32_t width = 0, height = 0, tiles_x = 0, tiles_y = 0, strips_x = 0;
+    uint32_t row0 = 0, row1 = 0;
+    bool band_set = false;
+    uint8_t *d_fb = nullptr;
+    size_t fb_stride = 0;
+    size_t fb_bytes = 0;
+
+    // binning state
+    uint32_t *d_arena = nullptr;
+    uint32_t arena_cap = 0;
+    uint32_t *d_striprow = nullptr;
+    uint32_t *d_queue = nullptr;
+    pm::Counters *d_ctr = nullptr;  // [2]
+    uint32_t frame = 0;
+    bool arena_dirty = true;
+
+    // tables
+    uint32_t *d_lut_srgb2lin = nullptr;
+    uint32_t *d_lut_unorm2h = nullptr;
+    uint8_t *d_lut_lin2srgb = nullptr;
+
+    pm::FrameParams last_params{};
+    bool have_frame = false;
+};
+
+namespace {
+
+uint32_t BandRows(const pm_ctx *c) { return c->row1 - c->row0; }
+
+void FreeViewport(pm_ctx *c) {
+    if (c->d_fb) (void)hipFree(c->d_fb);
+    if (c->d_striprow) (void)hipFree(c->d_striprow);
+    if (c->d_queue) (void)hipFree(c->d_queue);
+    c->d_fb = nullptr;
+    c->d_striprow = nullptr;
+    c->d_queue = nullptr;
+}
+
+int AllocViewport(pm_ctx *c) {
+    FreeViewport(c);
+    const uint32_t rows = BandRows(c);
+    c->fb_stride = static_cast<size_t>(c->width) * 4;
+    c->fb_bytes = c->fb_stride * static_cast<size_t>(rows) * pm::kTileH;
+    PM_TRY(hipMalloc(&c->d_fb, std::max<size_t>(c->fb_bytes, 16)));
+    PM_TRY(hipMalloc(&c->d_striprow, std::max<size_t>(static_cast<size_t>(rows) * c->strips_x, 1) * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&c->d_queue, std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));
+    c->arena_dirty = true;
+    c->have_frame = false;
+    return PM_OK;
+}
+
+// Walks header + bboxes + items (host copy) and checks every offset the kernels
+// will dereference.  The kernels trust the scene after this.
+int ValidateScene(const uint8_t *meta, size_t meta_len, size_t scene_bytes, uint32_t *n_items_out) {
+    if (scene_bytes < 8 || meta_len < 8) return PM_ERR_SCENE;
+    uint32_t n, items_ix;
+    std::memcpy(&n, meta, 4);
+    std::memcpy(&items_ix, meta + 4, 4);
+    const uint64_t bbox_end = 8ull + 8ull * n;
+    const uint64_t items_end = static_cast<uint64_t>(items_ix) + 32ull * n;
+    if (bbox_end > scene_bytes || items_end > scene_bytes || items_ix < bbox_end) return PM_ERR_SCENE;
+    if (items_end > meta_len) return PM_ERR_SCENE;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint8_t *it = meta + items_ix + 32ull * i;
+        uint32_t tag, npt, pix;
+        std::memcpy(&tag, it, 4);
+        tag &= 0xffffu;
+        if (tag == pm::kItemFill || tag == pm::kItemPoly) {
+            std::memcpy(&npt, it + 12, 4);
+            std::memcpy(&pix, it + 16, 4);
+            if ((pix & 7u) != 0 || static_cast<uint64_t>(pix) + 8ull * npt > scene_bytes) return PM_ERR_SCENE;
+        }
+    }
+    *n_items_out = n;
+    return PM_OK;
+}
+
+// Exact upper bound (dwords) of what pm_bin_kernel can allocate for this scene,
+// viewport and band: every (strip row, candidate item) costs a candidate record
+// plus 16 B per stream element, every (strip row, batch) a header.
+uint64_t ArenaBound(const pm_ctx *c) {
+    const uint8_t *meta = c->item_meta.data();
+    uint32_t n, items_ix;
+    std::memcpy(&n, meta, 4);
+    std::memcpy(&items_ix, meta + 4, 4);
+    const uint64_t striprows = static_cast<uint64_t>(BandRows(c)) * c->strips_x;
+    uint64_t total = pm::kArenaBase + striprows * pm::kRecHdrDwords * ((n + 255u) / 256u);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint16_t bb[4];
+        std::memcpy(bb, meta + 8 + 8ull * i, 8);
+        const uint8_t *it = meta + items_ix + 32ull * i;
+        uint32_t tag, npt = 0;
+        std::memcpy(&tag, it, 4);
+        tag &= 0xffffu;
+        std::memcpy(&npt, it + 12, 4);
+        uint64_t nseg = 1;
+        if (tag == pm::kItemFill && npt > 1) nseg = npt;
+        if (tag == pm::kItemPoly && npt > 2) nseg = npt - 1;
+        // strips: bz >= sx0 && bx < sx0 + 256 ; rows: bw >= y0 && by < y0 + 16
+        const int64_t s_lo = bb[0] / 256, s_hi = std::min<int64_t>(bb[2] / 256, static_cast<int64_t>(c->strips_x) - 1);
+        const int64_t r_lo = std::max<int64_t>(bb[1] / 16, c->row0), r_hi = std::min<int64_t>(bb[3] / 16, static_cast<int64_t>(c->row1) - 1);
+        if (s_hi < s_lo || r_hi < r_lo) continue;
+        total += static_cast<uint64_t>(s_hi - s_lo + 1) * static_cast<uint64_t>(r_hi - r_lo + 1) * (pm::kCandDwords + 4ull * nseg);
+    }
+    return total;
+}
+
+int EnsureArena(pm_ctx *c) {
+    if (!c->arena_dirty && c->d_arena) return PM_OK;
+    if (c->item_meta.empty() || c->tiles_x == 0) return PM_OK;  // nothing to size against yet
+    uint64_t need = ArenaBound(c);
+    need += need / 16 + 1024;  // slack
+    if (need > 0xfffffff0ull) {
+        SetError("scene x viewport needs a binning arena beyond 16 GiB");
+        return PM_ERR_CAPACITY;
+    }
+    if (!c->d_arena || need > c->arena_cap) {
+        if (c->d_arena) (void)hipFree(c->d_arena);
+        c->d_arena = nullptr;
+        PM_TRY(hipMalloc(&c->d_arena, need * sizeof(uint32_t)));
+        c->arena_cap = static_cast<uint32_t>(need);
+    }
+    c->arena_dirty = false;
+    return PM_OK;
+}
+
+int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
+    if (!c->d_scene || c->scene_bytes < 8) {
+        SetError("no scene resident (pm_upload_scene / pm_flatten_and_encode first)");
+        return PM_ERR_INVALID;
+    }
+    if (c->tiles_x == 0 || BandRows(c) == 0) {
+        SetError("no viewport (pm_resize first)");
+        return PM_ERR_INVALID;
+    }
+    int r = EnsureArena(c);
+    if (r != PM_OK) return r;
+    p->scene = c->d_scene;
+    p->scene_bytes = static_cast<uint32_t>(c->scene_bytes);
+    p->width = c->width;
+    p->height = c->height;
+    p->tiles_x = c->tiles_x;
+    p->tiles_y = c->tiles_y;
+    p->row0 = c->row0;
+    p->row1 = c->row1;
+    p->strips_x = c->strips_x;
+    p->fb = fb;
+    p->fb_stride = static_cast<uint32_t>(stride);
+    p->fb_vec16 = ((reinterpret_cast<uintptr_t>(fb) & 15u) == 0 && (stride & 15u) == 0) ? 1u : 0u;
+    p->arena = c->d_arena;
+    p->arena_cap = c->arena_cap;
+    p->striprow_head = c->d_striprow;
+    p->queue = c->d_queue;
+    p->ctr_cur = c->d_ctr + (c->frame & 1u);
+    p->ctr_next = c->d_ctr + ((c->frame + 1u) & 1u);
+    p->lut_srgb2lin = c->d_lut_srgb2lin;
+    p->lut_unorm2h = c->d_lut_unorm2h;
+    p->lut_lin2srgb = c->d_lut_lin2srgb;
+    p->dbg_counts = nullptr;
+    p->dbg_solid = nullptr;
+    p->dbg_cmds = nullptr;
+    p->dbg_max = 0;
+    return PM_OK;
+}
+
+uint32_t TileGrid(const pm_ctx *c) {
+    // persistent workgroups: enough to fill every CU at the kernel's occupancy
+    const uint32_t tiles = BandRows(c) * c->tiles_x;
+    const uint32_t cap = static_cast<uint32_t>(c->n_cus) * 8u;
+    return std::max(1u, std::min(tiles, cap));
+}
+
+int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t stream) {
+    pm::FrameParams p;
+    int r = BuildParams(c, fb, stride, &p);
+    if (r != PM_OK) return r;
+    pm::LaunchBin(p, BandRows(c) * c->strips_x, stream);
+    pm::LaunchTiles(p, TileGrid(c), false, stream);
+    PM_TRY(hipGetLastError());
+    c->last_params = p;
+    c->have_frame = true;
+    c->frame += 1;
+    return PM_OK;
+}
+
+int SetScene(pm_ctx *c, size_t bytes) {
+    // keep a host copy of header + bboxes + items for validation and arena sizing
+    if (bytes < 8) return PM_ERR_SCENE;
+    uint32_t hdr[2];
+    PM_TRY(hipMemcpyAsync(hdr, c->d_scene, 8, hipMemcpyDeviceToHost, c->stream));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t meta_len = static_cast<uint64_t>(hdr[1]) + 32ull * hdr[0];
+    if (meta_len > bytes || hdr[1] < 8ull + 8ull * hdr[0]) {
+        SetError("scene header out of range");
+        return PM_ERR_SCENE;
+    }
+    c->item_meta.resize(meta_len);
+    PM_TRY(hipMemcpyAsync(c->item_meta.data(), c->d_scene, meta_len, hipMemcpyDeviceToHost, c->stream));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    uint32_t n = 0;
+    const int r = ValidateScene(c->item_meta.data(), c->item_meta.size(), bytes, &n);
+    if (r != PM_OK) {
+        SetError("scene buffer failed validation");
+        c->scene_bytes = 0;
+        return r;
+    }
+    c->scene_bytes = bytes;
+    c->n_items = n;
+    c->arena_dirty = true;
+    c->have_frame = false;
+    return PM_OK;
+}
+
+int ReserveScene(pm_ctx *c, size_t cap) {
+    if (cap <= c->scene_cap) return PM_OK;
+    uint8_t *h = nullptr, *d = nullptr;
+    PM_TRY(hipHostMalloc(&h, cap, hipHostMallocDefault));
+    hipError_t e = hipMalloc(&d, cap);
+    if (e != hipSuccess) {
+        (void)hipHostFree(h);
+        return HipFail(e, "hipMalloc(scene)");
+    }
+    std::memset(h, 0, cap);
+    if (c->h_scene) {
+        std::memcpy(h, c->h_scene, c->scene_cap);
+        (void)hipHostFree(c->h_scene);
+    }
+    if (c->d_scene) {
+        if (c->scene_bytes) (void)hipMemcpy(d, c->d_scene, c->scene_bytes, hipMemcpyDeviceToDevice);
+        (void)hipFree(c->d_scene);
+    }
+    c->h_scene = h;
+    c->d_scene = d;
+    c->scene_cap = cap;
+    return PM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *pm_last_error(void) { return g_last_error.c_str(); }
+
+pm_ctx *pm_create(int device, int *err) {
+    int dummy;
+    if (!err) err = &dummy;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        SetError("no HIP device visible: piet_metal_amd has no CPU fallback");
+        *err = PM_ERR_NO_DEVICE;
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        SetError("device index out of range");
+        *err = PM_ERR_INVALID;
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        SetError(std::string("device is not gfx950 (MI355X): ") + prop.gcnArchName);
+        *err = PM_ERR_NO_DEVICE;
+        return nullptr;
+    }
+    pm_ctx *c = new (std::nothrow) pm_ctx();
+    if (!c) {
+        *err = PM_ERR_CAPACITY;
+        return nullptr;
+    }
+    c->device = device;
+    c->n_cus = prop.multiProcessorCount;
+    auto fail = [&](hipError_t e, const char *what) {
+        HipFail(e, what);
+        *err = PM_ERR_HIP;
+        pm_destroy(c);
+        return static_cast<pm_ctx *>(nullptr);
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    for (auto &ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipMalloc(&c->d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
+    pm::Counters init[2];
+    for (auto &k : init) {
+        k.arena_top = pm::kArenaBase;
+        k.queue_count = 0;
+        k.overflow = 0;
+        k.pad = 0;
+    }
+    if ((e = hipMemcpy(c->d_ctr, init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(counters)");
+    Luts *l = new (std::nothrow) Luts();
+    if (!l) {
+        *err = PM_ERR_CAPACITY;
+        pm_destroy(c);
+        return nullptr;
+    }
+    BuildLuts(l);
+    e = hipMalloc(&c->d_lut_srgb2lin, sizeof(l->srgb2lin));
+    if (e == hipSuccess) e = hipMalloc(&c->d_lut_unorm2h, sizeof(l->unorm2h));
+    if (e == hipSuccess) e = hipMalloc(&c->d_lut_lin2srgb, sizeof(l->lin2srgb));
+    if (e == hipSuccess) e = hipMemcpy(c->d_lut_srgb2lin, l->srgb2lin, sizeof(l->srgb2lin), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_lut_unorm2h, l->unorm2h, sizeof(l->unorm2h), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->d_lut_lin2srgb, l->lin2srgb, sizeof(l->lin2srgb), hipMemcpyHostToDevice);
+    delete l;
+    if (e != hipSuccess) return fail(e, "lookup tables");
+    if (ReserveScene(c, 16u << 20) != PM_OK) {  // 16 MiB like PietRenderer.m:53
+        *err = PM_ERR_HIP;
+        pm_destroy(c);
+        return nullptr;
+    }
+    *err = PM_OK;
+    return c;
+}
+
+void pm_destroy(pm_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    FreeViewport(c);
+    if (c->d_arena) (void)hipFree(c->d_arena);
+    if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->d_scene) (void)hipFree(c->d_scene);
+    if (c->h_scene) (void)hipHostFree(c->h_scene);
+    if (c->d_lut_srgb2lin) (void)hipFree(c->d_lut_srgb2lin);
+    if (c->d_lut_unorm2h) (void)hipFree(c->d_lut_unorm2h);
+    if (c->d_lut_lin2srgb) (void)hipFree(c->d_lut_lin2srgb);
+    for (auto &ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int pm_resize(pm_ctx *c, uint32_t width, uint32_t height) {
+    if (!c || width == 0 || height == 0 || width > 65535 || height > 65535) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    c->width = width;
+    c->height = height;
+    c->tiles_x = (width + pm::kTileW - 1) / pm::kTileW;   // PietRenderer.m:63-64
+    c->tiles_y = (height + pm::kTileH - 1) / pm::kTileH;
+    c->strips_x = (c->tiles_x + pm::kStripTiles - 1) / pm::kStripTiles;
+    c->row0 = 0;
+    c->row1 = c->tiles_y;
+    c->band_set = false;
+    return AllocViewport(c);
+}
+
+int pm_set_band(pm_ctx *c, uint32_t tile_row0, uint32_t tile_row1) {
+    if (!c || c->tiles_y == 0 || tile_row0 >= tile_row1 || tile_row1 > c->tiles_y) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    c->row0 = tile_row0;
+    c->row1 = tile_row1;
+    c->band_set = true;
+    return AllocViewport(c);
+}
+
+uint8_t *pm_scene_buffer(pm_ctx *c, size_t *cap) {
+    if (!c) return nullptr;
+    if (cap) *cap = c->scene_cap;
+    return c->h_scene;
+}
+
+int pm_scene_reserve(pm_ctx *c, size_t cap) {
+    if (!c) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    return ReserveScene(c, cap);
+}
+
+int pm_upload_scene(pm_ctx *c, size_t bytes) {
+    if (!c || bytes > c->scene_cap || bytes < 8) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    PM_TRY(hipMemcpyAsync(c->d_scene, c->h_scene, bytes, hipMemcpyHostToDevice, c->stream));
+    return SetScene(c, bytes);
+}
+
+int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const pm_path_el *els, size_t n_els,
+                          const double affine[6], float width_scale, size_t *scene_bytes, uint32_t *n_items) {
+    if (!c || !affine || (n_paths && !paths) || (n_els && !els)) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    size_t bytes = 0;
+    uint32_t items = 0;
+    hipError_t he = hipSuccess;
+    int r = pm::FlattenEncodeOnDevice(c->stream, paths, n_paths, els, n_els, affine, width_scale, c->d_scene, c->scene_cap,
+                                      &bytes, &items, &he);
+    if (r == PM_ERR_CAPACITY && bytes > c->scene_cap) {
+        // grow the scene buffers and retry once
+        const int rr = ReserveScene(c, bytes + (bytes >> 3));
+        if (rr != PM_OK) return rr;
+        r = pm::FlattenEncodeOnDevice(c->stream, paths, n_paths, els, n_els, affine, width_scale, c->d_scene, c->scene_cap,
+                                      &bytes, &items, &he);
+    }
+    if (r == PM_ERR_HIP) return HipFail(he, "flatten kernels");
+    if (r != PM_OK) {
+        SetError("flatten/encode rejected the paths");
+        return r;
+    }
+    r = SetScene(c, bytes);
+    if (r != PM_OK) return r;
+    if (scene_bytes) *scene_bytes = bytes;
+    if (n_items) *n_items = items;
+    return PM_OK;
+}
+
+int pm_download_scene(pm_ctx *c, uint8_t *dst, size_t cap, size_t *bytes) {
+    if (!c || !dst) return PM_ERR_INVALID;
+    if (bytes) *bytes = c->scene_bytes;
+    if (cap < c->scene_bytes) return PM_ERR_CAPACITY;
+    PM_TRY(hipSetDevice(c->device));
+    PM_TRY(hipMemcpyAsync(dst, c->d_scene, c->scene_bytes, hipMemcpyDeviceToHost, c->stream));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    return PM_OK;
+}
+
+int pm_render(pm_ctx *c) {
+    if (!c) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    return Enqueue(c, c->d_fb, c->fb_stride, c->stream);
+}
+
+int pm_render_to(pm_ctx *c, void *dev_framebuffer, size_t stride_bytes, void *hip_stream) {
+    if (!c || !dev_framebuffer || (stride_bytes & 3u) || stride_bytes < static_cast<size_t>(c->width) * 4) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    return Enqueue(c, static_cast<uint8_t *>(dev_framebuffer), stride_bytes, s);
+}
+
+int pm_sync(pm_ctx *c) {
+    if (!c) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    if (c->have_frame) {
+        pm::Counters k;
+        PM_TRY(hipMemcpy(&k, c->last_params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
+        if (k.overflow) {
+            SetError("binning arena overflow (internal sizing error)");
+            return PM_ERR_CAPACITY;
+        }
+    }
+    return PM_OK;
+}
+
+int pm_read_pixels(pm_ctx *c, uint8_t *dst, size_t dst_stride, int fmt) {
+    if (!c || !dst || !c->d_fb || dst_stride < static_cast<size_t>(c->width) * 4) return PM_ERR_INVALID;
+    const int r = pm_sync(c);
+    if (r != PM_OK) return r;
+    const uint32_t rows = std::min(BandRows(c) * pm::kTileH, c->height - c->row0 * pm::kTileH);
+    PM_TRY(hipMemcpy2D(dst, dst_stride, c->d_fb, c->fb_stride, static_cast<size_t>(c->width) * 4, rows, hipMemcpyDeviceToHost));
+    if (fmt == PM_FMT_BGRA8) {
+        for (uint32_t y = 0; y < rows; ++y) {
+            uint8_t *row = dst + static_cast<size_t>(y) * dst_stride;
+            for (uint32_t x = 0; x < c->width; ++x) std::swap(row[4 * x], row[4 * x + 2]);
+        }
+    }
+    return PM_OK;
+}
+
+void *pm_framebuffer_device_ptr(pm_ctx *c, size_t *stride_bytes, uint32_t *rows) {
+    if (!c) return nullptr;
+    if (stride_bytes) *stride_bytes = c->fb_stride;
+    if (rows) *rows = BandRows(c) * pm::kTileH;
+    return c->d_fb;
+}
+
+void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes) {
+    if (!c) return nullptr;
+    if (bytes) *bytes = c->scene_bytes;
+    return c->d_scene;
+}
+
+int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *k1_ms, float *k2_ms) {
+    if (!c || iters <= 0) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    int r;
+    if (total_ms) {
+        PM_TRY(hipEventRecord(c->ev[0], c->stream));
+        for (int i = 0; i < iters; ++i)
+            if ((r = Enqueue(c, c->d_fb, c->fb_stride, c->stream)) != PM_OK) return r;
+        PM_TRY(hipEventRecord(c->ev[1], c->stream));
+        PM_TRY(hipEventSynchronize(c->ev[1]));
+        PM_TRY(hipEventElapsedTime(total_ms, c->ev[0], c->ev[1]));
+    }
+    if (k1_ms || k2_ms) {
+        double a1 = 0, a2 = 0;
+        for (int i = 0; i < iters; ++i) {
+            pm::FrameParams p;
+            if ((r = BuildParams(c, c->d_fb, c->fb_stride, &p)) != PM_OK) return r;
+            PM_TRY(hipEventRecord(c->ev[0], c->stream));
+            pm::LaunchBin(p, BandRows(c) * c->strips_x, c->stream);
+            PM_TRY(hipEventRecord(c->ev[1], c->stream));
+            pm::LaunchTiles(p, TileGrid(c), false, c->stream);
+            PM_TRY(hipEventRecord(c->ev[2], c->stream));
+            PM_TRY(hipEventSynchronize(c->ev[2]));
+            c->last_params = p;
+            c->have_frame = true;
+            c->frame += 1;
+            float t1 = 0, t2 = 0;
+            PM_TRY(hipEventElapsedTime(&t1, c->ev[0], c->ev[1]));
+            PM_TRY(hipEventElapsedTime(&t2, c->ev[1], c->ev[2]));
+            a1 += t1;
+            a2 += t2;
+        }
+        if (k1_ms) *k1_ms = static_cast<float>(a1 / iters);
+        if (k2_ms) *k2_ms = static_cast<float>(a2 / iters);
+    }
+    return pm_sync(c);
+}
+
+int pm_get_stats(pm_ctx *c, pm_stats *out) {
+    if (!c || !out) return PM_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    PM_TRY(hipSetDevice(c->device));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    out->tiles_x = c->tiles_x;
+    out->tiles_y = c->tiles_y;
+    out->band_row0 = c->row0;
+    out->band_row1 = c->row1;
+    out->n_items = c->n_items;
+    out->arena_cap_dwords = c->arena_cap;
+    out->scene_bytes = static_cast<uint32_t>(c->scene_bytes);
+    if (c->have_frame) {
+        pm::Counters k;
+        PM_TRY(hipMemcpy(&k, c->last_params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
+        out->queued_tiles = k.queue_count;
+        out->arena_used_dwords = k.arena_top;
+        out->overflow = k.overflow;
+    }
+    return PM_OK;
+}
+
+int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *counts, uint32_t *solid, pm_cmd *cmds) {
+    if (!c || !counts || !solid || (max_cmds_per_tile && !cmds)) return PM_ERR_INVALID;
+    if (!c->have_frame) {
+        SetError("pm_debug_capture_ptcl needs a rendered frame");
+        return PM_ERR_INVALID;
+    }
+    PM_TRY(hipSetDevice(c->device));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    const size_t tiles = static_cast<size_t>(BandRows(c)) * c->tiles_x;
+    uint32_t *d_counts = nullptr, *d_solid = nullptr;
+    pm::Cmd *d_cmds = nullptr;
+    PM_TRY(hipMalloc(&d_counts, tiles * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&d_solid, tiles * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&d_cmds, std::max<size_t>(tiles * max_cmds_per_tile, 1) * sizeof(pm::Cmd)));
+    // tiles the binning kernel cleared itself never reach the tile kernel: {Bail}, white
+    std::vector<uint32_t> h_counts(tiles, 1u), h_solid(tiles, 0xffffffffu);
+    std::vector<pm::Cmd> h_cmds(tiles * max_cmds_per_tile);
+    for (size_t t = 0; t < tiles && max_cmds_per_tile; ++t) {
+        h_cmds[t * max_cmds_per_tile].tag = pm::kCmdBail;
+        std::memset(h_cmds[t * max_cmds_per_tile].body, 0, sizeof(h_cmds[0].body));
+    }
+    int status = PM_OK;
+    hipError_t e = hipMemcpy(d_counts, h_counts.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_solid, h_solid.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && max_cmds_per_tile) e = hipMemcpy(d_cmds, h_cmds.data(), h_cmds.size() * sizeof(pm::Cmd), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        pm::FrameParams p = c->last_params;  // same arena / queue / counters as the last frame
+        p.dbg_counts = d_counts;
+        p.dbg_solid = d_solid;
+        p.dbg_cmds = d_cmds;
+        p.dbg_max = max_cmds_per_tile;
+        pm::LaunchTiles(p, TileGrid(c), true, c->stream);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(counts, d_counts, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(solid, d_solid, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && max_cmds_per_tile) e = hipMemcpy(cmds, d_cmds, tiles * max_cmds_per_tile * sizeof(pm::Cmd), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) status = HipFail(e, "ptcl capture");
+    (void)hipFree(d_counts);
+    (void)hipFree(d_solid);
+    (void)hipFree(d_cmds);
+    return status;
+}
+
+// Drop-in for include/piet_metal.h:3 / src/lib.rs:387-393 (make_test_scene -> make_tiger).
+void init_test_scene(uint8_t *buf, ssize_t buf_size) {
+    if (!buf || buf_size <= 0) {
+        SetError("init_test_scene: bad buffer");
+        return;
+    }
+    int err = PM_OK;
+    pm_ctx *c = pm_create(0, &err);
+    if (!c) return;
+    pm_svg *svg = pm_svg_tiger(0, &err);
+    if (svg) {
+        const double scale = 8.0;  // src/lib.rs:287
+        const double affine[6] = {scale, 0.0, 0.0, scale, 0.0, 0.0};
+        size_t bytes = 0;
+        uint32_t items = 0;
+        err = pm_flatten_and_encode(c, pm_svg_paths(svg), pm_svg_n_paths(svg), pm_svg_els(svg), pm_svg_n_els(svg), affine,
+                                    static_cast<float>(scale), &bytes, &items);
+        if (err == PM_OK) {
+            if (bytes > static_cast<size_t>(buf_size)) SetError("init_test_scene: buffer too small for the Tiger scene");
+            else (void)pm_download_scene(c, buf, static_cast<size_t>(buf_size), &bytes);
+        }
+        pm_svg_free(svg);
+    }
+    pm_destroy(c);
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Device-side frame description shared by the host context and the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pm_layout.h"
+
+namespace pm {
+
+// Per-frame counters; two copies alternate between frames so that frame N's binning
+// kernel can reset frame N+1's copy (no memset launch on the critical path).
+struct Counters {
+    uint32_t arena_top;    // bump pointer into the arena, in dwords
+    uint32_t queue_count;  // tiles pushed for the per-tile kernel
+    uint32_t overflow;     // set if the arena ran out
+    uint32_t pad;
+};
+
+// Arena record written by pm_bin_kernel for one (strip row, batch of <=256 items):
+//   [0] next record offset (0 = end)   [1] ncand   [2] stream elements tested
+//   [3] segments that survived phase 1
+//   ncand x 8 dwords: { tag | hitmask16 << 16, rgba, aux0, aux1, seg_off, item_ix, -, - }
+//       aux0/aux1 = bbox words (circle) or width bits (line, polyline)
+//   survived segments, 16 B each (start.xy, end.xy), in paint order
+constexpr uint32_t kArenaBase = 4;     // offset 0 means "none"
+constexpr uint32_t kRecHdrDwords = 4;
+constexpr uint32_t kCandDwords = 8;
+
+struct FrameParams {
+    const uint8_t *scene;
+    uint32_t scene_bytes;
+    uint32_t width, height;
+    uint32_t tiles_x, tiles_y;
+    uint32_t row0, row1;  // band of tile rows rendered by this context
+    uint32_t strips_x;
+    uint8_t *fb;          // band framebuffer, RGBA8, row 0 = pixel row row0*16
+    uint32_t fb_stride;
+    uint32_t fb_vec16;    // 1 if fb and stride are 16-byte aligned
+    uint32_t *arena;
+    uint32_t arena_cap;   // dwords
+    uint32_t *striprow_head;
+    uint32_t *queue;
+    Counters *ctr_cur;
+    Counters *ctr_next;
+    const uint32_t *lut_srgb2lin;  // [256] binary16 bits of the sRGB EOTF
+    const uint32_t *lut_unorm2h;   // [256] binary16 bits of a/255
+    const uint8_t *lut_lin2srgb;   // [65536] binary16 bits -> sRGB unorm8
+    // command capture (debug / parity tests only)
+    uint32_t *dbg_counts;
+    uint32_t *dbg_solid;
+    Cmd *dbg_cmds;
+    uint32_t dbg_max;
+};
+
+void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream);
+void LaunchTiles(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream);
+
+}  // namespace pm

@@ -1,0 +1,229 @@
+// Host-side scene encoder: the piet-metal `Encoder` API surface and byte layout
+// (src/lib.rs:79-254), re-implemented in C++ behind the C ABI of
+// include/piet_metal_amd.h.  Pure host code; writes into a caller-owned buffer
+// (normally the pinned staging buffer returned by pm_scene_buffer).
+#include "pm_encoder.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+namespace pm {
+
+namespace {
+
+// u32::to_be() on a little-endian host: colours are stored R,G,B,A in memory
+// (src/lib.rs:181, :200, :213).
+inline uint32_t ByteSwap(uint32_t v) { return __builtin_bswap32(v); }
+
+struct Rect {
+    double x0, y0, x1, y1;
+    static Rect FromPoint(double x, double y) { return {x, y, x, y}; }
+    void UnionPt(double x, double y) {
+        x0 = std::fmin(x0, x);
+        y0 = std::fmin(y0, y);
+        x1 = std::fmax(x1, x);
+        y1 = std::fmax(y1, y);
+    }
+    Rect Inflate(double w, double h) const { return {x0 - w, y0 - h, x1 + w, y1 + h}; }
+};
+
+inline uint16_t SatU16(double v) { return static_cast<uint16_t>(std::fmin(std::fmax(v, 0.0), 65535.0)); }
+
+// ShortBbox::from_rect (src/lib.rs:88-97): floor the min corner, ceil the max.
+inline ShortBbox ToShortBbox(const Rect &r) {
+    return {SatU16(std::floor(r.x0)), SatU16(std::floor(r.y0)), SatU16(std::ceil(r.x1)),
+            SatU16(std::ceil(r.y1))};
+}
+
+}  // namespace
+
+Encoder::Encoder(uint8_t *buf, size_t cap) : buf_(buf), cap_(cap) {}
+
+size_t Encoder::Alloc(size_t size) {
+    const size_t at = free_space_;
+    free_space_ += size;
+    if (free_space_ > cap_) status_ = kCapacity;
+    return at;
+}
+
+void Encoder::Put(size_t at, const void *src, size_t len) {
+    if (at + len > cap_) {
+        status_ = kCapacity;
+        return;
+    }
+    std::memcpy(buf_ + at, src, len);
+}
+
+void Encoder::BeginGroup(size_t n_items) {
+    const size_t item_start = sizeof(SimpleGroup) + n_items * sizeof(ShortBbox);
+    group_start_ = Alloc(item_start + n_items * kItemSize);
+    group_count_ = n_items;
+    SimpleGroup g{static_cast<uint32_t>(n_items), static_cast<uint32_t>(group_start_ + item_start)};
+    Put(group_start_, &g, sizeof(g));
+}
+
+void Encoder::EndGroup() {
+    if (group_ix_ != group_count_ && status_ == kOk) status_ = kMisuse;  // assert_eq!, :147
+}
+
+template <typename Item>
+void Encoder::AddItem(const Item &item, const ShortBbox &bbox) {
+    if (group_ix_ >= group_count_) {  // assert!, :152
+        if (status_ == kOk) status_ = kMisuse;
+        return;
+    }
+    Put(group_start_ + sizeof(SimpleGroup) + group_ix_ * sizeof(ShortBbox), &bbox, sizeof(bbox));
+    Put(group_start_ + sizeof(SimpleGroup) + group_count_ * sizeof(ShortBbox) + group_ix_ * kItemSize,
+        &item, sizeof(Item));
+    ++group_ix_;
+}
+
+void Encoder::Circle(double cx, double cy, double r) {
+    PietCircle item{kItemCircle};
+    AddItem(item, ToShortBbox(Rect{cx - r, cy - r, cx + r, cy + r}));
+}
+
+void Encoder::StrokeLine(double x0, double y0, double x1, double y1, float width, uint32_t rgba) {
+    PietStrokeLine item{};
+    item.item_type = kItemLine;
+    item.flags = 0;
+    item.rgba = ByteSwap(rgba);
+    item.width = width;
+    item.start[0] = static_cast<float>(x0);
+    item.start[1] = static_cast<float>(y0);
+    item.end[0] = static_cast<float>(x1);
+    item.end[1] = static_cast<float>(y1);
+    const double hw = static_cast<double>(width * 0.5f);
+    Rect bb = Rect::FromPoint(x0, y0);
+    bb.UnionPt(x1, y1);
+    AddItem(item, ToShortBbox(bb.Inflate(hw, hw)));
+}
+
+size_t Encoder::EncodePoints(const double *pts_xy, size_t n, double bbox_out[4]) {
+    const size_t points_ix = Alloc(n * 2 * sizeof(float));
+    if (n == 0) {  // .expect("encoded empty points vector"), :238
+        if (status_ == kOk) status_ = kMisuse;
+        return points_ix;
+    }
+    Rect bb = Rect::FromPoint(pts_xy[0], pts_xy[1]);
+    size_t at = points_ix;
+    for (size_t i = 0; i < n; ++i, at += 2 * sizeof(float)) {
+        const double x = pts_xy[2 * i], y = pts_xy[2 * i + 1];
+        if (i) bb.UnionPt(x, y);
+        const float xy[2] = {static_cast<float>(x), static_cast<float>(y)};
+        Put(at, xy, sizeof(xy));
+    }
+    bbox_out[0] = bb.x0;
+    bbox_out[1] = bb.y0;
+    bbox_out[2] = bb.x1;
+    bbox_out[3] = bb.y1;
+    return points_ix;
+}
+
+void Encoder::Fill(const double *pts_xy, size_t n, uint32_t rgba) {
+    double bb[4] = {0, 0, 0, 0};
+    const size_t points_ix = EncodePoints(pts_xy, n, bb);
+    PietFill item{kItemFill, 0, ByteSwap(rgba), static_cast<uint32_t>(n),
+                  static_cast<uint32_t>(points_ix)};
+    AddItem(item, ToShortBbox(Rect{bb[0], bb[1], bb[2], bb[3]}));
+}
+
+void Encoder::Polyline(const double *pts_xy, size_t n, uint32_t rgba, float width) {
+    double bb[4] = {0, 0, 0, 0};
+    const size_t points_ix = EncodePoints(pts_xy, n, bb);
+    PietStrokePolyLine item{kItemPoly, ByteSwap(rgba), width, static_cast<uint32_t>(n),
+                            static_cast<uint32_t>(points_ix)};
+    const double hw = static_cast<double>(width * 0.5f);
+    AddItem(item, ToShortBbox(Rect{bb[0], bb[1], bb[2], bb[3]}.Inflate(hw, hw)));
+}
+
+// ---- the reference's flatten-free test scenes ---------------------------------
+
+int64_t SceneCardioid(uint8_t *buf, size_t cap) {  // make_cardioid, src/lib.rs:257-270
+    Encoder enc(buf, cap);
+    constexpr int n = 97;
+    const double dth = M_PI * 2.0 / static_cast<double>(n);
+    constexpr double cx = 1024.0, cy = 768.0, r = 750.0;
+    enc.BeginGroup((n - 1) * 2);
+    for (int i = 1; i < n; ++i) {
+        const double a0 = static_cast<double>(i) * dth;
+        const double a1 = static_cast<double>((i * 2) % n) * dth;
+        const double p0x = cx + std::cos(a0) * r, p0y = cy + std::sin(a0) * r;
+        const double p1x = cx + std::cos(a1) * r, p1y = cy + std::sin(a1) * r;
+        enc.Circle(p0x, p0y, 8.0);
+        enc.StrokeLine(p0x, p0y, p1x, p1y, 2.0f, 0x000080e0u);
+    }
+    enc.EndGroup();
+    return enc.ok() ? static_cast<int64_t>(enc.bytes_used()) : enc.c_status();
+}
+
+int64_t ScenePathTest(uint8_t *buf, size_t cap) {  // make_path_test, src/lib.rs:273-284
+    Encoder enc(buf, cap);
+    enc.BeginGroup(1);
+    const double tri[] = {10.0, 10.0, 15.0, 800.0, 300.0, 500.0};
+    enc.Fill(tri, 3, 0x80e0u);
+    enc.EndGroup();
+    return enc.ok() ? static_cast<int64_t>(enc.bytes_used()) : enc.c_status();
+}
+
+}  // namespace pm
+
+// ---- C ABI -------------------------------------------------------------------------
+
+struct pm_encoder {
+    pm::Encoder enc;
+    pm_encoder(uint8_t *b, size_t c) : enc(b, c) {}
+};
+
+extern "C" {
+
+pm_encoder *pm_encoder_new(uint8_t *buf, size_t cap) {
+    if (!buf) return nullptr;
+    return new (std::nothrow) pm_encoder(buf, cap);
+}
+void pm_encoder_free(pm_encoder *e) { delete e; }
+size_t pm_encoder_alloc(pm_encoder *e, size_t size) { return e ? e->enc.Alloc(size) : 0; }
+int pm_encoder_begin_group(pm_encoder *e, size_t n_items) {
+    if (!e) return PM_ERR_INVALID;
+    e->enc.BeginGroup(n_items);
+    return e->enc.c_status();
+}
+int pm_encoder_end_group(pm_encoder *e) {
+    if (!e) return PM_ERR_INVALID;
+    e->enc.EndGroup();
+    return e->enc.c_status();
+}
+int pm_encoder_circle(pm_encoder *e, double cx, double cy, double r) {
+    if (!e) return PM_ERR_INVALID;
+    e->enc.Circle(cx, cy, r);
+    return e->enc.c_status();
+}
+int pm_encoder_stroke_line(pm_encoder *e, double x0, double y0, double x1, double y1, float width,
+                           uint32_t rgba) {
+    if (!e) return PM_ERR_INVALID;
+    e->enc.StrokeLine(x0, y0, x1, y1, width, rgba);
+    return e->enc.c_status();
+}
+int pm_encoder_fill(pm_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba) {
+    if (!e || (!pts_xy && n_points)) return PM_ERR_INVALID;
+    e->enc.Fill(pts_xy, n_points, rgba);
+    return e->enc.c_status();
+}
+int pm_encoder_polyline(pm_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba,
+                        float width) {
+    if (!e || (!pts_xy && n_points)) return PM_ERR_INVALID;
+    e->enc.Polyline(pts_xy, n_points, rgba, width);
+    return e->enc.c_status();
+}
+size_t pm_encoder_bytes_used(const pm_encoder *e) { return e ? e->enc.bytes_used() : 0; }
+
+int64_t pm_scene_cardioid(uint8_t *buf, size_t cap) {
+    return buf ? pm::SceneCardioid(buf, cap) : PM_ERR_INVALID;
+}
+int64_t pm_scene_path_test(uint8_t *buf, size_t cap) {
+    return buf ? pm::ScenePathTest(buf, cap) : PM_ERR_INVALID;
+}
+
+}  // extern "C"

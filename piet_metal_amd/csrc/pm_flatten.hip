@@ -1,0 +1,447 @@
+// On-device flatten + encode: src/flatten.rs:10-47 and make_tiger's two passes
+// (src/lib.rs:293-367) moved onto the GPU.  Input: SVG-style path elements in
+// f64 (what kurbo::BezPath holds), output: the piet-metal scene buffer, resident
+// in HBM, byte-identical to what the reference's CPU encoder would write.
+//
+// The reference flattens every path 3-4 times on the CPU (count pass + encode
+// pass, fill + stroke, src/lib.rs:293-326).  Here:
+//   K_count   one thread per element: subdivision count n of each cubic
+//             (kurbo CubicBez::to_quads rule, see oracle/pmo_flatten.c header)
+//   K_scan    one workgroup: exclusive scans over elements (points, sub-paths)
+//             and over paths (item / point bases) -> exact output layout
+//   K_points  one thread per element: evaluates the cubic at (k+1)/n in f64,
+//             rounds to f32, writes the fill copy and the stroke copy of the
+//             points, keeps the element's f64 bounding box
+//   K_items   one thread per sub-path: unions the element boxes, writes the
+//             ShortBbox + PietFill / PietStrokePolyLine records (thin-line rule
+//             of src/lib.rs:353-362 included)
+// f64 arithmetic is kept (gfx950 has full-rate f64 FMA pipes; 2k cubics is
+// nothing) so that the bytes match the CPU path exactly.  -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/piet_metal_amd.h"
+#include "pm_flatten.h"
+#include "pm_layout.h"
+
+namespace pm {
+
+namespace {
+
+constexpr double kTolerance = 0.1;  // src/lib.rs:330
+constexpr float kThinLine = 0.7f;   // src/lib.rs:351
+
+struct Affine {
+    double m[6];
+};
+
+__device__ __forceinline__ void Xform(const Affine &a, double x, double y, double *ox, double *oy) {
+    // kurbo Affine * Point
+    *ox = a.m[0] * x + a.m[2] * y + a.m[4];
+    *oy = a.m[1] * x + a.m[3] * y + a.m[5];
+}
+
+// End point of the nearest earlier Move/Line/Curve element of the same path
+// (flatten.rs keeps last_pt only across those; QuadTo / ClosePath fall to `_ => ()`).
+__device__ bool LastPoint(const pm_path_el *els, uint32_t el_begin, uint32_t i, const Affine &a, double *lx, double *ly) {
+    for (uint32_t j = i; j > el_begin;) {
+        --j;
+        const uint32_t t = els[j].tag;
+        if (t == PM_EL_MOVE || t == PM_EL_LINE) {
+            Xform(a, els[j].p[0], els[j].p[1], lx, ly);
+            return true;
+        }
+        if (t == PM_EL_CURVE) {
+            Xform(a, els[j].p[4], els[j].p[5], lx, ly);
+            return true;
+        }
+    }
+    return false;
+}
+
+__device__ __forceinline__ uint32_t PathOf(const pm_path *paths, uint32_t n_paths, uint32_t el) {
+    uint32_t lo = 0, hi = n_paths;  // paths are consecutive element ranges
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (paths[mid].el_begin <= el) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ double CubicEval(double p0, double p1, double p2, double p3, double t) {
+    const double mt = 1.0 - t;  // kurbo CubicBez::eval
+    return p0 * (mt * mt * mt) + (p1 * (mt * mt * 3.0) + (p2 * (mt * 3.0) + p3 * t) * t) * t;
+}
+
+__global__ void KCount(const pm_path *paths, uint32_t n_paths, const pm_path_el *els, uint32_t n_els, Affine aff,
+                       uint32_t *el_npts, uint32_t *el_move, uint32_t *err) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_els) return;
+    const uint32_t p = PathOf(paths, n_paths, i);
+    const uint32_t tag = els[i].tag;
+    uint32_t n = 0, mv = 0;
+    if (i >= paths[p].el_begin && i < paths[p].el_end) {
+        if (tag == PM_EL_MOVE) {
+            n = 1;
+            mv = 1;
+        } else if (tag == PM_EL_LINE || tag == PM_EL_CURVE) {
+            double lx, ly;
+            // a sub-path must have been opened (cur_path.as_mut().unwrap(), flatten.rs:24,:36)
+            bool opened = false;
+            for (uint32_t j = i; j > paths[p].el_begin;) {
+                --j;
+                if (els[j].tag == PM_EL_MOVE) { opened = true; break; }
+            }
+            if (!opened) {
+                atomicExch(err, 1u);
+            } else if (tag == PM_EL_LINE) {
+                n = 1;
+            } else {
+                LastPoint(els, paths[p].el_begin, i, aff, &lx, &ly);
+                double p1x, p1y, p2x, p2y, p3x, p3y;
+                Xform(aff, els[i].p[0], els[i].p[1], &p1x, &p1y);
+                Xform(aff, els[i].p[2], els[i].p[3], &p2x, &p2y);
+                Xform(aff, els[i].p[4], els[i].p[5], &p3x, &p3y);
+                const double accuracy = kTolerance * 1e-2;  // flatten.rs:35
+                const double max_hypot2 = 432.0 * accuracy * accuracy;
+                const double ax = p1x * 3.0 - lx, ay = p1y * 3.0 - ly;
+                const double bx = p2x * 3.0 - p3x, by = p2y * 3.0 - p3y;
+                const double dx = bx - ax, dy = by - ay;
+                const double e = dx * dx + dy * dy;
+                const double nf = ceil(pow(e / max_hypot2, 1.0 / 6.0));
+                n = (nf >= 1.0) ? static_cast<uint32_t>(nf) : 1u;
+            }
+        }
+    }
+    el_npts[i] = n;
+    el_move[i] = mv;
+}
+
+// One workgroup.  Exclusive scans with totals at index n.
+constexpr int kScanThreads = 1024;
+
+__device__ uint32_t BlockScan1024(uint32_t v, uint32_t *s_w, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= static_cast<uint32_t>(d)) incl += t;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < kScanThreads / 64; ++w) {
+        const uint32_t x = s_w[w];
+        if (w < wave) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void KScan(const pm_path *paths, uint32_t n_paths, uint32_t n_els,
+                                                      const uint32_t *el_npts, const uint32_t *el_move,
+                                                      uint32_t *el_ptoff, uint32_t *el_mvoff,
+                                                      uint32_t *path_item_base, uint32_t *path_pt_base,
+                                                      uint32_t *totals) {
+    __shared__ uint32_t s_w[kScanThreads / 64];
+    uint32_t carry_p = 0, carry_m = 0;
+    for (uint32_t base = 0; base < n_els; base += kScanThreads) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t vp = (i < n_els) ? el_npts[i] : 0u;
+        const uint32_t vm = (i < n_els) ? el_move[i] : 0u;
+        uint32_t tp, tm;
+        const uint32_t op = BlockScan1024(vp, s_w, &tp);
+        const uint32_t om = BlockScan1024(vm, s_w, &tm);
+        if (i < n_els) {
+            el_ptoff[i] = carry_p + op;
+            el_mvoff[i] = carry_m + om;
+        }
+        carry_p += tp;
+        carry_m += tm;
+    }
+    if (threadIdx.x == 0) {
+        el_ptoff[n_els] = carry_p;
+        el_mvoff[n_els] = carry_m;
+    }
+    __syncthreads();
+    __threadfence_block();
+    uint32_t carry_i = 0, carry_q = 0;
+    for (uint32_t base = 0; base < n_paths; base += kScanThreads) {
+        const uint32_t p = base + threadIdx.x;
+        uint32_t vi = 0, vq = 0;
+        if (p < n_paths) {
+            const uint32_t mult = ((paths[p].flags & PM_PATH_FILL) ? 1u : 0u) + ((paths[p].flags & PM_PATH_STROKE) ? 1u : 0u);
+            vi = (el_mvoff[paths[p].el_end] - el_mvoff[paths[p].el_begin]) * mult;
+            vq = (el_ptoff[paths[p].el_end] - el_ptoff[paths[p].el_begin]) * mult;
+        }
+        uint32_t ti, tq;
+        const uint32_t oi = BlockScan1024(vi, s_w, &ti);
+        const uint32_t oq = BlockScan1024(vq, s_w, &tq);
+        if (p < n_paths) {
+            path_item_base[p] = carry_i + oi;
+            path_pt_base[p] = carry_q + oq;
+        }
+        carry_i += ti;
+        carry_q += tq;
+    }
+    if (threadIdx.x == 0) {
+        totals[0] = carry_i;  // n_items
+        totals[1] = carry_q;  // encoded points (fill + stroke copies)
+        totals[2] = carry_m;  // sub-paths
+    }
+}
+
+__global__ void KPoints(const pm_path *paths, uint32_t n_paths, const pm_path_el *els, uint32_t n_els, Affine aff,
+                        const uint32_t *el_npts, const uint32_t *el_ptoff, const uint32_t *el_mvoff,
+                        const uint32_t *path_pt_base, uint32_t n_items, uint8_t *scene, uint32_t scene_cap,
+                        double *el_bbox, uint32_t *sub_first_el) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_els) return;
+    const uint32_t n = el_npts[i];
+    if (n == 0) return;
+    const uint32_t p = PathOf(paths, n_paths, i);
+    const pm_path path = paths[p];
+    const uint32_t tag = els[i].tag;
+    if (tag == PM_EL_MOVE) sub_first_el[el_mvoff[i]] = i;
+    const uint32_t path_pts = el_ptoff[path.el_end] - el_ptoff[path.el_begin];
+    const uint32_t local = el_ptoff[i] - el_ptoff[path.el_begin];
+    const size_t points_start = sizeof(SimpleGroup) + static_cast<size_t>(n_items) * (sizeof(ShortBbox) + kItemSize);
+    const bool has_fill = (path.flags & PM_PATH_FILL) != 0;
+    const bool has_stroke = (path.flags & PM_PATH_STROKE) != 0;
+    const size_t dst0 = points_start + 8 * (static_cast<size_t>(path_pt_base[p]) + local);
+    const size_t dst1 = dst0 + 8 * static_cast<size_t>(path_pts);  // stroke copy when a fill copy exists
+    double bx0, by0, bx1, by1;
+    auto emit = [&](uint32_t k, double x, double y) {
+        if (k == 0) {
+            bx0 = bx1 = x;  // Rect::from_points(pt, pt)
+            by0 = by1 = y;
+        } else {
+            bx0 = fmin(bx0, x); by0 = fmin(by0, y);  // Rect::union_pt
+            bx1 = fmax(bx1, x); by1 = fmax(by1, y);
+        }
+        const float2 f = make_float2(static_cast<float>(x), static_cast<float>(y));  // point_to_f32s
+        const size_t o = static_cast<size_t>(k) * 8;
+        if (has_fill) {
+            if (dst0 + o + 8 <= scene_cap) *reinterpret_cast<float2 *>(scene + dst0 + o) = f;
+            if (has_stroke && dst1 + o + 8 <= scene_cap) *reinterpret_cast<float2 *>(scene + dst1 + o) = f;
+        } else if (has_stroke) {
+            if (dst0 + o + 8 <= scene_cap) *reinterpret_cast<float2 *>(scene + dst0 + o) = f;
+        }
+    };
+    if (tag == PM_EL_MOVE || tag == PM_EL_LINE) {
+        double x, y;
+        Xform(aff, els[i].p[0], els[i].p[1], &x, &y);
+        emit(0, x, y);
+    } else {  // curve
+        double lx = 0.0, ly = 0.0;
+        LastPoint(els, path.el_begin, i, aff, &lx, &ly);
+        double p1x, p1y, p2x, p2y, p3x, p3y;
+        Xform(aff, els[i].p[0], els[i].p[1], &p1x, &p1y);
+        Xform(aff, els[i].p[2], els[i].p[3], &p2x, &p2y);
+        Xform(aff, els[i].p[4], els[i].p[5], &p3x, &p3y);
+        for (uint32_t k = 0; k < n; ++k) {
+            const double t1 = static_cast<double>(k + 1) / static_cast<double>(n);
+            emit(k, CubicEval(lx, p1x, p2x, p3x, t1), CubicEval(ly, p1y, p2y, p3y, t1));
+        }
+    }
+    el_bbox[4 * static_cast<size_t>(i) + 0] = bx0;
+    el_bbox[4 * static_cast<size_t>(i) + 1] = by0;
+    el_bbox[4 * static_cast<size_t>(i) + 2] = bx1;
+    el_bbox[4 * static_cast<size_t>(i) + 3] = by1;
+}
+
+__device__ __forceinline__ uint16_t SatU16(double v) { return static_cast<uint16_t>(fmin(fmax(v, 0.0), 65535.0)); }
+
+__global__ void KItems(const pm_path *paths, uint32_t n_paths, const pm_path_el *els, uint32_t n_subs, float width_scale,
+                       const uint32_t *el_npts, const uint32_t *el_ptoff, const uint32_t *el_mvoff,
+                       const uint32_t *path_item_base, const uint32_t *path_pt_base, const uint32_t *sub_first_el,
+                       const double *el_bbox, uint32_t n_items, uint8_t *scene, uint32_t scene_cap) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_subs) return;
+    (void)els;
+    const uint32_t first = sub_first_el[s];
+    const uint32_t p = PathOf(paths, n_paths, first);
+    const pm_path path = paths[p];
+    const uint32_t sub0 = el_mvoff[path.el_begin];         // first sub-path of this path
+    const uint32_t n_sub_path = el_mvoff[path.el_end] - sub0;
+    const uint32_t j = s - sub0;
+    const uint32_t last = (j + 1 < n_sub_path) ? sub_first_el[s + 1] : path.el_end;
+    // union of the element boxes (f64), elements without output are skipped
+    double bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+    bool any = false;
+    for (uint32_t i = first; i < last; ++i) {
+        if (el_npts[i] == 0) continue;
+        const double *b = el_bbox + 4 * static_cast<size_t>(i);
+        if (!any) {
+            bx0 = b[0]; by0 = b[1]; bx1 = b[2]; by1 = b[3];
+            any = true;
+        } else {
+            bx0 = fmin(bx0, b[0]); by0 = fmin(by0, b[1]);
+            bx1 = fmax(bx1, b[2]); by1 = fmax(by1, b[3]);
+        }
+    }
+    const uint32_t n_points = el_ptoff[last] - el_ptoff[first];
+    const uint32_t path_pts = el_ptoff[path.el_end] - el_ptoff[path.el_begin];
+    const uint32_t local = el_ptoff[first] - el_ptoff[path.el_begin];
+    const size_t bbox_start = sizeof(SimpleGroup);
+    const size_t items_start = bbox_start + static_cast<size_t>(n_items) * sizeof(ShortBbox);
+    const size_t points_start = items_start + static_cast<size_t>(n_items) * kItemSize;
+    const bool has_fill = (path.flags & PM_PATH_FILL) != 0;
+    const bool has_stroke = (path.flags & PM_PATH_STROKE) != 0;
+    uint32_t item = path_item_base[p] + j;
+    size_t pts_ix = points_start + 8 * (static_cast<size_t>(path_pt_base[p]) + local);
+    if (has_fill) {
+        // Encoder::fill, src/lib.rs:195-207
+        if (items_start + (static_cast<size_t>(item) + 1) * kItemSize <= scene_cap) {
+            ShortBbox sb{SatU16(floor(bx0)), SatU16(floor(by0)), SatU16(ceil(bx1)), SatU16(ceil(by1))};
+            *reinterpret_cast<ShortBbox *>(scene + bbox_start + static_cast<size_t>(item) * sizeof(ShortBbox)) = sb;
+            uint32_t *it = reinterpret_cast<uint32_t *>(scene + items_start + static_cast<size_t>(item) * kItemSize);
+            it[0] = kItemFill;
+            it[1] = 0;
+            it[2] = __builtin_bswap32(path.fill_rgba);
+            it[3] = n_points;
+            it[4] = static_cast<uint32_t>(pts_ix);
+        }
+        item += n_sub_path;
+        pts_ix += 8 * static_cast<size_t>(path_pts);
+    }
+    if (has_stroke) {
+        // encode_path_stroke + Encoder::polyline, src/lib.rs:353-367, :209-222
+        float width = path.stroke_width * width_scale;  // src/lib.rs:320
+        uint32_t rgba = path.stroke_rgba;
+        if (width < kThinLine) {
+            float alpha = static_cast<float>(rgba & 0xffu);
+            alpha = alpha * sqrtf(width / kThinLine);
+            rgba = (rgba & ~0xffu) | static_cast<uint32_t>(alpha);
+            width = kThinLine;
+        }
+        if (items_start + (static_cast<size_t>(item) + 1) * kItemSize <= scene_cap) {
+            const double hw = static_cast<double>(width * 0.5f);
+            ShortBbox sb{SatU16(floor(bx0 - hw)), SatU16(floor(by0 - hw)), SatU16(ceil(bx1 + hw)), SatU16(ceil(by1 + hw))};
+            *reinterpret_cast<ShortBbox *>(scene + bbox_start + static_cast<size_t>(item) * sizeof(ShortBbox)) = sb;
+            uint32_t *it = reinterpret_cast<uint32_t *>(scene + items_start + static_cast<size_t>(item) * kItemSize);
+            it[0] = kItemPoly;
+            it[1] = __builtin_bswap32(rgba);
+            it[2] = __float_as_uint(width);
+            it[3] = n_points;
+            it[4] = static_cast<uint32_t>(pts_ix);
+        }
+    }
+}
+
+__global__ void KHeader(uint8_t *scene, uint32_t n_items) {
+    // Encoder::begin_group, src/lib.rs:132-144
+    SimpleGroup g;
+    g.n_items = n_items;
+    g.items_ix = static_cast<uint32_t>(sizeof(SimpleGroup) + static_cast<size_t>(n_items) * sizeof(ShortBbox));
+    *reinterpret_cast<SimpleGroup *>(scene) = g;
+}
+
+}  // namespace
+
+#define PM_HIP_TRY(expr)                        \
+    do {                                        \
+        hipError_t e_ = (expr);                 \
+        if (e_ != hipSuccess) { hip_err = e_; goto fail; } \
+    } while (0)
+
+int FlattenEncodeOnDevice(hipStream_t stream, const pm_path *h_paths, size_t n_paths, const pm_path_el *h_els,
+                          size_t n_els, const double affine[6], float width_scale, uint8_t *d_scene, size_t scene_cap,
+                          size_t *scene_bytes, uint32_t *n_items_out, hipError_t *hip_error) {
+    hipError_t hip_err = hipSuccess;
+    int status = PM_OK;
+    pm_path *d_paths = nullptr;
+    pm_path_el *d_els = nullptr;
+    uint32_t *d_u32 = nullptr;  // el_npts, el_move, el_ptoff(+1), el_mvoff(+1), path_item_base, path_pt_base, sub_first, totals(4), err
+    double *d_bbox = nullptr;
+    uint32_t totals[4] = {0, 0, 0, 0};
+    Affine aff;
+    for (int k = 0; k < 6; ++k) aff.m[k] = affine[k];
+    const uint32_t ne = static_cast<uint32_t>(n_els), np = static_cast<uint32_t>(n_paths);
+    const size_t n_u32 = static_cast<size_t>(ne) * 2 + (static_cast<size_t>(ne) + 1) * 2 + static_cast<size_t>(np) * 2 + ne + 8;
+
+    // host-side structural check: paths must tile the element array in order
+    {
+        uint32_t expect = 0;
+        for (size_t p = 0; p < n_paths; ++p) {
+            if (h_paths[p].el_begin != expect || h_paths[p].el_end < h_paths[p].el_begin || h_paths[p].el_end > ne) return PM_ERR_INVALID;
+            expect = h_paths[p].el_end;
+        }
+        if (expect != ne) return PM_ERR_INVALID;
+    }
+    if (n_paths == 0 || n_els == 0) {
+        // empty group
+        if (scene_cap < sizeof(SimpleGroup)) return PM_ERR_CAPACITY;
+        hipLaunchKernelGGL(KHeader, dim3(1), dim3(1), 0, stream, d_scene, 0u);
+        PM_HIP_TRY(hipStreamSynchronize(stream));
+        *scene_bytes = sizeof(SimpleGroup);
+        *n_items_out = 0;
+        return PM_OK;
+    }
+
+    PM_HIP_TRY(hipMalloc(&d_paths, n_paths * sizeof(pm_path)));
+    PM_HIP_TRY(hipMalloc(&d_els, n_els * sizeof(pm_path_el)));
+    PM_HIP_TRY(hipMalloc(&d_u32, n_u32 * sizeof(uint32_t)));
+    PM_HIP_TRY(hipMalloc(&d_bbox, n_els * 4 * sizeof(double)));
+    PM_HIP_TRY(hipMemcpyAsync(d_paths, h_paths, n_paths * sizeof(pm_path), hipMemcpyHostToDevice, stream));
+    PM_HIP_TRY(hipMemcpyAsync(d_els, h_els, n_els * sizeof(pm_path_el), hipMemcpyHostToDevice, stream));
+    {
+        uint32_t *el_npts = d_u32;
+        uint32_t *el_move = el_npts + ne;
+        uint32_t *el_ptoff = el_move + ne;
+        uint32_t *el_mvoff = el_ptoff + ne + 1;
+        uint32_t *path_item_base = el_mvoff + ne + 1;
+        uint32_t *path_pt_base = path_item_base + np;
+        uint32_t *sub_first = path_pt_base + np;
+        uint32_t *d_totals = sub_first + ne;
+        uint32_t *d_err = d_totals + 4;
+        PM_HIP_TRY(hipMemsetAsync(d_totals, 0, 8 * sizeof(uint32_t), stream));
+        const uint32_t tb = 256;
+        hipLaunchKernelGGL(KCount, dim3((ne + tb - 1) / tb), dim3(tb), 0, stream, d_paths, np, d_els, ne, aff, el_npts, el_move, d_err);
+        hipLaunchKernelGGL(KScan, dim3(1), dim3(kScanThreads), 0, stream, d_paths, np, ne, el_npts, el_move, el_ptoff, el_mvoff,
+                           path_item_base, path_pt_base, d_totals);
+        PM_HIP_TRY(hipMemcpyAsync(totals, d_totals, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, stream));
+        uint32_t h_err = 0;
+        PM_HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        PM_HIP_TRY(hipStreamSynchronize(stream));
+        if (h_err) {
+            status = PM_ERR_INVALID;  // LineTo/CurveTo before MoveTo: the reference panics
+            goto fail;
+        }
+        const uint32_t n_items = totals[0];
+        const size_t need = sizeof(SimpleGroup) + static_cast<size_t>(n_items) * (sizeof(ShortBbox) + kItemSize) + static_cast<size_t>(totals[1]) * 8;
+        if (need > scene_cap || need > 0xffffffffull) {
+            status = PM_ERR_CAPACITY;
+            *scene_bytes = need;
+            goto fail;
+        }
+        hipLaunchKernelGGL(KHeader, dim3(1), dim3(1), 0, stream, d_scene, n_items);
+        hipLaunchKernelGGL(KPoints, dim3((ne + tb - 1) / tb), dim3(tb), 0, stream, d_paths, np, d_els, ne, aff, el_npts, el_ptoff,
+                           el_mvoff, path_pt_base, n_items, d_scene, static_cast<uint32_t>(scene_cap), d_bbox, sub_first);
+        const uint32_t n_subs = totals[2];
+        if (n_subs)
+            hipLaunchKernelGGL(KItems, dim3((n_subs + tb - 1) / tb), dim3(tb), 0, stream, d_paths, np, d_els, n_subs, width_scale,
+                               el_npts, el_ptoff, el_mvoff, path_item_base, path_pt_base, sub_first, d_bbox, n_items, d_scene,
+                               static_cast<uint32_t>(scene_cap));
+        PM_HIP_TRY(hipGetLastError());
+        PM_HIP_TRY(hipStreamSynchronize(stream));
+        *scene_bytes = need;
+        *n_items_out = n_items;
+    }
+fail:
+    if (d_paths) (void)hipFree(d_paths);
+    if (d_els) (void)hipFree(d_els);
+    if (d_u32) (void)hipFree(d_u32);
+    if (d_bbox) (void)hipFree(d_bbox);
+    if (hip_err != hipSuccess) {
+        if (hip_error) *hip_error = hip_err;
+        return PM_ERR_HIP;
+    }
+    return status;
+}
+
+}  // namespace pm

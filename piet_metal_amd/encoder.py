@@ -1,0 +1,173 @@
+"""Scene encoder: the piet-metal `Encoder` API (src/lib.rs:79-254) over the C ABI.
+
+Method names, argument order and error behaviour follow the Rust type: a misuse
+that panics there (assert!/unwrap) raises PietMetalError here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class Encoder:
+    """`Encoder::new(buf)`: writes the scene into a caller-owned byte buffer."""
+
+    def __init__(self, buf: np.ndarray):
+        if buf.dtype != np.uint8 or not buf.flags["C_CONTIGUOUS"]:
+            raise TypeError("Encoder needs a contiguous uint8 buffer")
+        self._lib = _lib.load()
+        self._buf = buf  # keep alive
+        self._h = self._lib.pm_encoder_new(buf.ctypes.data, buf.size)
+        if not self._h:
+            raise MemoryError("pm_encoder_new failed")
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.pm_encoder_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc(self, size: int) -> int:
+        return int(self._lib.pm_encoder_alloc(self._h, size))
+
+    def begin_group(self, n_items: int) -> None:
+        _lib.check(self._lib.pm_encoder_begin_group(self._h, n_items), "begin_group")
+
+    def end_group(self) -> None:
+        _lib.check(self._lib.pm_encoder_end_group(self._h), "end_group")
+
+    def circle(self, center, radius: float) -> None:
+        _lib.check(self._lib.pm_encoder_circle(self._h, center[0], center[1], radius), "circle")
+
+    def stroke_line(self, p0, p1, width: float, rgba: int) -> None:
+        _lib.check(
+            self._lib.pm_encoder_stroke_line(self._h, p0[0], p0[1], p1[0], p1[1], width, rgba & 0xFFFFFFFF),
+            "stroke_line",
+        )
+
+    @staticmethod
+    def _pts(points) -> np.ndarray:
+        a = np.ascontiguousarray(points, dtype=np.float64)
+        if a.ndim != 2 or a.shape[1] != 2:
+            raise ValueError("points must be (n, 2)")
+        return a
+
+    def fill(self, points, rgba: int) -> None:
+        a = self._pts(points)
+        _lib.check(self._lib.pm_encoder_fill(self._h, a.ctypes.data, a.shape[0], rgba & 0xFFFFFFFF), "fill")
+
+    def polyline(self, points, rgba: int, width: float) -> None:
+        a = self._pts(points)
+        _lib.check(
+            self._lib.pm_encoder_polyline(self._h, a.ctypes.data, a.shape[0], rgba & 0xFFFFFFFF, width), "polyline"
+        )
+
+    @property
+    def bytes_used(self) -> int:
+        return int(self._lib.pm_encoder_bytes_used(self._h))
+
+
+def scene_cardioid(buf: np.ndarray) -> int:
+    """make_cardioid (src/lib.rs:257-270); returns bytes written."""
+    n = _lib.load().pm_scene_cardioid(buf.ctypes.data, buf.size)
+    if n < 0:
+        raise _lib.PietMetalError(int(n), "pm_scene_cardioid")
+    return int(n)
+
+
+def scene_path_test(buf: np.ndarray) -> int:
+    """make_path_test (src/lib.rs:273-284); returns bytes written."""
+    n = _lib.load().pm_scene_path_test(buf.ctypes.data, buf.size)
+    if n < 0:
+        raise _lib.PietMetalError(int(n), "pm_scene_path_test")
+    return int(n)
+
+
+def parse_color(s: str) -> int:
+    """parse_color (src/lib.rs:375-385)."""
+    return int(_lib.load().pm_parse_color(s.encode()))
+
+
+_PATH_DTYPE = np.dtype(
+    [("el_begin", "<u4"), ("el_end", "<u4"), ("flags", "<u4"), ("fill_rgba", "<u4"), ("stroke_rgba", "<u4"), ("stroke_width", "<f4")]
+)
+_EL_DTYPE = np.dtype([("tag", "<u4"), ("pad", "<u4"), ("p", "<f8", (6,))])
+assert _PATH_DTYPE.itemsize == 24 and _EL_DTYPE.itemsize == 56
+
+
+class PathSet:
+    """Parsed paths: `paths` (structured, 24 B) and `els` (structured, 56 B) arrays
+    in the layout of pm_path / pm_path_el."""
+
+    PATH_DTYPE = _PATH_DTYPE
+    EL_DTYPE = _EL_DTYPE
+
+    def __init__(self, paths: np.ndarray, els: np.ndarray):
+        self.paths = np.ascontiguousarray(paths, dtype=_PATH_DTYPE)
+        self.els = np.ascontiguousarray(els, dtype=_EL_DTYPE)
+
+    @classmethod
+    def _from_handle(cls, lib, h) -> "PathSet":
+        try:
+            npaths, nels = lib.pm_svg_n_paths(h), lib.pm_svg_n_els(h)
+            paths = np.frombuffer(C.string_at(lib.pm_svg_paths(h), npaths * 24), dtype=_PATH_DTYPE).copy() if npaths else np.zeros(0, _PATH_DTYPE)
+            els = np.frombuffer(C.string_at(lib.pm_svg_els(h), nels * 56), dtype=_EL_DTYPE).copy() if nels else np.zeros(0, _EL_DTYPE)
+        finally:
+            lib.pm_svg_free(h)
+        return cls(paths, els)
+
+    @classmethod
+    def from_svg(cls, text: bytes | str, reject_arc_paths: bool = False) -> "PathSet":
+        lib = _lib.load()
+        data = text.encode() if isinstance(text, str) else bytes(text)
+        err = C.c_int(0)
+        h = lib.pm_svg_parse(data, len(data), _lib.PM_SVG_REJECT_ARC_PATHS if reject_arc_paths else 0, C.byref(err))
+        if not h:
+            raise _lib.PietMetalError(err.value, "pm_svg_parse")
+        return cls._from_handle(lib, h)
+
+    @classmethod
+    def tiger(cls, reject_arc_paths: bool = False) -> "PathSet":
+        """The embedded Ghostscript_Tiger.svg (src/lib.rs:288)."""
+        lib = _lib.load()
+        err = C.c_int(0)
+        h = lib.pm_svg_tiger(_lib.PM_SVG_REJECT_ARC_PATHS if reject_arc_paths else 0, C.byref(err))
+        if not h:
+            raise _lib.PietMetalError(err.value, "pm_svg_tiger")
+        return cls._from_handle(lib, h)
+
+    def fills_only(self) -> "PathSet":
+        p = self.paths.copy()
+        p["flags"] &= _lib.PM_PATH_FILL
+        return PathSet(p, self.els)
+
+    @staticmethod
+    def concat(sets: list["PathSet"]) -> "PathSet":
+        paths, els, base = [], [], 0
+        for s in sets:
+            p = s.paths.copy()
+            p["el_begin"] += base
+            p["el_end"] += base
+            base += len(s.els)
+            paths.append(p)
+            els.append(s.els)
+        return PathSet(np.concatenate(paths), np.concatenate(els))
+
+    def transformed(self, affine) -> "PathSet":
+        """Apply an affine [a b c d e f] to the element coordinates on the host
+        (used to lay out multi-copy scenes before the device flatten)."""
+        a, b, c, d, e, f = [float(v) for v in affine]
+        els = self.els.copy()
+        p = els["p"]
+        x, y = p[:, 0::2].copy(), p[:, 1::2].copy()
+        p[:, 0::2] = a * x + c * y + e
+        p[:, 1::2] = b * x + d * y + f
+        return PathSet(self.paths, els)

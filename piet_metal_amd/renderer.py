@@ -1,0 +1,161 @@
+"""Renderer: the host-side mirror of PietRenderer (TestApp/PietRenderer.{h,m}).
+
+    PietRenderer                          piet_metal_amd.Renderer
+    -initWithMetalKitView:                Renderer(device)
+    -mtkView:drawableSizeWillChange:      resize(w, h)          (+ set_band for multi-GPU)
+    initScene / init_test_scene           scene_buffer() + upload_scene(), or
+                                          flatten_and_encode(paths, affine)
+    -drawInMTKView:                       render() / render_to(tensor)
+
+All work happens in libpiet_metal_amd.so (HIP kernels); this file only moves
+pointers.  torch is optional here and only used as a device-memory / stream
+provider (render_to) -- plumbing, not the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .encoder import PathSet
+
+
+class Renderer:
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()
+        err = C.c_int(0)
+        self._h = self._lib.pm_create(device, C.byref(err))
+        if not self._h:
+            raise _lib.PietMetalError(err.value, "pm_create")
+        self.device = device
+        self.width = self.height = 0
+        self.row0 = self.row1 = 0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.pm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- viewport ---------------------------------------------------------------
+    def resize(self, width: int, height: int) -> None:
+        _lib.check(self._lib.pm_resize(self._h, width, height), "pm_resize")
+        self.width, self.height = width, height
+        self.row0, self.row1 = 0, (height + 15) // 16
+
+    def set_band(self, tile_row0: int, tile_row1: int) -> None:
+        _lib.check(self._lib.pm_set_band(self._h, tile_row0, tile_row1), "pm_set_band")
+        self.row0, self.row1 = tile_row0, tile_row1
+
+    @property
+    def band_pixel_rows(self) -> int:
+        return min(self.row1 * 16, self.height) - self.row0 * 16
+
+    # ---- scene --------------------------------------------------------------------
+    def scene_buffer(self) -> np.ndarray:
+        """Pinned host staging buffer (the reference's _sceneBuf.contents)."""
+        cap = C.c_size_t(0)
+        p = self._lib.pm_scene_buffer(self._h, C.byref(cap))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(cap.value,))
+
+    def reserve_scene(self, nbytes: int) -> None:
+        _lib.check(self._lib.pm_scene_reserve(self._h, nbytes), "pm_scene_reserve")
+
+    def upload_scene(self, nbytes: int) -> None:
+        _lib.check(self._lib.pm_upload_scene(self._h, nbytes), "pm_upload_scene")
+
+    def set_scene_bytes(self, data: bytes | np.ndarray) -> None:
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        if a.size > self.scene_buffer().size:
+            self.reserve_scene(int(a.size))
+        self.scene_buffer()[: a.size] = a
+        self.upload_scene(int(a.size))
+
+    def flatten_and_encode(self, paths: PathSet, affine, width_scale: float) -> tuple[int, int]:
+        """On-device flatten + encode; returns (scene_bytes, n_items)."""
+        aff = (C.c_double * 6)(*[float(v) for v in affine])
+        nbytes, nitems = C.c_size_t(0), C.c_uint32(0)
+        _lib.check(
+            self._lib.pm_flatten_and_encode(
+                self._h, paths.paths.ctypes.data, len(paths.paths), paths.els.ctypes.data, len(paths.els), aff,
+                float(width_scale), C.byref(nbytes), C.byref(nitems),
+            ),
+            "pm_flatten_and_encode",
+        )
+        return nbytes.value, nitems.value
+
+    def download_scene(self) -> np.ndarray:
+        nbytes = C.c_size_t(0)
+        self._lib.pm_scene_device_ptr(self._h, C.byref(nbytes))
+        out = np.zeros(max(nbytes.value, 8), np.uint8)
+        _lib.check(self._lib.pm_download_scene(self._h, out.ctypes.data, out.size, C.byref(nbytes)), "pm_download_scene")
+        return out[: nbytes.value]
+
+    # ---- frames ---------------------------------------------------------------------
+    def render(self) -> None:
+        _lib.check(self._lib.pm_render(self._h), "pm_render")
+
+    def render_to(self, tensor, stream=None) -> None:
+        """Render into a torch uint8 CUDA tensor of shape [band_rows, width, 4]."""
+        if tensor.dtype.__str__() != "torch.uint8" or not tensor.is_cuda or tensor.dim() != 3 or tensor.shape[2] != 4:
+            raise TypeError("render_to needs a CUDA uint8 tensor [rows, width, 4]")
+        if tensor.shape[1] != self.width or tensor.shape[0] < self.band_pixel_rows or tensor.stride(1) != 4 or tensor.stride(2) != 1:
+            raise ValueError("tensor does not match the viewport band")
+        s = stream.cuda_stream if stream is not None else None
+        _lib.check(self._lib.pm_render_to(self._h, tensor.data_ptr(), tensor.stride(0), s), "pm_render_to")
+
+    def sync(self) -> None:
+        _lib.check(self._lib.pm_sync(self._h), "pm_sync")
+
+    def read_pixels(self, bgra: bool = False) -> np.ndarray:
+        out = np.zeros((self.band_pixel_rows, self.width, 4), np.uint8)
+        _lib.check(
+            self._lib.pm_read_pixels(self._h, out.ctypes.data, self.width * 4, _lib.PM_FMT_BGRA8 if bgra else _lib.PM_FMT_RGBA8),
+            "pm_read_pixels",
+        )
+        return out
+
+    def time_frames(self, iters: int, per_kernel: bool = True) -> dict:
+        tot, k1, k2 = C.c_float(0), C.c_float(0), C.c_float(0)
+        _lib.check(
+            self._lib.pm_time_frames(self._h, iters, C.byref(tot), C.byref(k1) if per_kernel else None, C.byref(k2) if per_kernel else None),
+            "pm_time_frames",
+        )
+        return {"total_ms": tot.value, "bin_ms": k1.value, "tile_ms": k2.value, "iters": iters}
+
+    def stats(self) -> dict:
+        s = _lib.Stats()
+        _lib.check(self._lib.pm_get_stats(self._h, C.byref(s)), "pm_get_stats")
+        return {name: getattr(s, name) for name, _ in s._fields_}
+
+    def capture_ptcl(self, max_cmds_per_tile: int = 512):
+        """Per-tile command lists of the last frame in the reference's 24-byte layout.
+        Returns (counts[rows, tiles_x], solid[rows, tiles_x], cmds[rows, tiles_x, max, 6])."""
+        st = self.stats()
+        rows, tx = st["band_row1"] - st["band_row0"], st["tiles_x"]
+        counts = np.zeros((rows, tx), np.uint32)
+        solid = np.zeros((rows, tx), np.uint32)
+        cmds = np.zeros((rows, tx, max_cmds_per_tile, 6), np.uint32)
+        _lib.check(
+            self._lib.pm_debug_capture_ptcl(self._h, max_cmds_per_tile, counts.ctypes.data, solid.ctypes.data, cmds.ctypes.data),
+            "pm_debug_capture_ptcl",
+        )
+        return counts, solid, cmds
+
+
+def init_test_scene(buf: np.ndarray) -> None:
+    """The reference's one FFI symbol (include/piet_metal.h:3): Tiger at scale 8."""
+    lib = _lib.load()
+    lib.init_test_scene(buf.ctypes.data, buf.size)
