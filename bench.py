@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- the metric BASELINE.json names: Mpixels/s on the Ghostscript Tiger at
+3840x2160 (fills + strokes, BASELINE config 3), 1/2/4/8 GPUs, with the HBM-roofline
+fraction of the dominant kernel and the CPU oracle timed beside it.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame of the hot path: pm_bin_kernel + pm_tile_kernel over the scene
+already resident in HBM (flatten/encode happens once per scene, like the reference
+encodes once per resize, PietRenderer.m:145).
+
+N = 1 : one 3840x2160 Tiger frame per step.
+N > 1 : weak scaling -- the viewport is 3840 x (2160*N) with one Tiger per 2160-row
+        band; rank r renders the tile rows of band r (the scene is replicated, no
+        exchange while rendering) and every step ends with the ONE collective of the
+        design: the framebuffer bands are gathered to rank 0 over RCCL/xGMI
+        (--no-gather measures rendering alone).  value = all pixels of all ranks / time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def stacked_tigers(pm, n: int):
+    """n Tigers at the config-3 scale (10.8), one per 2160-row band."""
+    wl = pm.workloads.tiger(3840, 2160)
+    if n == 1:
+        return wl
+    scale = wl.width_scale
+    sets = [wl.paths.transformed((1.0, 0.0, 0.0, 1.0, 0.0, 2160.0 * k / scale)) for k in range(n)]
+    wl.paths = pm.PathSet.concat(sets)
+    wl.height = 2160 * n
+    wl.name = f"tiger_3840x2160_x{n}"
+    return wl
+
+
+def cpu_baseline(pm, wl_single, seconds_budget: float = 12.0):
+    """The oracle (a scalar C port of the reference algorithm) on this host, rank 0 only."""
+    from oracle import pmo
+
+    scene, _ = pmo.scene_from_paths(pmo.scaled_paths(wl_single.paths.paths, wl_single.width_scale), wl_single.paths.els, wl_single.affine)
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        pmo.render(scene, wl_single.width, wl_single.height)
+        frames += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or frames >= 8:
+            break
+    mpix = wl_single.width * wl_single.height * frames / el / 1e6
+    return {
+        "value": round(mpix, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
+        "sample": f"{frames} full 3840x2160 Tiger frames (tileKernel+renderKernel restatement, oracle/), {el:.1f} s on 1 of {os.cpu_count()} host cores",
+    }
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    import piet_metal_amd as pm
+    from piet_metal_amd import dist as pmd
+
+    rank, world, local = pmd.env_rank_world()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", file=sys.stderr)
+            return 2
+    if not torch.cuda.is_available():
+        print("bench.py needs an MI355X: there is no CPU fallback for the product path", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local)
+    if world > 1:
+        pmd.init_process_group("nccl")
+        import torch.distributed as dist
+
+    wl = stacked_tigers(pm, world)
+    r = pm.Renderer(local)
+    r.resize(wl.width, wl.height)
+    scene_bytes, n_items = r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    layout = pmd.band_layout(wl.height, world)
+    r0, r1, rows = layout[rank]
+    if world > 1:
+        r.set_band(r0, r1)
+    pad_rows = pmd.padded_band_rows(wl.height, world)
+    band = torch.zeros((pad_rows, wl.width, 4), dtype=torch.uint8, device=f"cuda:{local}")
+    full = torch.empty((wl.height, wl.width, 4), dtype=torch.uint8, device=f"cuda:{local}") if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream()
+    do_gather = world > 1 and not args.no_gather
+
+    def step():
+        if world == 1:
+            r.render()
+        else:
+            r.render_to(band, stream)
+            if do_gather:
+                pmd.gather_framebuffer(band, wl.height, dst=0, full=full)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        r.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel durations with HIP events on the stream the kernels run on (ctx stream)
+    tm = r.time_frames(max(10, min(args.steps, 100)))
+    st = r.stats()
+    band_px = wl.width * rows
+    total_px = wl.width * wl.height
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_px / (elapsed / args.steps) / 1e6
+
+    if rank == 0:
+        # algorithmic bytes of one launch of the dominant kernel = one frame of this
+        # rank's band: scene read once + every RGBA8 pixel written once
+        b_alg = scene_bytes + 4 * band_px
+        dom = "pm_tile_kernel" if tm["tile_ms"] >= tm["bin_ms"] else "pm_bin_kernel"
+        dom_ms = max(tm["tile_ms"], tm["bin_ms"])
+        achieved = b_alg / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpixels/s, Ghostscript Tiger 3840x2160 (fills+strokes)",
+            "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 geometry + f16 accumulators (as the reference)", "data": "synthetic: embedded Ghostscript_Tiger.svg, scale 10.8, flattened on device",
+            "config": {
+                "workload": "BASELINE config 3: Ghostscript Tiger 3840x2160, fills + strokes" + ("" if world == 1 else f", one Tiger per 2160-row band x {world} (weak scaling)"),
+                "viewport": [wl.width, wl.height], "items": n_items, "scene_bytes": scene_bytes,
+                "parallelism": "1 GPU" if world == 1 else f"tile-row bands x{world}, scene replicated, " + ("RCCL gather of bands to rank 0 every step" if do_gather else "no gather"),
+                "queued_tiles_rank0": st["queued_tiles"],
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(dom_ms, 5),
+                "bin_kernel_ms": round(tm["bin_ms"], 5), "tile_kernel_ms": round(tm["tile_ms"], 5),
+                "frame_ms_events": round(tm["total_ms"] / tm["iters"], 5),
+                "frame_frac": round(b_alg / (tm["total_ms"] / tm["iters"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pm, pm.workloads.tiger(3840, 2160))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    r.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

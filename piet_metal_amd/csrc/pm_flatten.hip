@@ -305,6 +305,7 @@ __global__ void KItems(const pm_path *paths, uint32_t n_paths, const pm_path_el 
             it[2] = __builtin_bswap32(path.fill_rgba);
             it[3] = n_points;
             it[4] = static_cast<uint32_t>(pts_ix);
+            it[5] = it[6] = it[7] = 0;  // write_struct copies 20 bytes; the Metal buffer starts zeroed
         }
         item += n_sub_path;
         pts_ix += 8 * static_cast<size_t>(path_pts);
@@ -329,6 +330,7 @@ __global__ void KItems(const pm_path *paths, uint32_t n_paths, const pm_path_el 
             it[2] = __float_as_uint(width);
             it[3] = n_points;
             it[4] = static_cast<uint32_t>(pts_ix);
+            it[5] = it[6] = it[7] = 0;
         }
     }
 }

@@ -1,0 +1,46 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Make sure both shared libraries exist (no-op when __graft_entry__.build() already ran)."""
+    lib = os.path.join(ROOT, "piet_metal_amd", "lib", "libpiet_metal_amd.so")
+    ora = os.path.join(ROOT, "oracle", "libpmo_oracle.so")
+    if not (os.path.exists(lib) and os.path.exists(ora)):
+        import __graft_entry__ as g
+
+        g.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def pm(built):
+    import piet_metal_amd
+
+    return piet_metal_amd
+
+
+@pytest.fixture(scope="session")
+def pmo(built):
+    from oracle import pmo as m
+
+    m.load()
+    return m
+
+
+@pytest.fixture(scope="session")
+def renderer(pm):
+    r = pm.Renderer(0)
+    yield r
+    r.close()

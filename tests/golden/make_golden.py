@@ -1,0 +1,74 @@
+"""Generates tests/golden/golden.json: the pins this repo creates because the
+reference has none (no tests, no golden images).
+
+Everything here is produced by the CPU oracle (oracle/) in the build container
+from inputs both sides share: the reference's three scene generators
+(src/lib.rs:257-328) and the BASELINE configs.  Run from the repo root:
+
+    python tests/golden/make_golden.py
+
+Inputs that need the product's SVG front-end (Tiger path elements) are hashed too,
+so a parser change shows up as a golden mismatch instead of silently moving both
+sides.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import piet_metal_amd as pm  # noqa: E402
+from oracle import pmo  # noqa: E402
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def scene_entry(scene, w, h, with_image=True):
+    P = pmo.Ptcl(scene, w, h)
+    tot, mx = P.total_cmds()
+    e = {"scene_bytes": int(scene.size), "scene_sha256": sha(scene), "viewport": [w, h], "total_cmds": tot, "max_cmds_per_tile": mx}
+    if with_image:
+        img = P.render()
+        e["rgba_sha256"] = sha(img)
+        e["rgba_sum"] = int(img.astype(np.uint64).sum())
+        f32 = P.render(pmo.MODE_F32)
+        e["half_vs_f32_max_lsb"] = int(np.abs(img.astype(int) - f32.astype(int)).max())
+    solid = np.array([[P.solid(tx, ty) for tx in range(P.tiles_x)] for ty in range(P.tiles_y)], np.uint32)
+    e["solid_sha256"] = sha(solid)
+    P.close()
+    return e
+
+
+def main():
+    out = {}
+    out["path_test_512x832"] = scene_entry(pmo.scene_path_test(), 512, 832)
+    out["cardioid_2048x1536"] = scene_entry(pmo.scene_cardioid(), 2048, 1536)
+    tig = pm.PathSet.tiger()
+    out["tiger_paths"] = {"n_paths": len(tig.paths), "n_els": len(tig.els), "paths_sha256": sha(tig.paths), "els_sha256": sha(tig.els)}
+    tig_na = pm.PathSet.tiger(reject_arc_paths=True)
+    out["tiger_paths_no_arcs"] = {"n_paths": len(tig_na.paths), "n_els": len(tig_na.els)}
+    for wl in [pm.workloads.tiger_reference(), pm.workloads.tiger(1920, 1080, fills_only=True), pm.workloads.tiger(3840, 2160),
+               pm.workloads.tiger(480, 270), pm.workloads.config1_rect(), pm.workloads.config1_rect(True)]:
+        scene, n_items = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
+        e = scene_entry(scene, wl.width, wl.height)
+        e["n_items"] = n_items
+        out[wl.name] = e
+    # a 64x64 px crop of the reference Tiger (eye region) as raw RGBA for eyeballing / exact compare
+    wl = pm.workloads.tiger_reference()
+    scene, _ = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
+    img = pmo.render(scene, wl.width, wl.height)
+    np.save(os.path.join(os.path.dirname(__file__), "tiger_x8_crop_704_496_64x64.npy"), img[496:560, 704:768].copy())
+    a, b, c = pmo.luts()
+    out["luts"] = {"srgb2lin_sha256": sha(a), "unorm2h_sha256": sha(b), "lin2srgb_sha256": sha(c)}
+    with open(os.path.join(os.path.dirname(__file__), "golden.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

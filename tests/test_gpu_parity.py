@@ -1,0 +1,246 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, must be
+byte-identical to the oracle on the same encoded scene -- RGBA8 pixels, per-tile
+command lists, and the device-flattened scene bytes.  Full-size configurations are
+covered through committed golden hashes and size-independent properties
+(band-vs-full equality, idempotence, clip-invariance)."""
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from test_host_cpu import encode_ops, random_ops
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+        return json.load(f)
+
+
+def gpu_render(renderer, scene, w, h):
+    renderer.resize(w, h)
+    renderer.set_scene_bytes(scene)
+    renderer.render()
+    renderer.sync()
+    return renderer.read_pixels()
+
+
+def assert_ptcl_equal(renderer, pmo, scene, w, h, maxc=1024):
+    P = pmo.Ptcl(scene, w, h)
+    counts, solid, cmds = renderer.capture_ptcl(maxc)
+    for ty in range(P.tiles_y):
+        for tx in range(P.tiles_x):
+            oc = P.cmds(tx, ty)
+            assert counts[ty, tx] == len(oc), (tx, ty)
+            assert solid[ty, tx] == P.solid(tx, ty), (tx, ty)
+            assert np.array_equal(cmds[ty, tx, : len(oc)], oc), (tx, ty)
+    P.close()
+
+
+def test_extension_is_loaded_and_device_is_gfx950(pm, renderer):
+    assert os.path.exists(pm._lib.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    assert "libpiet_metal_amd.so" in maps
+
+
+@pytest.mark.parametrize("name,w,h", [("path_test", 512, 832), ("cardioid", 2048, 1536), ("cardioid", 1999, 1501), ("cardioid", 300, 200)])
+def test_reference_scenes_pixels_and_lists(pm, pmo, renderer, name, w, h):
+    scene = pmo.scene_path_test() if name == "path_test" else pmo.scene_cardioid()
+    got = gpu_render(renderer, scene, w, h)
+    assert np.array_equal(got, pmo.render(scene, w, h))
+    assert_ptcl_equal(renderer, pmo, scene, w, h)
+
+
+def test_host_encoded_scene_through_pinned_buffer(pm, pmo, renderer):
+    # the drop-in flow of PietRenderer.m:203-205: encode into the renderer's own buffer
+    renderer.resize(640, 480)
+    buf = renderer.scene_buffer()
+    buf[:8192] = 0
+    n = pm.scene_cardioid(buf)
+    renderer.upload_scene(n)
+    renderer.render()
+    assert np.array_equal(renderer.read_pixels(), pmo.render(pmo.scene_cardioid(), 640, 480))
+    bgra = renderer.read_pixels(bgra=True)
+    assert np.array_equal(bgra[..., [2, 1, 0, 3]], renderer.read_pixels())
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_random_scenes(pm, pmo, renderer, seed):
+    # circles, lines, fills (incl. vertices on tile boundaries / axis-aligned edges: quirks
+    # Q1-Q3), polylines (quirk Q4), opaque and translucent colours
+    scene = encode_ops(pm, random_ops(seed, 120, extent=900.0))
+    w, h = 928, 912
+    got = gpu_render(renderer, scene, w, h)
+    want = pmo.render(scene, w, h)
+    assert np.array_equal(got, want)
+    assert_ptcl_equal(renderer, pmo, scene, w, h)
+
+
+def test_many_items_multiple_batches_and_long_lists(pm, pmo, renderer):
+    # > 256 items (several binning batches) stacked on few tiles: lists far beyond the
+    # reference's 170-command tile buffer (quirk Q5) and beyond one LDS flush
+    rng = np.random.default_rng(7)
+    ops = []
+    for i in range(700):
+        c = rng.uniform(40, 200, 2)
+        pts = c + rng.uniform(-60, 60, (int(rng.integers(3, 9)), 2))
+        rgba = (int(rng.integers(0, 1 << 24)) << 8) | (0xFF if i % 97 == 0 else int(rng.integers(0x20, 0xFF)))
+        ops.append(("fill", pts, rgba) if i % 3 else ("poly", pts, rgba, float(rng.uniform(0.5, 6))))
+    scene = encode_ops(pm, ops, cap=1 << 22)
+    got = gpu_render(renderer, scene, 256, 256)
+    P = pmo.Ptcl(scene, 256, 256)
+    assert P.total_cmds()[1] > 800
+    assert np.array_equal(got, P.render())
+    assert_ptcl_equal(renderer, pmo, scene, 256, 256, maxc=4096)
+
+
+def test_empty_scene_and_tiny_viewports(pm, pmo, renderer):
+    empty = np.frombuffer(struct.pack("<II", 0, 8), np.uint8)
+    assert (gpu_render(renderer, empty, 40, 24) == 255).all()
+    scene = pmo.scene_cardioid()
+    for w, h in ((1, 1), (15, 17), (257, 33)):
+        assert np.array_equal(gpu_render(renderer, scene, w, h), pmo.render(scene, w, h))
+
+
+def test_malformed_scene_is_rejected(pm, renderer):
+    renderer.resize(64, 64)
+    bad = np.frombuffer(struct.pack("<II", 1000, 8), np.uint8)  # items run past the buffer
+    with pytest.raises(pm.PietMetalError) as ei:
+        renderer.set_scene_bytes(bad)
+    assert ei.value.status == pm._lib.PM_ERR_SCENE
+
+
+def _flatten_case(pm, pmo, renderer, wl):
+    renderer.resize(wl.width, wl.height)
+    nbytes, nitems = renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    dev = renderer.download_scene()
+    ref, ref_items = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
+    assert nitems == ref_items and nbytes == ref.size
+    assert np.array_equal(dev, ref)  # flatten.rs on device == CPU encoder, byte for byte
+    return ref
+
+
+def test_device_flatten_tiger_reference_scale_golden(pm, pmo, renderer, golden):
+    wl = pm.workloads.tiger_reference()
+    scene = _flatten_case(pm, pmo, renderer, wl)
+    assert sha(scene) == golden["tiger_x8"]["scene_sha256"]
+    renderer.render()
+    got = renderer.read_pixels()
+    assert sha(got) == golden["tiger_x8"]["rgba_sha256"]
+    crop = np.load(os.path.join(ROOT, "tests", "golden", "tiger_x8_crop_704_496_64x64.npy"))
+    assert np.array_equal(got[496:560, 704:768], crop)
+    assert_ptcl_equal(renderer, pmo, scene, wl.width, wl.height)
+
+
+def test_init_test_scene_drop_in(pm, pmo, golden):
+    buf = np.zeros(16 << 20, np.uint8)  # the reference's 16 MiB shared buffer (PietRenderer.m:53)
+    pm.init_test_scene(buf)
+    n = golden["tiger_x8"]["scene_bytes"]
+    assert sha(buf[:n]) == golden["tiger_x8"]["scene_sha256"]
+    assert not buf[n:].any()
+
+
+@pytest.mark.parametrize("cfg", ["config1", "config1_rot", "config2", "config3"])
+def test_baseline_configs(pm, pmo, renderer, golden, cfg):
+    wl = {
+        "config1": lambda: pm.workloads.config1_rect(),
+        "config1_rot": lambda: pm.workloads.config1_rect(True),
+        "config2": lambda: pm.workloads.tiger(1920, 1080, fills_only=True),
+        "config3": lambda: pm.workloads.tiger(3840, 2160),
+    }[cfg]()
+    scene = _flatten_case(pm, pmo, renderer, wl)
+    assert sha(scene) == golden[wl.name]["scene_sha256"]
+    renderer.render()
+    got = renderer.read_pixels()
+    assert sha(got) == golden[wl.name]["rgba_sha256"]          # committed pin
+    assert np.array_equal(got, pmo.render(scene, wl.width, wl.height))  # live oracle
+    st = renderer.stats()
+    assert st["overflow"] == 0 and st["arena_used_dwords"] <= st["arena_cap_dwords"]
+
+
+def test_config4_blobs_reduced_vs_oracle_and_full_properties(pm, pmo, renderer):
+    # oracle-sized: 600 blobs at 1024^2, byte-exact
+    wl = pm.workloads.config4_blobs(600, 1024)
+    scene = _flatten_case(pm, pmo, renderer, wl)
+    renderer.render()
+    assert np.array_equal(renderer.read_pixels(), pmo.render(scene, wl.width, wl.height))
+    # full size (10k blobs, 4096^2): idempotence + band-vs-full + oracle on one band of rows
+    wl = pm.workloads.config4_blobs()
+    renderer.resize(wl.width, wl.height)
+    renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    scene = renderer.download_scene()
+    renderer.render()
+    full = renderer.read_pixels()
+    renderer.render()
+    assert np.array_equal(full, renderer.read_pixels())
+    renderer.set_band(100, 110)
+    renderer.render()
+    band = renderer.read_pixels()
+    assert np.array_equal(band, full[1600:1760])
+    P = pmo.Ptcl(scene, wl.width, wl.height)
+    assert np.array_equal(band[:32], P.render_rows(100, 102))
+    P.close()
+
+
+def test_bands_reassemble_to_full_frame(pm, pmo, renderer):
+    # the multi-GPU sharding on one GPU: every band of an 8-way split equals the
+    # corresponding rows of the full frame
+    wl = pm.workloads.tiger(1920, 1080)
+    renderer.resize(wl.width, wl.height)
+    renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    renderer.render()
+    full = renderer.read_pixels()
+    from piet_metal_amd import dist as pmd
+
+    for world in (2, 8):
+        for rank, (r0, r1, rows) in enumerate(pmd.band_layout(wl.height, world)):
+            renderer.set_band(r0, r1)
+            renderer.render()
+            band = renderer.read_pixels()
+            assert band.shape[0] == rows
+            assert np.array_equal(band, full[r0 * 16 : r0 * 16 + rows]), (world, rank)
+
+
+def test_config5_tiger_grid_reduced(pm, pmo, renderer):
+    # 2x2 Tigers at scale 4 in 2048^2 (oracle-sized stand-in for the 8192^2 grid), full + bands
+    wl = pm.workloads.config5_tiger_grid(2048, 2, 4.0)
+    scene = _flatten_case(pm, pmo, renderer, wl)
+    renderer.render()
+    full = renderer.read_pixels()
+    assert np.array_equal(full, pmo.render(scene, wl.width, wl.height))
+    renderer.set_band(64, 128)
+    renderer.render()
+    assert np.array_equal(renderer.read_pixels(), full[1024:2048])
+
+
+def test_render_to_torch_tensor_on_torch_stream(pm, pmo, renderer):
+    import torch
+
+    wl = pm.workloads.tiger(480, 270)
+    renderer.resize(wl.width, wl.height)
+    renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    scene = renderer.download_scene()
+    t = torch.zeros((272, 480, 4), dtype=torch.uint8, device="cuda:0")
+    renderer.render_to(t, torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    assert np.array_equal(t[:270].cpu().numpy(), pmo.render(scene, 480, 270))
+
+
+def test_back_to_back_frames_and_timing_api(pm, pmo, renderer):
+    scene = pmo.scene_cardioid()
+    renderer.resize(1024, 768)
+    renderer.set_scene_bytes(scene)
+    tm = renderer.time_frames(10)
+    assert tm["total_ms"] > 0 and tm["bin_ms"] > 0 and tm["tile_ms"] > 0
+    assert np.array_equal(renderer.read_pixels(), pmo.render(scene, 1024, 768))
