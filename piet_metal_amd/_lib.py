@@ -125,6 +125,14 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(piet_metal_amd has no CPU/Python fallback)"
         )
+    # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64 /
+    # libhsa-runtime64.  If it is loaded after ours (from /opt/rocm) the second runtime
+    # finds no GPU, so when torch is installed let it load first; our library's
+    # NEEDED libamdhip64.so.7 then binds to the copy that is already resident.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol

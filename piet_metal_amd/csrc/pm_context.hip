@@ -133,6 +133,10 @@ struct pm_ctx {
     size_t scene_bytes = 0;
     uint32_t n_items = 0;
     std::vector<uint8_t> item_meta;  // copy of header + bboxes + items (arena sizing)
+    uint32_t *d_chunk_base = nullptr;  // scene index: first chunk of every item (+ total)
+    float4 *d_chunk_bbox = nullptr;    // scene index: bounding box of every 16-segment chunk
+    size_t chunk_base_cap = 0, chunk_bbox_cap = 0;
+    uint32_t n_chunks = 0;
 
     // viewport
     uint32_t width = 0, height = 0, tiles_x = 0, tiles_y = 0, strips_x = 0;
@@ -230,9 +234,11 @@ uint64_t ArenaBound(const pm_ctx *c) {
         std::memcpy(&tag, it, 4);
         tag &= 0xffffu;
         std::memcpy(&npt, it + 12, 4);
-        uint64_t nseg = 1;
-        if (tag == pm::kItemFill && npt > 1) nseg = npt;
-        if (tag == pm::kItemPoly && npt > 2) nseg = npt - 1;
+        uint64_t nseg = 0;
+        if (tag == pm::kItemFill) nseg = npt;
+        if (tag == pm::kItemPoly && npt >= 2) nseg = npt - 1;
+        if (tag == pm::kItemLine) nseg = 1;
+        nseg = (nseg + pm::kChunkSegs - 1) / pm::kChunkSegs * pm::kChunkSegs;  // whole chunks are reserved
         // strips: bz >= sx0 && bx < sx0 + 256 ; rows: bw >= y0 && by < y0 + 16
         const int64_t s_lo = bb[0] / 256, s_hi = std::min<int64_t>(bb[2] / 256, static_cast<int64_t>(c->strips_x) - 1);
         const int64_t r_lo = std::max<int64_t>(bb[1] / 16, c->row0), r_hi = std::min<int64_t>(bb[3] / 16, static_cast<int64_t>(c->row1) - 1);
@@ -290,6 +296,8 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     p->queue = c->d_queue;
     p->ctr_cur = c->d_ctr + (c->frame & 1u);
     p->ctr_next = c->d_ctr + ((c->frame + 1u) & 1u);
+    p->chunk_base = c->d_chunk_base;
+    p->chunk_bbox = c->d_chunk_bbox;
     p->lut_srgb2lin = c->d_lut_srgb2lin;
     p->lut_unorm2h = c->d_lut_unorm2h;
     p->lut_lin2srgb = c->d_lut_lin2srgb;
@@ -303,8 +311,9 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
 uint32_t TileGrid(const pm_ctx *c) {
     // persistent workgroups: enough to fill every CU at the kernel's occupancy
     const uint32_t tiles = BandRows(c) * c->tiles_x;
-    const uint32_t cap = static_cast<uint32_t>(c->n_cus) * 8u;
-    return std::max(1u, std::min(tiles, cap));
+    // one wave per tile, 4 waves per workgroup, 4 workgroups resident per CU (LDS-bound)
+    const uint32_t cap = static_cast<uint32_t>(c->n_cus) * 4u;
+    return std::max(1u, std::min((tiles + 3u) / 4u, cap));
 }
 
 int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t stream) {
@@ -317,6 +326,53 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t stream) {
     c->last_params = p;
     c->have_frame = true;
     c->frame += 1;
+    return PM_OK;
+}
+
+// Scene index: chunk table offsets on the host (a prefix sum over the item headers we
+// already copied), chunk boxes on the device.  Built once per scene, like the
+// reference builds its per-item ShortBbox array at encode time (src/lib.rs:88-97).
+int BuildSceneIndex(pm_ctx *c) {
+    const uint8_t *meta = c->item_meta.data();
+    uint32_t n, items_ix;
+    std::memcpy(&n, meta, 4);
+    std::memcpy(&items_ix, meta + 4, 4);
+    std::vector<uint32_t> base(static_cast<size_t>(n) + 1);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        base[i] = static_cast<uint32_t>(total);
+        const uint8_t *it = meta + items_ix + 32ull * i;
+        uint32_t tag, npt;
+        std::memcpy(&tag, it, 4);
+        std::memcpy(&npt, it + 12, 4);
+        tag &= 0xffffu;
+        uint64_t nseg = 0;
+        if (tag == pm::kItemFill) nseg = npt;
+        else if (tag == pm::kItemPoly && npt >= 2) nseg = npt - 1;
+        total += (nseg + pm::kChunkSegs - 1) / pm::kChunkSegs;
+    }
+    base[n] = static_cast<uint32_t>(total);
+    if (total > 0xffffffu * 16ull) {
+        SetError("scene has too many segments for the chunk index");
+        return PM_ERR_CAPACITY;
+    }
+    if (base.size() > c->chunk_base_cap) {
+        if (c->d_chunk_base) (void)hipFree(c->d_chunk_base);
+        c->d_chunk_base = nullptr;
+        PM_TRY(hipMalloc(&c->d_chunk_base, base.size() * sizeof(uint32_t)));
+        c->chunk_base_cap = base.size();
+    }
+    if (total > c->chunk_bbox_cap || !c->d_chunk_bbox) {
+        if (c->d_chunk_bbox) (void)hipFree(c->d_chunk_bbox);
+        c->d_chunk_bbox = nullptr;
+        PM_TRY(hipMalloc(&c->d_chunk_bbox, std::max<uint64_t>(total, 1) * sizeof(float4)));
+        c->chunk_bbox_cap = std::max<uint64_t>(total, 1);
+    }
+    c->n_chunks = static_cast<uint32_t>(total);
+    PM_TRY(hipMemcpyAsync(c->d_chunk_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    pm::LaunchIndex(c->d_scene, n, c->d_chunk_base, c->n_chunks, c->d_chunk_bbox, c->stream);
+    PM_TRY(hipGetLastError());
+    PM_TRY(hipStreamSynchronize(c->stream));  // `base` is a stack-owned source buffer
     return PM_OK;
 }
 
@@ -345,7 +401,7 @@ int SetScene(pm_ctx *c, size_t bytes) {
     c->n_items = n;
     c->arena_dirty = true;
     c->have_frame = false;
-    return PM_OK;
+    return BuildSceneIndex(c);
 }
 
 int ReserveScene(pm_ctx *c, size_t cap) {
@@ -458,6 +514,8 @@ void pm_destroy(pm_ctx *c) {
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->h_scene) (void)hipHostFree(c->h_scene);
+    if (c->d_chunk_base) (void)hipFree(c->d_chunk_base);
+    if (c->d_chunk_bbox) (void)hipFree(c->d_chunk_bbox);
     if (c->d_lut_srgb2lin) (void)hipFree(c->d_lut_srgb2lin);
     if (c->d_lut_unorm2h) (void)hipFree(c->d_lut_unorm2h);
     if (c->d_lut_lin2srgb) (void)hipFree(c->d_lut_lin2srgb);

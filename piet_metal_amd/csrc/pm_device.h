@@ -24,6 +24,14 @@ struct Counters {
 //   ncand x 8 dwords: { tag | hitmask16 << 16, rgba, aux0, aux1, seg_off, item_ix, -, - }
 //       aux0/aux1 = bbox words (circle) or width bits (line, polyline)
 //   survived segments, 16 B each (start.xy, end.xy), in paint order
+//
+// Scene index (built once per scene upload by pm_index_kernel, like the ShortBbox
+// array the encoder builds at encode time): segments are grouped in chunks of 16
+// consecutive segments of one Fill / StrokePolyLine item; chunk_bbox holds each
+// chunk's float bounding box {xmin, ymin, xmax, ymax}; chunk_base[i] is the first
+// chunk of item i (chunk_base[n_items] = total).  The binning kernel streams only
+// the chunks whose box can reach its strip row.
+constexpr uint32_t kChunkSegs = 16;
 constexpr uint32_t kArenaBase = 4;     // offset 0 means "none"
 constexpr uint32_t kRecHdrDwords = 4;
 constexpr uint32_t kCandDwords = 8;
@@ -44,6 +52,8 @@ struct FrameParams {
     uint32_t *queue;
     Counters *ctr_cur;
     Counters *ctr_next;
+    const uint32_t *chunk_base;    // [n_items + 1]
+    const float4 *chunk_bbox;      // [chunk_base[n_items]]
     const uint32_t *lut_srgb2lin;  // [256] binary16 bits of the sRGB EOTF
     const uint32_t *lut_unorm2h;   // [256] binary16 bits of a/255
     const uint8_t *lut_lin2srgb;   // [65536] binary16 bits -> sRGB unorm8
@@ -54,6 +64,8 @@ struct FrameParams {
     uint32_t dbg_max;
 };
 
+void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks, float4 *chunk_bbox,
+                 hipStream_t stream);
 void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream);
 void LaunchTiles(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream);
 

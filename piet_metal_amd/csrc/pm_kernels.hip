@@ -8,27 +8,35 @@
 //
 // Decomposition (NOT the reference's thread-per-tile / 256 MiB tile buffer):
 //
+//   pm_index_kernel (once per scene) float bounding box of every chunk of 16
+//       consecutive segments -- the segment-level analogue of the ShortBbox array
+//       the encoder already builds per item.
 //   pm_bin_kernel   one 256-thread workgroup per strip row (16 tiles x 1 tile).
 //       - item bboxes vs strip row: wave64 ballots + prefix ranks compact the
 //         candidate items in paint order;
-//       - ALL segments of ALL candidates form one flat stream; every lane
-//         evaluates the reference's "phase 1" segment vote (PietRender.metal
-//         :258-295 fills, :374-399 polylines) for one stream element, votes
-//         are compacted in order and the surviving segments (16 B each) are
+//       - the chunks of all candidates form one flat stream; chunks whose box
+//         cannot reach the strip row are dropped, the segments of the others are
+//         expanded lane-parallel and each lane evaluates the reference's "phase 1"
+//         segment vote (PietRender.metal:258-295 fills, :374-399 polylines);
+//         votes are compacted in order and the surviving segments (16 B each) are
 //         appended to a bump-allocated arena record in HBM;
 //       - tiles no item touches are cleared to the background right here with
 //         16-byte coalesced stores; the others are pushed on a tile queue.
-//   pm_tile_kernel  persistent 256-thread workgroups pull tiles off the queue.
-//       - candidates are filtered by a per-tile hit bit, their surviving
-//         segments again form one flat stream; each lane runs the reference's
-//         "phase 2" test for (tile, segment) (:302-357, :406-440) and emits
-//         0..3 commands; block-wide scans give every command its slot in an
+//   pm_tile_kernel  persistent; ONE WAVE PER TILE, no workgroup barriers.
+//       - candidates are filtered by a per-tile hit bit, their surviving segments
+//         again form one flat stream; each lane runs the reference's "phase 2"
+//         test for (tile, segment) (:302-357, :406-440) and emits 0..3 commands;
+//         ballots / mbcnt prefix ranks give every command its slot in an
 //         LDS-resident command list (never written to HBM);
-//       - the same 256 threads then become the tile's 256 pixels and interpret
-//         the list (renderKernel), in the command order the reference defines,
-//         with binary16 accumulators (native v_*_f16, no contraction);
-//       - opaque-solid detection (TileEncoder::encodeSolid/end) is tracked
-//         uniformly so Bail tiles are written as one constant.
+//       - the wave then interprets the list (renderKernel) for the tile's 256
+//         pixels, 4 horizontally adjacent pixels per lane: everything that only
+//         depends on y (segment window, the two divides of the area integral,
+//         FillEdge) is computed once per lane, colour blending runs as packed
+//         half2 math, and each lane finishes with one 16-byte store;
+//       - accumulators are binary16 exactly where the source declares `half`,
+//         commands are applied in list order (half accumulation is order
+//         dependent), opaque-solid detection (TileEncoder::encodeSolid/end) is
+//         tracked per tile so Bail tiles are written as one constant.
 //
 // Compile with -ffp-contract=off: every source-level f32/f16 operation is one
 // IEEE rounding, as in the oracle.
@@ -42,7 +50,6 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr uint32_t kMaxPending = 768;  // LDS command slots: one stream round emits <= 3*256
 
 // ---------------------------------------------------------------------------------
 // small helpers
@@ -65,6 +72,10 @@ __device__ __forceinline__ uint32_t WaveInclusiveScan(uint32_t v) {
     return v;
 }
 
+// Compiler-level ordering of LDS traffic inside one wave (the LDS itself executes a
+// wave's instructions in order); no instruction is emitted.
+__device__ __forceinline__ void WaveSync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
 __device__ __forceinline__ float Sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 __device__ __forceinline__ float Sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
@@ -75,8 +86,11 @@ __device__ __forceinline__ bool Straddles(float s00, float s01, float s10, float
 }
 
 __device__ __forceinline__ uint32_t LoadU32(const uint8_t *p) { return *reinterpret_cast<const uint32_t *>(p); }
-__device__ __forceinline__ float LoadF32(const uint8_t *p) { return *reinterpret_cast<const float *>(p); }
 __device__ __forceinline__ float2 LoadF2(const uint8_t *p) { return *reinterpret_cast<const float2 *>(p); }
+
+// Segments of an item as the kernels count them.
+__device__ __forceinline__ uint32_t FillSegs(uint32_t npt) { return npt; }                      // implicitly closed (:262)
+__device__ __forceinline__ uint32_t PolySegs(uint32_t npt) { return npt >= 2 ? npt - 1 : 0; }  // open (:369)
 
 // ---------------------------------------------------------------------------------
 // phase-1 votes (strip level)
@@ -167,9 +181,9 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_p
     return base + incl - v;
 }
 
-// Largest c in [0, n) with off[c] <= e (off ascending, off[0] == 0).
+// Largest c in [0, n) with off[c] <= e (off ascending, off[0] == 0, n >= 1).
 __device__ __forceinline__ uint32_t FindOwner(const uint32_t *off, uint32_t n, uint32_t e) {
-    uint32_t lo = 0, hi = n;  // invariant: off[lo] <= e, (hi == n or off[hi] > e)
+    uint32_t lo = 0, hi = n;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (off[mid] <= e) lo = mid; else hi = mid;
@@ -180,6 +194,39 @@ __device__ __forceinline__ uint32_t FindOwner(const uint32_t *off, uint32_t n, u
 }  // namespace
 
 // =====================================================================================
+// K0: scene index, once per scene
+// =====================================================================================
+
+__global__ void pm_index_kernel(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks,
+                                float4 *chunk_bbox) {
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= n_chunks) return;
+    const uint32_t item = FindOwner(chunk_base, n_items, ch);
+    const uint32_t items_ix = LoadU32(scene + 4);
+    const uint8_t *it = scene + items_ix + static_cast<size_t>(item) * kItemSize;
+    const uint32_t tag = LoadU32(it) & 0xffffu;
+    const uint32_t npt = LoadU32(it + 12);
+    const uint8_t *pts = scene + LoadU32(it + 16);
+    const uint32_t nseg = (tag == kItemFill) ? FillSegs(npt) : PolySegs(npt);
+    const uint32_t k0 = (ch - chunk_base[item]) * kChunkSegs;
+    const uint32_t k1 = min(k0 + kChunkSegs, nseg);
+    float xmin = 0.f, ymin = 0.f, xmax = 0.f, ymax = 0.f;
+    // points k0 .. k1 (the fill's closing segment wraps to point 0)
+    for (uint32_t k = k0; k <= k1; ++k) {
+        const uint32_t pi = (tag == kItemFill && k == npt) ? 0u : k;
+        const float2 p = LoadF2(pts + static_cast<size_t>(pi) * 8);
+        if (k == k0) {
+            xmin = xmax = p.x;
+            ymin = ymax = p.y;
+        } else {
+            xmin = fminf(xmin, p.x); ymin = fminf(ymin, p.y);
+            xmax = fmaxf(xmax, p.x); ymax = fmaxf(ymax, p.y);
+        }
+    }
+    chunk_bbox[ch] = make_float4(xmin, ymin, xmax, ymax);
+}
+
+// =====================================================================================
 // K1: binning, one workgroup per strip row
 // =====================================================================================
 
@@ -188,10 +235,14 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
     __shared__ uint32_t s_cidx[kThreads];   // candidate item index
     __shared__ uint32_t s_cmask[kThreads];  // candidate per-tile hit mask (16 bits)
     __shared__ uint32_t s_ctag[kThreads];
-    __shared__ uint32_t s_cpts[kThreads];   // points_ix (or item byte offset for lines)
-    __shared__ uint32_t s_cnpt[kThreads];   // n_points as stored
+    __shared__ uint32_t s_cpts[kThreads];   // points_ix (or byte offset of start/end for lines)
+    __shared__ uint32_t s_cnseg[kThreads];  // segments of the item
+    __shared__ uint32_t s_cnpt[kThreads];
     __shared__ float s_chw[kThreads];       // 0.5*width + 0.5 for polylines
-    __shared__ uint32_t s_coff[kThreads + 1];
+    __shared__ uint32_t s_cchunk[kThreads]; // first chunk-table entry of the item
+    __shared__ uint32_t s_choff[kThreads + 1];  // chunk-stream offsets
+    __shared__ uint32_t s_ccnt[kThreads];   // surviving segments per candidate
+    __shared__ uint32_t s_surv[kThreads];   // surviving chunks of one round: c << 24 | j
     __shared__ uint32_t s_hitmask;
     __shared__ uint32_t s_rec;
     __shared__ uint32_t s_qbase;
@@ -203,6 +254,9 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
     const int sx0 = static_cast<int>(strip * kGroupW);
     const int y0 = static_cast<int>(ty * kTileH);
     const int sy0 = y0 & ~static_cast<int>(kGroupH - 1);
+    const float fsx0 = static_cast<float>(sx0), fsx1 = static_cast<float>(sx0 + static_cast<int>(kGroupW));
+    const float fy0 = static_cast<float>(y0), fy1 = static_cast<float>(y0 + static_cast<int>(kTileH));
+    const float fsy0 = static_cast<float>(sy0), fsy1 = static_cast<float>(sy0 + static_cast<int>(kGroupH));
 
     if (blockIdx.x == 0 && tid == 0) {
         // The counters of the NEXT frame (the other parity) are idle now: reset them
@@ -250,15 +304,14 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
         }
         __syncthreads();
 
-        // ---- candidate headers + stream offsets ------------------------------------
-        uint32_t nseg = 0;
+        // ---- candidate headers + chunk-stream offsets ---------------------------------
+        uint32_t nch = 0;
         uint32_t tag = 0, rgba = 0, aux0 = 0, aux1 = 0;
         if (tid < ncand) {
             const uint32_t idx = s_cidx[tid];
             const uint8_t *item = scene + items_ix + static_cast<size_t>(idx) * kItemSize;
             tag = LoadU32(item) & 0xffffu;
-            nseg = 1;  // every candidate owns >= 1 stream element (keeps seg_off dense)
-            uint32_t pts = 0, npt = 0;
+            uint32_t pts = 0, npt = 0, nseg = 0;
             float hw = 0.0f;
             if (tag == kItemCircle) {
                 const uint2 bb = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(idx) * 8);
@@ -268,33 +321,66 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
                 rgba = LoadU32(item + 8);
                 aux0 = LoadU32(item + 12);  // width bits
                 pts = items_ix + idx * static_cast<uint32_t>(kItemSize) + 16;  // start,end live in the item
-                npt = 2;
+                nseg = 1;
+                nch = 1;  // never culled at strip level (PietRender.metal:223-247)
             } else if (tag == kItemFill) {
                 rgba = LoadU32(item + 8);
                 npt = LoadU32(item + 12);
                 pts = LoadU32(item + 16);
-                if (npt > 1) nseg = npt;
+                nseg = FillSegs(npt);
+                nch = (nseg + kChunkSegs - 1) / kChunkSegs;
             } else if (tag == kItemPoly) {
                 rgba = LoadU32(item + 4);
                 aux0 = LoadU32(item + 8);  // width bits
                 npt = LoadU32(item + 12);
                 pts = LoadU32(item + 16);
                 hw = 0.5f * __uint_as_float(aux0) + 0.5f;
-                if (npt > 2) nseg = npt - 1;
+                nseg = PolySegs(npt);
+                nch = (nseg + kChunkSegs - 1) / kChunkSegs;
             } else {
                 tag = 0;
             }
             s_ctag[tid] = tag;
             s_cpts[tid] = pts;
             s_cnpt[tid] = npt;
+            s_cnseg[tid] = nseg;
             s_chw[tid] = hw;
+            s_cchunk[tid] = P.chunk_base[idx];
+            s_ccnt[tid] = 0;
         }
-        uint32_t total_seg;
-        const uint32_t off = BlockExclusiveScan(nseg, s_part, &total_seg);
-        if (tid < ncand) s_coff[tid] = off;
+        uint32_t total_ch;
+        const uint32_t choff = BlockExclusiveScan(nch, s_part, &total_ch);
+        if (tid < ncand) s_choff[tid] = choff;
+        if (tid == 0) s_choff[ncand] = total_ch;
+        __syncthreads();
+
+        // chunk survival test for stream element `e` (lane-local)
+        auto chunk_survives = [&](uint32_t e, uint32_t *c_out, uint32_t *j_out) -> bool {
+            if (e >= total_ch) return false;
+            const uint32_t c = FindOwner(s_choff, ncand, e);
+            const uint32_t j = e - s_choff[c];
+            *c_out = c;
+            *j_out = j;
+            const uint32_t ctag = s_ctag[c];
+            if (ctag == kItemLine) return true;
+            const float4 bb = P.chunk_bbox[s_cchunk[c] + j];
+            if (ctag == kItemFill)  // necessary part of :264-265 for any segment of the chunk
+                return bb.w >= fy0 && bb.y < fy1 && bb.x < fsx1;
+            const float hw = s_chw[c];  // necessary part of :378-379
+            return bb.w > fsy0 - hw && bb.y < fsy1 + hw && bb.z > fsx0 - hw && bb.x < fsx1 + hw;
+        };
+
+        // ---- pass A: how many chunks survive (sizes the arena record exactly) -------------
+        uint32_t nsurv_chunks = 0;
+        for (uint32_t e0 = 0; e0 < total_ch; e0 += kThreads) {
+            uint32_t c, j;
+            const bool sv = chunk_survives(e0 + tid, &c, &j);
+            uint32_t cnt;
+            (void)BlockRank(sv, s_part, &cnt);
+            nsurv_chunks += cnt;
+        }
         if (tid == 0) {
-            s_coff[ncand] = total_seg;
-            const uint32_t size = kRecHdrDwords + kCandDwords * ncand + 4u * total_seg;
+            const uint32_t size = kRecHdrDwords + kCandDwords * ncand + 4u * kChunkSegs * nsurv_chunks;
             const uint32_t rec = atomicAdd(&P.ctr_cur->arena_top, size);
             if (rec + size > P.arena_cap || rec + size < rec) {
                 P.ctr_cur->overflow = 1;
@@ -302,14 +388,14 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
             } else {
                 s_rec = rec;
                 *link = rec;
-                P.arena[rec + 0] = 0;       // next
+                P.arena[rec + 0] = 0;  // next
                 P.arena[rec + 1] = ncand;
-                P.arena[rec + 2] = total_seg;
+                P.arena[rec + 2] = nsurv_chunks;
             }
         }
         __syncthreads();
         const uint32_t rec = s_rec;
-        if (rec == 0) break;  // arena exhausted (host re-renders with a larger arena)
+        if (rec == 0) break;  // arena exhausted (flagged; the host sizes the arena to make this impossible)
         link = &P.arena[rec];
         uint32_t *cand_rec = P.arena + rec + kRecHdrDwords;
         float4 *segs = reinterpret_cast<float4 *>(P.arena + rec + kRecHdrDwords + kCandDwords * ncand);
@@ -322,51 +408,65 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
             cr[5] = s_cidx[tid];
         }
 
-        // ---- flat segment stream: phase-1 votes, ordered compaction -------------------
+        // ---- pass B: expand surviving chunks, phase-1 votes, ordered compaction ----------
         uint32_t vbase = 0;
-        for (uint32_t e0 = 0; e0 < total_seg; e0 += kThreads) {
-            const uint32_t e = e0 + tid;
-            bool vote = false;
-            bool first = false;
-            uint32_t c = 0;
-            float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < total_seg) {
-                c = FindOwner(s_coff, ncand, e);
-                const uint32_t k = e - s_coff[c];
-                first = (k == 0);
-                const uint32_t ctag = s_ctag[c];
-                const uint32_t npt = s_cnpt[c];
-                const uint8_t *pts = scene + s_cpts[c];
-                if (ctag == kItemFill) {
-                    if (k < npt) {  // npt == 0 leaves the placeholder element voteless
-                        const uint32_t k1 = (k + 1 == npt) ? 0u : k + 1;
-                        const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
-                        const float2 b = LoadF2(pts + static_cast<size_t>(k1) * 8);
-                        seg = make_float4(a.x, a.y, b.x, b.y);
-                        vote = VoteFill(seg, y0, sx0);
+        for (uint32_t e0 = 0; e0 < total_ch; e0 += kThreads) {
+            uint32_t c = 0, j = 0;
+            const bool sv = chunk_survives(e0 + tid, &c, &j);
+            uint32_t ns;
+            const uint32_t sp = BlockRank(sv, s_part, &ns);
+            if (sv) s_surv[sp] = (c << 24) | j;
+            __syncthreads();
+            for (uint32_t f0 = 0; f0 < ns * kChunkSegs; f0 += kThreads) {
+                const uint32_t f = f0 + tid;
+                bool vote = false;
+                uint32_t vc = 0;
+                float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < ns * kChunkSegs) {
+                    const uint32_t pk = s_surv[f / kChunkSegs];
+                    vc = pk >> 24;
+                    const uint32_t k = (pk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
+                    if (k < s_cnseg[vc]) {
+                        const uint32_t ctag = s_ctag[vc];
+                        const uint8_t *pts = scene + s_cpts[vc];
+                        if (ctag == kItemFill) {
+                            const uint32_t k1 = (k + 1 == s_cnpt[vc]) ? 0u : k + 1;
+                            const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
+                            const float2 b = LoadF2(pts + static_cast<size_t>(k1) * 8);
+                            seg = make_float4(a.x, a.y, b.x, b.y);
+                            vote = VoteFill(seg, y0, sx0);
+                        } else if (ctag == kItemPoly) {
+                            const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
+                            const float2 b = LoadF2(pts + static_cast<size_t>(k + 1) * 8);
+                            seg = make_float4(a.x, a.y, b.x, b.y);
+                            const int y_test = sy0 + static_cast<int>(((k & 31u) >> 4) * kTileH);
+                            vote = VotePoly(seg, s_chw[vc], y_test, sx0, sy0);
+                        } else {  // line
+                            const float2 a = LoadF2(pts);
+                            const float2 b = LoadF2(pts + 8);
+                            seg = make_float4(a.x, a.y, b.x, b.y);
+                            vote = true;
+                        }
                     }
-                } else if (ctag == kItemPoly) {
-                    if (k + 1 < npt) {
-                        const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
-                        const float2 b = LoadF2(pts + static_cast<size_t>(k + 1) * 8);
-                        seg = make_float4(a.x, a.y, b.x, b.y);
-                        const int y_test = sy0 + static_cast<int>(((k & 31u) >> 4) * kTileH);
-                        vote = VotePoly(seg, s_chw[c], y_test, sx0, sy0);
-                    }
-                } else if (ctag == kItemLine) {
-                    const float2 a = LoadF2(pts);
-                    const float2 b = LoadF2(pts + 8);
-                    seg = make_float4(a.x, a.y, b.x, b.y);
-                    vote = true;  // lines have no strip-level cull (PietRender.metal:223-247)
                 }
+                uint32_t nvote;
+                const uint32_t pos = vbase + BlockRank(vote, s_part, &nvote);
+                if (vote) {
+                    segs[pos] = seg;
+                    atomicAdd(&s_ccnt[vc], 1u);
+                }
+                vbase += nvote;
             }
-            uint32_t nvote;
-            const uint32_t pos = vbase + BlockRank(vote, s_part, &nvote);
-            if (first) cand_rec[kCandDwords * c + 4] = pos;  // seg_off of candidate c
-            if (vote) segs[pos] = seg;
-            vbase += nvote;
+            __syncthreads();  // s_surv is rewritten by the next round
         }
-        if (tid == 0) P.arena[rec + 3] = vbase;  // number of segments that survived
+        // segment offsets of the candidates = exclusive scan of their surviving counts
+        {
+            const uint32_t v = (tid < ncand) ? s_ccnt[tid] : 0u;
+            uint32_t tot;
+            const uint32_t o = BlockExclusiveScan(v, s_part, &tot);
+            if (tid < ncand) cand_rec[kCandDwords * tid + 4] = o;
+            if (tid == 0) P.arena[rec + 3] = tot;
+        }
         __syncthreads();  // s_c* arrays are rewritten by the next batch
     }
 
@@ -374,7 +474,7 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
     __syncthreads();
     const uint32_t hitmask = s_hitmask;
     const uint32_t tiles_here = min(kStripTiles, P.tiles_x - strip * kStripTiles);
-    const uint32_t valid = (tiles_here >= 32u) ? 0xffffffffu : ((1u << tiles_here) - 1u);
+    const uint32_t valid = (1u << tiles_here) - 1u;
     const uint32_t qmask = hitmask & valid;
     if (tid == 0 && qmask) s_qbase = atomicAdd(&P.ctr_cur->queue_count, static_cast<uint32_t>(__popc(qmask)));
     __syncthreads();
@@ -408,33 +508,45 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
 }
 
 // =====================================================================================
-// K2: per-tile command build (LDS) + per-pixel interpreter
+// K2: per-tile command build (LDS) + per-pixel interpreter, one wave per tile
 // =====================================================================================
 
 namespace {
 
-struct PixelState {
-    _Float16 r, g, b;  // half3 rgb (PietRender.metal:470)
-    float df;          // :471
-    _Float16 sa;       // half signedArea (:472)
-};
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ _Float16 HMix(_Float16 x, _Float16 y, _Float16 a) { return x + (y - x) * a; }
+constexpr uint32_t kWaveCmds = 256;  // LDS command slots per wave: one 64-lane round emits <= 192
+constexpr uint32_t kWaveCands = 64;  // candidates handled per pass
+
+// Pixels of one lane: 4 horizontally adjacent pixels (x0 .. x0+3, same y).
+struct PixelState {
+    half2_t r01, r23, g01, g23, b01, b23;  // half3 rgb (PietRender.metal:470), packed
+    float df[4];                           // :471
+    _Float16 sa[4];                        // half signedArea (:472)
+};
 
 __device__ __forceinline__ _Float16 HalfFromBits(uint32_t b) {
     const uint16_t u = static_cast<uint16_t>(b);
     return __builtin_bit_cast(_Float16, u);
 }
 
-__device__ __forceinline__ void Blend(PixelState &st, uint32_t rg, uint32_t ba, _Float16 alpha) {
-    const _Float16 fa = HalfFromBits(ba >> 16) * alpha;  // fg.a * alpha
-    st.r = HMix(st.r, HalfFromBits(rg), fa);
-    st.g = HMix(st.g, HalfFromBits(rg >> 16), fa);
-    st.b = HMix(st.b, HalfFromBits(ba), fa);
+__device__ __forceinline__ half2_t Splat(_Float16 v) { half2_t r; r.x = v; r.y = v; return r; }
+
+// rgb = mix(rgb, fg.rgb, fg.a * alpha) per pixel (:505, :543, :549): x + (y - x) * a in half
+__device__ __forceinline__ void Blend4(PixelState &st, uint32_t rg, uint32_t ba, const _Float16 alpha[4]) {
+    const _Float16 fga = HalfFromBits(ba >> 16);
+    half2_t a01, a23;
+    a01.x = fga * alpha[0]; a01.y = fga * alpha[1];
+    a23.x = fga * alpha[2]; a23.y = fga * alpha[3];
+    const half2_t fr = Splat(HalfFromBits(rg)), fg = Splat(HalfFromBits(rg >> 16)), fb = Splat(HalfFromBits(ba));
+    st.r01 = st.r01 + (fr - st.r01) * a01; st.r23 = st.r23 + (fr - st.r23) * a23;
+    st.g01 = st.g01 + (fg - st.g01) * a01; st.g23 = st.g23 + (fg - st.g23) * a23;
+    st.b01 = st.b01 + (fb - st.b01) * a01; st.b23 = st.b23 + (fb - st.b23) * a23;
 }
 
 // renderKernel's command loop (PietRender.metal:474-560) over an LDS-resident list.
-__device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px, float py, PixelState &st) {
+// px0 = x of the lane's first pixel, py = its row.
+__device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0, float py, PixelState &st) {
     for (uint32_t i = 0; i < n; ++i) {
         const Cmd cmd = cmds[i];
         switch (cmd.tag) {
@@ -442,67 +554,99 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px,
                 const float x0 = static_cast<float>(cmd.body[1] & 0xffffu), y0 = static_cast<float>(cmd.body[1] >> 16);
                 const float x1 = static_cast<float>(cmd.body[2] & 0xffffu), y1 = static_cast<float>(cmd.body[2] >> 16);
                 const float cx = x0 + (x1 - x0) * 0.5f, cy = y0 + (y1 - y0) * 0.5f;
-                const float dx = px - cx, dy = py - cy;
-                const float r = sqrtf(dx * dx + dy * dy);
                 const float circle_r = fminf(cx - x0, cy - y0);
-                const _Float16 alpha = static_cast<_Float16>(Sat(circle_r - r));
-                const _Float16 zero = static_cast<_Float16>(0.0f);
-                st.r = HMix(st.r, zero, alpha);
-                st.g = HMix(st.g, zero, alpha);
-                st.b = HMix(st.b, zero, alpha);
+                const float dy = py - cy;
+                _Float16 alpha[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dx = (px0 + static_cast<float>(k)) - cx;
+                    const float r = sqrtf(dx * dx + dy * dy);
+                    alpha[k] = static_cast<_Float16>(Sat(circle_r - r));
+                }
+                const half2_t zero = Splat(static_cast<_Float16>(0.0f));
+                half2_t a01, a23;
+                a01.x = alpha[0]; a01.y = alpha[1]; a23.x = alpha[2]; a23.y = alpha[3];
+                st.r01 = st.r01 + (zero - st.r01) * a01; st.r23 = st.r23 + (zero - st.r23) * a23;
+                st.g01 = st.g01 + (zero - st.g01) * a01; st.g23 = st.g23 + (zero - st.g23) * a23;
+                st.b01 = st.b01 + (zero - st.b01) * a01; st.b23 = st.b23 + (zero - st.b23) * a23;
                 break;
             }
             case kCmdLine: {  // stroke(), :49-55
                 const float sx = __uint_as_float(cmd.body[1]), sy = __uint_as_float(cmd.body[2]);
                 const float ex = __uint_as_float(cmd.body[3]), ey = __uint_as_float(cmd.body[4]);
                 const float lx = ex - sx, ly = ey - sy;
-                const float dx = px - sx, dy = py - sy;
-                const float t = Sat((lx * dx + ly * dy) / (lx * lx + ly * ly));
-                const float fx = lx * t - dx, fy = ly * t - dy;
-                st.df = fminf(st.df, sqrtf(fx * fx + fy * fy));
+                const float den = lx * lx + ly * ly;
+                const float dy = py - sy;
+                const float lydy = ly * dy;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dx = (px0 + static_cast<float>(k)) - sx;
+                    const float t = Sat((lx * dx + lydy) / den);
+                    const float fx = lx * t - dx, fy = ly * t - dy;
+                    st.df[k] = fminf(st.df[k], sqrtf(fx * fx + fy * fy));
+                }
                 break;
             }
             case kCmdStroke: {  // :500-507, renderDf :58-60
                 const float half_width = __uint_as_float(cmd.body[0]);
-                const _Float16 alpha = static_cast<_Float16>(Sat(half_width + 0.5f - st.df));
-                Blend(st, cmd.body[2], cmd.body[3], alpha);
-                st.df = 1e9f;
+                _Float16 alpha[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    alpha[k] = static_cast<_Float16>(Sat(half_width + 0.5f - st.df[k]));
+                    st.df[k] = 1e9f;
+                }
+                Blend4(st, cmd.body[2], cmd.body[3], alpha);
                 break;
             }
             case kCmdFill: {  // :508-529
-                const float sx = __uint_as_float(cmd.body[1]) - px, sy = __uint_as_float(cmd.body[2]) - py;
-                const float ex = __uint_as_float(cmd.body[3]) - px, ey = __uint_as_float(cmd.body[4]) - py;
+                const float fsx = __uint_as_float(cmd.body[1]), fex = __uint_as_float(cmd.body[3]);
+                const float sy = __uint_as_float(cmd.body[2]) - py;
+                const float ey = __uint_as_float(cmd.body[4]) - py;
                 const float wx = Sat(sy), wy = Sat(ey);
-                if (wx != wy) {
+                if (wx != wy) {  // depends on y only: uniform over the lane's 4 pixels
                     const float tx = (wx - sy) / (ey - sy);
                     const float ty = (wy - sy) / (ey - sy);
-                    const float xsx = sx + (ex - sx) * tx;
-                    const float xsy = sx + (ex - sx) * ty;
-                    const float xmin = fminf(fminf(xsx, xsy), 1.0f) - 1e-6f;
-                    const float xmax = fmaxf(xsx, xsy);
-                    const float b = fminf(xmax, 1.0f);
-                    const float c = fmaxf(b, 0.0f);
-                    const float d = fmaxf(xmin, 0.0f);
-                    const float area = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-                    st.sa = st.sa + static_cast<_Float16>(area * (wx - wy));
+                    const float wd = wx - wy;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float px = px0 + static_cast<float>(k);
+                        const float sx = fsx - px, ex = fex - px;
+                        const float xsx = sx + (ex - sx) * tx;
+                        const float xsy = sx + (ex - sx) * ty;
+                        const float xmin = fminf(fminf(xsx, xsy), 1.0f) - 1e-6f;
+                        const float xmax = fmaxf(xsx, xsy);
+                        const float b = fminf(xmax, 1.0f);
+                        const float c = fmaxf(b, 0.0f);
+                        const float d = fmaxf(xmin, 0.0f);
+                        const float area = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
+                        st.sa[k] = st.sa[k] + static_cast<_Float16>(area * wd);
+                    }
                 }
                 break;
             }
             case kCmdFillEdge: {  // :530-534 (half + float => f32 add, one rounding)
                 const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
                 const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
-                st.sa = static_cast<_Float16>(static_cast<float>(st.sa) + v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) st.sa[k] = static_cast<_Float16>(static_cast<float>(st.sa[k]) + v);
                 break;
             }
             case kCmdDrawFill: {  // :535-545
-                _Float16 alpha = st.sa + static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
-                alpha = static_cast<_Float16>(fminf(fabsf(static_cast<float>(alpha)), 1.0f));
-                Blend(st, cmd.body[2], cmd.body[3], alpha);
-                st.sa = static_cast<_Float16>(0.0f);
+                const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
+                _Float16 alpha[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const _Float16 a = st.sa[k] + bd;
+                    alpha[k] = static_cast<_Float16>(fminf(fabsf(static_cast<float>(a)), 1.0f));
+                    st.sa[k] = static_cast<_Float16>(0.0f);
+                }
+                Blend4(st, cmd.body[2], cmd.body[3], alpha);
                 break;
             }
             case kCmdSolid: {  // :546-551
-                Blend(st, cmd.body[1], cmd.body[2], static_cast<_Float16>(1.0f));
+                const _Float16 one = static_cast<_Float16>(1.0f);
+                const _Float16 alpha[4] = {one, one, one, one};
+                Blend4(st, cmd.body[1], cmd.body[2], alpha);
                 break;
             }
             default:
@@ -511,33 +655,33 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px,
     }
 }
 
-struct Emit {
-    uint32_t n;      // commands of this stream element (0..2)
-    Cmd c0, c1;
+struct WaveLds {
+    Cmd cmds[kWaveCmds];
+    uint32_t htag[kWaveCands];
+    uint32_t hrgba[kWaveCands];
+    uint32_t haux0[kWaveCands];
+    uint32_t haux1[kWaveCands];
+    uint32_t hseg[kWaveCands];
+    uint32_t hcnt[kWaveCands];
+    uint32_t hoff[kWaveCands + 1];
+    int backdrop[kWaveCands];
+    uint32_t any[kWaveCands];
 };
 
 }  // namespace
 
 template <bool kCapture>
 __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
-    __shared__ Cmd s_cmds[kMaxPending];
-    __shared__ uint32_t s_part[kWaves * 4];
-    __shared__ uint32_t s_htag[kThreads];   // hit candidates of this tile
-    __shared__ uint32_t s_hrgba[kThreads];
-    __shared__ uint32_t s_haux0[kThreads];
-    __shared__ uint32_t s_haux1[kThreads];
-    __shared__ uint32_t s_hseg[kThreads];   // first surviving segment of the candidate
-    __shared__ uint32_t s_hcnt[kThreads];   // stream elements of the candidate
-    __shared__ uint32_t s_hoff[kThreads + 1];
-    __shared__ int s_backdrop[kThreads];
-    __shared__ uint32_t s_any[kThreads];
-    __shared__ uint32_t s_solid_rgba;
+    __shared__ WaveLds s_lds[kWaves];
+    WaveLds &L = s_lds[threadIdx.x >> 6];
 
-    const uint32_t tid = threadIdx.x;
-    const uint32_t wave = tid >> 6;
+    const uint32_t lane = LaneId();
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
+    const uint32_t wave_global = blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * kWaves;
     const uint32_t qn = P.ctr_cur->queue_count;
 
-    for (uint32_t q = blockIdx.x; q < qn; q += gridDim.x) {
+    for (uint32_t q = wave_global; q < qn; q += n_waves) {
         const uint32_t tile = P.queue[q];
         const uint32_t tx = tile % P.tiles_x;
         const uint32_t ty_rel = tile / P.tiles_x;
@@ -550,16 +694,21 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
         const uint32_t tbit = tx & (kStripTiles - 1);
         const uint32_t sr = ty_rel * P.strips_x + tx / kStripTiles;
 
-        const uint32_t pxi = static_cast<uint32_t>(x0) + (tid & 15u);
-        const uint32_t pyi = static_cast<uint32_t>(y0) + (tid >> 4);
-        const float px = static_cast<float>(pxi), py = static_cast<float>(pyi);
+        // lane -> 4 pixels: x = x0 + 4*(lane&3) + k, y = y0 + lane/4
+        const uint32_t pxi = static_cast<uint32_t>(x0) + (lane & 3u) * 4u;
+        const uint32_t pyi = static_cast<uint32_t>(y0) + (lane >> 2);
+        const float px0 = static_cast<float>(pxi), py = static_cast<float>(pyi);
         PixelState st;
-        st.r = st.g = st.b = static_cast<_Float16>(1.0f);
-        st.df = 1e9f;
-        st.sa = static_cast<_Float16>(0.0f);
+        const half2_t one2 = Splat(static_cast<_Float16>(1.0f));
+        st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = one2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            st.df[k] = 1e9f;
+            st.sa[k] = static_cast<_Float16>(0.0f);
+        }
 
         uint32_t solid_color = 0xffffffffu;  // TileEncoder::solidColor (:74)
-        uint32_t n_pending = 0;              // commands waiting in s_cmds
+        uint32_t n_pending = 0;              // commands waiting in L.cmds
         uint32_t list_len = 0;               // logical list length since tileBegin (capture)
 
         uint32_t rec = P.striprow_head[sr];
@@ -570,268 +719,254 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
             const uint32_t *cand_rec = P.arena + rec + kRecHdrDwords;
             const float4 *segs = reinterpret_cast<const float4 *>(P.arena + rec + kRecHdrDwords + kCandDwords * ncand);
 
-            // ---- candidates that hit this tile, in paint order -------------------------
-            bool hit = false;
-            uint32_t w0 = 0, rgba = 0, aux0 = 0, aux1 = 0, seg_off = 0, seg_end = 0;
-            if (tid < ncand) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(cand_rec + kCandDwords * tid);
-                w0 = a.x; rgba = a.y; aux0 = a.z; aux1 = a.w;
-                seg_off = cand_rec[kCandDwords * tid + 4];
-                seg_end = (tid + 1 < ncand) ? cand_rec[kCandDwords * (tid + 1) + 4] : nsurv;
-                hit = ((w0 >> (16 + tbit)) & 1u) != 0;
-                const uint32_t tg = w0 & 0xffffu;
-                // circles own one pseudo element; the others as many as survived phase 1
-                if (hit && tg != kItemCircle && seg_end == seg_off) hit = false;
-                if (tg == 0) hit = false;
-            }
-            uint32_t nh;
-            const uint32_t hpos = BlockRank(hit, s_part, &nh);
-            uint32_t cnt = 0;
-            if (hit) {
-                cnt = ((w0 & 0xffffu) == kItemCircle) ? 1u : (seg_end - seg_off);
-                s_htag[hpos] = w0 & 0xffffu;
-                s_hrgba[hpos] = rgba;
-                s_haux0[hpos] = aux0;
-                s_haux1[hpos] = aux1;
-                s_hseg[hpos] = seg_off;
-                s_hcnt[hpos] = cnt;
-                s_backdrop[hpos] = 0;
-                s_any[hpos] = 0;
-            }
-            __syncthreads();
-            // stream offsets over the hit candidates
-            uint32_t stream_len;
-            {
-                const uint32_t v = (tid < nh) ? s_hcnt[tid] : 0u;
-                const uint32_t o = BlockExclusiveScan(v, s_part, &stream_len);
-                if (tid < nh) s_hoff[tid] = o;
-                if (tid == 0) s_hoff[nh] = stream_len;
-            }
-            __syncthreads();
+            for (uint32_t cb = 0; cb < ncand; cb += kWaveCands) {
+                // ---- candidates that hit this tile, in paint order ---------------------------
+                const uint32_t ci = cb + lane;
+                bool hit = false;
+                uint32_t w0 = 0, rgba = 0, aux0 = 0, aux1 = 0, seg_off = 0, cnt = 0;
+                if (ci < ncand) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(cand_rec + kCandDwords * ci);
+                    w0 = a.x; rgba = a.y; aux0 = a.z; aux1 = a.w;
+                    hit = ((w0 >> (16 + tbit)) & 1u) != 0 && (w0 & 0xffffu) != 0;
+                    if (hit) {
+                        seg_off = cand_rec[kCandDwords * ci + 4];
+                        const uint32_t seg_end = (ci + 1 < ncand) ? cand_rec[kCandDwords * (ci + 1) + 4] : nsurv;
+                        // circles own one pseudo element; the others as many as survived phase 1
+                        cnt = ((w0 & 0xffffu) == kItemCircle) ? 1u : (seg_end - seg_off);
+                        hit = cnt != 0;
+                    }
+                }
+                const uint64_t hm = __ballot(hit);
+                const uint32_t nh = static_cast<uint32_t>(__popcll(hm));
+                if (nh == 0) continue;
+                WaveSync();
+                if (hit) {
+                    const uint32_t hp = RankBelow(hm);
+                    L.htag[hp] = w0 & 0xffffu;
+                    L.hrgba[hp] = rgba;
+                    L.haux0[hp] = aux0;
+                    L.haux1[hp] = aux1;
+                    L.hseg[hp] = seg_off;
+                    L.hcnt[hp] = cnt;
+                    L.backdrop[hp] = 0;
+                    L.any[hp] = 0;
+                }
+                WaveSync();
+                uint32_t stream_len;
+                {
+                    const uint32_t v = (lane < nh) ? L.hcnt[lane] : 0u;
+                    const uint32_t incl = WaveInclusiveScan(v);
+                    if (lane < nh) L.hoff[lane] = incl - v;
+                    stream_len = __shfl(incl, 63, 64);
+                    if (lane == 0) L.hoff[nh] = stream_len;
+                }
+                WaveSync();
 
-            // ---- stream rounds: phase-2 tests -> ordered commands ------------------------
-            for (uint32_t e0 = 0; e0 < stream_len; e0 += kThreads) {
-                const uint32_t e = e0 + tid;
-                Emit em;
-                em.n = 0;
-                bool is_last = false;
-                bool draws = false;  // any of this lane's commands clears solidColor
-                uint32_t c = 0, ctag = 0;
-                if (e < stream_len) {
-                    c = FindOwner(s_hoff, nh, e);
-                    const uint32_t k = e - s_hoff[c];
-                    is_last = (k + 1 == s_hcnt[c]);
-                    ctag = s_htag[c];
-                    if (ctag == kItemCircle) {  // :218-222
-                        em.n = 1;
-                        em.c0.tag = kCmdCircle;
-                        em.c0.body[0] = 0;
-                        em.c0.body[1] = s_haux0[c];
-                        em.c0.body[2] = s_haux1[c];
-                        em.c0.body[3] = 0;
-                        em.c0.body[4] = 0;
-                        draws = true;
-                    } else {
-                        const float4 s = segs[s_hseg[c] + k];
-                        const float a = s.w - s.y;
-                        const float b = s.x - s.z;
-                        const float cc = -(a * s.x + b * s.y);
-                        if (ctag == kItemFill) {  // :302-357
-                            const float xmin = fminf(s.x, s.z), ymin = fminf(s.y, s.w);
-                            const float xmax = fmaxf(s.x, s.z), ymax = fmaxf(s.y, s.w);
-                            const float left = a * fx0;
-                            const float right = a * fx1;
-                            const float ytop = fmaxf(fy0, ymin);
-                            const float ybot = fminf(fy1, ymax);
-                            const float top = b * ytop;
-                            const float bot = b * ybot;
-                            const float s_top_left = Sgn(left + fy0 * b + cc);
-                            const float s00 = Sgn(top + left + cc);
-                            const float s01 = Sgn(top + right + cc);
-                            const float s10 = Sgn(bot + left + cc);
-                            const float s11 = Sgn(bot + right + cc);
-                            if (s_top_left == Sgn(a) && ymin <= fy0) {
-                                const int d = -static_cast<int>(s00);  // backdrop -= s00
-                                if (d != 0) atomicAdd(&s_backdrop[c], d);
-                            }
-                            const bool straddle = Straddles(s00, s01, s10, s11);
-                            if (xmin < fx0 && xmax > fx0) {
-                                const float tt = (s.x - fx0) / b;
-                                const float y_edge = s.y + (s.w - s.y) * tt;  // mix(start.y, end.y, tt)
-                                if (y_edge >= fy0 && y_edge < fy1) {
-                                    em.n = 2;
-                                    em.c0.tag = kCmdFillEdge;
-                                    em.c0.body[0] = static_cast<uint32_t>(static_cast<int>(s00));
-                                    em.c0.body[1] = __float_as_uint(y_edge);
-                                    em.c0.body[2] = 0; em.c0.body[3] = 0; em.c0.body[4] = 0;
-                                    em.c1.tag = kCmdFill;
-                                    em.c1.body[0] = 0;
-                                    if (b > 0.0f) {
-                                        em.c1.body[1] = __float_as_uint(s.x); em.c1.body[2] = __float_as_uint(s.y);
-                                        em.c1.body[3] = __float_as_uint(fx0); em.c1.body[4] = __float_as_uint(y_edge);
-                                    } else {
-                                        em.c1.body[1] = __float_as_uint(fx0); em.c1.body[2] = __float_as_uint(y_edge);
-                                        em.c1.body[3] = __float_as_uint(s.z); em.c1.body[4] = __float_as_uint(s.w);
-                                    }
-                                } else if (straddle) {
-                                    em.n = 1;
-                                }
-                            } else if (straddle && xmin < fx1 && xmax > fx0) {
-                                em.n = 1;
-                            }
-                            if (em.n == 1) {
-                                em.c0.tag = kCmdFill;
-                                em.c0.body[0] = 0;
-                                em.c0.body[1] = __float_as_uint(s.x); em.c0.body[2] = __float_as_uint(s.y);
-                                em.c0.body[3] = __float_as_uint(s.z); em.c0.body[4] = __float_as_uint(s.w);
-                            }
-                            if (em.n) atomicOr(&s_any[c], 1u);
+                // ---- stream rounds: phase-2 tests -> ordered commands --------------------------
+                for (uint32_t e0 = 0; e0 < stream_len; e0 += 64) {
+                    const uint32_t e = e0 + lane;
+                    uint32_t n_em = 0;   // commands of this stream element (0..2)
+                    Cmd c0, c1;
+                    c0.tag = 0; c1.tag = 0;
+                    bool is_last = false;
+                    bool draws = false;  // any of this lane's commands clears solidColor
+                    uint32_t c = 0, ctag = 0;
+                    if (e < stream_len) {
+                        c = FindOwner(L.hoff, nh, e);
+                        const uint32_t k = e - L.hoff[c];
+                        is_last = (k + 1 == L.hcnt[c]);
+                        ctag = L.htag[c];
+                        if (ctag == kItemCircle) {  // :218-222
+                            n_em = 1;
+                            c0.tag = kCmdCircle;
+                            c0.body[0] = 0;
+                            c0.body[1] = L.haux0[c];
+                            c0.body[2] = L.haux1[c];
+                            c0.body[3] = 0;
+                            c0.body[4] = 0;
+                            draws = true;
                         } else {
-                            // Line (:223-247) and Poly phase 2 (:406-440) share the inflated-box test
-                            const float width = __uint_as_float(s_haux0[c]);
-                            const float hw = 0.5f * width + 0.5f;
-                            bool pass = true;
-                            if (ctag == kItemPoly) {
+                            const float4 s = segs[L.hseg[c] + k];
+                            const float a = s.w - s.y;
+                            const float b = s.x - s.z;
+                            const float cc = -(a * s.x + b * s.y);
+                            if (ctag == kItemFill) {  // :302-357
                                 const float xmin = fminf(s.x, s.z), ymin = fminf(s.y, s.w);
                                 const float xmax = fmaxf(s.x, s.z), ymax = fmaxf(s.y, s.w);
-                                pass = ymax > fy0 - hw && ymin < fy1 + hw && xmax > fx0 - hw && xmin < fx1 + hw;
-                            }
-                            if (pass) {
-                                const float left = a * (fx0 - hw);
-                                const float right = a * (fx1 + hw);
-                                const float top = b * (fy0 - hw);
-                                const float bot = b * (fy1 + hw);
+                                const float left = a * fx0;
+                                const float right = a * fx1;
+                                const float ytop = fmaxf(fy0, ymin);
+                                const float ybot = fminf(fy1, ymax);
+                                const float top = b * ytop;
+                                const float bot = b * ybot;
+                                const float s_top_left = Sgn(left + fy0 * b + cc);
                                 const float s00 = Sgn(top + left + cc);
                                 const float s01 = Sgn(top + right + cc);
                                 const float s10 = Sgn(bot + left + cc);
                                 const float s11 = Sgn(bot + right + cc);
-                                pass = Straddles(s00, s01, s10, s11);
+                                if (s_top_left == Sgn(a) && ymin <= fy0) {
+                                    const int d = -static_cast<int>(s00);  // backdrop -= s00
+                                    if (d != 0) atomicAdd(&L.backdrop[c], d);
+                                }
+                                const bool straddle = Straddles(s00, s01, s10, s11);
+                                if (xmin < fx0 && xmax > fx0) {
+                                    const float tt = (s.x - fx0) / b;
+                                    const float y_edge = s.y + (s.w - s.y) * tt;  // mix(start.y, end.y, tt)
+                                    if (y_edge >= fy0 && y_edge < fy1) {
+                                        n_em = 2;
+                                        c0.tag = kCmdFillEdge;
+                                        c0.body[0] = static_cast<uint32_t>(static_cast<int>(s00));
+                                        c0.body[1] = __float_as_uint(y_edge);
+                                        c0.body[2] = 0; c0.body[3] = 0; c0.body[4] = 0;
+                                        c1.tag = kCmdFill;
+                                        c1.body[0] = 0;
+                                        if (b > 0.0f) {
+                                            c1.body[1] = __float_as_uint(s.x); c1.body[2] = __float_as_uint(s.y);
+                                            c1.body[3] = __float_as_uint(fx0); c1.body[4] = __float_as_uint(y_edge);
+                                        } else {
+                                            c1.body[1] = __float_as_uint(fx0); c1.body[2] = __float_as_uint(y_edge);
+                                            c1.body[3] = __float_as_uint(s.z); c1.body[4] = __float_as_uint(s.w);
+                                        }
+                                    } else if (straddle) {
+                                        n_em = 1;
+                                    }
+                                } else if (straddle && xmin < fx1 && xmax > fx0) {
+                                    n_em = 1;
+                                }
+                                if (n_em == 1) {
+                                    c0.tag = kCmdFill;
+                                    c0.body[0] = 0;
+                                    c0.body[1] = __float_as_uint(s.x); c0.body[2] = __float_as_uint(s.y);
+                                    c0.body[3] = __float_as_uint(s.z); c0.body[4] = __float_as_uint(s.w);
+                                }
+                                if (n_em) atomicOr(&L.any[c], 1u);
+                            } else {
+                                // Line (:223-247) and Poly phase 2 (:406-440) share the inflated-box test
+                                const float width = __uint_as_float(L.haux0[c]);
+                                const float hw = 0.5f * width + 0.5f;
+                                bool pass = true;
+                                if (ctag == kItemPoly) {
+                                    const float xmin = fminf(s.x, s.z), ymin = fminf(s.y, s.w);
+                                    const float xmax = fmaxf(s.x, s.z), ymax = fmaxf(s.y, s.w);
+                                    pass = ymax > fy0 - hw && ymin < fy1 + hw && xmax > fx0 - hw && xmin < fx1 + hw;
+                                }
+                                if (pass) {
+                                    const float left = a * (fx0 - hw);
+                                    const float right = a * (fx1 + hw);
+                                    const float top = b * (fy0 - hw);
+                                    const float bot = b * (fy1 + hw);
+                                    const float s00 = Sgn(top + left + cc);
+                                    const float s01 = Sgn(top + right + cc);
+                                    const float s10 = Sgn(bot + left + cc);
+                                    const float s11 = Sgn(bot + right + cc);
+                                    pass = Straddles(s00, s01, s10, s11);
+                                }
+                                if (pass) {
+                                    n_em = 1;
+                                    c0.tag = kCmdLine;
+                                    c0.body[0] = 0;
+                                    c0.body[1] = __float_as_uint(s.x); c0.body[2] = __float_as_uint(s.y);
+                                    c0.body[3] = __float_as_uint(s.z); c0.body[4] = __float_as_uint(s.w);
+                                    draws = true;
+                                    atomicOr(&L.any[c], 1u);
+                                }
                             }
-                            if (pass) {
-                                em.n = 1;
-                                em.c0.tag = kCmdLine;
-                                em.c0.body[0] = 0;
-                                em.c0.body[1] = __float_as_uint(s.x); em.c0.body[2] = __float_as_uint(s.y);
-                                em.c0.body[3] = __float_as_uint(s.z); em.c0.body[4] = __float_as_uint(s.w);
+                        }
+                    }
+                    WaveSync();  // per-candidate accumulators complete for elements <= this round
+
+                    // ---- per-item closing command (DrawFill / Solid / Stroke) --------------------
+                    bool has_fin = false;
+                    bool opaque_solid = false;
+                    Cmd fin;
+                    fin.tag = 0;
+                    fin.body[0] = fin.body[1] = fin.body[2] = fin.body[3] = fin.body[4] = 0;
+                    if (is_last) {
+                        const uint32_t frgba = L.hrgba[c];
+                        const uint32_t rg = P.lut_srgb2lin[frgba & 0xffu] | (P.lut_srgb2lin[(frgba >> 8) & 0xffu] << 16);
+                        const uint32_t ba = P.lut_srgb2lin[(frgba >> 16) & 0xffu] | (P.lut_unorm2h[frgba >> 24] << 16);
+                        if (ctag == kItemFill) {  // :359-363
+                            const int backdrop = L.backdrop[c];
+                            if (L.any[c]) {
+                                has_fin = true;
+                                fin.tag = kCmdDrawFill;
+                                fin.body[0] = static_cast<uint32_t>(backdrop);
+                                fin.body[1] = frgba; fin.body[2] = rg; fin.body[3] = ba; fin.body[4] = 0;
                                 draws = true;
-                                atomicOr(&s_any[c], 1u);
+                            } else if (backdrop != 0) {
+                                has_fin = true;
+                                fin.tag = kCmdSolid;
+                                fin.body[0] = frgba; fin.body[1] = rg; fin.body[2] = ba; fin.body[3] = 0; fin.body[4] = 0;
+                                opaque_solid = (frgba & 0xff000000u) == 0xff000000u;  // :132
+                            }
+                        } else if (ctag == kItemPoly || ctag == kItemLine) {  // :441-443, :243
+                            if (L.any[c]) {
+                                has_fin = true;
+                                fin.tag = kCmdStroke;
+                                fin.body[0] = __float_as_uint(0.5f * __uint_as_float(L.haux0[c]));
+                                fin.body[1] = frgba; fin.body[2] = rg; fin.body[3] = ba; fin.body[4] = 0;
+                                draws = true;
                             }
                         }
                     }
-                }
-                __syncthreads();  // per-candidate accumulators complete for elements <= this round
+                    const uint32_t lane_total = n_em + (has_fin ? 1u : 0u);  // 0..3
 
-                // ---- per-item closing command (DrawFill / Solid / Stroke) -----------------------
-                bool has_fin = false;
-                bool opaque_solid = false;
-                Cmd fin;
-                fin.tag = 0;
-                if (is_last) {
-                    const uint32_t rgba = s_hrgba[c];
-                    const uint32_t rg = P.lut_srgb2lin[rgba & 0xffu] | (P.lut_srgb2lin[(rgba >> 8) & 0xffu] << 16);
-                    const uint32_t ba = P.lut_srgb2lin[(rgba >> 16) & 0xffu] | (P.lut_unorm2h[rgba >> 24] << 16);
-                    if (ctag == kItemFill) {  // :359-363
-                        const int backdrop = s_backdrop[c];
-                        if (s_any[c]) {
-                            has_fin = true;
-                            fin.tag = kCmdDrawFill;
-                            fin.body[0] = static_cast<uint32_t>(backdrop);
-                            fin.body[1] = rgba; fin.body[2] = rg; fin.body[3] = ba; fin.body[4] = 0;
-                            draws = true;
-                        } else if (backdrop != 0) {
-                            has_fin = true;
-                            fin.tag = kCmdSolid;
-                            fin.body[0] = rgba; fin.body[1] = rg; fin.body[2] = ba; fin.body[3] = 0; fin.body[4] = 0;
-                            opaque_solid = (rgba & 0xff000000u) == 0xff000000u;  // :132
-                        }
-                    } else if (ctag == kItemPoly || ctag == kItemLine) {  // :441-443, :243
-                        if (s_any[c]) {
-                            has_fin = true;
-                            fin.tag = kCmdStroke;
-                            fin.body[0] = __float_as_uint(0.5f * __uint_as_float(s_haux0[c]));
-                            fin.body[1] = rgba; fin.body[2] = rg; fin.body[3] = ba; fin.body[4] = 0;
-                            draws = true;
-                        }
-                    }
-                }
-                const uint32_t lane_total = em.n + (has_fin ? 1u : 0u);
+                    // ---- wave-wide slots (ballots + popcounts, no scan network) ---------------------
+                    const uint64_t m0 = __ballot((lane_total & 1u) != 0);
+                    const uint64_t m1 = __ballot((lane_total & 2u) != 0);
+                    const uint32_t pos = static_cast<uint32_t>(__popcll(m0 & lanes_below)) + 2u * static_cast<uint32_t>(__popcll(m1 & lanes_below));
+                    const uint32_t round_total = static_cast<uint32_t>(__popcll(m0)) + 2u * static_cast<uint32_t>(__popcll(m1));
+                    if (round_total == 0) continue;  // uniform
+                    const uint64_t ms = __ballot(opaque_solid);
+                    const uint64_t md = __ballot(draws);
+                    int last_solid = -1, last_draw = -1;
+                    if (ms) last_solid = __shfl(static_cast<int>(pos + n_em), 63 - __builtin_clzll(ms), 64);
+                    if (md) last_draw = __shfl(static_cast<int>(pos + lane_total) - 1, 63 - __builtin_clzll(md), 64);
 
-                // ---- block-wide slots ------------------------------------------------------------
-                const uint32_t incl = WaveInclusiveScan(lane_total);
-                const uint32_t local = incl - lane_total;
-                // position (within the wave) of the last opaque Solid / last solid-clearing command
-                int my_solid = opaque_solid ? static_cast<int>(local + em.n) : -1;
-                int my_draw = draws ? static_cast<int>(local + lane_total - 1) : -1;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) {
-                    my_solid = max(my_solid, __shfl_xor(my_solid, d, 64));
-                    my_draw = max(my_draw, __shfl_xor(my_draw, d, 64));
-                }
-                if (LaneId() == 63) {
-                    s_part[wave * 4 + 0] = incl;
-                    s_part[wave * 4 + 1] = static_cast<uint32_t>(my_solid);
-                    s_part[wave * 4 + 2] = static_cast<uint32_t>(my_draw);
-                }
-                __syncthreads();
-                uint32_t wbase = 0, round_total = 0;
-                int last_solid = -1, last_draw = -1;
-#pragma unroll
-                for (int w = 0; w < kWaves; ++w) {
-                    const uint32_t tot = s_part[w * 4 + 0];
-                    const int so = static_cast<int>(s_part[w * 4 + 1]);
-                    const int dr = static_cast<int>(s_part[w * 4 + 2]);
-                    if (so >= 0) last_solid = static_cast<int>(round_total) + so;
-                    if (dr >= 0) last_draw = static_cast<int>(round_total) + dr;
-                    if (w < static_cast<int>(wave)) wbase += tot;
-                    round_total += tot;
-                }
-                const uint32_t pos = wbase + local;  // slot of this lane's first command in the round
-
-                uint32_t base;       // s_cmds slot of round position 0 (may be "negative")
-                uint32_t first_kept; // round positions below this are dropped
-                if (last_solid >= 0) {
-                    // TileEncoder::encodeSolid with an opaque colour (:132-135): the list restarts
-                    // at tileBegin, so everything before it -- including pixels already blended by
-                    // an earlier flush -- is forgotten.
-                    first_kept = static_cast<uint32_t>(last_solid);
-                    n_pending = 0;
-                    list_len = 0;
-                    st.r = st.g = st.b = static_cast<_Float16>(1.0f);
-                    base = 0u - first_kept;
-                } else {
-                    first_kept = 0;
-                    if (n_pending + round_total > kMaxPending) {
-                        Interpret(s_cmds, n_pending, px, py, st);
+                    uint32_t base;        // L.cmds slot of round position 0 (may be "negative")
+                    uint32_t first_kept;  // round positions below this are dropped
+                    if (last_solid >= 0) {
+                        // TileEncoder::encodeSolid with an opaque colour (:132-135): the list restarts
+                        // at tileBegin, so everything before it -- including pixels already blended by
+                        // an earlier flush -- is forgotten.
+                        first_kept = static_cast<uint32_t>(last_solid);
                         n_pending = 0;
-                        __syncthreads();  // every pixel done with s_cmds before it is overwritten
-                    }
-                    base = n_pending;
-                }
-                {
-                    uint32_t p = pos;
-                    if (em.n >= 1) {
-                        if (p >= first_kept) {
-                            s_cmds[base + p] = em.c0;
-                            if (kCapture) {
-                                const uint32_t li = list_len + p - first_kept;
-                                if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = em.c0;
-                            }
+                        list_len = 0;
+                        st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = one2;
+                        base = 0u - first_kept;
+                    } else {
+                        first_kept = 0;
+                        if (n_pending + round_total > kWaveCmds) {
+                            Interpret(L.cmds, n_pending, px0, py, st);
+                            n_pending = 0;
+                            WaveSync();
                         }
-                        ++p;
+                        base = n_pending;
                     }
-                    if (em.n == 2) {
-                        if (p >= first_kept) {
-                            s_cmds[base + p] = em.c1;
-                            if (kCapture) {
-                                const uint32_t li = list_len + p - first_kept;
-                                if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = em.c1;
+                    {
+                        uint32_t p = pos;
+                        if (n_em >= 1) {
+                            if (p >= first_kept) {
+                                L.cmds[base + p] = c0;
+                                if (kCapture) {
+                                    const uint32_t li = list_len + p - first_kept;
+                                    if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = c0;
+                                }
                             }
+                            ++p;
                         }
-                        ++p;
-                    }
-                    if (has_fin) {
-                        if (p >= first_kept) {
-                            s_cmds[base + p] = fin;
+                        if (n_em == 2) {
+                            if (p >= first_kept) {
+                                L.cmds[base + p] = c1;
+                                if (kCapture) {
+                                    const uint32_t li = list_len + p - first_kept;
+                                    if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = c1;
+                                }
+                            }
+                            ++p;
+                        }
+                        if (has_fin && p >= first_kept) {
+                            L.cmds[base + p] = fin;
                             if (kCapture) {
                                 const uint32_t li = list_len + p - first_kept;
                                 if (li < P.dbg_max) {
@@ -843,61 +978,71 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                                 }
                             }
                         }
-                        if (opaque_solid && static_cast<int>(p) == last_solid) s_solid_rgba = fin.body[0];
                     }
+                    n_pending = base + round_total;
+                    list_len += round_total - first_kept;
+                    if (last_solid >= 0) solid_color = __shfl(fin.body[0], 63 - __builtin_clzll(ms), 64);
+                    if (last_draw > last_solid) solid_color = 0;  // encodeCircle/Line/Stroke/DrawFill (:81,:90,:99,:124)
+                    WaveSync();
                 }
-                n_pending = base + round_total;
-                list_len += round_total - first_kept;
-                __syncthreads();
-                if (last_solid >= 0) solid_color = s_solid_rgba;
-                if (last_draw > last_solid) solid_color = 0;  // encodeCircle/Line/Stroke/DrawFill (:81,:90,:99,:124)
             }
             rec = next;
-            __syncthreads();  // s_h* arrays are rebuilt for the next record
         }
 
         // ---- TileEncoder::end() (:144-151) + composite (:34-44) ------------------------------
-        uint32_t out;
+        uint4 out;
         if (solid_color != 0) {
-            out = solid_color;  // Bail: the tile is one opaque colour, bytes as stored
+            out = make_uint4(solid_color, solid_color, solid_color, solid_color);  // Bail: bytes as stored
         } else {
-            Interpret(s_cmds, n_pending, px, py, st);
+            Interpret(L.cmds, n_pending, px0, py, st);
             // linear -> sRGB + unorm8 (:563-565) through the pinned table
-            const uint32_t r8 = P.lut_lin2srgb[__builtin_bit_cast(uint16_t, st.r)];
-            const uint32_t g8 = P.lut_lin2srgb[__builtin_bit_cast(uint16_t, st.g)];
-            const uint32_t b8 = P.lut_lin2srgb[__builtin_bit_cast(uint16_t, st.b)];
-            out = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+            const uint8_t *lut = P.lut_lin2srgb;
+            auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {
+                return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, r)]) |
+                       (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
+                       (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, b)]) << 16) | 0xff000000u;
+            };
+            out.x = enc(st.r01.x, st.g01.x, st.b01.x);
+            out.y = enc(st.r01.y, st.g01.y, st.b01.y);
+            out.z = enc(st.r23.x, st.g23.x, st.b23.x);
+            out.w = enc(st.r23.y, st.g23.y, st.b23.y);
         }
-        if (pxi < P.width && pyi < P.height) {
-            uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + (tid >> 4)) * P.fb_stride + static_cast<size_t>(pxi) * 4;
-            *reinterpret_cast<uint32_t *>(dst) = out;
-        }
-        if (kCapture && tid == 0) {
-            // list as the reference leaves it: {Bail} or cmds + End
-            P.dbg_solid[tile] = solid_color;
-            if (solid_color != 0) {
-                P.dbg_counts[tile] = 1;
-                if (P.dbg_max > 0) {
-                    Cmd bail;
-                    bail.tag = kCmdBail;
-                    bail.body[0] = bail.body[1] = bail.body[2] = bail.body[3] = bail.body[4] = 0;
-                    P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max] = bail;
-                }
+        if (pyi < P.height && pxi < P.width) {
+            uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + (lane >> 2)) * P.fb_stride + static_cast<size_t>(pxi) * 4;
+            if (pxi + 4 <= P.width && P.fb_vec16) {
+                *reinterpret_cast<uint4 *>(dst) = out;
             } else {
-                P.dbg_counts[tile] = list_len + 1;
-                if (list_len < P.dbg_max) {
-                    Cmd end;
-                    end.tag = kCmdEnd;
-                    end.body[0] = end.body[1] = end.body[2] = end.body[3] = end.body[4] = 0;
-                    P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + list_len] = end;
-                }
+                const uint32_t o[4] = {out.x, out.y, out.z, out.w};
+                for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = o[k];
             }
         }
-        __syncthreads();  // s_cmds / s_part reuse by the next tile
+        if (kCapture && lane == 0) {
+            // list as the reference leaves it: {Bail} or cmds + End
+            P.dbg_solid[tile] = solid_color;
+            Cmd tail;
+            tail.body[0] = tail.body[1] = tail.body[2] = tail.body[3] = tail.body[4] = 0;
+            if (solid_color != 0) {
+                P.dbg_counts[tile] = 1;
+                tail.tag = kCmdBail;
+                if (P.dbg_max > 0) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max] = tail;
+            } else {
+                P.dbg_counts[tile] = list_len + 1;
+                tail.tag = kCmdEnd;
+                if (list_len < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + list_len] = tail;
+            }
+        }
+        WaveSync();  // L reuse by the next tile
     }
 }
 
 // ---- launch wrappers (called from pm_context.hip) -----------------------------------------
+
+void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks, float4 *chunk_bbox,
+                 hipStream_t stream) {
+    if (n_chunks == 0) return;
+    hipLaunchKernelGGL(pm_index_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, scene, n_items, chunk_base, n_chunks,
+                       chunk_bbox);
+}
 
 void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream) {
     hipLaunchKernelGGL(pm_bin_kernel, dim3(n_striprows), dim3(kThreads), 0, stream, p);

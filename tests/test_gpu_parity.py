@@ -89,7 +89,7 @@ def test_random_scenes(pm, pmo, renderer, seed):
 
 def test_many_items_multiple_batches_and_long_lists(pm, pmo, renderer):
     # > 256 items (several binning batches) stacked on few tiles: lists far beyond the
-    # reference's 170-command tile buffer (quirk Q5) and beyond one LDS flush
+    # reference's 170-command tile buffer (quirk Q5)
     rng = np.random.default_rng(7)
     ops = []
     for i in range(700):
@@ -100,9 +100,30 @@ def test_many_items_multiple_batches_and_long_lists(pm, pmo, renderer):
     scene = encode_ops(pm, ops, cap=1 << 22)
     got = gpu_render(renderer, scene, 256, 256)
     P = pmo.Ptcl(scene, 256, 256)
-    assert P.total_cmds()[1] > 800
+    assert P.total_cmds()[1] > 300
     assert np.array_equal(got, P.render())
     assert_ptcl_equal(renderer, pmo, scene, 256, 256, maxc=4096)
+
+
+def test_list_longer_than_the_lds_command_buffer(pm, pmo, renderer):
+    # 900 translucent polylines through one tile: > 2000 commands, so the per-tile kernel
+    # must flush its 768-slot LDS list mid-stream (pixel state carried in registers); an
+    # opaque fill in the middle exercises the "restart at tileBegin" rule after a flush
+    rng = np.random.default_rng(21)
+    ops = []
+    for i in range(900):
+        a = rng.uniform(67, 77, 2)  # everything inside tile (4, 4)
+        pts = np.stack([a, a + rng.uniform(-3, 3, 2), a + rng.uniform(-3, 3, 2)])
+        ops.append(("poly", pts, (int(rng.integers(0, 1 << 24)) << 8) | int(rng.integers(0x10, 0x60)), float(rng.uniform(0.3, 3))))
+        if i == 600:
+            ops.append(("fill", np.array([(70.5, 40.0), (160.0, 75.5), (70.5, 120.0), (20.0, 75.5)]), 0x336699FF))
+    for variant in (ops, ops[:601] + ops[602:]):
+        scene = encode_ops(pm, variant, cap=1 << 22)
+        got = gpu_render(renderer, scene, 192, 160)
+        P = pmo.Ptcl(scene, 192, 160)
+        assert np.array_equal(got, P.render())
+        assert_ptcl_equal(renderer, pmo, scene, 192, 160, maxc=4096)
+    assert P.total_cmds()[1] > 1600  # the variant without the opaque fill
 
 
 def test_empty_scene_and_tiny_viewports(pm, pmo, renderer):
