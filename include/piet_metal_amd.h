@@ -169,6 +169,7 @@ typedef struct {
     uint32_t arena_cap_dwords;
     uint32_t overflow;            /* 1 if the last frame ran out of arena */
     uint32_t scene_bytes;
+    uint32_t heavy_tiles;         /* of queued_tiles: scheduled first (long segment streams) */
 } pm_stats;
 int pm_get_stats(pm_ctx *c, pm_stats *out); /* synchronises */
 

@@ -53,6 +53,7 @@ class Stats(C.Structure):
         ("arena_cap_dwords", C.c_uint32),
         ("overflow", C.c_uint32),
         ("scene_bytes", C.c_uint32),
+        ("heavy_tiles", C.c_uint32),
     ]
 
 

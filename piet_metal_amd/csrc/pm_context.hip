@@ -225,7 +225,7 @@ uint64_t ArenaBound(const pm_ctx *c) {
     std::memcpy(&n, meta, 4);
     std::memcpy(&items_ix, meta + 4, 4);
     const uint64_t striprows = static_cast<uint64_t>(BandRows(c)) * c->strips_x;
-    uint64_t total = pm::kArenaBase + striprows * pm::kRecHdrDwords * ((n + 255u) / 256u);
+    uint64_t total = pm::kArenaBase + striprows * (pm::kRecHdrDwords + 3u) * ((n + 255u) / 256u);  // header + mask-table padding
     for (uint32_t i = 0; i < n; ++i) {
         uint16_t bb[4];
         std::memcpy(bb, meta + 8 + 8ull * i, 8);
@@ -243,7 +243,7 @@ uint64_t ArenaBound(const pm_ctx *c) {
         const int64_t s_lo = bb[0] / 256, s_hi = std::min<int64_t>(bb[2] / 256, static_cast<int64_t>(c->strips_x) - 1);
         const int64_t r_lo = std::max<int64_t>(bb[1] / 16, c->row0), r_hi = std::min<int64_t>(bb[3] / 16, static_cast<int64_t>(c->row1) - 1);
         if (s_hi < s_lo || r_hi < r_lo) continue;
-        total += static_cast<uint64_t>(s_hi - s_lo + 1) * static_cast<uint64_t>(r_hi - r_lo + 1) * (pm::kCandDwords + 4ull * nseg);
+        total += static_cast<uint64_t>(s_hi - s_lo + 1) * static_cast<uint64_t>(r_hi - r_lo + 1) * (pm::kCandDwords + 1u + 4ull * nseg);  // record + mask word + whole chunks
     }
     return total;
 }
@@ -294,6 +294,7 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     p->arena_cap = c->arena_cap;
     p->striprow_head = c->d_striprow;
     p->queue = c->d_queue;
+    p->queue_cap = std::max<uint32_t>(BandRows(c) * c->tiles_x, 1u);
     p->ctr_cur = c->d_ctr + (c->frame & 1u);
     p->ctr_next = c->d_ctr + ((c->frame + 1u) & 1u);
     p->chunk_base = c->d_chunk_base;
@@ -474,12 +475,8 @@ pm_ctx *pm_create(int device, int *err) {
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipMalloc(&c->d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
     pm::Counters init[2];
-    for (auto &k : init) {
-        k.arena_top = pm::kArenaBase;
-        k.queue_count = 0;
-        k.overflow = 0;
-        k.pad = 0;
-    }
+    std::memset(init, 0, sizeof(init));
+    for (auto &k : init) k.arena_top = pm::kArenaBase;
     if ((e = hipMemcpy(c->d_ctr, init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(counters)");
     Luts *l = new (std::nothrow) Luts();
     if (!l) {
@@ -717,7 +714,8 @@ int pm_get_stats(pm_ctx *c, pm_stats *out) {
     if (c->have_frame) {
         pm::Counters k;
         PM_TRY(hipMemcpy(&k, c->last_params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
-        out->queued_tiles = k.queue_count;
+        out->queued_tiles = k.heavy_count + k.light_count;
+        out->heavy_tiles = k.heavy_count;
         out->arena_used_dwords = k.arena_top;
         out->overflow = k.overflow;
     }
@@ -755,8 +753,12 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
         p.dbg_solid = d_solid;
         p.dbg_cmds = d_cmds;
         p.dbg_max = max_cmds_per_tile;
-        pm::LaunchTiles(p, TileGrid(c), true, c->stream);
-        e = hipStreamSynchronize(c->stream);
+        // the capture pass replays the last frame's queue: rewind its cursor
+        e = hipMemsetAsync(&p.ctr_cur->cursor, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) {
+            pm::LaunchTiles(p, TileGrid(c), true, c->stream);
+            e = hipStreamSynchronize(c->stream);
+        }
     }
     if (e == hipSuccess) e = hipMemcpy(counts, d_counts, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(solid, d_solid, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);

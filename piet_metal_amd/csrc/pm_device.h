@@ -13,17 +13,27 @@ namespace pm {
 // kernel can reset frame N+1's copy (no memset launch on the critical path).
 struct Counters {
     uint32_t arena_top;    // bump pointer into the arena, in dwords
-    uint32_t queue_count;  // tiles pushed for the per-tile kernel
+    uint32_t heavy_count;  // tiles pushed at the front of the queue (long segment streams)
     uint32_t overflow;     // set if the arena ran out
-    uint32_t pad;
+    uint32_t light_count;  // tiles pushed at the back of the queue
+    uint32_t cursor;       // next queue slot handed to a wave of the per-tile kernel
+    uint32_t pad[3];
 };
 
 // Arena record written by pm_bin_kernel for one (strip row, batch of <=256 items):
-//   [0] next record offset (0 = end)   [1] ncand   [2] stream elements tested
+//   [0] next record offset (0 = end)   [1] ncand   [2] surviving chunks
 //   [3] segments that survived phase 1
-//   ncand x 8 dwords: { tag | hitmask16 << 16, rgba, aux0, aux1, seg_off, item_ix, -, - }
+//   mask table: ncand dwords { tag | hitmask16 << 16 }, padded to a multiple of 4
+//       (one 16-byte load per lane of the tile kernel covers 256 candidates)
+//   ncand x 8 dwords: { tag | hitmask16 << 16, rgba, aux0, aux1, seg_off, item_ix, rg, ba }
 //       aux0/aux1 = bbox words (circle) or width bits (line, polyline)
+//       rg/ba = the colour already through unpack_unorm4x8_srgb_to_half (4 x binary16)
 //   survived segments, 16 B each (start.xy, end.xy), in paint order
+//
+// Tile queue: tiles whose segment stream is long are pushed from the front
+// (queue[0 .. heavy_count)), the others from the back (queue[cap-1-i]); the tile
+// kernel hands slots out front first through `cursor`, so the expensive tiles start
+// first and the cheap ones fill the tail.
 //
 // Scene index (built once per scene upload by pm_index_kernel, like the ShortBbox
 // array the encoder builds at encode time): segments are grouped in chunks of 16
@@ -50,6 +60,7 @@ struct FrameParams {
     uint32_t arena_cap;   // dwords
     uint32_t *striprow_head;
     uint32_t *queue;
+    uint32_t queue_cap;
     Counters *ctr_cur;
     Counters *ctr_next;
     const uint32_t *chunk_base;    // [n_items + 1]

@@ -50,6 +50,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
+constexpr uint32_t kHeavyStream = 160;  // stream elements above which a tile is scheduled first
 
 // ---------------------------------------------------------------------------------
 // small helpers
@@ -243,9 +244,9 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
     __shared__ uint32_t s_choff[kThreads + 1];  // chunk-stream offsets
     __shared__ uint32_t s_ccnt[kThreads];   // surviving segments per candidate
     __shared__ uint32_t s_surv[kThreads];   // surviving chunks of one round: c << 24 | j
-    __shared__ uint32_t s_hitmask;
+    __shared__ uint32_t s_est[kStripTiles];  // per tile: stream elements the tile kernel will test
     __shared__ uint32_t s_rec;
-    __shared__ uint32_t s_qbase;
+    __shared__ uint32_t s_qbase[2];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t strip = blockIdx.x % P.strips_x;
@@ -262,13 +263,13 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
         // The counters of the NEXT frame (the other parity) are idle now: reset them
         // here so that no separate memset launch is needed.
         P.ctr_next->arena_top = kArenaBase;
-        P.ctr_next->queue_count = 0;
+        P.ctr_next->heavy_count = 0;
+        P.ctr_next->light_count = 0;
+        P.ctr_next->cursor = 0;
         P.ctr_next->overflow = 0;
     }
-    if (tid == 0) {
-        s_hitmask = 0;
-        P.striprow_head[blockIdx.x] = 0;
-    }
+    if (tid < kStripTiles) s_est[tid] = 0;
+    if (tid == 0) P.striprow_head[blockIdx.x] = 0;
     __syncthreads();
 
     const uint8_t *scene = P.scene;
@@ -300,7 +301,6 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
         if (cand) {
             s_cidx[cpos] = i;
             s_cmask[cpos] = mask;
-            atomicOr(&s_hitmask, mask);
         }
         __syncthreads();
 
@@ -379,8 +379,9 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
             (void)BlockRank(sv, s_part, &cnt);
             nsurv_chunks += cnt;
         }
+        const uint32_t mask_dwords = (ncand + 3u) & ~3u;
         if (tid == 0) {
-            const uint32_t size = kRecHdrDwords + kCandDwords * ncand + 4u * kChunkSegs * nsurv_chunks;
+            const uint32_t size = kRecHdrDwords + mask_dwords + kCandDwords * ncand + 4u * kChunkSegs * nsurv_chunks;
             const uint32_t rec = atomicAdd(&P.ctr_cur->arena_top, size);
             if (rec + size > P.arena_cap || rec + size < rec) {
                 P.ctr_cur->overflow = 1;
@@ -397,16 +398,9 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
         const uint32_t rec = s_rec;
         if (rec == 0) break;  // arena exhausted (flagged; the host sizes the arena to make this impossible)
         link = &P.arena[rec];
-        uint32_t *cand_rec = P.arena + rec + kRecHdrDwords;
-        float4 *segs = reinterpret_cast<float4 *>(P.arena + rec + kRecHdrDwords + kCandDwords * ncand);
-        if (tid < ncand) {
-            uint32_t *cr = cand_rec + kCandDwords * tid;
-            cr[0] = tag | (s_cmask[tid] << 16);
-            cr[1] = rgba;
-            cr[2] = aux0;
-            cr[3] = aux1;
-            cr[5] = s_cidx[tid];
-        }
+        uint32_t *mask_tab = P.arena + rec + kRecHdrDwords;
+        uint32_t *cand_rec = mask_tab + mask_dwords;
+        float4 *segs = reinterpret_cast<float4 *>(cand_rec + kCandDwords * ncand);
 
         // ---- pass B: expand surviving chunks, phase-1 votes, ordered compaction ----------
         uint32_t vbase = 0;
@@ -459,12 +453,29 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
             }
             __syncthreads();  // s_surv is rewritten by the next round
         }
-        // segment offsets of the candidates = exclusive scan of their surviving counts
+        // segment offsets of the candidates = exclusive scan of their surviving counts;
+        // candidate records + mask table; per-tile stream-length estimate
         {
             const uint32_t v = (tid < ncand) ? s_ccnt[tid] : 0u;
             uint32_t tot;
             const uint32_t o = BlockExclusiveScan(v, s_part, &tot);
-            if (tid < ncand) cand_rec[kCandDwords * tid + 4] = o;
+            if (tid < mask_dwords) {
+                uint32_t w0 = 0;
+                if (tid < ncand) {
+                    // a candidate none of whose segments survived cannot emit anything (circles
+                    // own one pseudo element): drop its hit bits so that no tile looks at it
+                    const uint32_t elems = (tag == kItemCircle) ? 1u : v;
+                    const uint32_t hm = (elems != 0 && tag != 0) ? s_cmask[tid] : 0u;
+                    w0 = tag | (hm << 16);
+                    const uint32_t rg = P.lut_srgb2lin[rgba & 0xffu] | (P.lut_srgb2lin[(rgba >> 8) & 0xffu] << 16);
+                    const uint32_t ba = P.lut_srgb2lin[(rgba >> 16) & 0xffu] | (P.lut_unorm2h[rgba >> 24] << 16);
+                    uint4 *cr = reinterpret_cast<uint4 *>(cand_rec + kCandDwords * tid);
+                    cr[0] = make_uint4(w0, rgba, aux0, aux1);
+                    cr[1] = make_uint4(o, elems, rg, ba);
+                    for (uint32_t m = hm; m; m &= m - 1) atomicAdd(&s_est[__builtin_ctz(m)], elems);
+                }
+                mask_tab[tid] = w0;
+            }
             if (tid == 0) P.arena[rec + 3] = tot;
         }
         __syncthreads();  // s_c* arrays are rewritten by the next batch
@@ -472,17 +483,29 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
 
     // ---- queue the touched tiles, clear the untouched ones ------------------------------
     __syncthreads();
-    const uint32_t hitmask = s_hitmask;
     const uint32_t tiles_here = min(kStripTiles, P.tiles_x - strip * kStripTiles);
     const uint32_t valid = (1u << tiles_here) - 1u;
-    const uint32_t qmask = hitmask & valid;
-    if (tid == 0 && qmask) s_qbase = atomicAdd(&P.ctr_cur->queue_count, static_cast<uint32_t>(__popc(qmask)));
-    __syncthreads();
-    if (tid < kStripTiles && ((qmask >> tid) & 1u)) {
-        const uint32_t rank = __popc(qmask & ((1u << tid) - 1u));
-        P.queue[s_qbase + rank] = row_rel * P.tiles_x + strip * kStripTiles + tid;
+    uint32_t heavy = 0, light = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < kStripTiles; ++t) {
+        const uint32_t est = s_est[t];
+        if (est > kHeavyStream) heavy |= 1u << t;
+        else if (est != 0) light |= 1u << t;
     }
-    const uint32_t clear = ~hitmask & valid;
+    heavy &= valid;
+    light &= valid;
+    if (tid == 0 && heavy) s_qbase[0] = atomicAdd(&P.ctr_cur->heavy_count, static_cast<uint32_t>(__popc(heavy)));
+    if (tid == 1 && light) s_qbase[1] = atomicAdd(&P.ctr_cur->light_count, static_cast<uint32_t>(__popc(light)));
+    __syncthreads();
+    if (tid < kStripTiles) {
+        const uint32_t tile = row_rel * P.tiles_x + strip * kStripTiles + tid;
+        const uint32_t below = (1u << tid) - 1u;
+        if ((heavy >> tid) & 1u) P.queue[s_qbase[0] + __popc(heavy & below)] = tile;
+        if ((light >> tid) & 1u) P.queue[P.queue_cap - 1u - (s_qbase[1] + __popc(light & below))] = tile;
+    }
+    // tiles with nothing to test are background: no item touches them, or every touching
+    // item lost all its segments in phase 1 (the reference writes Bail/white for them)
+    const uint32_t clear = ~(heavy | light) & valid;
     if (clear) {
         // 16 pixel rows x 1024 B: thread -> (row = it*4 + tid/64, 16 B = 4 px at lane*4)
         const uint32_t lane16 = tid & 63u;
@@ -515,7 +538,10 @@ namespace {
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
-constexpr uint32_t kWaveCmds = 256;  // LDS command slots per wave: one 64-lane round emits <= 192
+#ifndef PM_WAVE_CMDS
+#define PM_WAVE_CMDS 256
+#endif
+constexpr uint32_t kWaveCmds = PM_WAVE_CMDS;  // LDS command slots per wave: one 64-lane round emits <= 192
 constexpr uint32_t kWaveCands = 64;  // candidates handled per pass
 
 // Pixels of one lane: 4 horizontally adjacent pixels (x0 .. x0+3, same y).
@@ -657,12 +683,15 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0
 
 struct WaveLds {
     Cmd cmds[kWaveCmds];
+    uint32_t hidx[kThreads];  // candidates of the record that hit this tile (indices)
     uint32_t htag[kWaveCands];
     uint32_t hrgba[kWaveCands];
     uint32_t haux0[kWaveCands];
     uint32_t haux1[kWaveCands];
     uint32_t hseg[kWaveCands];
     uint32_t hcnt[kWaveCands];
+    uint32_t hrg[kWaveCands];
+    uint32_t hba[kWaveCands];
     uint32_t hoff[kWaveCands + 1];
     int backdrop[kWaveCands];
     uint32_t any[kWaveCands];
@@ -677,12 +706,21 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
 
     const uint32_t lane = LaneId();
     const uint64_t lanes_below = (1ull << lane) - 1ull;
+    const uint32_t n_heavy = P.ctr_cur->heavy_count;
+    const uint32_t n_total = n_heavy + P.ctr_cur->light_count;
+
+    // Static snake hand-out over [heavy tiles..., light tiles...]: pass k gives wave g the
+    // slot k*G + g (k even) or k*G + (G-1-g) (k odd).  The waves that start with the most
+    // expensive tiles are the ones that get the last (or no) tile of the final pass.  No
+    // atomics: one device-scope counter tops out near 90 dequeues/us on this chip, far
+    // below the tile rate.
     const uint32_t wave_global = blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWaves;
-    const uint32_t qn = P.ctr_cur->queue_count;
 
-    for (uint32_t q = wave_global; q < qn; q += n_waves) {
-        const uint32_t tile = P.queue[q];
+    for (uint32_t pass = 0; pass * n_waves < n_total; ++pass) {
+        const uint32_t slot = pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
+        if (slot >= n_total) continue;
+        const uint32_t tile = (slot < n_heavy) ? P.queue[slot] : P.queue[P.queue_cap - 1u - (slot - n_heavy)];
         const uint32_t tx = tile % P.tiles_x;
         const uint32_t ty_rel = tile / P.tiles_x;
         const uint32_t ty = P.row0 + ty_rel;
@@ -713,43 +751,53 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
 
         uint32_t rec = P.striprow_head[sr];
         while (rec != 0) {
-            const uint32_t next = P.arena[rec + 0];
-            const uint32_t ncand = P.arena[rec + 1];
-            const uint32_t nsurv = P.arena[rec + 3];
-            const uint32_t *cand_rec = P.arena + rec + kRecHdrDwords;
-            const float4 *segs = reinterpret_cast<const float4 *>(P.arena + rec + kRecHdrDwords + kCandDwords * ncand);
+            // header and mask table sit next to each other: both loads are in flight together
+            const uint4 hdr = *reinterpret_cast<const uint4 *>(P.arena + rec);
+            const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * lane);
+            const uint32_t next = hdr.x;
+            const uint32_t ncand = hdr.y;
+            const uint32_t mask_dwords = (ncand + 3u) & ~3u;
+            const uint32_t *cand_rec = P.arena + rec + kRecHdrDwords + mask_dwords;
+            const float4 *segs = reinterpret_cast<const float4 *>(cand_rec + kCandDwords * ncand);
 
-            for (uint32_t cb = 0; cb < ncand; cb += kWaveCands) {
-                // ---- candidates that hit this tile, in paint order ---------------------------
-                const uint32_t ci = cb + lane;
-                bool hit = false;
-                uint32_t w0 = 0, rgba = 0, aux0 = 0, aux1 = 0, seg_off = 0, cnt = 0;
-                if (ci < ncand) {
-                    const uint4 a = *reinterpret_cast<const uint4 *>(cand_rec + kCandDwords * ci);
-                    w0 = a.x; rgba = a.y; aux0 = a.z; aux1 = a.w;
-                    hit = ((w0 >> (16 + tbit)) & 1u) != 0 && (w0 & 0xffffu) != 0;
-                    if (hit) {
-                        seg_off = cand_rec[kCandDwords * ci + 4];
-                        const uint32_t seg_end = (ci + 1 < ncand) ? cand_rec[kCandDwords * (ci + 1) + 4] : nsurv;
-                        // circles own one pseudo element; the others as many as survived phase 1
-                        cnt = ((w0 & 0xffffu) == kItemCircle) ? 1u : (seg_end - seg_off);
-                        hit = cnt != 0;
-                    }
-                }
-                const uint64_t hm = __ballot(hit);
-                const uint32_t nh = static_cast<uint32_t>(__popcll(hm));
-                if (nh == 0) continue;
-                WaveSync();
-                if (hit) {
-                    const uint32_t hp = RankBelow(hm);
-                    L.htag[hp] = w0 & 0xffffu;
-                    L.hrgba[hp] = rgba;
-                    L.haux0[hp] = aux0;
-                    L.haux1[hp] = aux1;
-                    L.hseg[hp] = seg_off;
-                    L.hcnt[hp] = cnt;
-                    L.backdrop[hp] = 0;
-                    L.any[hp] = 0;
+            // ---- candidates that hit this tile, in paint order (lane owns 4 consecutive) ------
+            const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+            uint32_t hbits = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (4u * lane + k < ncand && ((mw[k] >> (16 + tbit)) & 1u)) hbits |= 1u << k;
+            const uint32_t hcount = __popc(hbits);
+            const uint32_t hincl = WaveInclusiveScan(hcount);
+            const uint32_t nhit = __shfl(hincl, 63, 64);
+            if (nhit == 0) {
+                rec = next;
+                continue;
+            }
+            WaveSync();
+            {
+                uint32_t hp = hincl - hcount;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if ((hbits >> k) & 1u) L.hidx[hp++] = 4u * lane + k;
+            }
+            WaveSync();
+
+            for (uint32_t cb = 0; cb < nhit; cb += kWaveCands) {
+                const uint32_t nh = min(kWaveCands, nhit - cb);
+                if (lane < nh) {
+                    const uint4 *cr = reinterpret_cast<const uint4 *>(cand_rec + kCandDwords * L.hidx[cb + lane]);
+                    const uint4 a = cr[0];
+                    const uint4 b = cr[1];
+                    L.htag[lane] = a.x & 0xffffu;
+                    L.hrgba[lane] = a.y;
+                    L.haux0[lane] = a.z;
+                    L.haux1[lane] = a.w;
+                    L.hseg[lane] = b.x;
+                    L.hcnt[lane] = b.y;
+                    L.hrg[lane] = b.z;
+                    L.hba[lane] = b.w;
+                    L.backdrop[lane] = 0;
+                    L.any[lane] = 0;
                 }
                 WaveSync();
                 uint32_t stream_len;
@@ -883,8 +931,7 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                     fin.body[0] = fin.body[1] = fin.body[2] = fin.body[3] = fin.body[4] = 0;
                     if (is_last) {
                         const uint32_t frgba = L.hrgba[c];
-                        const uint32_t rg = P.lut_srgb2lin[frgba & 0xffu] | (P.lut_srgb2lin[(frgba >> 8) & 0xffu] << 16);
-                        const uint32_t ba = P.lut_srgb2lin[(frgba >> 16) & 0xffu] | (P.lut_unorm2h[frgba >> 24] << 16);
+                        const uint32_t rg = L.hrg[c], ba = L.hba[c];
                         if (ctag == kItemFill) {  // :359-363
                             const int backdrop = L.backdrop[c];
                             if (L.any[c]) {
@@ -933,6 +980,13 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                         n_pending = 0;
                         list_len = 0;
                         st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = one2;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            // an item cut in two by a flush may lose its closing DrawFill / Stroke to
+                            // this restart: the interpreter state must be the fresh one of :470-472
+                            st.df[k] = 1e9f;
+                            st.sa[k] = static_cast<_Float16>(0.0f);
+                        }
                         base = 0u - first_kept;
                     } else {
                         first_kept = 0;
