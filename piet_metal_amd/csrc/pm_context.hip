@@ -243,7 +243,7 @@ uint64_t ArenaBound(const pm_ctx *c) {
         const int64_t s_lo = bb[0] / 256, s_hi = std::min<int64_t>(bb[2] / 256, static_cast<int64_t>(c->strips_x) - 1);
         const int64_t r_lo = std::max<int64_t>(bb[1] / 16, c->row0), r_hi = std::min<int64_t>(bb[3] / 16, static_cast<int64_t>(c->row1) - 1);
         if (s_hi < s_lo || r_hi < r_lo) continue;
-        total += static_cast<uint64_t>(s_hi - s_lo + 1) * static_cast<uint64_t>(r_hi - r_lo + 1) * (pm::kCandDwords + 1u + 4ull * nseg);  // record + mask word + whole chunks
+        total += static_cast<uint64_t>(s_hi - s_lo + 1) * static_cast<uint64_t>(r_hi - r_lo + 1) * (pm::kCandDwords + pm::kCtDwords + 1u + 5ull * nseg);  // records + mask word + whole chunks (seg + meta)
     }
     return total;
 }
@@ -312,8 +312,8 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
 uint32_t TileGrid(const pm_ctx *c) {
     // persistent workgroups: enough to fill every CU at the kernel's occupancy
     const uint32_t tiles = BandRows(c) * c->tiles_x;
-    // one wave per tile, 4 waves per workgroup, 4 workgroups resident per CU (LDS-bound)
-    const uint32_t cap = static_cast<uint32_t>(c->n_cus) * 4u;
+    // one wave per tile, 4 waves per workgroup, 3 workgroups resident per CU (LDS / VGPR bound)
+    const uint32_t cap = static_cast<uint32_t>(c->n_cus) * 3u;
     return std::max(1u, std::min((tiles + 3u) / 4u, cap));
 }
 

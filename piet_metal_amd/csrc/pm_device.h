@@ -22,13 +22,18 @@ struct Counters {
 
 // Arena record written by pm_bin_kernel for one (strip row, batch of <=256 items):
 //   [0] next record offset (0 = end)   [1] ncand   [2] surviving chunks
-//   [3] segments that survived phase 1
+//   [3] V = segments that survived phase 1
 //   mask table: ncand dwords { tag | hitmask16 << 16 }, padded to a multiple of 4
-//       (one 16-byte load per lane of the tile kernel covers 256 candidates)
-//   ncand x 8 dwords: { tag | hitmask16 << 16, rgba, aux0, aux1, seg_off, item_ix, rg, ba }
+//       (one 16-byte load per lane of the tile kernel covers 256 candidates); a hit
+//       bit survives only where the candidate can emit a command
+//   ncand x 8 dwords: { tag | hitmask16 << 16, rgba, aux0, aux1, seg_off, seg_cnt, rg, ba }
 //       aux0/aux1 = bbox words (circle) or width bits (line, polyline)
 //       rg/ba = the colour already through unpack_unorm4x8_srgb_to_half (4 x binary16)
-//   survived segments, 16 B each (start.xy, end.xy), in paint order
+//   ncand x 16 dwords: per tile of the strip { backdrop << 20 | relevant segments }
+//       backdrop = the reference's per-tile left-ray winding sum (PietRender.metal
+//       :326-333) over all voted segments of the item, done once here
+//   segs: V x 16 B (start.xy, end.xy), in paint order (space for 16 per surviving chunk)
+//   meta: V x 4 B { tiles of the strip where the segment can emit (16 bits) | candidate << 16 }
 //
 // Tile queue: tiles whose segment stream is long are pushed from the front
 // (queue[0 .. heavy_count)), the others from the back (queue[cap-1-i]); the tile
@@ -45,6 +50,9 @@ constexpr uint32_t kChunkSegs = 16;
 constexpr uint32_t kArenaBase = 4;     // offset 0 means "none"
 constexpr uint32_t kRecHdrDwords = 4;
 constexpr uint32_t kCandDwords = 8;
+constexpr uint32_t kCtDwords = 16;           // per candidate: one word per tile of the strip
+constexpr uint32_t kCtShift = 20;            // word = backdrop << 20 | relevant-segment count
+constexpr uint32_t kCtCountMask = (1u << kCtShift) - 1u;
 
 struct FrameParams {
     const uint8_t *scene;

@@ -50,7 +50,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr uint32_t kHeavyStream = 160;  // stream elements above which a tile is scheduled first
+constexpr uint32_t kHeavyStream = 48;  // stream elements above which a tile is scheduled first
 
 // ---------------------------------------------------------------------------------
 // small helpers
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
     __shared__ uint32_t s_cchunk[kThreads]; // first chunk-table entry of the item
     __shared__ uint32_t s_choff[kThreads + 1];  // chunk-stream offsets
     __shared__ uint32_t s_ccnt[kThreads];   // surviving segments per candidate
+    __shared__ uint32_t s_ct[kThreads * kStripTiles];  // per (candidate, tile): backdrop << 20 | relevant segments
     __shared__ uint32_t s_surv[kThreads];   // surviving chunks of one round: c << 24 | j
     __shared__ uint32_t s_est[kStripTiles];  // per tile: stream elements the tile kernel will test
     __shared__ uint32_t s_rec;
@@ -347,6 +348,8 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
             s_chw[tid] = hw;
             s_cchunk[tid] = P.chunk_base[idx];
             s_ccnt[tid] = 0;
+#pragma unroll
+            for (uint32_t t = 0; t < kStripTiles; ++t) s_ct[tid * kStripTiles + t] = 0;
         }
         uint32_t total_ch;
         const uint32_t choff = BlockExclusiveScan(nch, s_part, &total_ch);
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
         }
         const uint32_t mask_dwords = (ncand + 3u) & ~3u;
         if (tid == 0) {
-            const uint32_t size = kRecHdrDwords + mask_dwords + kCandDwords * ncand + 4u * kChunkSegs * nsurv_chunks;
+            const uint32_t size = kRecHdrDwords + mask_dwords + (kCandDwords + kCtDwords) * ncand + 5u * kChunkSegs * nsurv_chunks;
             const uint32_t rec = atomicAdd(&P.ctr_cur->arena_top, size);
             if (rec + size > P.arena_cap || rec + size < rec) {
                 P.ctr_cur->overflow = 1;
@@ -400,7 +403,9 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
         link = &P.arena[rec];
         uint32_t *mask_tab = P.arena + rec + kRecHdrDwords;
         uint32_t *cand_rec = mask_tab + mask_dwords;
-        float4 *segs = reinterpret_cast<float4 *>(cand_rec + kCandDwords * ncand);
+        uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
+        float4 *segs = reinterpret_cast<float4 *>(ct_tab + kCtDwords * ncand);
+        uint32_t *meta = reinterpret_cast<uint32_t *>(segs + kChunkSegs * nsurv_chunks);
 
         // ---- pass B: expand surviving chunks, phase-1 votes, ordered compaction ----------
         uint32_t vbase = 0;
@@ -446,15 +451,60 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
                 uint32_t nvote;
                 const uint32_t pos = vbase + BlockRank(vote, s_part, &nvote);
                 if (vote) {
+                    // Per tile of the strip: (a) can this segment emit a command there -- the
+                    // x/box pre-conditions of phase 2 (:334, :349-350, :416-417), evaluated with
+                    // the very comparisons phase 2 uses; (b) for fills, the backdrop term of
+                    // :326-333, which the reference accumulates over EVERY voted segment of the
+                    // row, is summed here once per (item, tile) instead of once per tile wave.
+                    const uint32_t ctag = s_ctag[vc];
+                    const uint32_t hm = s_cmask[vc];
+                    uint32_t M = 0;
+                    const float xmin = fminf(seg.x, seg.z), ymin = fminf(seg.y, seg.w);
+                    const float xmax = fmaxf(seg.x, seg.z), ymax = fmaxf(seg.y, seg.w);
+                    if (ctag == kItemFill) {
+                        const float a = seg.w - seg.y;
+                        const float b = seg.x - seg.z;
+                        const float cc = -(a * seg.x + b * seg.y);
+                        const float top = b * fmaxf(fy0, ymin);
+                        const float sa = Sgn(a);
+                        const bool crosses = ymin <= fy0;
+#pragma unroll
+                        for (uint32_t t = 0; t < kStripTiles; ++t) {
+                            const float fx0 = static_cast<float>(sx0 + static_cast<int>(t * kTileW));
+                            const float fx1 = static_cast<float>(sx0 + static_cast<int>((t + 1) * kTileW));
+                            if (xmin < fx1 && xmax > fx0) M |= 1u << t;
+                            if (crosses && ((hm >> t) & 1u)) {
+                                const float left = a * fx0;
+                                if (Sgn(left + fy0 * b + cc) == sa) {
+                                    const int d = -static_cast<int>(Sgn(top + left + cc));  // backdrop -= s00
+                                    if (d != 0) atomicAdd(&s_ct[vc * kStripTiles + t], static_cast<uint32_t>(d) << kCtShift);
+                                }
+                            }
+                        }
+                    } else if (ctag == kItemPoly) {
+                        const float hw = s_chw[vc];
+                        if (ymax > fy0 - hw && ymin < fy1 + hw) {
+#pragma unroll
+                            for (uint32_t t = 0; t < kStripTiles; ++t) {
+                                const float fx0 = static_cast<float>(sx0 + static_cast<int>(t * kTileW));
+                                const float fx1 = static_cast<float>(sx0 + static_cast<int>((t + 1) * kTileW));
+                                if (xmax > fx0 - hw && xmin < fx1 + hw) M |= 1u << t;
+                            }
+                        }
+                    } else {
+                        M = 0xffffu;  // a line is tested by every tile its bbox hits (:223-247)
+                    }
+                    M &= hm;
+                    for (uint32_t m = M; m; m &= m - 1) atomicAdd(&s_ct[vc * kStripTiles + __builtin_ctz(m)], 1u);
                     segs[pos] = seg;
+                    meta[pos] = M | (vc << 16);
                     atomicAdd(&s_ccnt[vc], 1u);
                 }
                 vbase += nvote;
             }
             __syncthreads();  // s_surv is rewritten by the next round
         }
-        // segment offsets of the candidates = exclusive scan of their surviving counts;
-        // candidate records + mask table; per-tile stream-length estimate
+        // candidate records, per-(candidate, tile) table, mask table, per-tile stream estimate
         {
             const uint32_t v = (tid < ncand) ? s_ccnt[tid] : 0u;
             uint32_t tot;
@@ -462,17 +512,31 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
             if (tid < mask_dwords) {
                 uint32_t w0 = 0;
                 if (tid < ncand) {
-                    // a candidate none of whose segments survived cannot emit anything (circles
-                    // own one pseudo element): drop its hit bits so that no tile looks at it
-                    const uint32_t elems = (tag == kItemCircle) ? 1u : v;
-                    const uint32_t hm = (elems != 0 && tag != 0) ? s_cmask[tid] : 0u;
+                    // keep a hit bit only where the candidate can emit something: a relevant
+                    // segment, a non-zero backdrop (Solid / DrawFill), or a circle
+                    uint32_t hm = 0;
+                    uint32_t ct[kStripTiles];
+#pragma unroll
+                    for (uint32_t t = 0; t < kStripTiles; ++t) {
+                        ct[t] = s_ct[tid * kStripTiles + t];
+                        const uint32_t cnt = ct[t] & kCtCountMask;
+                        const int bd = static_cast<int>(ct[t]) >> kCtShift;
+                        const bool pseudo = tag == kItemCircle || (tag == kItemFill && bd != 0);
+                        const uint32_t n_el = cnt ? cnt : (pseudo ? 1u : 0u);
+                        if (n_el && ((s_cmask[tid] >> t) & 1u) && tag != 0) {
+                            hm |= 1u << t;
+                            atomicAdd(&s_est[t], n_el);
+                        }
+                    }
                     w0 = tag | (hm << 16);
                     const uint32_t rg = P.lut_srgb2lin[rgba & 0xffu] | (P.lut_srgb2lin[(rgba >> 8) & 0xffu] << 16);
                     const uint32_t ba = P.lut_srgb2lin[(rgba >> 16) & 0xffu] | (P.lut_unorm2h[rgba >> 24] << 16);
                     uint4 *cr = reinterpret_cast<uint4 *>(cand_rec + kCandDwords * tid);
                     cr[0] = make_uint4(w0, rgba, aux0, aux1);
-                    cr[1] = make_uint4(o, elems, rg, ba);
-                    for (uint32_t m = hm; m; m &= m - 1) atomicAdd(&s_est[__builtin_ctz(m)], elems);
+                    cr[1] = make_uint4(o, v, rg, ba);
+                    uint4 *ctw = reinterpret_cast<uint4 *>(ct_tab + kCtDwords * tid);
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) ctw[q] = make_uint4(ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]);
                 }
                 mask_tab[tid] = w0;
             }
@@ -543,6 +607,7 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 #endif
 constexpr uint32_t kWaveCmds = PM_WAVE_CMDS;  // LDS command slots per wave: one 64-lane round emits <= 192
 constexpr uint32_t kWaveCands = 64;  // candidates handled per pass
+constexpr uint32_t kRing = 512;      // >= 64 (one round) + 255 (scan overshoot), power of two
 
 // Pixels of one lane: 4 horizontally adjacent pixels (x0 .. x0+3, same y).
 struct PixelState {
@@ -683,13 +748,15 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0
 
 struct WaveLds {
     Cmd cmds[kWaveCmds];
-    uint32_t hidx[kThreads];  // candidates of the record that hit this tile (indices)
+    uint32_t ring[kRing];     // indices of the record's segments relevant to this tile
+    uint8_t hidx[kThreads];   // candidates of the record that hit this tile (indices)
     uint32_t htag[kWaveCands];
     uint32_t hrgba[kWaveCands];
     uint32_t haux0[kWaveCands];
     uint32_t haux1[kWaveCands];
-    uint32_t hseg[kWaveCands];
-    uint32_t hcnt[kWaveCands];
+    uint32_t hrel[kWaveCands];   // relevant segments of the candidate in this tile
+    uint32_t hwoff[kWaveCands];  // index of its first relevant segment (ring position)
+    uint32_t hcnt[kWaveCands];   // stream elements (relevant segments, or 1 pseudo element)
     uint32_t hrg[kWaveCands];
     uint32_t hba[kWaveCands];
     uint32_t hoff[kWaveCands + 1];
@@ -756,9 +823,18 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
             const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * lane);
             const uint32_t next = hdr.x;
             const uint32_t ncand = hdr.y;
+            const uint32_t n_surv = hdr.w;  // segments that survived phase 1 in this record
             const uint32_t mask_dwords = (ncand + 3u) & ~3u;
             const uint32_t *cand_rec = P.arena + rec + kRecHdrDwords + mask_dwords;
-            const float4 *segs = reinterpret_cast<const float4 *>(cand_rec + kCandDwords * ncand);
+            const uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
+            const float4 *segs = reinterpret_cast<const float4 *>(ct_tab + kCtDwords * ncand);
+            const uint32_t *meta = reinterpret_cast<const uint32_t *>(segs + kChunkSegs * hdr.z);
+            // Worklist of the segments that matter to THIS tile: the record's segment metas are
+            // scanned linearly (4 per lane per step, independent loads) and the indices of those
+            // with this tile's bit are kept, in paint order, in a small LDS ring.
+            uint32_t scan_pos = 0;  // next segment to scan
+            uint32_t ring_cnt = 0;  // relevant segments found so far (ring write position)
+            uint32_t rel_done = 0;  // relevant segments owned by earlier candidate passes
 
             // ---- candidates that hit this tile, in paint order (lane owns 4 consecutive) ------
             const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
@@ -778,7 +854,7 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                 uint32_t hp = hincl - hcount;
 #pragma unroll
                 for (uint32_t k = 0; k < 4; ++k)
-                    if ((hbits >> k) & 1u) L.hidx[hp++] = 4u * lane + k;
+                    if ((hbits >> k) & 1u) L.hidx[hp++] = static_cast<uint8_t>(4u * lane + k);
             }
             WaveSync();
 
@@ -792,20 +868,28 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                     L.hrgba[lane] = a.y;
                     L.haux0[lane] = a.z;
                     L.haux1[lane] = a.w;
-                    L.hseg[lane] = b.x;
-                    L.hcnt[lane] = b.y;
+                    const uint32_t ct = ct_tab[kCtDwords * L.hidx[cb + lane] + tbit];
+                    const uint32_t rel = ct & kCtCountMask;
+                    L.hrel[lane] = rel;
+                    L.hcnt[lane] = rel ? rel : 1u;  // circle / backdrop-only fill: one pseudo element
                     L.hrg[lane] = b.z;
                     L.hba[lane] = b.w;
-                    L.backdrop[lane] = 0;
+                    L.backdrop[lane] = static_cast<int>(ct) >> kCtShift;
                     L.any[lane] = 0;
                 }
                 WaveSync();
-                uint32_t stream_len;
+                uint32_t stream_len, pass_rel;
                 {
                     const uint32_t v = (lane < nh) ? L.hcnt[lane] : 0u;
+                    const uint32_t r = (lane < nh) ? L.hrel[lane] : 0u;
                     const uint32_t incl = WaveInclusiveScan(v);
-                    if (lane < nh) L.hoff[lane] = incl - v;
+                    const uint32_t rincl = WaveInclusiveScan(r);
+                    if (lane < nh) {
+                        L.hoff[lane] = incl - v;
+                        L.hwoff[lane] = rel_done + rincl - r;  // first relevant segment of the candidate
+                    }
                     stream_len = __shfl(incl, 63, 64);
+                    pass_rel = __shfl(rincl, 63, 64);
                     if (lane == 0) L.hoff[nh] = stream_len;
                 }
                 WaveSync();
@@ -833,8 +917,42 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                             c0.body[3] = 0;
                             c0.body[4] = 0;
                             draws = true;
-                        } else {
-                            const float4 s = segs[L.hseg[c] + k];
+                        }
+                    }
+                    // make sure the ring holds every relevant segment this round needs
+                    {
+                        const bool wants = (e < stream_len) && ctag != kItemCircle && L.hrel[c] != 0;
+                        const uint64_t wm = __ballot(wants);
+                        if (wm) {
+                            const uint32_t my_need = wants ? (L.hwoff[c] + (e - L.hoff[c]) + 1u) : 0u;
+                            const uint32_t need = __shfl(my_need, 63 - __builtin_clzll(wm), 64);
+                            while (ring_cnt < need && scan_pos < n_surv) {
+                                const uint32_t i0 = scan_pos + 4u * lane;
+                                uint4 mv = make_uint4(0u, 0u, 0u, 0u);
+                                if (i0 < n_surv) mv = *reinterpret_cast<const uint4 *>(meta + i0);
+                                const uint32_t ma[4] = {mv.x, mv.y, mv.z, mv.w};
+                                uint32_t rb = 0;
+#pragma unroll
+                                for (uint32_t q = 0; q < 4; ++q)
+                                    if (i0 + q < n_surv && ((ma[q] >> tbit) & 1u)) rb |= 1u << q;
+                                const uint32_t rc = __popc(rb);
+                                const uint32_t rincl = WaveInclusiveScan(rc);
+                                uint32_t wp = ring_cnt + rincl - rc;
+#pragma unroll
+                                for (uint32_t q = 0; q < 4; ++q)
+                                    if ((rb >> q) & 1u) L.ring[(wp++) & (kRing - 1u)] = i0 + q;
+                                ring_cnt += __shfl(rincl, 63, 64);
+                                scan_pos += 256u;
+                            }
+                            WaveSync();
+                        }
+                    }
+                    if (e < stream_len) {
+                        if (ctag == kItemFill && L.hrel[c] == 0) {
+                            // backdrop-only fill: nothing to test, the closing command decides
+                        } else if (ctag != kItemCircle) {
+                            const uint32_t k = e - L.hoff[c];
+                            const float4 s = segs[L.ring[(L.hwoff[c] + k) & (kRing - 1u)]];
                             const float a = s.w - s.y;
                             const float b = s.x - s.z;
                             const float cc = -(a * s.x + b * s.y);
@@ -847,15 +965,11 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                                 const float ybot = fminf(fy1, ymax);
                                 const float top = b * ytop;
                                 const float bot = b * ybot;
-                                const float s_top_left = Sgn(left + fy0 * b + cc);
                                 const float s00 = Sgn(top + left + cc);
                                 const float s01 = Sgn(top + right + cc);
                                 const float s10 = Sgn(bot + left + cc);
                                 const float s11 = Sgn(bot + right + cc);
-                                if (s_top_left == Sgn(a) && ymin <= fy0) {
-                                    const int d = -static_cast<int>(s00);  // backdrop -= s00
-                                    if (d != 0) atomicAdd(&L.backdrop[c], d);
-                                }
+                                // (the backdrop term of :326-333 was summed by the binning kernel)
                                 const bool straddle = Straddles(s00, s01, s10, s11);
                                 if (xmin < fx0 && xmax > fx0) {
                                     const float tt = (s.x - fx0) / b;
@@ -1039,6 +1153,7 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                     if (last_draw > last_solid) solid_color = 0;  // encodeCircle/Line/Stroke/DrawFill (:81,:90,:99,:124)
                     WaveSync();
                 }
+                rel_done += pass_rel;
             }
             rec = next;
         }
