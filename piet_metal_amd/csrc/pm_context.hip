@@ -150,6 +150,7 @@ struct pm_ctx {
     uint32_t *d_arena = nullptr;
     uint32_t arena_cap = 0;
     uint32_t *d_striprow = nullptr;
+    uint32_t *d_sr_base = nullptr;  // private arena region of every strip row
     uint32_t *d_queue = nullptr;
     pm::Counters *d_ctr = nullptr;  // [2]
     uint32_t frame = 0;
@@ -219,13 +220,17 @@ int ValidateScene(const uint8_t *meta, size_t meta_len, size_t scene_bytes, uint
 // Exact upper bound (dwords) of what pm_bin_kernel can allocate for this scene,
 // viewport and band: every (strip row, candidate item) costs a candidate record
 // plus 16 B per stream element, every (strip row, batch) a header.
-uint64_t ArenaBound(const pm_ctx *c) {
+// Worst-case arena demand of every strip row of the band (dwords): each batch of 256 items
+// costs a header (+ mask-table padding), every candidate item a mask word + its record +
+// its per-tile table + 16 segment slots (16 B) and 16 meta words per chunk.  The binning
+// kernel bump-allocates inside these private regions, so the bound must be exact or larger.
+void StripRowBounds(const pm_ctx *c, std::vector<uint64_t> *need) {
     const uint8_t *meta = c->item_meta.data();
     uint32_t n, items_ix;
     std::memcpy(&n, meta, 4);
     std::memcpy(&items_ix, meta + 4, 4);
-    const uint64_t striprows = static_cast<uint64_t>(BandRows(c)) * c->strips_x;
-    uint64_t total = pm::kArenaBase + striprows * (pm::kRecHdrDwords + 3u) * ((n + 255u) / 256u);  // header + mask-table padding
+    const uint32_t rows = BandRows(c);
+    need->assign(static_cast<size_t>(rows) * c->strips_x, static_cast<uint64_t>(pm::kRecHdrDwords + 3u) * ((n + 255u) / 256u));
     for (uint32_t i = 0; i < n; ++i) {
         uint16_t bb[4];
         std::memcpy(bb, meta + 8 + 8ull * i, 8);
@@ -238,31 +243,42 @@ uint64_t ArenaBound(const pm_ctx *c) {
         if (tag == pm::kItemFill) nseg = npt;
         if (tag == pm::kItemPoly && npt >= 2) nseg = npt - 1;
         if (tag == pm::kItemLine) nseg = 1;
-        nseg = (nseg + pm::kChunkSegs - 1) / pm::kChunkSegs * pm::kChunkSegs;  // whole chunks are reserved
+        const uint64_t nch = (nseg + pm::kChunkSegs - 1) / pm::kChunkSegs;
+        const uint64_t per = 1u + pm::kCandDwords + pm::kCtDwords + 5ull * pm::kChunkSegs * nch;
         // strips: bz >= sx0 && bx < sx0 + 256 ; rows: bw >= y0 && by < y0 + 16
         const int64_t s_lo = bb[0] / 256, s_hi = std::min<int64_t>(bb[2] / 256, static_cast<int64_t>(c->strips_x) - 1);
         const int64_t r_lo = std::max<int64_t>(bb[1] / 16, c->row0), r_hi = std::min<int64_t>(bb[3] / 16, static_cast<int64_t>(c->row1) - 1);
-        if (s_hi < s_lo || r_hi < r_lo) continue;
-        total += static_cast<uint64_t>(s_hi - s_lo + 1) * static_cast<uint64_t>(r_hi - r_lo + 1) * (pm::kCandDwords + pm::kCtDwords + 1u + 5ull * nseg);  // records + mask word + whole chunks (seg + meta)
+        for (int64_t r = r_lo; r <= r_hi; ++r)
+            for (int64_t sx = s_lo; sx <= s_hi; ++sx) (*need)[static_cast<size_t>(r - c->row0) * c->strips_x + sx] += per;
     }
-    return total;
 }
 
 int EnsureArena(pm_ctx *c) {
     if (!c->arena_dirty && c->d_arena) return PM_OK;
     if (c->item_meta.empty() || c->tiles_x == 0) return PM_OK;  // nothing to size against yet
-    uint64_t need = ArenaBound(c);
-    need += need / 16 + 1024;  // slack
-    if (need > 0xfffffff0ull) {
-        SetError("scene x viewport needs a binning arena beyond 16 GiB");
-        return PM_ERR_CAPACITY;
+    std::vector<uint64_t> need;
+    StripRowBounds(c, &need);
+    std::vector<uint32_t> base(need.size() + 1);
+    uint64_t total = pm::kArenaBase;  // offset 0 means "no record"
+    for (size_t i = 0; i < need.size(); ++i) {
+        base[i] = static_cast<uint32_t>(total);
+        total += (need[i] + 3u) & ~3ull;
+        if (total > 0xfffffff0ull) {
+            SetError("scene x viewport needs a binning arena beyond 16 GiB");
+            return PM_ERR_CAPACITY;
+        }
     }
-    if (!c->d_arena || need > c->arena_cap) {
+    base[need.size()] = static_cast<uint32_t>(total);
+    if (!c->d_arena || total > c->arena_cap) {
         if (c->d_arena) (void)hipFree(c->d_arena);
         c->d_arena = nullptr;
-        PM_TRY(hipMalloc(&c->d_arena, need * sizeof(uint32_t)));
-        c->arena_cap = static_cast<uint32_t>(need);
+        PM_TRY(hipMalloc(&c->d_arena, total * sizeof(uint32_t)));
+        c->arena_cap = static_cast<uint32_t>(total);
     }
+    if (c->d_sr_base) (void)hipFree(c->d_sr_base);
+    c->d_sr_base = nullptr;
+    PM_TRY(hipMalloc(&c->d_sr_base, base.size() * sizeof(uint32_t)));
+    PM_TRY(hipMemcpy(c->d_sr_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     c->arena_dirty = false;
     return PM_OK;
 }
@@ -293,6 +309,7 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     p->arena = c->d_arena;
     p->arena_cap = c->arena_cap;
     p->striprow_head = c->d_striprow;
+    p->sr_base = c->d_sr_base;
     p->queue = c->d_queue;
     p->queue_cap = std::max<uint32_t>(BandRows(c) * c->tiles_x, 1u);
     p->ctr_cur = c->d_ctr + (c->frame & 1u);
@@ -476,7 +493,6 @@ pm_ctx *pm_create(int device, int *err) {
     if ((e = hipMalloc(&c->d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
     pm::Counters init[2];
     std::memset(init, 0, sizeof(init));
-    for (auto &k : init) k.arena_top = pm::kArenaBase;
     if ((e = hipMemcpy(c->d_ctr, init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(counters)");
     Luts *l = new (std::nothrow) Luts();
     if (!l) {
@@ -508,6 +524,7 @@ void pm_destroy(pm_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     FreeViewport(c);
     if (c->d_arena) (void)hipFree(c->d_arena);
+    if (c->d_sr_base) (void)hipFree(c->d_sr_base);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->h_scene) (void)hipHostFree(c->h_scene);

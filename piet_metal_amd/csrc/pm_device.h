@@ -21,8 +21,8 @@ struct Counters {
 };
 
 // Arena record written by pm_bin_kernel for one (strip row, batch of <=256 items):
-//   [0] next record offset (0 = end)   [1] ncand   [2] surviving chunks
-//   [3] V = segments that survived phase 1
+//   [0] next record offset (0 = end)   [1] ncand   [2] chunks streamed (sizes segs/meta)
+//   [4 .. 4+W) segments written by each of the W binning waves   [4+W .. 4+2W) first slot of each extent
 //   mask table: ncand dwords { tag | hitmask16 << 16 }, padded to a multiple of 4
 //       (one 16-byte load per lane of the tile kernel covers 256 candidates); a hit
 //       bit survives only where the candidate can emit a command
@@ -32,8 +32,13 @@ struct Counters {
 //   ncand x 16 dwords: per tile of the strip { backdrop << 20 | relevant segments }
 //       backdrop = the reference's per-tile left-ray winding sum (PietRender.metal
 //       :326-333) over all voted segments of the item, done once here
-//   segs: V x 16 B (start.xy, end.xy), in paint order (space for 16 per surviving chunk)
-//   meta: V x 4 B { tiles of the strip where the segment can emit (16 bits) | candidate << 16 }
+//   segs: 16 B slots (start.xy, end.xy), 16 per streamed chunk; the survivors of binning wave w
+//       occupy slots [start_w, start_w + count_w), extents in paint order
+//   meta: one word per slot { tiles of the strip where the segment can emit | candidate << 16 }
+//
+// Every strip row owns a private arena region [sr_base[i], sr_base[i+1]) sized by the host for
+// the worst case, so the binning kernel allocates with plain arithmetic: no atomics, no
+// counting pass.
 //
 // Tile queue: tiles whose segment stream is long are pushed from the front
 // (queue[0 .. heavy_count)), the others from the back (queue[cap-1-i]); the tile
@@ -48,7 +53,8 @@ struct Counters {
 // the chunks whose box can reach its strip row.
 constexpr uint32_t kChunkSegs = 16;
 constexpr uint32_t kArenaBase = 4;     // offset 0 means "none"
-constexpr uint32_t kRecHdrDwords = 4;
+constexpr int kBinWaves = 4;                          // waves of one binning workgroup (one extent each)
+constexpr uint32_t kRecHdrDwords = 4 + 2 * kBinWaves;  // 4 + extent counts + extent starts
 constexpr uint32_t kCandDwords = 8;
 constexpr uint32_t kCtDwords = 16;           // per candidate: one word per tile of the strip
 constexpr uint32_t kCtShift = 20;            // word = backdrop << 20 | relevant-segment count
@@ -66,6 +72,7 @@ struct FrameParams {
     uint32_t fb_vec16;    // 1 if fb and stride are 16-byte aligned
     uint32_t *arena;
     uint32_t arena_cap;   // dwords
+    const uint32_t *sr_base;  // [n_striprows + 1] private arena region of every strip row
     uint32_t *striprow_head;
     uint32_t *queue;
     uint32_t queue_cap;

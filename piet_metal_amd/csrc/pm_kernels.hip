@@ -48,8 +48,10 @@ namespace pm {
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;   // tile kernel workgroup
 constexpr int kWaves = kThreads / 64;
+constexpr int kBinThreads = 64 * kBinWaves;  // binning workgroup: its waves share one strip row's segment stream
+constexpr uint32_t kBatch = 256;   // candidate items per binning batch
 constexpr uint32_t kHeavyStream = 48;  // stream elements above which a tile is scheduled first
 
 // ---------------------------------------------------------------------------------
@@ -145,8 +147,9 @@ __device__ __forceinline__ bool VotePoly(float4 s, float hw, int y_test, int sx0
     return Straddles(s00, s01, s10, s11);
 }
 
-// Block-wide ordered rank of a predicate (256 threads, 4 waves).  s_part must
-// hold kWaves words.  Contains two barriers.
+// Block-wide ordered rank of a predicate (NW waves).  s_part must hold NW words.
+// Contains two barriers.
+template <int NW>
 __device__ __forceinline__ uint32_t BlockRank(bool pred, uint32_t *s_part, uint32_t *total) {
     const uint64_t m = __ballot(pred);
     const uint32_t wave = threadIdx.x >> 6;
@@ -154,7 +157,7 @@ __device__ __forceinline__ uint32_t BlockRank(bool pred, uint32_t *s_part, uint3
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const uint32_t v = s_part[w];
         if (w < static_cast<int>(wave)) base += v;
         tot += v;
@@ -165,6 +168,7 @@ __device__ __forceinline__ uint32_t BlockRank(bool pred, uint32_t *s_part, uint3
 }
 
 // Block-wide exclusive scan of arbitrary u32 values.  Two barriers.
+template <int NW>
 __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_part, uint32_t *total) {
     const uint32_t incl = WaveInclusiveScan(v);
     const uint32_t wave = threadIdx.x >> 6;
@@ -172,7 +176,7 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_p
     __syncthreads();
     uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const uint32_t x = s_part[w];
         if (w < static_cast<int>(wave)) base += x;
         tot += x;
@@ -231,8 +235,8 @@ __global__ void pm_index_kernel(const uint8_t *scene, uint32_t n_items, const ui
 // K1: binning, one workgroup per strip row
 // =====================================================================================
 
-__global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
-    __shared__ uint32_t s_part[kWaves];
+__global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
+    __shared__ uint32_t s_part[kBinWaves];
     __shared__ uint32_t s_cidx[kThreads];   // candidate item index
     __shared__ uint32_t s_cmask[kThreads];  // candidate per-tile hit mask (16 bits)
     __shared__ uint32_t s_ctag[kThreads];
@@ -242,14 +246,14 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
     __shared__ float s_chw[kThreads];       // 0.5*width + 0.5 for polylines
     __shared__ uint32_t s_cchunk[kThreads]; // first chunk-table entry of the item
     __shared__ uint32_t s_choff[kThreads + 1];  // chunk-stream offsets
-    __shared__ uint32_t s_ccnt[kThreads];   // surviving segments per candidate
-    __shared__ uint32_t s_ct[kThreads * kStripTiles];  // per (candidate, tile): backdrop << 20 | relevant segments
-    __shared__ uint32_t s_surv[kThreads];   // surviving chunks of one round: c << 24 | j
-    __shared__ uint32_t s_est[kStripTiles];  // per tile: stream elements the tile kernel will test
-    __shared__ uint32_t s_rec;
+    __shared__ uint32_t s_ct[kThreads * kStripTiles];  // per (candidate, tile): backdrop steps << 20 | relevant segments
+    __shared__ uint32_t s_surv[kBinWaves][64];  // surviving chunks of one wave round: c << 24 | j
+    __shared__ uint32_t s_est[kStripTiles];  // per tile: stream elements the tile kernel will see
     __shared__ uint32_t s_qbase[2];
 
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = LaneId();
+    const uint32_t wave = tid >> 6;
     const uint32_t strip = blockIdx.x % P.strips_x;
     const uint32_t row_rel = blockIdx.x / P.strips_x;
     const uint32_t ty = P.row0 + row_rel;
@@ -263,27 +267,31 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
     if (blockIdx.x == 0 && tid == 0) {
         // The counters of the NEXT frame (the other parity) are idle now: reset them
         // here so that no separate memset launch is needed.
-        P.ctr_next->arena_top = kArenaBase;
+        P.ctr_next->arena_top = 0;
         P.ctr_next->heavy_count = 0;
         P.ctr_next->light_count = 0;
-        P.ctr_next->cursor = 0;
         P.ctr_next->overflow = 0;
     }
     if (tid < kStripTiles) s_est[tid] = 0;
-    if (tid == 0) P.striprow_head[blockIdx.x] = 0;
     __syncthreads();
 
     const uint8_t *scene = P.scene;
     const uint32_t n_items = LoadU32(scene);
     const uint32_t items_ix = LoadU32(scene + 4);
-    uint32_t *link = &P.striprow_head[blockIdx.x];  // where the next record offset goes
+    // This strip row owns arena[sr_base[b] .. sr_base[b+1]): the host sized it for the worst
+    // case (every chunk of every candidate survives), so records are bump-allocated without
+    // atomics and without a counting pass.
+    uint32_t cursor = P.sr_base[blockIdx.x];
+    const uint32_t region_end = P.sr_base[blockIdx.x + 1];
+    uint32_t head = 0;       // first record of this strip row
+    uint32_t prev_rec = 0;   // record whose `next` field is still open
 
-    for (uint32_t ib = 0; ib < n_items; ib += kThreads) {
+    for (uint32_t ib = 0; ib < n_items; ib += kBatch) {
         // ---- candidate items of this batch, in paint order ----------------------
         const uint32_t i = ib + tid;
         bool cand = false;
         uint32_t mask = 0;
-        if (i < n_items) {
+        if (tid < kBatch && i < n_items) {
             const uint2 bb = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(i) * 8);
             const int bx = static_cast<int>(bb.x & 0xffffu), by = static_cast<int>(bb.x >> 16);
             const int bz = static_cast<int>(bb.y & 0xffffu), bw = static_cast<int>(bb.y >> 16);
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
             }
         }
         uint32_t ncand;
-        const uint32_t cpos = BlockRank(cand, s_part, &ncand);
+        const uint32_t cpos = BlockRank<kBinWaves>(cand, s_part, &ncand);
         if (ncand == 0) continue;  // uniform
         if (cand) {
             s_cidx[cpos] = i;
@@ -347,205 +355,213 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
             s_cnseg[tid] = nseg;
             s_chw[tid] = hw;
             s_cchunk[tid] = P.chunk_base[idx];
-            s_ccnt[tid] = 0;
-#pragma unroll
-            for (uint32_t t = 0; t < kStripTiles; ++t) s_ct[tid * kStripTiles + t] = 0;
+            uint4 *z = reinterpret_cast<uint4 *>(&s_ct[tid * kStripTiles]);
+            z[0] = z[1] = z[2] = z[3] = make_uint4(0u, 0u, 0u, 0u);
         }
         uint32_t total_ch;
-        const uint32_t choff = BlockExclusiveScan(nch, s_part, &total_ch);
+        const uint32_t choff = BlockExclusiveScan<kBinWaves>(nch, s_part, &total_ch);
         if (tid < ncand) s_choff[tid] = choff;
         if (tid == 0) s_choff[ncand] = total_ch;
-        __syncthreads();
 
-        // chunk survival test for stream element `e` (lane-local)
-        auto chunk_survives = [&](uint32_t e, uint32_t *c_out, uint32_t *j_out) -> bool {
-            if (e >= total_ch) return false;
-            const uint32_t c = FindOwner(s_choff, ncand, e);
-            const uint32_t j = e - s_choff[c];
-            *c_out = c;
-            *j_out = j;
-            const uint32_t ctag = s_ctag[c];
-            if (ctag == kItemLine) return true;
-            const float4 bb = P.chunk_bbox[s_cchunk[c] + j];
-            if (ctag == kItemFill)  // necessary part of :264-265 for any segment of the chunk
-                return bb.w >= fy0 && bb.y < fy1 && bb.x < fsx1;
-            const float hw = s_chw[c];  // necessary part of :378-379
-            return bb.w > fsy0 - hw && bb.y < fsy1 + hw && bb.z > fsx0 - hw && bb.x < fsx1 + hw;
-        };
-
-        // ---- pass A: how many chunks survive (sizes the arena record exactly) -------------
-        uint32_t nsurv_chunks = 0;
-        for (uint32_t e0 = 0; e0 < total_ch; e0 += kThreads) {
-            uint32_t c, j;
-            const bool sv = chunk_survives(e0 + tid, &c, &j);
-            uint32_t cnt;
-            (void)BlockRank(sv, s_part, &cnt);
-            nsurv_chunks += cnt;
-        }
+        // ---- the record (uniform arithmetic, no allocation traffic) -----------------------
         const uint32_t mask_dwords = (ncand + 3u) & ~3u;
-        if (tid == 0) {
-            const uint32_t size = kRecHdrDwords + mask_dwords + (kCandDwords + kCtDwords) * ncand + 5u * kChunkSegs * nsurv_chunks;
-            const uint32_t rec = atomicAdd(&P.ctr_cur->arena_top, size);
-            if (rec + size > P.arena_cap || rec + size < rec) {
-                P.ctr_cur->overflow = 1;
-                s_rec = 0;
-            } else {
-                s_rec = rec;
-                *link = rec;
-                P.arena[rec + 0] = 0;  // next
-                P.arena[rec + 1] = ncand;
-                P.arena[rec + 2] = nsurv_chunks;
-            }
+        const uint32_t rec = cursor;
+        const uint32_t size = kRecHdrDwords + mask_dwords + (kCandDwords + kCtDwords) * ncand + 5u * kChunkSegs * total_ch;
+        if (rec + size > region_end) {  // cannot happen unless the host bound is wrong
+            if (tid == 0) P.ctr_cur->overflow = 1;
+            break;
         }
-        __syncthreads();
-        const uint32_t rec = s_rec;
-        if (rec == 0) break;  // arena exhausted (flagged; the host sizes the arena to make this impossible)
-        link = &P.arena[rec];
-        uint32_t *mask_tab = P.arena + rec + kRecHdrDwords;
+        cursor += size;
+        uint32_t *hdr = P.arena + rec;
+        uint32_t *mask_tab = hdr + kRecHdrDwords;
         uint32_t *cand_rec = mask_tab + mask_dwords;
         uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
         float4 *segs = reinterpret_cast<float4 *>(ct_tab + kCtDwords * ncand);
-        uint32_t *meta = reinterpret_cast<uint32_t *>(segs + kChunkSegs * nsurv_chunks);
+        uint32_t *meta = reinterpret_cast<uint32_t *>(segs + kChunkSegs * total_ch);
+        if (tid == 0) {
+            if (prev_rec) P.arena[prev_rec] = rec;
+            hdr[0] = 0;  // next
+            hdr[1] = ncand;
+            hdr[2] = total_ch;
+        }
+        if (head == 0) head = rec;
+        prev_rec = rec;
+        __syncthreads();  // s_choff, s_c* visible to every wave
 
-        // ---- pass B: expand surviving chunks, phase-1 votes, ordered compaction ----------
-        uint32_t vbase = 0;
-        for (uint32_t e0 = 0; e0 < total_ch; e0 += kThreads) {
-            uint32_t c = 0, j = 0;
-            const bool sv = chunk_survives(e0 + tid, &c, &j);
-            uint32_t ns;
-            const uint32_t sp = BlockRank(sv, s_part, &ns);
-            if (sv) s_surv[sp] = (c << 24) | j;
-            __syncthreads();
-            for (uint32_t f0 = 0; f0 < ns * kChunkSegs; f0 += kThreads) {
-                const uint32_t f = f0 + tid;
-                bool vote = false;
-                uint32_t vc = 0;
-                float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (f < ns * kChunkSegs) {
-                    const uint32_t pk = s_surv[f / kChunkSegs];
-                    vc = pk >> 24;
-                    const uint32_t k = (pk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
-                    if (k < s_cnseg[vc]) {
-                        const uint32_t ctag = s_ctag[vc];
-                        const uint8_t *pts = scene + s_cpts[vc];
-                        if (ctag == kItemFill) {
-                            const uint32_t k1 = (k + 1 == s_cnpt[vc]) ? 0u : k + 1;
-                            const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
-                            const float2 b = LoadF2(pts + static_cast<size_t>(k1) * 8);
-                            seg = make_float4(a.x, a.y, b.x, b.y);
-                            vote = VoteFill(seg, y0, sx0);
-                        } else if (ctag == kItemPoly) {
-                            const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
-                            const float2 b = LoadF2(pts + static_cast<size_t>(k + 1) * 8);
-                            seg = make_float4(a.x, a.y, b.x, b.y);
-                            const int y_test = sy0 + static_cast<int>(((k & 31u) >> 4) * kTileH);
-                            vote = VotePoly(seg, s_chw[vc], y_test, sx0, sy0);
-                        } else {  // line
-                            const float2 a = LoadF2(pts);
-                            const float2 b = LoadF2(pts + 8);
-                            seg = make_float4(a.x, a.y, b.x, b.y);
-                            vote = true;
+        // ---- each wave takes a contiguous 1/kBinWaves of the chunk stream ----------------------
+        // Chunks whose box cannot reach the strip row are dropped; the segments of the others
+        // are expanded 4 chunks x 16 segments per step, voted (phase 1), and the survivors
+        // are compacted -- all inside the wave: ballots and mbcnt ranks, no workgroup barrier.
+        {
+            const uint32_t q_lo = static_cast<uint32_t>((static_cast<uint64_t>(total_ch) * wave) / kBinWaves);
+            const uint32_t q_hi = static_cast<uint32_t>((static_cast<uint64_t>(total_ch) * (wave + 1)) / kBinWaves);
+            const uint32_t ext_base = q_lo * kChunkSegs;  // first segment slot of this wave's extent
+            uint32_t vcount = 0;
+            for (uint32_t e0 = q_lo; e0 < q_hi; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                bool sv = false;
+                uint32_t pk = 0;
+                if (e < q_hi) {
+                    const uint32_t c = FindOwner(s_choff, ncand, e);
+                    const uint32_t j = e - s_choff[c];
+                    const uint32_t ctag = s_ctag[c];
+                    pk = (c << 24) | j;
+                    if (ctag == kItemLine) {
+                        sv = true;
+                    } else {
+                        const float4 bb = P.chunk_bbox[s_cchunk[c] + j];
+                        if (ctag == kItemFill) {  // necessary part of :264-265 for any segment of the chunk
+                            sv = bb.w >= fy0 && bb.y < fy1 && bb.x < fsx1;
+                        } else {  // necessary part of :378-379
+                            const float hw = s_chw[c];
+                            sv = bb.w > fsy0 - hw && bb.y < fsy1 + hw && bb.z > fsx0 - hw && bb.x < fsx1 + hw;
                         }
                     }
                 }
-                uint32_t nvote;
-                const uint32_t pos = vbase + BlockRank(vote, s_part, &nvote);
-                if (vote) {
-                    // Per tile of the strip: (a) can this segment emit a command there -- the
-                    // x/box pre-conditions of phase 2 (:334, :349-350, :416-417), evaluated with
-                    // the very comparisons phase 2 uses; (b) for fills, the backdrop term of
-                    // :326-333, which the reference accumulates over EVERY voted segment of the
-                    // row, is summed here once per (item, tile) instead of once per tile wave.
-                    const uint32_t ctag = s_ctag[vc];
-                    const uint32_t hm = s_cmask[vc];
-                    uint32_t M = 0;
-                    const float xmin = fminf(seg.x, seg.z), ymin = fminf(seg.y, seg.w);
-                    const float xmax = fmaxf(seg.x, seg.z), ymax = fmaxf(seg.y, seg.w);
-                    if (ctag == kItemFill) {
-                        const float a = seg.w - seg.y;
-                        const float b = seg.x - seg.z;
-                        const float cc = -(a * seg.x + b * seg.y);
-                        const float top = b * fmaxf(fy0, ymin);
-                        const float sa = Sgn(a);
-                        const bool crosses = ymin <= fy0;
-#pragma unroll
-                        for (uint32_t t = 0; t < kStripTiles; ++t) {
-                            const float fx0 = static_cast<float>(sx0 + static_cast<int>(t * kTileW));
-                            const float fx1 = static_cast<float>(sx0 + static_cast<int>((t + 1) * kTileW));
-                            if (xmin < fx1 && xmax > fx0) M |= 1u << t;
-                            if (crosses && ((hm >> t) & 1u)) {
-                                const float left = a * fx0;
-                                if (Sgn(left + fy0 * b + cc) == sa) {
-                                    const int d = -static_cast<int>(Sgn(top + left + cc));  // backdrop -= s00
-                                    if (d != 0) atomicAdd(&s_ct[vc * kStripTiles + t], static_cast<uint32_t>(d) << kCtShift);
+                const uint64_t svm = __ballot(sv);
+                const uint32_t ns = static_cast<uint32_t>(__popcll(svm));
+                if (ns == 0) continue;
+                WaveSync();
+                if (sv) s_surv[wave][RankBelow(svm)] = pk;
+                WaveSync();
+                for (uint32_t f0 = 0; f0 < ns * kChunkSegs; f0 += 64) {
+                    const uint32_t f = f0 + lane;
+                    bool vote = false;
+                    uint32_t vc = 0;
+                    float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (f < ns * kChunkSegs) {
+                        const uint32_t spk = s_surv[wave][f / kChunkSegs];
+                        vc = spk >> 24;
+                        const uint32_t k = (spk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
+                        if (k < s_cnseg[vc]) {
+                            const uint32_t ctag = s_ctag[vc];
+                            const uint8_t *pts = scene + s_cpts[vc];
+                            if (ctag == kItemFill) {
+                                const uint32_t k1 = (k + 1 == s_cnpt[vc]) ? 0u : k + 1;
+                                const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
+                                const float2 b = LoadF2(pts + static_cast<size_t>(k1) * 8);
+                                seg = make_float4(a.x, a.y, b.x, b.y);
+                                vote = VoteFill(seg, y0, sx0);
+                            } else if (ctag == kItemPoly) {
+                                const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
+                                const float2 b = LoadF2(pts + static_cast<size_t>(k + 1) * 8);
+                                seg = make_float4(a.x, a.y, b.x, b.y);
+                                const int y_test = sy0 + static_cast<int>(((k & 31u) >> 4) * kTileH);
+                                vote = VotePoly(seg, s_chw[vc], y_test, sx0, sy0);
+                            } else {  // line
+                                const float2 a = LoadF2(pts);
+                                const float2 b = LoadF2(pts + 8);
+                                seg = make_float4(a.x, a.y, b.x, b.y);
+                                vote = true;
+                            }
+                        }
+                    }
+                    const uint64_t vm = __ballot(vote);
+                    if (vote) {
+                        // Per tile of the strip: (a) can this segment emit a command there -- the
+                        // x/box pre-conditions of phase 2 (:334, :349-350, :416-417); (b) for fills,
+                        // the backdrop term of :326-333, which the reference accumulates per tile over
+                        // EVERY voted segment of the row, is summed once per (item, tile) here.
+                        const uint32_t ctag = s_ctag[vc];
+                        const uint32_t hm = s_cmask[vc];
+                        uint32_t M = 0;
+                        const float xmin = fminf(seg.x, seg.z), ymin = fminf(seg.y, seg.w);
+                        const float xmax = fmaxf(seg.x, seg.z), ymax = fmaxf(seg.y, seg.w);
+                        if (ctag == kItemFill) {
+                            // xmin < fx1 and xmax > fx0 against integer tile edges: exact in integers
+                            const int fl = static_cast<int>(floorf(fmaxf(fminf(xmin, 1048576.0f), -1048576.0f)));
+                            const int ce = static_cast<int>(ceilf(fmaxf(fminf(xmax, 1048576.0f), -1048576.0f)));
+                            const int t_lo = max(0, (fl - sx0) >> 4);                 // first t with x0+16 > xmin
+                            const int t_hi = min(15, ((ce - sx0 + 15) >> 4) - 1);      // last t with x0 < xmax
+                            if (t_hi >= t_lo) M = ((2u << t_hi) - 1u) & ~((1u << t_lo) - 1u);
+                            if (ymin <= fy0) {
+                                // backdrop: sign(line(x0, y0)) == sign(a) holds on a suffix of the tiles
+                                // (every rounding in a*x0 + y0*b + c is monotone in x0), so one bisection
+                                // finds the first tile; there s00 is the same expression, i.e. sign(a).
+                                const float a = seg.w - seg.y;
+                                const float b = seg.x - seg.z;
+                                const float cc = -(a * seg.x + b * seg.y);
+                                const float sa = Sgn(a);
+                                const float yb = fy0 * b;
+                                if (sa != 0.0f) {
+                                    int lo = 0, hi = 16;  // first t in [0,16] where the predicate holds
+                                    while (lo < hi) {
+                                        const int mid = (lo + hi) >> 1;
+                                        const float fxm = static_cast<float>(sx0 + mid * static_cast<int>(kTileW));
+                                        if (Sgn(a * fxm + yb + cc) == sa) hi = mid; else lo = mid + 1;
+                                    }
+                                    if (lo < 16) atomicAdd(&s_ct[vc * kStripTiles + lo], static_cast<uint32_t>(-static_cast<int>(sa)) << kCtShift);
                                 }
                             }
-                        }
-                    } else if (ctag == kItemPoly) {
-                        const float hw = s_chw[vc];
-                        if (ymax > fy0 - hw && ymin < fy1 + hw) {
-#pragma unroll
-                            for (uint32_t t = 0; t < kStripTiles; ++t) {
-                                const float fx0 = static_cast<float>(sx0 + static_cast<int>(t * kTileW));
-                                const float fx1 = static_cast<float>(sx0 + static_cast<int>((t + 1) * kTileW));
-                                if (xmax > fx0 - hw && xmin < fx1 + hw) M |= 1u << t;
+                        } else if (ctag == kItemPoly) {
+                            const float hw = s_chw[vc];
+                            if (ymax > fy0 - hw && ymin < fy1 + hw) {
+#pragma unroll 4
+                                for (uint32_t t = 0; t < kStripTiles; ++t) {
+                                    const float fx0 = static_cast<float>(sx0 + static_cast<int>(t * kTileW));
+                                    const float fx1 = static_cast<float>(sx0 + static_cast<int>((t + 1) * kTileW));
+                                    if (xmax > fx0 - hw && xmin < fx1 + hw) M |= 1u << t;
+                                }
                             }
+                        } else {
+                            M = 0xffffu;  // a line is tested by every tile its bbox hits (:223-247)
                         }
-                    } else {
-                        M = 0xffffu;  // a line is tested by every tile its bbox hits (:223-247)
+                        M &= hm;
+                        for (uint32_t m = M; m; m &= m - 1) atomicAdd(&s_ct[vc * kStripTiles + __builtin_ctz(m)], 1u);
+                        const uint32_t pos = ext_base + vcount + RankBelow(vm);
+                        segs[pos] = seg;
+                        meta[pos] = M | (vc << 16);
                     }
-                    M &= hm;
-                    for (uint32_t m = M; m; m &= m - 1) atomicAdd(&s_ct[vc * kStripTiles + __builtin_ctz(m)], 1u);
-                    segs[pos] = seg;
-                    meta[pos] = M | (vc << 16);
-                    atomicAdd(&s_ccnt[vc], 1u);
+                    vcount += static_cast<uint32_t>(__popcll(vm));
                 }
-                vbase += nvote;
             }
-            __syncthreads();  // s_surv is rewritten by the next round
+            if (lane == 0) {
+                hdr[4 + wave] = vcount;                // segments in this wave's extent
+                hdr[4 + kBinWaves + wave] = ext_base;  // first slot of the extent
+            }
         }
-        // candidate records, per-(candidate, tile) table, mask table, per-tile stream estimate
-        {
-            const uint32_t v = (tid < ncand) ? s_ccnt[tid] : 0u;
-            uint32_t tot;
-            const uint32_t o = BlockExclusiveScan(v, s_part, &tot);
-            if (tid < mask_dwords) {
-                uint32_t w0 = 0;
-                if (tid < ncand) {
-                    // keep a hit bit only where the candidate can emit something: a relevant
-                    // segment, a non-zero backdrop (Solid / DrawFill), or a circle
-                    uint32_t hm = 0;
-                    uint32_t ct[kStripTiles];
-#pragma unroll
-                    for (uint32_t t = 0; t < kStripTiles; ++t) {
-                        ct[t] = s_ct[tid * kStripTiles + t];
-                        const uint32_t cnt = ct[t] & kCtCountMask;
-                        const int bd = static_cast<int>(ct[t]) >> kCtShift;
-                        const bool pseudo = tag == kItemCircle || (tag == kItemFill && bd != 0);
-                        const uint32_t n_el = cnt ? cnt : (pseudo ? 1u : 0u);
-                        if (n_el && ((s_cmask[tid] >> t) & 1u) && tag != 0) {
-                            hm |= 1u << t;
-                            atomicAdd(&s_est[t], n_el);
-                        }
+        __syncthreads();  // every wave's s_ct contributions are in
+
+        // ---- candidate records, per-(candidate, tile) table, mask table, per-tile estimate ---
+        if (tid < mask_dwords) {
+            uint32_t w0 = 0;
+            if (tid < ncand) {
+                // keep a hit bit only where the candidate can emit something: a relevant
+                // segment, a non-zero backdrop (Solid / DrawFill), or a circle
+                uint32_t hm = 0;
+                int run = 0;  // backdrop steps were recorded at the first tile they apply to
+                uint32_t *ctw = ct_tab + kCtDwords * tid;
+                const uint32_t cm = s_cmask[tid];
+#pragma unroll 4
+                for (uint32_t t = 0; t < kStripTiles; ++t) {
+                    const uint32_t raw = s_ct[tid * kStripTiles + t];
+                    const uint32_t cnt = raw & kCtCountMask;
+                    run += static_cast<int>(raw) >> kCtShift;
+                    ctw[t] = (static_cast<uint32_t>(run) << kCtShift) | cnt;
+                    const bool pseudo = tag == kItemCircle || (tag == kItemFill && run != 0);
+                    const uint32_t n_el = cnt ? cnt : (pseudo ? 1u : 0u);
+                    if (n_el && ((cm >> t) & 1u) && tag != 0) {
+                        hm |= 1u << t;
+                        atomicAdd(&s_est[t], n_el);
                     }
-                    w0 = tag | (hm << 16);
-                    const uint32_t rg = P.lut_srgb2lin[rgba & 0xffu] | (P.lut_srgb2lin[(rgba >> 8) & 0xffu] << 16);
-                    const uint32_t ba = P.lut_srgb2lin[(rgba >> 16) & 0xffu] | (P.lut_unorm2h[rgba >> 24] << 16);
-                    uint4 *cr = reinterpret_cast<uint4 *>(cand_rec + kCandDwords * tid);
-                    cr[0] = make_uint4(w0, rgba, aux0, aux1);
-                    cr[1] = make_uint4(o, v, rg, ba);
-                    uint4 *ctw = reinterpret_cast<uint4 *>(ct_tab + kCtDwords * tid);
-#pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) ctw[q] = make_uint4(ct[4 * q], ct[4 * q + 1], ct[4 * q + 2], ct[4 * q + 3]);
                 }
-                mask_tab[tid] = w0;
+                w0 = tag | (hm << 16);
+                const uint32_t rg = P.lut_srgb2lin[rgba & 0xffu] | (P.lut_srgb2lin[(rgba >> 8) & 0xffu] << 16);
+                const uint32_t ba = P.lut_srgb2lin[(rgba >> 16) & 0xffu] | (P.lut_unorm2h[rgba >> 24] << 16);
+                uint4 *cr = reinterpret_cast<uint4 *>(cand_rec + kCandDwords * tid);
+                cr[0] = make_uint4(w0, rgba, aux0, aux1);
+                cr[1] = make_uint4(s_cidx[tid], 0u, rg, ba);
             }
-            if (tid == 0) P.arena[rec + 3] = tot;
+            mask_tab[tid] = w0;
         }
         __syncthreads();  // s_c* arrays are rewritten by the next batch
     }
+    if (tid == 0) {
+        P.striprow_head[blockIdx.x] = head;
+        atomicAdd(&P.ctr_cur->arena_top, cursor - P.sr_base[blockIdx.x]);  // dwords used (stats only)
+    }
 
-    // ---- queue the touched tiles, clear the untouched ones ------------------------------
+    // ---- queue the tiles with something to draw, clear the others ------------------------
     __syncthreads();
     const uint32_t tiles_here = min(kStripTiles, P.tiles_x - strip * kStripTiles);
     const uint32_t valid = (1u << tiles_here) - 1u;
@@ -567,18 +583,17 @@ __global__ __launch_bounds__(kThreads) void pm_bin_kernel(FrameParams P) {
         if ((heavy >> tid) & 1u) P.queue[s_qbase[0] + __popc(heavy & below)] = tile;
         if ((light >> tid) & 1u) P.queue[P.queue_cap - 1u - (s_qbase[1] + __popc(light & below))] = tile;
     }
-    // tiles with nothing to test are background: no item touches them, or every touching
+    // tiles with nothing to draw are background: no item touches them, or every touching
     // item lost all its segments in phase 1 (the reference writes Bail/white for them)
     const uint32_t clear = ~(heavy | light) & valid;
     if (clear) {
         // 16 pixel rows x 1024 B: thread -> (row = it*4 + tid/64, 16 B = 4 px at lane*4)
-        const uint32_t lane16 = tid & 63u;
-        const uint32_t t = lane16 >> 2;  // tile of these 4 pixels
+        const uint32_t t = lane >> 2;  // tile of these 4 pixels
         if ((clear >> t) & 1u) {
-            const uint32_t px = static_cast<uint32_t>(sx0) + lane16 * 4u;
+            const uint32_t px = static_cast<uint32_t>(sx0) + lane * 4u;
 #pragma unroll
-            for (uint32_t it = 0; it < 4; ++it) {
-                const uint32_t r = it * 4u + (tid >> 6);
+            for (uint32_t it = 0; it < kTileH / kBinWaves; ++it) {
+                const uint32_t r = it * kBinWaves + wave;
                 const uint32_t py = static_cast<uint32_t>(y0) + r;
                 if (py < P.height && px < P.width) {
                     uint8_t *dst = P.fb + static_cast<size_t>(row_rel * kTileH + r) * P.fb_stride + static_cast<size_t>(px) * 4;
@@ -749,6 +764,7 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0
 struct WaveLds {
     Cmd cmds[kWaveCmds];
     uint32_t ring[kRing];     // indices of the record's segments relevant to this tile
+    uint32_t ext[2 * kBinWaves];  // extent table of the record (counts, first slots)
     uint8_t hidx[kThreads];   // candidates of the record that hit this tile (indices)
     uint32_t htag[kWaveCands];
     uint32_t hrgba[kWaveCands];
@@ -818,20 +834,25 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
 
         uint32_t rec = P.striprow_head[sr];
         while (rec != 0) {
-            // header and mask table sit next to each other: both loads are in flight together
+            // header and mask table sit next to each other: all loads are in flight together
             const uint4 hdr = *reinterpret_cast<const uint4 *>(P.arena + rec);
+            const uint32_t ext_word = (lane < 2u * kBinWaves) ? P.arena[rec + 4u + lane] : 0u;  // extent table
             const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * lane);
             const uint32_t next = hdr.x;
             const uint32_t ncand = hdr.y;
-            const uint32_t n_surv = hdr.w;  // segments that survived phase 1 in this record
             const uint32_t mask_dwords = (ncand + 3u) & ~3u;
             const uint32_t *cand_rec = P.arena + rec + kRecHdrDwords + mask_dwords;
             const uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
             const float4 *segs = reinterpret_cast<const float4 *>(ct_tab + kCtDwords * ncand);
             const uint32_t *meta = reinterpret_cast<const uint32_t *>(segs + kChunkSegs * hdr.z);
-            // Worklist of the segments that matter to THIS tile: the record's segment metas are
-            // scanned linearly (4 per lane per step, independent loads) and the indices of those
-            // with this tile's bit are kept, in paint order, in a small LDS ring.
+            // Worklist of the segments that matter to THIS tile: the record's segment metas
+            // (one extent per binning wave, in paint order) are scanned linearly, 4 per
+            // lane per step with independent loads, and the slots of those carrying this
+            // tile's bit are kept, in order, in a small LDS ring.
+            WaveSync();
+            if (lane < 2u * kBinWaves) L.ext[lane] = ext_word;  // [0,16) counts, [16,32) first slots
+            WaveSync();
+            uint32_t ext = 0;       // extent being scanned
             uint32_t scan_pos = 0;  // next segment to scan
             uint32_t ring_cnt = 0;  // relevant segments found so far (ring write position)
             uint32_t rel_done = 0;  // relevant segments owned by earlier candidate passes
@@ -926,21 +947,28 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                         if (wm) {
                             const uint32_t my_need = wants ? (L.hwoff[c] + (e - L.hoff[c]) + 1u) : 0u;
                             const uint32_t need = __shfl(my_need, 63 - __builtin_clzll(wm), 64);
-                            while (ring_cnt < need && scan_pos < n_surv) {
+                            while (ring_cnt < need && ext < static_cast<uint32_t>(kBinWaves)) {
+                                const uint32_t cnt_x = L.ext[ext];
+                                const uint32_t st_x = L.ext[kBinWaves + ext];
+                                if (scan_pos >= cnt_x) {
+                                    ++ext;
+                                    scan_pos = 0;
+                                    continue;
+                                }
                                 const uint32_t i0 = scan_pos + 4u * lane;
                                 uint4 mv = make_uint4(0u, 0u, 0u, 0u);
-                                if (i0 < n_surv) mv = *reinterpret_cast<const uint4 *>(meta + i0);
+                                if (i0 < cnt_x) mv = *reinterpret_cast<const uint4 *>(meta + st_x + i0);
                                 const uint32_t ma[4] = {mv.x, mv.y, mv.z, mv.w};
                                 uint32_t rb = 0;
 #pragma unroll
                                 for (uint32_t q = 0; q < 4; ++q)
-                                    if (i0 + q < n_surv && ((ma[q] >> tbit) & 1u)) rb |= 1u << q;
+                                    if (i0 + q < cnt_x && ((ma[q] >> tbit) & 1u)) rb |= 1u << q;
                                 const uint32_t rc = __popc(rb);
                                 const uint32_t rincl = WaveInclusiveScan(rc);
                                 uint32_t wp = ring_cnt + rincl - rc;
 #pragma unroll
                                 for (uint32_t q = 0; q < 4; ++q)
-                                    if ((rb >> q) & 1u) L.ring[(wp++) & (kRing - 1u)] = i0 + q;
+                                    if ((rb >> q) & 1u) L.ring[(wp++) & (kRing - 1u)] = st_x + i0 + q;
                                 ring_cnt += __shfl(rincl, 63, 64);
                                 scan_pos += 256u;
                             }
@@ -1214,7 +1242,7 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_b
 }
 
 void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream) {
-    hipLaunchKernelGGL(pm_bin_kernel, dim3(n_striprows), dim3(kThreads), 0, stream, p);
+    hipLaunchKernelGGL(pm_bin_kernel, dim3(n_striprows), dim3(kBinThreads), 0, stream, p);
 }
 
 void LaunchTiles(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream) {
