@@ -186,6 +186,11 @@ typedef struct {
 int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *counts,
                           uint32_t *solid, pm_cmd *cmds);
 
+/* Developer profiling hook: re-run the last frame's per-tile kernel recording, per queue
+ * slot, {start clock, end clock (100 MHz wall clock), tile | quarter << 31,
+ * wave << 32 | commands interpreted}.  out receives 4 u64 per slot. */
+int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_slots);
+
 #ifdef __cplusplus
 }
 #endif

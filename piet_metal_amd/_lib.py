@@ -105,6 +105,7 @@ SIGNATURES = {
     "pm_time_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "pm_debug_capture_ptcl": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pm_debug_time_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
 _lib = None

@@ -152,6 +152,7 @@ struct pm_ctx {
     uint32_t *d_striprow = nullptr;
     uint32_t *d_sr_base = nullptr;  // private arena region of every strip row
     uint32_t *d_queue = nullptr;
+    uint32_t *d_tile_state = nullptr;
     pm::Counters *d_ctr = nullptr;  // [2]
     uint32_t frame = 0;
     bool arena_dirty = true;
@@ -173,6 +174,8 @@ void FreeViewport(pm_ctx *c) {
     if (c->d_fb) (void)hipFree(c->d_fb);
     if (c->d_striprow) (void)hipFree(c->d_striprow);
     if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->d_tile_state) (void)hipFree(c->d_tile_state);
+    c->d_tile_state = nullptr;
     c->d_fb = nullptr;
     c->d_striprow = nullptr;
     c->d_queue = nullptr;
@@ -186,6 +189,7 @@ int AllocViewport(pm_ctx *c) {
     PM_TRY(hipMalloc(&c->d_fb, std::max<size_t>(c->fb_bytes, 16)));
     PM_TRY(hipMalloc(&c->d_striprow, std::max<size_t>(static_cast<size_t>(rows) * c->strips_x, 1) * sizeof(uint32_t)));
     PM_TRY(hipMalloc(&c->d_queue, std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&c->d_tile_state, std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));
     c->arena_dirty = true;
     c->have_frame = false;
     return PM_OK;
@@ -312,6 +316,7 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     p->sr_base = c->d_sr_base;
     p->queue = c->d_queue;
     p->queue_cap = std::max<uint32_t>(BandRows(c) * c->tiles_x, 1u);
+    p->tile_state = c->d_tile_state;
     p->ctr_cur = c->d_ctr + (c->frame & 1u);
     p->ctr_next = c->d_ctr + ((c->frame + 1u) & 1u);
     p->chunk_base = c->d_chunk_base;
@@ -323,14 +328,17 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     p->dbg_solid = nullptr;
     p->dbg_cmds = nullptr;
     p->dbg_max = 0;
+    p->dbg_time = nullptr;
     return PM_OK;
 }
+
+constexpr uint32_t kTileWgPerCu = 3;  // resident 256-thread workgroups of pm_tile_kernel per CU (VGPR / LDS budget)
 
 uint32_t TileGrid(const pm_ctx *c) {
     // persistent workgroups: enough to fill every CU at the kernel's occupancy
     const uint32_t tiles = BandRows(c) * c->tiles_x;
     // one wave per tile, 4 waves per workgroup, 3 workgroups resident per CU (LDS / VGPR bound)
-    const uint32_t cap = static_cast<uint32_t>(c->n_cus) * 3u;
+    const uint32_t cap = static_cast<uint32_t>(c->n_cus) * kTileWgPerCu;
     return std::max(1u, std::min((tiles + 3u) / 4u, cap));
 }
 
@@ -754,7 +762,9 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
     PM_TRY(hipMalloc(&d_solid, tiles * sizeof(uint32_t)));
     PM_TRY(hipMalloc(&d_cmds, std::max<size_t>(tiles * max_cmds_per_tile, 1) * sizeof(pm::Cmd)));
     // tiles the binning kernel cleared itself never reach the tile kernel: {Bail}, white
+    // tiles the binning kernel resolved itself never reach the tile kernel: {Bail} + its colour
     std::vector<uint32_t> h_counts(tiles, 1u), h_solid(tiles, 0xffffffffu);
+    if (tiles) PM_TRY(hipMemcpy(h_solid.data(), c->d_tile_state, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::vector<pm::Cmd> h_cmds(tiles * max_cmds_per_tile);
     for (size_t t = 0; t < tiles && max_cmds_per_tile; ++t) {
         h_cmds[t * max_cmds_per_tile].tag = pm::kCmdBail;
@@ -785,6 +795,27 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
     (void)hipFree(d_solid);
     (void)hipFree(d_cmds);
     return status;
+}
+
+int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_slots) {
+    if (!c || !out || !c->have_frame) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    pm::Counters k;
+    PM_TRY(hipMemcpy(&k, c->last_params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
+    const size_t slots = 4ull * k.heavy_count + k.light_count;
+    if (n_slots) *n_slots = slots;
+    if (slots > max_slots) return PM_ERR_CAPACITY;
+    unsigned long long *d = nullptr;
+    PM_TRY(hipMalloc(&d, std::max<size_t>(slots, 1) * 4 * sizeof(unsigned long long)));
+    pm::FrameParams p = c->last_params;
+    p.dbg_time = d;
+    pm::LaunchTiles(p, TileGrid(c), false, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d, slots * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return HipFail(e, "tile timeline");
+    return PM_OK;
 }
 
 // Drop-in for include/piet_metal.h:3 / src/lib.rs:387-393 (make_test_scene -> make_tiger).

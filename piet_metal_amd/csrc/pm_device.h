@@ -76,6 +76,7 @@ struct FrameParams {
     uint32_t *striprow_head;
     uint32_t *queue;
     uint32_t queue_cap;
+    uint32_t *tile_state;     // [tiles of the band] 0 = queued for pm_tile_kernel, else resolved colour
     Counters *ctr_cur;
     Counters *ctr_next;
     const uint32_t *chunk_base;    // [n_items + 1]
@@ -88,6 +89,9 @@ struct FrameParams {
     uint32_t *dbg_solid;
     Cmd *dbg_cmds;
     uint32_t dbg_max;
+    // per-slot timeline of the tile kernel (developer profiling only): 4 x u64 per slot
+    // {start clock, end clock, tile | quarter << 31, wave << 32 | commands interpreted}
+    unsigned long long *dbg_time;
 };
 
 void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks, float4 *chunk_bbox,

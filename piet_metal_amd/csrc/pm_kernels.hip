@@ -249,6 +249,12 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     __shared__ uint32_t s_ct[kThreads * kStripTiles];  // per (candidate, tile): backdrop steps << 20 | relevant segments
     __shared__ uint32_t s_surv[kBinWaves][64];  // surviving chunks of one wave round: c << 24 | j
     __shared__ uint32_t s_est[kStripTiles];  // per tile: stream elements the tile kernel will see
+    // per tile, in paint order across batches: the last candidate that can emit anything, and the
+    // last one that is nothing but an opaque Solid (backdrop-only fill, alpha 0xff).  If they
+    // coincide the tile's list is {Solid(opaque)} -> Bail: the tile is that colour, written here.
+    __shared__ uint32_t s_last_kept[kStripTiles];
+    __shared__ uint32_t s_last_solid[kStripTiles];
+    __shared__ uint32_t s_solid_rgba[kStripTiles];
     __shared__ uint32_t s_qbase[2];
 
     const uint32_t tid = threadIdx.x;
@@ -272,7 +278,12 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
         P.ctr_next->light_count = 0;
         P.ctr_next->overflow = 0;
     }
-    if (tid < kStripTiles) s_est[tid] = 0;
+    if (tid < kStripTiles) {
+        s_est[tid] = 0;
+        s_last_kept[tid] = 0;
+        s_last_solid[tid] = 0;
+        s_solid_rgba[tid] = 0;
+    }
     __syncthreads();
 
     const uint8_t *scene = P.scene;
@@ -286,12 +297,16 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     uint32_t head = 0;       // first record of this strip row
     uint32_t prev_rec = 0;   // record whose `next` field is still open
 
-    for (uint32_t ib = 0; ib < n_items; ib += kBatch) {
-        // ---- candidate items of this batch, in paint order ----------------------
+    // Records hold up to kBatch CANDIDATES (not items): item bboxes are scanned kBatch at a time
+    // and the survivors accumulate; a record is cut only when the next scan step would not fit.
+    // Most strip rows therefore produce a single record.
+    uint32_t ncand = 0;
+    for (uint32_t ib = 0;; ib += kBatch) {
+        const bool more = ib < n_items;  // uniform
         const uint32_t i = ib + tid;
         bool cand = false;
         uint32_t mask = 0;
-        if (tid < kBatch && i < n_items) {
+        if (more && tid < kBatch && i < n_items) {
             const uint2 bb = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(i) * 8);
             const int bx = static_cast<int>(bb.x & 0xffffu), by = static_cast<int>(bb.x >> 16);
             const int bz = static_cast<int>(bb.y & 0xffffu), bw = static_cast<int>(bb.y >> 16);
@@ -304,14 +319,23 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
                 mask = ((2u << t_hi) - 1u) & ~((1u << t_lo) - 1u);
             }
         }
-        uint32_t ncand;
-        const uint32_t cpos = BlockRank<kBinWaves>(cand, s_part, &ncand);
-        if (ncand == 0) continue;  // uniform
-        if (cand) {
-            s_cidx[cpos] = i;
-            s_cmask[cpos] = mask;
+        uint32_t nb = 0;
+        uint32_t cpos = 0;
+        if (more) cpos = BlockRank<kBinWaves>(cand, s_part, &nb);
+        if (more && ncand + nb <= kBatch) {
+            // append and keep scanning
+            if (cand) {
+                s_cidx[ncand + cpos] = i;
+                s_cmask[ncand + cpos] = mask;
+            }
+            ncand += nb;
+            continue;
         }
-        __syncthreads();
+        if (ncand == 0) {
+            if (!more) break;
+            continue;  // (nb > kBatch cannot happen: a scan step tests kBatch items)
+        }
+        __syncthreads();  // the appended candidates are visible
 
         // ---- candidate headers + chunk-stream offsets ---------------------------------
         uint32_t nch = 0;
@@ -543,6 +567,11 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
                     if (n_el && ((cm >> t) & 1u) && tag != 0) {
                         hm |= 1u << t;
                         atomicAdd(&s_est[t], n_el);
+                        const uint32_t key = s_cidx[tid] + 1u;  // paint order
+                        atomicMax(&s_last_kept[t], key);
+                        if (tag == kItemFill && cnt == 0 && (rgba & 0xff000000u) == 0xff000000u) {
+                            atomicMax(&s_last_solid[t], key);
+                        }
                     }
                 }
                 w0 = tag | (hm << 16);
@@ -554,7 +583,26 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
             }
             mask_tab[tid] = w0;
         }
-        __syncthreads();  // s_c* arrays are rewritten by the next batch
+        __syncthreads();
+        if (tid < ncand) {
+            // colour of the newest opaque-solid candidate of each tile (this batch may own it)
+            const uint32_t key = s_cidx[tid] + 1u;
+            const uint32_t w0 = mask_tab[tid];
+            const uint32_t rgba_c = cand_rec[kCandDwords * tid + 1];
+            if ((w0 & 0xffffu) == kItemFill && (rgba_c & 0xff000000u) == 0xff000000u)
+                for (uint32_t m = w0 >> 16; m; m &= m - 1) {
+                    const uint32_t t = __builtin_ctz(m);
+                    if (s_last_solid[t] == key) s_solid_rgba[t] = rgba_c;
+                }
+        }
+        __syncthreads();  // s_c* arrays are rewritten by the next record
+        ncand = 0;
+        if (!more) break;
+        if (cand) {  // the scan step that did not fit opens the next record
+            s_cidx[cpos] = i;
+            s_cmask[cpos] = mask;
+        }
+        ncand = nb;
     }
     if (tid == 0) {
         P.striprow_head[blockIdx.x] = head;
@@ -565,11 +613,12 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     __syncthreads();
     const uint32_t tiles_here = min(kStripTiles, P.tiles_x - strip * kStripTiles);
     const uint32_t valid = (1u << tiles_here) - 1u;
-    uint32_t heavy = 0, light = 0;
+    uint32_t heavy = 0, light = 0, solid = 0;
 #pragma unroll
     for (uint32_t t = 0; t < kStripTiles; ++t) {
         const uint32_t est = s_est[t];
-        if (est > kHeavyStream) heavy |= 1u << t;
+        if (est != 0 && s_last_kept[t] == s_last_solid[t]) solid |= 1u << t;  // {Solid(opaque)} -> Bail
+        else if (est > kHeavyStream) heavy |= 1u << t;
         else if (est != 0) light |= 1u << t;
     }
     heavy &= valid;
@@ -585,11 +634,15 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     }
     // tiles with nothing to draw are background: no item touches them, or every touching
     // item lost all its segments in phase 1 (the reference writes Bail/white for them)
-    const uint32_t clear = ~(heavy | light) & valid;
+    const uint32_t clear = ~(heavy | light) & valid;  // background (white) or one opaque colour
+    if (tid < tiles_here)  // what this kernel decided per tile: 0 = queued, else the tile's colour
+        P.tile_state[row_rel * P.tiles_x + strip * kStripTiles + tid] =
+            ((clear >> tid) & 1u) ? (((solid >> tid) & 1u) ? s_solid_rgba[tid] : 0xffffffffu) : 0u;
     if (clear) {
-        // 16 pixel rows x 1024 B: thread -> (row = it*4 + tid/64, 16 B = 4 px at lane*4)
+        // 16 pixel rows x 1024 B: thread -> (row = it*4 + wave, 16 B = 4 px at lane*4)
         const uint32_t t = lane >> 2;  // tile of these 4 pixels
         if ((clear >> t) & 1u) {
+            const uint32_t col = ((solid >> t) & 1u) ? s_solid_rgba[t] : 0xffffffffu;
             const uint32_t px = static_cast<uint32_t>(sx0) + lane * 4u;
 #pragma unroll
             for (uint32_t it = 0; it < kTileH / kBinWaves; ++it) {
@@ -598,10 +651,10 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
                 if (py < P.height && px < P.width) {
                     uint8_t *dst = P.fb + static_cast<size_t>(row_rel * kTileH + r) * P.fb_stride + static_cast<size_t>(px) * 4;
                     if (px + 4 <= P.width && P.fb_vec16) {
-                        *reinterpret_cast<uint4 *>(dst) = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+                        *reinterpret_cast<uint4 *>(dst) = make_uint4(col, col, col, col);
                     } else {
                         for (uint32_t k = 0; k < 4 && px + k < P.width; ++k)
-                            reinterpret_cast<uint32_t *>(dst)[k] = 0xffffffffu;
+                            reinterpret_cast<uint32_t *>(dst)[k] = col;
                     }
                 }
             }
@@ -618,11 +671,11 @@ namespace {
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 #ifndef PM_WAVE_CMDS
-#define PM_WAVE_CMDS 256
+#define PM_WAVE_CMDS 200
 #endif
 constexpr uint32_t kWaveCmds = PM_WAVE_CMDS;  // LDS command slots per wave: one 64-lane round emits <= 192
 constexpr uint32_t kWaveCands = 64;  // candidates handled per pass
-constexpr uint32_t kRing = 512;      // >= 64 (one round) + 255 (scan overshoot), power of two
+constexpr uint32_t kRing = 256;      // >= 64 (one round) + 127 (scan overshoot), power of two
 
 // Pixels of one lane: 4 horizontally adjacent pixels (x0 .. x0+3, same y).
 struct PixelState {
@@ -761,6 +814,123 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0
     }
 }
 
+
+// ---- quarter-tile mode: one pixel per lane ---------------------------------------------
+// Tiles with long command lists are rendered by four waves (4 pixel rows each): the list
+// is walked in order by every wave, but a lone pixel per lane leaves the divide/area chains
+// without instruction-level parallelism, so runs of consecutive Fill commands are evaluated
+// four at a time (independent chains) and only ACCUMULATED in list order.
+struct PixelState1 {
+    _Float16 r, g, b;
+    float df;
+    _Float16 sa;
+};
+
+__device__ __forceinline__ void Blend1(PixelState1 &st, uint32_t rg, uint32_t ba, _Float16 alpha) {
+    const _Float16 fa = HalfFromBits(ba >> 16) * alpha;
+    const _Float16 fr = HalfFromBits(rg), fg = HalfFromBits(rg >> 16), fb = HalfFromBits(ba);
+    st.r = st.r + (fr - st.r) * fa;
+    st.g = st.g + (fg - st.g) * fa;
+    st.b = st.b + (fb - st.b) * fa;
+}
+
+__device__ __forceinline__ void Interpret1(const Cmd *cmds, uint32_t n, float px, float py, PixelState1 &st) {
+    for (uint32_t i = 0; i < n; ++i) {
+        const Cmd cmd = cmds[i];
+        switch (cmd.tag) {
+            case kCmdCircle: {
+                const float x0 = static_cast<float>(cmd.body[1] & 0xffffu), y0 = static_cast<float>(cmd.body[1] >> 16);
+                const float x1 = static_cast<float>(cmd.body[2] & 0xffffu), y1 = static_cast<float>(cmd.body[2] >> 16);
+                const float cx = x0 + (x1 - x0) * 0.5f, cy = y0 + (y1 - y0) * 0.5f;
+                const float dx = px - cx, dy = py - cy;
+                const float r = sqrtf(dx * dx + dy * dy);
+                const _Float16 alpha = static_cast<_Float16>(Sat(fminf(cx - x0, cy - y0) - r));
+                const _Float16 zero = static_cast<_Float16>(0.0f);
+                st.r = st.r + (zero - st.r) * alpha;
+                st.g = st.g + (zero - st.g) * alpha;
+                st.b = st.b + (zero - st.b) * alpha;
+                break;
+            }
+            case kCmdLine: {
+                const float sx = __uint_as_float(cmd.body[1]), sy = __uint_as_float(cmd.body[2]);
+                const float ex = __uint_as_float(cmd.body[3]), ey = __uint_as_float(cmd.body[4]);
+                const float lx = ex - sx, ly = ey - sy;
+                const float dx = px - sx, dy = py - sy;
+                const float t = Sat((lx * dx + ly * dy) / (lx * lx + ly * ly));
+                const float fx = lx * t - dx, fy = ly * t - dy;
+                st.df = fminf(st.df, sqrtf(fx * fx + fy * fy));
+                break;
+            }
+            case kCmdStroke: {
+                const _Float16 alpha = static_cast<_Float16>(Sat(__uint_as_float(cmd.body[0]) + 0.5f - st.df));
+                Blend1(st, cmd.body[2], cmd.body[3], alpha);
+                st.df = 1e9f;
+                break;
+            }
+            case kCmdFill: {
+                uint32_t run = 1;
+                while (run < 4u && i + run < n && cmds[i + run].tag == kCmdFill) ++run;
+                float sy[4], ey[4], wx[4], wy[4], fsx[4], fex[4];
+                bool live[4];
+                bool any_live = false;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    const Cmd cu = cmds[min(i + u, n - 1u)];
+                    fsx[u] = __uint_as_float(cu.body[1]);
+                    fex[u] = __uint_as_float(cu.body[3]);
+                    sy[u] = __uint_as_float(cu.body[2]) - py;
+                    ey[u] = __uint_as_float(cu.body[4]) - py;
+                    wx[u] = Sat(sy[u]);
+                    wy[u] = Sat(ey[u]);
+                    live[u] = (u < run) && (wx[u] != wy[u]);
+                    any_live = any_live || live[u];
+                }
+                if (any_live) {
+                    float contrib[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {  // four independent chains
+                        const float tx = (wx[u] - sy[u]) / (ey[u] - sy[u]);
+                        const float ty = (wy[u] - sy[u]) / (ey[u] - sy[u]);
+                        const float sx = fsx[u] - px, ex = fex[u] - px;
+                        const float xsx = sx + (ex - sx) * tx;
+                        const float xsy = sx + (ex - sx) * ty;
+                        const float xmin = fminf(fminf(xsx, xsy), 1.0f) - 1e-6f;
+                        const float xmax = fmaxf(xsx, xsy);
+                        const float b = fminf(xmax, 1.0f);
+                        const float c = fmaxf(b, 0.0f);
+                        const float d = fmaxf(xmin, 0.0f);
+                        const float area = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
+                        contrib[u] = area * (wx[u] - wy[u]);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u)  // accumulate in list order (half adds do not commute)
+                        if (live[u]) st.sa = st.sa + static_cast<_Float16>(contrib[u]);
+                }
+                i += run - 1u;
+                break;
+            }
+            case kCmdFillEdge: {
+                const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
+                const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
+                st.sa = static_cast<_Float16>(static_cast<float>(st.sa) + v);
+                break;
+            }
+            case kCmdDrawFill: {
+                _Float16 alpha = st.sa + static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
+                alpha = static_cast<_Float16>(fminf(fabsf(static_cast<float>(alpha)), 1.0f));
+                Blend1(st, cmd.body[2], cmd.body[3], alpha);
+                st.sa = static_cast<_Float16>(0.0f);
+                break;
+            }
+            case kCmdSolid:
+                Blend1(st, cmd.body[1], cmd.body[2], static_cast<_Float16>(1.0f));
+                break;
+            default:
+                break;
+        }
+    }
+}
+
 struct WaveLds {
     Cmd cmds[kWaveCmds];
     uint32_t ring[kRing];     // indices of the record's segments relevant to this tile
@@ -800,10 +970,18 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
     const uint32_t wave_global = blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWaves;
 
-    for (uint32_t pass = 0; pass * n_waves < n_total; ++pass) {
+    // heavy tiles are rendered by four waves (quarter = 4 pixel rows, one pixel per lane)
+    const uint32_t n_heavy_slots = 4u * n_heavy;
+    const uint32_t n_slots = n_heavy_slots + (n_total - n_heavy);
+    for (uint32_t pass = 0; pass * n_waves < n_slots; ++pass) {
         const uint32_t slot = pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
-        if (slot >= n_total) continue;
-        const uint32_t tile = (slot < n_heavy) ? P.queue[slot] : P.queue[P.queue_cap - 1u - (slot - n_heavy)];
+        if (slot >= n_slots) continue;
+        const bool quarter = slot < n_heavy_slots;
+        const uint32_t part = slot & 3u;
+        const uint32_t tile = quarter ? P.queue[slot >> 2] : P.queue[P.queue_cap - 1u - (slot - n_heavy_slots)];
+        unsigned long long t_begin = 0, t_hdr = 0, t_bin = 0, t_int = 0;
+        uint32_t dbg_ncmd = 0;
+        if (P.dbg_time) t_begin = wall_clock64();
         const uint32_t tx = tile % P.tiles_x;
         const uint32_t ty_rel = tile / P.tiles_x;
         const uint32_t ty = P.row0 + ty_rel;
@@ -815,10 +993,16 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
         const uint32_t tbit = tx & (kStripTiles - 1);
         const uint32_t sr = ty_rel * P.strips_x + tx / kStripTiles;
 
-        // lane -> 4 pixels: x = x0 + 4*(lane&3) + k, y = y0 + lane/4
-        const uint32_t pxi = static_cast<uint32_t>(x0) + (lane & 3u) * 4u;
-        const uint32_t pyi = static_cast<uint32_t>(y0) + (lane >> 2);
+        // whole-tile mode: lane -> 4 pixels, x = x0 + 4*(lane&3) + k, y = y0 + lane/4
+        // quarter mode:    lane -> 1 pixel,  x = x0 + (lane&15),    y = y0 + 4*part + lane/16
+        const uint32_t pxi = static_cast<uint32_t>(x0) + (quarter ? (lane & 15u) : (lane & 3u) * 4u);
+        const uint32_t prow = quarter ? (4u * part + (lane >> 4)) : (lane >> 2);
+        const uint32_t pyi = static_cast<uint32_t>(y0) + prow;
         const float px0 = static_cast<float>(pxi), py = static_cast<float>(pyi);
+        PixelState1 s1;
+        s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
+        s1.df = 1e9f;
+        s1.sa = static_cast<_Float16>(0.0f);
         PixelState st;
         const half2_t one2 = Splat(static_cast<_Float16>(1.0f));
         st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = one2;
@@ -840,6 +1024,7 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
             const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * lane);
             const uint32_t next = hdr.x;
             const uint32_t ncand = hdr.y;
+            if (P.dbg_time && t_hdr == 0 && ncand != 0xffffffffu) t_hdr = wall_clock64();
             const uint32_t mask_dwords = (ncand + 3u) & ~3u;
             const uint32_t *cand_rec = P.arena + rec + kRecHdrDwords + mask_dwords;
             const uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
@@ -955,22 +1140,22 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                                     scan_pos = 0;
                                     continue;
                                 }
-                                const uint32_t i0 = scan_pos + 4u * lane;
-                                uint4 mv = make_uint4(0u, 0u, 0u, 0u);
-                                if (i0 < cnt_x) mv = *reinterpret_cast<const uint4 *>(meta + st_x + i0);
-                                const uint32_t ma[4] = {mv.x, mv.y, mv.z, mv.w};
+                                const uint32_t i0 = scan_pos + 2u * lane;
+                                uint2 mv = make_uint2(0u, 0u);
+                                if (i0 < cnt_x) mv = *reinterpret_cast<const uint2 *>(meta + st_x + i0);
+                                const uint32_t ma[2] = {mv.x, mv.y};
                                 uint32_t rb = 0;
 #pragma unroll
-                                for (uint32_t q = 0; q < 4; ++q)
+                                for (uint32_t q = 0; q < 2; ++q)
                                     if (i0 + q < cnt_x && ((ma[q] >> tbit) & 1u)) rb |= 1u << q;
                                 const uint32_t rc = __popc(rb);
                                 const uint32_t rincl = WaveInclusiveScan(rc);
                                 uint32_t wp = ring_cnt + rincl - rc;
 #pragma unroll
-                                for (uint32_t q = 0; q < 4; ++q)
+                                for (uint32_t q = 0; q < 2; ++q)
                                     if ((rb >> q) & 1u) L.ring[(wp++) & (kRing - 1u)] = st_x + i0 + q;
                                 ring_cnt += __shfl(rincl, 63, 64);
-                                scan_pos += 256u;
+                                scan_pos += 128u;
                             }
                             WaveSync();
                         }
@@ -1129,11 +1314,16 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                             st.df[k] = 1e9f;
                             st.sa[k] = static_cast<_Float16>(0.0f);
                         }
+                        s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
+                        s1.df = 1e9f;
+                        s1.sa = static_cast<_Float16>(0.0f);
                         base = 0u - first_kept;
                     } else {
                         first_kept = 0;
                         if (n_pending + round_total > kWaveCmds) {
-                            Interpret(L.cmds, n_pending, px0, py, st);
+                            if (quarter) Interpret1(L.cmds, n_pending, px0, py, s1);
+                            else Interpret(L.cmds, n_pending, px0, py, st);
+                            dbg_ncmd += n_pending;
                             n_pending = 0;
                             WaveSync();
                         }
@@ -1187,33 +1377,42 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
         }
 
         // ---- TileEncoder::end() (:144-151) + composite (:34-44) ------------------------------
-        uint4 out;
-        if (solid_color != 0) {
-            out = make_uint4(solid_color, solid_color, solid_color, solid_color);  // Bail: bytes as stored
+        if (P.dbg_time) t_bin = wall_clock64() + (n_pending & 0u);
+        const uint8_t *lut = P.lut_lin2srgb;
+        auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {  // linear -> sRGB + unorm8 (:563-565)
+            return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, r)]) |
+                   (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
+                   (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, b)]) << 16) | 0xff000000u;
+        };
+        uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
+        if (quarter) {
+            uint32_t o1 = solid_color;  // Bail: the tile is one opaque colour, bytes as stored
+            if (solid_color == 0) {
+                Interpret1(L.cmds, n_pending, px0, py, s1);
+                o1 = enc(s1.r, s1.g, s1.b);
+            }
+            if (pyi < P.height && pxi < P.width) *reinterpret_cast<uint32_t *>(dst) = o1;
         } else {
-            Interpret(L.cmds, n_pending, px0, py, st);
-            // linear -> sRGB + unorm8 (:563-565) through the pinned table
-            const uint8_t *lut = P.lut_lin2srgb;
-            auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {
-                return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, r)]) |
-                       (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
-                       (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, b)]) << 16) | 0xff000000u;
-            };
-            out.x = enc(st.r01.x, st.g01.x, st.b01.x);
-            out.y = enc(st.r01.y, st.g01.y, st.b01.y);
-            out.z = enc(st.r23.x, st.g23.x, st.b23.x);
-            out.w = enc(st.r23.y, st.g23.y, st.b23.y);
-        }
-        if (pyi < P.height && pxi < P.width) {
-            uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + (lane >> 2)) * P.fb_stride + static_cast<size_t>(pxi) * 4;
-            if (pxi + 4 <= P.width && P.fb_vec16) {
-                *reinterpret_cast<uint4 *>(dst) = out;
+            uint4 out;
+            if (solid_color != 0) {
+                out = make_uint4(solid_color, solid_color, solid_color, solid_color);
             } else {
-                const uint32_t o[4] = {out.x, out.y, out.z, out.w};
-                for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = o[k];
+                Interpret(L.cmds, n_pending, px0, py, st);
+                out.x = enc(st.r01.x, st.g01.x, st.b01.x);
+                out.y = enc(st.r01.y, st.g01.y, st.b01.y);
+                out.z = enc(st.r23.x, st.g23.x, st.b23.x);
+                out.w = enc(st.r23.y, st.g23.y, st.b23.y);
+            }
+            if (pyi < P.height && pxi < P.width) {
+                if (pxi + 4 <= P.width && P.fb_vec16) {
+                    *reinterpret_cast<uint4 *>(dst) = out;
+                } else {
+                    const uint32_t o[4] = {out.x, out.y, out.z, out.w};
+                    for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = o[k];
+                }
             }
         }
-        if (kCapture && lane == 0) {
+        if (kCapture && lane == 0 && (!quarter || part == 0)) {
             // list as the reference leaves it: {Bail} or cmds + End
             P.dbg_solid[tile] = solid_color;
             Cmd tail;
@@ -1227,6 +1426,13 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                 tail.tag = kCmdEnd;
                 if (list_len < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + list_len] = tail;
             }
+        }
+        if (P.dbg_time && lane == 0) {
+            unsigned long long *d = P.dbg_time + 4ull * slot;
+            d[0] = t_begin | ((t_hdr - t_begin) << 40);   // low 40 bits start, high 24: ticks to first header
+            d[1] = wall_clock64() | ((t_bin - t_begin) << 40);  // high 24: ticks until binning done
+            d[2] = tile | (quarter ? 0x80000000u : 0u);
+            d[3] = (static_cast<unsigned long long>(wave_global) << 32) | (dbg_ncmd + (solid_color ? 0u : n_pending));
         }
         WaveSync();  // L reuse by the next tile
     }

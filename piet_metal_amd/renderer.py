@@ -155,6 +155,18 @@ class Renderer:
         return counts, solid, cmds
 
 
+def _time_tiles(self, max_slots: int = 1 << 20) -> np.ndarray:
+    """Developer profiling: per-slot timeline of the tile kernel, rows =
+    (start, end, tile | quarter << 31, wave << 32 | commands)."""
+    out = np.zeros((max_slots, 4), np.uint64)
+    n = C.c_size_t(0)
+    _lib.check(self._lib.pm_debug_time_tiles(self._h, out.ctypes.data, max_slots, C.byref(n)), "pm_debug_time_tiles")
+    return out[: n.value]
+
+
+Renderer.time_tiles = _time_tiles
+
+
 def init_test_scene(buf: np.ndarray) -> None:
     """The reference's one FFI symbol (include/piet_metal.h:3): Tiger at scale 8."""
     lib = _lib.load()
