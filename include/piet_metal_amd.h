@@ -155,10 +155,10 @@ void *pm_framebuffer_device_ptr(pm_ctx *c, size_t *stride_bytes, uint32_t *rows)
 void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes);
 
 /* Time `iters` back-to-back frames with HIP events on the ctx stream.
- * total_ms = whole batch; k1_ms/k2_ms = average per-launch duration of the
- * binning and the per-tile kernels measured in separate event-bracketed passes
- * (any pointer may be NULL). */
-int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *k1_ms, float *k2_ms);
+ * total_ms = whole batch; bin/coarse/fine_ms = average per-launch duration of the three
+ * frame kernels (pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel) measured in a separate
+ * event-bracketed pass (any pointer may be NULL). */
+int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms);
 
 typedef struct {
     uint32_t tiles_x, tiles_y;    /* tile grid of the viewport */
@@ -170,6 +170,7 @@ typedef struct {
     uint32_t overflow;            /* 1 if the last frame ran out of arena */
     uint32_t scene_bytes;
     uint32_t heavy_tiles;         /* of queued_tiles: scheduled first (long segment streams) */
+    uint32_t ptcl_used_cmds;      /* command-list slots reserved last frame */
 } pm_stats;
 int pm_get_stats(pm_ctx *c, pm_stats *out); /* synchronises */
 
@@ -189,7 +190,7 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
 /* Developer profiling hook: re-run the last frame's per-tile kernel recording, per queue
  * slot, {start clock, end clock (100 MHz wall clock), tile | quarter << 31,
  * wave << 32 | commands interpreted}.  out receives 4 u64 per slot. */
-int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_slots);
+int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_slots); /* pm_fine_kernel */
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,7 @@ class Stats(C.Structure):
         ("overflow", C.c_uint32),
         ("scene_bytes", C.c_uint32),
         ("heavy_tiles", C.c_uint32),
+        ("ptcl_used_cmds", C.c_uint32),
     ]
 
 
@@ -102,7 +103,7 @@ SIGNATURES = {
     "pm_read_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "pm_framebuffer_device_ptr": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "pm_scene_device_ptr": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
-    "pm_time_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pm_time_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "pm_debug_capture_ptcl": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pm_debug_time_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

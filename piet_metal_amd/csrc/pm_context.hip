@@ -123,7 +123,7 @@ void BuildLuts(Luts *l) {
 struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
 
     // scene
@@ -153,6 +153,10 @@ struct pm_ctx {
     uint32_t *d_sr_base = nullptr;  // private arena region of every strip row
     uint32_t *d_queue = nullptr;
     uint32_t *d_tile_state = nullptr;
+    uint32_t *d_tile_ptcl = nullptr;
+    uint32_t *d_tile_ncmd = nullptr;
+    pm::Cmd *d_ptcl = nullptr;  // per-tile command lists
+    uint32_t ptcl_cap = 0;      // commands
     pm::Counters *d_ctr = nullptr;  // [2]
     uint32_t frame = 0;
     bool arena_dirty = true;
@@ -163,6 +167,7 @@ struct pm_ctx {
     uint8_t *d_lut_lin2srgb = nullptr;
 
     pm::FrameParams last_params{};
+    hipStream_t last_stream = nullptr;
     bool have_frame = false;
 };
 
@@ -175,7 +180,11 @@ void FreeViewport(pm_ctx *c) {
     if (c->d_striprow) (void)hipFree(c->d_striprow);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_tile_state) (void)hipFree(c->d_tile_state);
+    if (c->d_tile_ptcl) (void)hipFree(c->d_tile_ptcl);
+    if (c->d_tile_ncmd) (void)hipFree(c->d_tile_ncmd);
     c->d_tile_state = nullptr;
+    c->d_tile_ptcl = nullptr;
+    c->d_tile_ncmd = nullptr;
     c->d_fb = nullptr;
     c->d_striprow = nullptr;
     c->d_queue = nullptr;
@@ -188,8 +197,10 @@ int AllocViewport(pm_ctx *c) {
     c->fb_bytes = c->fb_stride * static_cast<size_t>(rows) * pm::kTileH;
     PM_TRY(hipMalloc(&c->d_fb, std::max<size_t>(c->fb_bytes, 16)));
     PM_TRY(hipMalloc(&c->d_striprow, std::max<size_t>(static_cast<size_t>(rows) * c->strips_x, 1) * sizeof(uint32_t)));
-    PM_TRY(hipMalloc(&c->d_queue, std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&c->d_queue, 3 * std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));  // three class queues
     PM_TRY(hipMalloc(&c->d_tile_state, std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&c->d_tile_ptcl, std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&c->d_tile_ncmd, std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));
     c->arena_dirty = true;
     c->have_frame = false;
     return PM_OK;
@@ -283,6 +294,14 @@ int EnsureArena(pm_ctx *c) {
     c->d_sr_base = nullptr;
     PM_TRY(hipMalloc(&c->d_sr_base, base.size() * sizeof(uint32_t)));
     PM_TRY(hipMemcpy(c->d_sr_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (!c->d_ptcl) {
+        // Command-list arena: lists are sized from what binning actually found, so there is no
+        // static bound; start generously (HBM is 288 GB) and let pm_sync grow it on overflow.
+        uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
+        cmds = std::min<uint64_t>(cmds, 0x7fffffffull);
+        PM_TRY(hipMalloc(&c->d_ptcl, cmds * sizeof(pm::Cmd)));
+        c->ptcl_cap = static_cast<uint32_t>(cmds);
+    }
     c->arena_dirty = false;
     return PM_OK;
 }
@@ -317,6 +336,10 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     p->queue = c->d_queue;
     p->queue_cap = std::max<uint32_t>(BandRows(c) * c->tiles_x, 1u);
     p->tile_state = c->d_tile_state;
+    p->ptcl = c->d_ptcl;
+    p->ptcl_cap = c->ptcl_cap;
+    p->tile_ptcl = c->d_tile_ptcl;
+    p->tile_ncmd = c->d_tile_ncmd;
     p->ctr_cur = c->d_ctr + (c->frame & 1u);
     p->ctr_next = c->d_ctr + ((c->frame + 1u) & 1u);
     p->chunk_base = c->d_chunk_base;
@@ -332,14 +355,18 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     return PM_OK;
 }
 
-constexpr uint32_t kTileWgPerCu = 3;  // resident 256-thread workgroups of pm_tile_kernel per CU (VGPR / LDS budget)
+// Persistent grids: workgroups of 4 waves, one wave per tile (or per quarter tile).
+constexpr uint32_t kCoarseWgPerCu = 6;  // pm_coarse_kernel: latency-bound, small register footprint
+constexpr uint32_t kFineWgPerCu = 4;    // pm_fine_kernel: VALU-bound interpreter
 
-uint32_t TileGrid(const pm_ctx *c) {
-    // persistent workgroups: enough to fill every CU at the kernel's occupancy
+uint32_t CoarseGrid(const pm_ctx *c) {
     const uint32_t tiles = BandRows(c) * c->tiles_x;
-    // one wave per tile, 4 waves per workgroup, 3 workgroups resident per CU (LDS / VGPR bound)
-    const uint32_t cap = static_cast<uint32_t>(c->n_cus) * kTileWgPerCu;
-    return std::max(1u, std::min((tiles + 3u) / 4u, cap));
+    return std::max(1u, std::min((tiles + 3u) / 4u, static_cast<uint32_t>(c->n_cus) * kCoarseWgPerCu));
+}
+
+uint32_t FineGrid(const pm_ctx *c) {
+    const uint32_t tiles = BandRows(c) * c->tiles_x;
+    return std::max(1u, std::min(tiles, static_cast<uint32_t>(c->n_cus) * kFineWgPerCu));
 }
 
 int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t stream) {
@@ -347,8 +374,10 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t stream) {
     int r = BuildParams(c, fb, stride, &p);
     if (r != PM_OK) return r;
     pm::LaunchBin(p, BandRows(c) * c->strips_x, stream);
-    pm::LaunchTiles(p, TileGrid(c), false, stream);
+    pm::LaunchCoarse(p, CoarseGrid(c), false, stream);
+    pm::LaunchFine(p, FineGrid(c), stream);
     PM_TRY(hipGetLastError());
+    c->last_stream = stream;
     c->last_params = p;
     c->have_frame = true;
     c->frame += 1;
@@ -533,6 +562,7 @@ void pm_destroy(pm_ctx *c) {
     FreeViewport(c);
     if (c->d_arena) (void)hipFree(c->d_arena);
     if (c->d_sr_base) (void)hipFree(c->d_sr_base);
+    if (c->d_ptcl) (void)hipFree(c->d_ptcl);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->h_scene) (void)hipHostFree(c->h_scene);
@@ -647,13 +677,25 @@ int pm_sync(pm_ctx *c) {
     if (!c) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
     PM_TRY(hipStreamSynchronize(c->stream));
-    if (c->have_frame) {
+    for (int attempt = 0; c->have_frame && attempt < 6; ++attempt) {
+        if (c->last_stream && c->last_stream != c->stream) PM_TRY(hipStreamSynchronize(c->last_stream));
         pm::Counters k;
         PM_TRY(hipMemcpy(&k, c->last_params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
-        if (k.overflow) {
-            SetError("binning arena overflow (internal sizing error)");
-            return PM_ERR_CAPACITY;
-        }
+        if (!k.overflow) return PM_OK;
+        // the command-list arena was too small for this frame: grow it and render the frame again
+        const uint64_t want = std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(4ull * c->ptcl_cap, 2ull * k.ptcl_top));
+        if (want <= c->ptcl_cap) break;
+        (void)hipFree(c->d_ptcl);
+        c->d_ptcl = nullptr;
+        PM_TRY(hipMalloc(&c->d_ptcl, want * sizeof(pm::Cmd)));
+        c->ptcl_cap = static_cast<uint32_t>(want);
+        const int r = Enqueue(c, c->last_params.fb, c->last_params.fb_stride, c->last_stream ? c->last_stream : c->stream);
+        if (r != PM_OK) return r;
+        PM_TRY(hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
+    }
+    if (c->have_frame) {
+        SetError("command-list arena overflow (frame needs more than 2^31 commands)");
+        return PM_ERR_CAPACITY;
     }
     return PM_OK;
 }
@@ -686,7 +728,7 @@ void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes) {
     return c->d_scene;
 }
 
-int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *k1_ms, float *k2_ms) {
+int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms) {
     if (!c || iters <= 0) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
     int r;
@@ -698,28 +740,34 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *k1_ms, float *k
         PM_TRY(hipEventSynchronize(c->ev[1]));
         PM_TRY(hipEventElapsedTime(total_ms, c->ev[0], c->ev[1]));
     }
-    if (k1_ms || k2_ms) {
-        double a1 = 0, a2 = 0;
+    if (bin_ms || coarse_ms || fine_ms) {
+        double a1 = 0, a2 = 0, a3 = 0;
         for (int i = 0; i < iters; ++i) {
             pm::FrameParams p;
             if ((r = BuildParams(c, c->d_fb, c->fb_stride, &p)) != PM_OK) return r;
             PM_TRY(hipEventRecord(c->ev[0], c->stream));
             pm::LaunchBin(p, BandRows(c) * c->strips_x, c->stream);
             PM_TRY(hipEventRecord(c->ev[1], c->stream));
-            pm::LaunchTiles(p, TileGrid(c), false, c->stream);
+            pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
             PM_TRY(hipEventRecord(c->ev[2], c->stream));
-            PM_TRY(hipEventSynchronize(c->ev[2]));
+            pm::LaunchFine(p, FineGrid(c), c->stream);
+            PM_TRY(hipEventRecord(c->ev[3], c->stream));
+            PM_TRY(hipEventSynchronize(c->ev[3]));
             c->last_params = p;
+            c->last_stream = c->stream;
             c->have_frame = true;
             c->frame += 1;
-            float t1 = 0, t2 = 0;
+            float t1 = 0, t2 = 0, t3 = 0;
             PM_TRY(hipEventElapsedTime(&t1, c->ev[0], c->ev[1]));
             PM_TRY(hipEventElapsedTime(&t2, c->ev[1], c->ev[2]));
+            PM_TRY(hipEventElapsedTime(&t3, c->ev[2], c->ev[3]));
             a1 += t1;
             a2 += t2;
+            a3 += t3;
         }
-        if (k1_ms) *k1_ms = static_cast<float>(a1 / iters);
-        if (k2_ms) *k2_ms = static_cast<float>(a2 / iters);
+        if (bin_ms) *bin_ms = static_cast<float>(a1 / iters);
+        if (coarse_ms) *coarse_ms = static_cast<float>(a2 / iters);
+        if (fine_ms) *fine_ms = static_cast<float>(a3 / iters);
     }
     return pm_sync(c);
 }
@@ -739,9 +787,10 @@ int pm_get_stats(pm_ctx *c, pm_stats *out) {
     if (c->have_frame) {
         pm::Counters k;
         PM_TRY(hipMemcpy(&k, c->last_params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
-        out->queued_tiles = k.heavy_count + k.light_count;
-        out->heavy_tiles = k.heavy_count;
+        out->queued_tiles = k.vheavy_count + k.heavy_count + k.light_count;
+        out->heavy_tiles = k.vheavy_count + k.heavy_count;
         out->arena_used_dwords = k.arena_top;
+        out->ptcl_used_cmds = k.ptcl_top;
         out->overflow = k.overflow;
     }
     return PM_OK;
@@ -780,12 +829,8 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
         p.dbg_solid = d_solid;
         p.dbg_cmds = d_cmds;
         p.dbg_max = max_cmds_per_tile;
-        // the capture pass replays the last frame's queue: rewind its cursor
-        e = hipMemsetAsync(&p.ctr_cur->cursor, 0, sizeof(uint32_t), c->stream);
-        if (e == hipSuccess) {
-            pm::LaunchTiles(p, TileGrid(c), true, c->stream);
-            e = hipStreamSynchronize(c->stream);
-        }
+        pm::LaunchCoarse(p, CoarseGrid(c), true, c->stream);  // replays the last frame's queue
+        e = hipStreamSynchronize(c->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(counts, d_counts, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(solid, d_solid, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);
@@ -803,14 +848,14 @@ int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_sl
     PM_TRY(hipStreamSynchronize(c->stream));
     pm::Counters k;
     PM_TRY(hipMemcpy(&k, c->last_params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
-    const size_t slots = 4ull * k.heavy_count + k.light_count;
+    const size_t slots = 16ull * k.vheavy_count + 4ull * k.heavy_count + k.light_count;
     if (n_slots) *n_slots = slots;
     if (slots > max_slots) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;
     PM_TRY(hipMalloc(&d, std::max<size_t>(slots, 1) * 4 * sizeof(unsigned long long)));
     pm::FrameParams p = c->last_params;
     p.dbg_time = d;
-    pm::LaunchTiles(p, TileGrid(c), false, c->stream);
+    pm::LaunchFine(p, FineGrid(c), c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d, slots * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(d);

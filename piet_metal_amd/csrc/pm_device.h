@@ -13,11 +13,12 @@ namespace pm {
 // kernel can reset frame N+1's copy (no memset launch on the critical path).
 struct Counters {
     uint32_t arena_top;    // bump pointer into the arena, in dwords
-    uint32_t heavy_count;  // tiles pushed at the front of the queue (long segment streams)
+    uint32_t heavy_count;  // tiles in queue B (long lists: 4 waves per tile)
     uint32_t overflow;     // set if the arena ran out
-    uint32_t light_count;  // tiles pushed at the back of the queue
-    uint32_t cursor;       // next queue slot handed to a wave of the per-tile kernel
-    uint32_t pad[3];
+    uint32_t light_count;  // tiles in queue C (one wave per tile)
+    uint32_t ptcl_top;     // bump pointer into the command-list arena, in commands
+    uint32_t vheavy_count; // tiles in queue A (very long lists: 16 waves per tile)
+    uint32_t pad[2];
 };
 
 // Arena record written by pm_bin_kernel for one (strip row, batch of <=256 items):
@@ -76,7 +77,11 @@ struct FrameParams {
     uint32_t *striprow_head;
     uint32_t *queue;
     uint32_t queue_cap;
-    uint32_t *tile_state;     // [tiles of the band] 0 = queued for pm_tile_kernel, else resolved colour
+    uint32_t *tile_state;     // [tiles of the band] 0 = queued for the tile kernels, else resolved colour
+    Cmd *ptcl;                // per-tile command lists (24-byte records, TestApp/GenTypes.h:430-495)
+    uint32_t ptcl_cap;        // in commands
+    uint32_t *tile_ptcl;      // [tiles] first command slot of the tile's list
+    uint32_t *tile_ncmd;      // [tiles] commands in the list (0: resolved to one colour)
     Counters *ctr_cur;
     Counters *ctr_next;
     const uint32_t *chunk_base;    // [n_items + 1]
@@ -97,6 +102,7 @@ struct FrameParams {
 void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks, float4 *chunk_bbox,
                  hipStream_t stream);
 void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream);
-void LaunchTiles(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream);
+void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream);
+void LaunchFine(const FrameParams &p, uint32_t grid, hipStream_t stream);
 
 }  // namespace pm

@@ -52,7 +52,8 @@ constexpr int kThreads = 256;   // tile kernel workgroup
 constexpr int kWaves = kThreads / 64;
 constexpr int kBinThreads = 64 * kBinWaves;  // binning workgroup: its waves share one strip row's segment stream
 constexpr uint32_t kBatch = 256;   // candidate items per binning batch
-constexpr uint32_t kHeavyStream = 48;  // stream elements above which a tile is scheduled first
+constexpr uint32_t kHeavyStream = 32;       // stream elements above which a tile is split over 4 waves
+constexpr uint32_t kVeryHeavyStream = 96;   // ... over 16 waves (one pixel row each)
 
 // ---------------------------------------------------------------------------------
 // small helpers
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     __shared__ uint32_t s_last_kept[kStripTiles];
     __shared__ uint32_t s_last_solid[kStripTiles];
     __shared__ uint32_t s_solid_rgba[kStripTiles];
-    __shared__ uint32_t s_qbase[2];
+    __shared__ uint32_t s_qbase[3];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = LaneId();
@@ -274,6 +275,8 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
         // The counters of the NEXT frame (the other parity) are idle now: reset them
         // here so that no separate memset launch is needed.
         P.ctr_next->arena_top = 0;
+        P.ctr_next->ptcl_top = 0;
+        P.ctr_next->vheavy_count = 0;
         P.ctr_next->heavy_count = 0;
         P.ctr_next->light_count = 0;
         P.ctr_next->overflow = 0;
@@ -613,28 +616,55 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     __syncthreads();
     const uint32_t tiles_here = min(kStripTiles, P.tiles_x - strip * kStripTiles);
     const uint32_t valid = (1u << tiles_here) - 1u;
-    uint32_t heavy = 0, light = 0, solid = 0;
+    uint32_t vheavy = 0, heavy = 0, light = 0, solid = 0;
 #pragma unroll
     for (uint32_t t = 0; t < kStripTiles; ++t) {
         const uint32_t est = s_est[t];
         if (est != 0 && s_last_kept[t] == s_last_solid[t]) solid |= 1u << t;  // {Solid(opaque)} -> Bail
+        else if (est > kVeryHeavyStream) vheavy |= 1u << t;
         else if (est > kHeavyStream) heavy |= 1u << t;
         else if (est != 0) light |= 1u << t;
     }
+    vheavy &= valid;
     heavy &= valid;
     light &= valid;
-    if (tid == 0 && heavy) s_qbase[0] = atomicAdd(&P.ctr_cur->heavy_count, static_cast<uint32_t>(__popc(heavy)));
-    if (tid == 1 && light) s_qbase[1] = atomicAdd(&P.ctr_cur->light_count, static_cast<uint32_t>(__popc(light)));
+    const uint32_t queued = vheavy | heavy | light;
+    // command-list slots of the queued tiles: an element emits at most 2 commands + its item's
+    // closing command, plus End -- one atomic per strip row on the list arena
+    if (tid == 0 && queued) {
+        uint32_t total = 0;
+        uint32_t off[kStripTiles];
+#pragma unroll
+        for (uint32_t t = 0; t < kStripTiles; ++t) {
+            off[t] = total;
+            if ((queued >> t) & 1u) total += 3u * s_est[t] + 1u;
+        }
+        const uint32_t base = atomicAdd(&P.ctr_cur->ptcl_top, total);
+        const bool fits = base + total <= P.ptcl_cap && base + total >= base;
+        if (!fits) P.ctr_cur->overflow = 1;
+#pragma unroll
+        for (uint32_t t = 0; t < kStripTiles; ++t)
+            if ((queued >> t) & 1u)
+                P.tile_ptcl[row_rel * P.tiles_x + strip * kStripTiles + t] = fits ? base + off[t] : 0xffffffffu;
+        if (!fits) s_est[0] = 0xffffffffu;  // poison: queue nothing from this strip row
+    }
+    __syncthreads();
+    if (s_est[0] == 0xffffffffu) vheavy = heavy = light = 0;
+    if (tid == 0 && vheavy) s_qbase[0] = atomicAdd(&P.ctr_cur->vheavy_count, static_cast<uint32_t>(__popc(vheavy)));
+    if (tid == 1 && heavy) s_qbase[1] = atomicAdd(&P.ctr_cur->heavy_count, static_cast<uint32_t>(__popc(heavy)));
+    if (tid == 2 && light) s_qbase[2] = atomicAdd(&P.ctr_cur->light_count, static_cast<uint32_t>(__popc(light)));
     __syncthreads();
     if (tid < kStripTiles) {
+        // three queues, by expected list length: the fine kernel starts with the longest
         const uint32_t tile = row_rel * P.tiles_x + strip * kStripTiles + tid;
         const uint32_t below = (1u << tid) - 1u;
-        if ((heavy >> tid) & 1u) P.queue[s_qbase[0] + __popc(heavy & below)] = tile;
-        if ((light >> tid) & 1u) P.queue[P.queue_cap - 1u - (s_qbase[1] + __popc(light & below))] = tile;
+        if ((vheavy >> tid) & 1u) P.queue[s_qbase[0] + __popc(vheavy & below)] = tile;
+        if ((heavy >> tid) & 1u) P.queue[P.queue_cap + s_qbase[1] + __popc(heavy & below)] = tile;
+        if ((light >> tid) & 1u) P.queue[2u * P.queue_cap + s_qbase[2] + __popc(light & below)] = tile;
     }
     // tiles with nothing to draw are background: no item touches them, or every touching
     // item lost all its segments in phase 1 (the reference writes Bail/white for them)
-    const uint32_t clear = ~(heavy | light) & valid;  // background (white) or one opaque colour
+    const uint32_t clear = ~queued & valid;  // background (white) or one opaque colour
     if (tid < tiles_here)  // what this kernel decided per tile: 0 = queued, else the tile's colour
         P.tile_state[row_rel * P.tiles_x + strip * kStripTiles + tid] =
             ((clear >> tid) & 1u) ? (((solid >> tid) & 1u) ? s_solid_rgba[tid] : 0xffffffffu) : 0u;
@@ -663,7 +693,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
 }
 
 // =====================================================================================
-// K2: per-tile command build (LDS) + per-pixel interpreter, one wave per tile
+// K2: per-tile command lists (tile-level half of tileKernel), one wave per tile
 // =====================================================================================
 
 namespace {
@@ -671,9 +701,9 @@ namespace {
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
 #ifndef PM_WAVE_CMDS
-#define PM_WAVE_CMDS 200
+#define PM_WAVE_CMDS 256
 #endif
-constexpr uint32_t kWaveCmds = PM_WAVE_CMDS;  // LDS command slots per wave: one 64-lane round emits <= 192
+constexpr uint32_t kFineChunk = PM_WAVE_CMDS;  // commands staged in LDS per wave by the interpreter
 constexpr uint32_t kWaveCands = 64;  // candidates handled per pass
 constexpr uint32_t kRing = 256;      // >= 64 (one round) + 127 (scan overshoot), power of two
 
@@ -931,8 +961,7 @@ __device__ __forceinline__ void Interpret1(const Cmd *cmds, uint32_t n, float px
     }
 }
 
-struct WaveLds {
-    Cmd cmds[kWaveCmds];
+struct CoarseLds {
     uint32_t ring[kRing];     // indices of the record's segments relevant to this tile
     uint32_t ext[2 * kBinWaves];  // extent table of the record (counts, first slots)
     uint8_t hidx[kThreads];   // candidates of the record that hit this tile (indices)
@@ -953,35 +982,28 @@ struct WaveLds {
 }  // namespace
 
 template <bool kCapture>
-__global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
-    __shared__ WaveLds s_lds[kWaves];
-    WaveLds &L = s_lds[threadIdx.x >> 6];
+__global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
+    __shared__ CoarseLds s_lds[kWaves];
+    CoarseLds &L = s_lds[threadIdx.x >> 6];
 
     const uint32_t lane = LaneId();
     const uint64_t lanes_below = (1ull << lane) - 1ull;
-    const uint32_t n_heavy = P.ctr_cur->heavy_count;
-    const uint32_t n_total = n_heavy + P.ctr_cur->light_count;
+    const uint32_t n_a = P.ctr_cur->vheavy_count, n_b = P.ctr_cur->heavy_count;
+    const uint32_t n_total = n_a + n_b + P.ctr_cur->light_count;
 
-    // Static snake hand-out over [heavy tiles..., light tiles...]: pass k gives wave g the
-    // slot k*G + g (k even) or k*G + (G-1-g) (k odd).  The waves that start with the most
-    // expensive tiles are the ones that get the last (or no) tile of the final pass.  No
-    // atomics: one device-scope counter tops out near 90 dequeues/us on this chip, far
-    // below the tile rate.
+    // Static snake hand-out over [longest lists..., shortest...]: pass k gives wave g the slot
+    // k*G + g (k even) or k*G + (G-1-g) (k odd).  No atomics: one device-scope counter tops out
+    // near 90 dequeues/us on this chip, far below the tile rate.
     const uint32_t wave_global = blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWaves;
 
-    // heavy tiles are rendered by four waves (quarter = 4 pixel rows, one pixel per lane)
-    const uint32_t n_heavy_slots = 4u * n_heavy;
-    const uint32_t n_slots = n_heavy_slots + (n_total - n_heavy);
-    for (uint32_t pass = 0; pass * n_waves < n_slots; ++pass) {
+    for (uint32_t pass = 0; pass * n_waves < n_total; ++pass) {
         const uint32_t slot = pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
-        if (slot >= n_slots) continue;
-        const bool quarter = slot < n_heavy_slots;
-        const uint32_t part = slot & 3u;
-        const uint32_t tile = quarter ? P.queue[slot >> 2] : P.queue[P.queue_cap - 1u - (slot - n_heavy_slots)];
-        unsigned long long t_begin = 0, t_hdr = 0, t_bin = 0, t_int = 0;
-        uint32_t dbg_ncmd = 0;
-        if (P.dbg_time) t_begin = wall_clock64();
+        if (slot >= n_total) continue;
+        const uint32_t tile = (slot < n_a) ? P.queue[slot]
+                              : (slot < n_a + n_b) ? P.queue[P.queue_cap + (slot - n_a)]
+                                                   : P.queue[2u * P.queue_cap + (slot - n_a - n_b)];
+        Cmd *const out_cmds = P.ptcl + P.tile_ptcl[tile];  // this tile's private command slots
         const uint32_t tx = tile % P.tiles_x;
         const uint32_t ty_rel = tile / P.tiles_x;
         const uint32_t ty = P.row0 + ty_rel;
@@ -993,27 +1015,8 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
         const uint32_t tbit = tx & (kStripTiles - 1);
         const uint32_t sr = ty_rel * P.strips_x + tx / kStripTiles;
 
-        // whole-tile mode: lane -> 4 pixels, x = x0 + 4*(lane&3) + k, y = y0 + lane/4
-        // quarter mode:    lane -> 1 pixel,  x = x0 + (lane&15),    y = y0 + 4*part + lane/16
-        const uint32_t pxi = static_cast<uint32_t>(x0) + (quarter ? (lane & 15u) : (lane & 3u) * 4u);
-        const uint32_t prow = quarter ? (4u * part + (lane >> 4)) : (lane >> 2);
-        const uint32_t pyi = static_cast<uint32_t>(y0) + prow;
-        const float px0 = static_cast<float>(pxi), py = static_cast<float>(pyi);
-        PixelState1 s1;
-        s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
-        s1.df = 1e9f;
-        s1.sa = static_cast<_Float16>(0.0f);
-        PixelState st;
-        const half2_t one2 = Splat(static_cast<_Float16>(1.0f));
-        st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = one2;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            st.df[k] = 1e9f;
-            st.sa[k] = static_cast<_Float16>(0.0f);
-        }
-
         uint32_t solid_color = 0xffffffffu;  // TileEncoder::solidColor (:74)
-        uint32_t n_pending = 0;              // commands waiting in L.cmds
+        uint32_t n_pending = 0;              // commands written to the tile's list so far
         uint32_t list_len = 0;               // logical list length since tileBegin (capture)
 
         uint32_t rec = P.striprow_head[sr];
@@ -1024,7 +1027,6 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
             const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * lane);
             const uint32_t next = hdr.x;
             const uint32_t ncand = hdr.y;
-            if (P.dbg_time && t_hdr == 0 && ncand != 0xffffffffu) t_hdr = wall_clock64();
             const uint32_t mask_dwords = (ncand + 3u) & ~3u;
             const uint32_t *cand_rec = P.arena + rec + kRecHdrDwords + mask_dwords;
             const uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
@@ -1297,43 +1299,23 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                     if (ms) last_solid = __shfl(static_cast<int>(pos + n_em), 63 - __builtin_clzll(ms), 64);
                     if (md) last_draw = __shfl(static_cast<int>(pos + lane_total) - 1, 63 - __builtin_clzll(md), 64);
 
-                    uint32_t base;        // L.cmds slot of round position 0 (may be "negative")
+                    uint32_t base;        // list slot of round position 0 (may be "negative")
                     uint32_t first_kept;  // round positions below this are dropped
                     if (last_solid >= 0) {
-                        // TileEncoder::encodeSolid with an opaque colour (:132-135): the list restarts
-                        // at tileBegin, so everything before it -- including pixels already blended by
-                        // an earlier flush -- is forgotten.
+                        // TileEncoder::encodeSolid with an opaque colour (:132-135): dst = tileBegin
                         first_kept = static_cast<uint32_t>(last_solid);
                         n_pending = 0;
                         list_len = 0;
-                        st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = one2;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            // an item cut in two by a flush may lose its closing DrawFill / Stroke to
-                            // this restart: the interpreter state must be the fresh one of :470-472
-                            st.df[k] = 1e9f;
-                            st.sa[k] = static_cast<_Float16>(0.0f);
-                        }
-                        s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
-                        s1.df = 1e9f;
-                        s1.sa = static_cast<_Float16>(0.0f);
                         base = 0u - first_kept;
                     } else {
                         first_kept = 0;
-                        if (n_pending + round_total > kWaveCmds) {
-                            if (quarter) Interpret1(L.cmds, n_pending, px0, py, s1);
-                            else Interpret(L.cmds, n_pending, px0, py, st);
-                            dbg_ncmd += n_pending;
-                            n_pending = 0;
-                            WaveSync();
-                        }
                         base = n_pending;
                     }
                     {
                         uint32_t p = pos;
                         if (n_em >= 1) {
                             if (p >= first_kept) {
-                                L.cmds[base + p] = c0;
+                                out_cmds[base + p] = c0;
                                 if (kCapture) {
                                     const uint32_t li = list_len + p - first_kept;
                                     if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = c0;
@@ -1343,7 +1325,7 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                         }
                         if (n_em == 2) {
                             if (p >= first_kept) {
-                                L.cmds[base + p] = c1;
+                                out_cmds[base + p] = c1;
                                 if (kCapture) {
                                     const uint32_t li = list_len + p - first_kept;
                                     if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = c1;
@@ -1352,7 +1334,7 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                             ++p;
                         }
                         if (has_fin && p >= first_kept) {
-                            L.cmds[base + p] = fin;
+                            out_cmds[base + p] = fin;
                             if (kCapture) {
                                 const uint32_t li = list_len + p - first_kept;
                                 if (li < P.dbg_max) {
@@ -1376,43 +1358,23 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
             rec = next;
         }
 
-        // ---- TileEncoder::end() (:144-151) + composite (:34-44) ------------------------------
-        if (P.dbg_time) t_bin = wall_clock64() + (n_pending & 0u);
-        const uint8_t *lut = P.lut_lin2srgb;
-        auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {  // linear -> sRGB + unorm8 (:563-565)
-            return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, r)]) |
-                   (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
-                   (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, b)]) << 16) | 0xff000000u;
-        };
-        uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
-        if (quarter) {
-            uint32_t o1 = solid_color;  // Bail: the tile is one opaque colour, bytes as stored
-            if (solid_color == 0) {
-                Interpret1(L.cmds, n_pending, px0, py, s1);
-                o1 = enc(s1.r, s1.g, s1.b);
-            }
-            if (pyi < P.height && pxi < P.width) *reinterpret_cast<uint32_t *>(dst) = o1;
-        } else {
-            uint4 out;
-            if (solid_color != 0) {
-                out = make_uint4(solid_color, solid_color, solid_color, solid_color);
-            } else {
-                Interpret(L.cmds, n_pending, px0, py, st);
-                out.x = enc(st.r01.x, st.g01.x, st.b01.x);
-                out.y = enc(st.r01.y, st.g01.y, st.b01.y);
-                out.z = enc(st.r23.x, st.g23.x, st.b23.x);
-                out.w = enc(st.r23.y, st.g23.y, st.b23.y);
-            }
+        // ---- TileEncoder::end() (:144-151): Bail tiles are finished here (composite :34-44) ----
+        if (lane == 0) P.tile_ncmd[tile] = solid_color ? 0u : n_pending;
+        if (solid_color != 0) {
+            // the tile is one opaque colour, bytes as stored: 64 lanes x 16 B = the whole tile
+            const uint32_t pxi = static_cast<uint32_t>(x0) + (lane & 3u) * 4u;
+            const uint32_t prow = lane >> 2;
+            const uint32_t pyi = static_cast<uint32_t>(y0) + prow;
             if (pyi < P.height && pxi < P.width) {
+                uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
                 if (pxi + 4 <= P.width && P.fb_vec16) {
-                    *reinterpret_cast<uint4 *>(dst) = out;
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(solid_color, solid_color, solid_color, solid_color);
                 } else {
-                    const uint32_t o[4] = {out.x, out.y, out.z, out.w};
-                    for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = o[k];
+                    for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = solid_color;
                 }
             }
         }
-        if (kCapture && lane == 0 && (!quarter || part == 0)) {
+        if (kCapture && lane == 0) {
             // list as the reference leaves it: {Bail} or cmds + End
             P.dbg_solid[tile] = solid_color;
             Cmd tail;
@@ -1427,14 +1389,118 @@ __global__ __launch_bounds__(kThreads) void pm_tile_kernel(FrameParams P) {
                 if (list_len < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + list_len] = tail;
             }
         }
+        WaveSync();  // L reuse by the next tile
+    }
+}
+
+// ---- launch wrappers (called from pm_context.hip) -----------------------------------------
+
+// =====================================================================================
+// K3: per-pixel interpreter (renderKernel :457-566) over the per-tile command lists
+// =====================================================================================
+// Light tiles: one wave per tile, 4 adjacent pixels per lane.  Tiles with long lists: four
+// waves per tile (4 pixel rows each, 1 pixel per lane, Fill runs evaluated 4 at a time).
+// The list is staged through LDS in chunks with coalesced loads; interpreter state stays
+// in registers across chunks.
+__global__ __launch_bounds__(kThreads) void pm_fine_kernel(FrameParams P) {
+    __shared__ Cmd s_cmds[kWaves][kFineChunk];
+    Cmd *const cmds = s_cmds[threadIdx.x >> 6];
+
+    const uint32_t lane = LaneId();
+    const uint32_t n_a = P.ctr_cur->vheavy_count, n_b = P.ctr_cur->heavy_count, n_c = P.ctr_cur->light_count;
+    const uint32_t wave_global = blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * kWaves;
+    // slots: 16 per very heavy tile (one pixel row per wave), 4 per heavy tile, 1 per light tile
+    const uint32_t s_a = 16u * n_a, s_b = 4u * n_b;
+    const uint32_t n_slots = s_a + s_b + n_c;
+    const uint8_t *lut = P.lut_lin2srgb;
+    auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {  // linear -> sRGB + unorm8 (:563-565)
+        return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, r)]) |
+               (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
+               (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, b)]) << 16) | 0xff000000u;
+    };
+
+    for (uint32_t pass = 0; pass * n_waves < n_slots; ++pass) {
+        const uint32_t slot = pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
+        if (slot >= n_slots) continue;
+        // rows of the tile this wave renders: [row0, row0 + nrows)
+        uint32_t tile, row0, nrows;
+        if (slot < s_a) {
+            tile = P.queue[slot >> 4];
+            row0 = slot & 15u;
+            nrows = 1;
+        } else if (slot < s_a + s_b) {
+            tile = P.queue[P.queue_cap + ((slot - s_a) >> 2)];
+            row0 = 4u * ((slot - s_a) & 3u);
+            nrows = 4;
+        } else {
+            tile = P.queue[2u * P.queue_cap + (slot - s_a - s_b)];
+            row0 = 0;
+            nrows = 16;
+        }
+        const bool quarter = nrows != 16u;  // one pixel per lane (lanes beyond nrows*16 idle)
+        unsigned long long t_begin = 0;
+        if (P.dbg_time) t_begin = wall_clock64();
+        const uint32_t n_cmd = P.tile_ncmd[tile];
+        if (n_cmd != 0) {  // 0: the coarse kernel found one opaque colour and wrote it
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(P.ptcl + P.tile_ptcl[tile]);
+            const uint32_t tx = tile % P.tiles_x;
+            const uint32_t ty_rel = tile / P.tiles_x;
+            const uint32_t x0 = tx * kTileW;
+            const uint32_t y0 = (P.row0 + ty_rel) * kTileH;
+            // whole-tile mode: lane -> 4 pixels, x = x0 + 4*(lane&3) + k, y = y0 + lane/4
+            // split mode:      lane -> 1 pixel,  x = x0 + (lane&15),    y = y0 + row0 + lane/16
+            const uint32_t pxi = x0 + (quarter ? (lane & 15u) : (lane & 3u) * 4u);
+            const uint32_t prow = quarter ? (row0 + (lane >> 4)) : (lane >> 2);
+            const uint32_t pyi = y0 + prow;
+            const bool lane_on = !quarter || (lane >> 4) < nrows;
+            const float px0 = static_cast<float>(pxi), py = static_cast<float>(pyi);
+            PixelState1 s1;
+            s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
+            s1.df = 1e9f;
+            s1.sa = static_cast<_Float16>(0.0f);
+            PixelState st;
+            st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = Splat(static_cast<_Float16>(1.0f));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                st.df[k] = 1e9f;
+                st.sa[k] = static_cast<_Float16>(0.0f);
+            }
+            for (uint32_t c0 = 0; c0 < n_cmd; c0 += kFineChunk) {
+                const uint32_t m = min(kFineChunk, n_cmd - c0);
+                WaveSync();
+                // 24-byte commands, 8-byte aligned: copy as 64-bit words, coalesced
+                const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
+                uint2 *l = reinterpret_cast<uint2 *>(cmds);
+                for (uint32_t w = lane; w < 3u * m; w += 64u) l[w] = g[w];
+                WaveSync();
+                if (quarter) Interpret1(cmds, m, px0, py, s1);
+                else Interpret(cmds, m, px0, py, st);
+            }
+            uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
+            if (quarter) {
+                if (lane_on && pyi < P.height && pxi < P.width) *reinterpret_cast<uint32_t *>(dst) = enc(s1.r, s1.g, s1.b);
+            } else if (pyi < P.height && pxi < P.width) {
+                uint4 out;
+                out.x = enc(st.r01.x, st.g01.x, st.b01.x);
+                out.y = enc(st.r01.y, st.g01.y, st.b01.y);
+                out.z = enc(st.r23.x, st.g23.x, st.b23.x);
+                out.w = enc(st.r23.y, st.g23.y, st.b23.y);
+                if (pxi + 4 <= P.width && P.fb_vec16) {
+                    *reinterpret_cast<uint4 *>(dst) = out;
+                } else {
+                    const uint32_t o[4] = {out.x, out.y, out.z, out.w};
+                    for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = o[k];
+                }
+            }
+        }
         if (P.dbg_time && lane == 0) {
             unsigned long long *d = P.dbg_time + 4ull * slot;
-            d[0] = t_begin | ((t_hdr - t_begin) << 40);   // low 40 bits start, high 24: ticks to first header
-            d[1] = wall_clock64() | ((t_bin - t_begin) << 40);  // high 24: ticks until binning done
+            d[0] = t_begin;
+            d[1] = wall_clock64();
             d[2] = tile | (quarter ? 0x80000000u : 0u);
-            d[3] = (static_cast<unsigned long long>(wave_global) << 32) | (dbg_ncmd + (solid_color ? 0u : n_pending));
+            d[3] = (static_cast<unsigned long long>(wave_global) << 32) | n_cmd;
         }
-        WaveSync();  // L reuse by the next tile
     }
 }
 
@@ -1451,11 +1517,15 @@ void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream) {
     hipLaunchKernelGGL(pm_bin_kernel, dim3(n_striprows), dim3(kBinThreads), 0, stream, p);
 }
 
-void LaunchTiles(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream) {
+void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream) {
     if (capture)
-        hipLaunchKernelGGL(pm_tile_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, p);
+        hipLaunchKernelGGL(pm_coarse_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, p);
     else
-        hipLaunchKernelGGL(pm_tile_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, p);
+        hipLaunchKernelGGL(pm_coarse_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, p);
+}
+
+void LaunchFine(const FrameParams &p, uint32_t grid, hipStream_t stream) {
+    hipLaunchKernelGGL(pm_fine_kernel, dim3(grid), dim3(kThreads), 0, stream, p);
 }
 
 }  // namespace pm

@@ -128,12 +128,13 @@ class Renderer:
         return out
 
     def time_frames(self, iters: int, per_kernel: bool = True) -> dict:
-        tot, k1, k2 = C.c_float(0), C.c_float(0), C.c_float(0)
+        tot, k1, k2, k3 = C.c_float(0), C.c_float(0), C.c_float(0), C.c_float(0)
+        pk = per_kernel
         _lib.check(
-            self._lib.pm_time_frames(self._h, iters, C.byref(tot), C.byref(k1) if per_kernel else None, C.byref(k2) if per_kernel else None),
+            self._lib.pm_time_frames(self._h, iters, C.byref(tot), C.byref(k1) if pk else None, C.byref(k2) if pk else None, C.byref(k3) if pk else None),
             "pm_time_frames",
         )
-        return {"total_ms": tot.value, "bin_ms": k1.value, "tile_ms": k2.value, "iters": iters}
+        return {"total_ms": tot.value, "bin_ms": k1.value, "coarse_ms": k2.value, "fine_ms": k3.value, "iters": iters}
 
     def stats(self) -> dict:
         s = _lib.Stats()

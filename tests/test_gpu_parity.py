@@ -263,5 +263,5 @@ def test_back_to_back_frames_and_timing_api(pm, pmo, renderer):
     renderer.resize(1024, 768)
     renderer.set_scene_bytes(scene)
     tm = renderer.time_frames(10)
-    assert tm["total_ms"] > 0 and tm["bin_ms"] > 0 and tm["tile_ms"] > 0
+    assert tm["total_ms"] > 0 and tm["bin_ms"] > 0 and tm["fine_ms"] > 0
     assert np.array_equal(renderer.read_pixels(), pmo.render(scene, 1024, 768))

@@ -11,10 +11,7 @@ for _ in range(3):
     r.render()
 r.sync()
 t = r.time_tiles()
-M40 = (1 << 40) - 1
-start, end = (t[:, 0] & np.uint64(M40)).astype(np.int64), (t[:, 1] & np.uint64(M40)).astype(np.int64)
-d_hdr = (t[:, 0] >> np.uint64(40)).astype(np.int64) * 1e-2
-d_bin = (t[:, 1] >> np.uint64(40)).astype(np.int64) * 1e-2
+start, end = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
 tile = (t[:, 2] & 0x7fffffff).astype(np.int64); quarter = (t[:, 2] >> 31).astype(bool)
 wave = (t[:, 3] >> 32).astype(np.int64); ncmd = (t[:, 3] & 0xffffffff).astype(np.int64)
 t0 = start.min(); us = 1e-2  # 100 MHz wall clock -> 10 ns ticks
@@ -31,9 +28,5 @@ print(f"first-slot start spread us: {((start[np.argsort(start)][:3000]-t0)*us).m
 for lo, hi in [(0,0),(1,4),(5,16),(17,48),(49,100),(101,1000)]:
     m = (ncmd >= lo) & (ncmd <= hi)
     if m.any(): print(f"ncmd {lo:3d}-{hi:4d}: {m.sum():6d} slots, mean dur {dur[m].mean():6.2f} us, total {dur[m].sum():8.0f} us, us/cmd {dur[m].sum()/max(1,ncmd[m].sum()):.3f}")
-print(f'phase means (us): to first header {d_hdr.mean():.2f}, to end of binning {d_bin.mean():.2f}, total {dur.mean():.2f}')
-for lo, hi in [(0,0),(1,4),(5,16),(17,48),(49,1000)]:
-    m = (ncmd >= lo) & (ncmd <= hi)
-    if m.any(): print(f'  ncmd {lo}-{hi}: hdr {d_hdr[m].mean():.2f} bin {d_bin[m].mean():.2f} total {dur[m].mean():.2f}')
 worst = np.argsort(-dur)[:8]
 for i in worst: print(f"  slot {i} tile {tile[i]} q={quarter[i]} ncmd {ncmd[i]} dur {dur[i]:.1f} us start {(start[i]-t0)*us:.1f}")
