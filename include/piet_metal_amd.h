@@ -191,6 +191,9 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
  * slot, {start clock, end clock (100 MHz wall clock), tile | quarter << 31,
  * wave << 32 | commands interpreted}.  out receives 4 u64 per slot. */
 int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_slots); /* pm_fine_kernel */
+/* Same for pm_bin_kernel: renders one frame recording 12 u64 per strip row {start, item scan done,
+ * headers done, segment stream done, record finalised, queues done, chunks streamed, end}. */
+int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows);
 
 #ifdef __cplusplus
 }

@@ -107,6 +107,7 @@ SIGNATURES = {
     "pm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "pm_debug_capture_ptcl": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pm_debug_time_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pm_debug_time_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
 _lib = None

@@ -352,6 +352,7 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     p->dbg_cmds = nullptr;
     p->dbg_max = 0;
     p->dbg_time = nullptr;
+    p->dbg_bin = nullptr;
     return PM_OK;
 }
 
@@ -840,6 +841,35 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
     (void)hipFree(d_solid);
     (void)hipFree(d_cmds);
     return status;
+}
+
+int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows) {
+    if (!c || !out) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    const size_t rows = static_cast<size_t>(BandRows(c)) * c->strips_x;
+    if (n_rows) *n_rows = rows;
+    if (rows > max_rows) return PM_ERR_CAPACITY;
+    unsigned long long *d = nullptr;
+    PM_TRY(hipMalloc(&d, std::max<size_t>(rows, 1) * 12 * sizeof(unsigned long long)));
+    pm::FrameParams p;
+    int r = BuildParams(c, c->d_fb, c->fb_stride, &p);
+    if (r == PM_OK) {
+        p.dbg_bin = d;
+        pm::LaunchBin(p, BandRows(c) * c->strips_x, c->stream);
+        pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
+        pm::LaunchFine(p, FineGrid(c), c->stream);
+        c->last_params = p;
+        c->last_params.dbg_bin = nullptr;
+        c->last_stream = c->stream;
+        c->have_frame = true;
+        c->frame += 1;
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(out, d, rows * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) r = HipFail(e, "bin timeline");
+    }
+    (void)hipFree(d);
+    return r;
 }
 
 int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_slots) {

@@ -23,7 +23,7 @@ struct Counters {
 
 // Arena record written by pm_bin_kernel for one (strip row, batch of <=256 items):
 //   [0] next record offset (0 = end)   [1] ncand   [2] chunks streamed (sizes segs/meta)
-//   [4 .. 4+W) segments written by each of the W binning waves   [4+W .. 4+2W) first slot of each extent
+//   [3] segment slots in use (= surviving chunks x kChunkSegs)
 //   mask table: ncand dwords { tag | hitmask16 << 16 }, padded to a multiple of 4
 //       (one 16-byte load per lane of the tile kernel covers 256 candidates); a hit
 //       bit survives only where the candidate can emit a command
@@ -33,9 +33,10 @@ struct Counters {
 //   ncand x 16 dwords: per tile of the strip { backdrop << 20 | relevant segments }
 //       backdrop = the reference's per-tile left-ray winding sum (PietRender.metal
 //       :326-333) over all voted segments of the item, done once here
-//   segs: 16 B slots (start.xy, end.xy), 16 per streamed chunk; the survivors of binning wave w
-//       occupy slots [start_w, start_w + count_w), extents in paint order
-//   meta: one word per slot { tiles of the strip where the segment can emit | candidate << 16 }
+//   segs: 16 B slots (start.xy, end.xy); surviving chunk s owns slots [s*kChunkSegs, (s+1)*kChunkSegs),
+//       one per segment of the chunk, paint order; slots of segments that lost the vote stay unused
+//   meta: one word per slot { tiles of the strip where the segment can emit | candidate << 16 |
+//       voted << 31 }, 0 for an unused slot
 //
 // Every strip row owns a private arena region [sr_base[i], sr_base[i+1]) sized by the host for
 // the worst case, so the binning kernel allocates with plain arithmetic: no atomics, no
@@ -52,10 +53,10 @@ struct Counters {
 // chunk's float bounding box {xmin, ymin, xmax, ymax}; chunk_base[i] is the first
 // chunk of item i (chunk_base[n_items] = total).  The binning kernel streams only
 // the chunks whose box can reach its strip row.
-constexpr uint32_t kChunkSegs = 16;
+constexpr uint32_t kChunkSegs = 8;
 constexpr uint32_t kArenaBase = 4;     // offset 0 means "none"
 constexpr int kBinWaves = 4;                          // waves of one binning workgroup (one extent each)
-constexpr uint32_t kRecHdrDwords = 4 + 2 * kBinWaves;  // 4 + extent counts + extent starts
+constexpr uint32_t kRecHdrDwords = 4;
 constexpr uint32_t kCandDwords = 8;
 constexpr uint32_t kCtDwords = 16;           // per candidate: one word per tile of the strip
 constexpr uint32_t kCtShift = 20;            // word = backdrop << 20 | relevant-segment count
@@ -97,6 +98,7 @@ struct FrameParams {
     // per-slot timeline of the tile kernel (developer profiling only): 4 x u64 per slot
     // {start clock, end clock, tile | quarter << 31, wave << 32 | commands interpreted}
     unsigned long long *dbg_time;
+    unsigned long long *dbg_bin;  // per strip row of pm_bin_kernel: 8 x u64 phase clocks (developer profiling)
 };
 
 void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks, float4 *chunk_bbox,

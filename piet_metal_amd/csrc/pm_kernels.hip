@@ -236,7 +236,8 @@ __global__ void pm_index_kernel(const uint8_t *scene, uint32_t n_items, const ui
 // K1: binning, one workgroup per strip row
 // =====================================================================================
 
-__global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
+template <bool kProfile>
+__global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     __shared__ uint32_t s_part[kBinWaves];
     __shared__ uint32_t s_cidx[kThreads];   // candidate item index
     __shared__ uint32_t s_cmask[kThreads];  // candidate per-tile hit mask (16 bits)
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     __shared__ uint32_t s_cchunk[kThreads]; // first chunk-table entry of the item
     __shared__ uint32_t s_choff[kThreads + 1];  // chunk-stream offsets
     __shared__ uint32_t s_ct[kThreads * kStripTiles];  // per (candidate, tile): backdrop steps << 20 | relevant segments
-    __shared__ uint32_t s_surv[kBinWaves][64];  // surviving chunks of one wave round: c << 24 | j
+    __shared__ uint32_t s_surv[kBinWaves][256];  // [0][..]: surviving chunks of one round (c << 24 | j); later scratch  // surviving chunks of one wave round: c << 24 | j
     __shared__ uint32_t s_est[kStripTiles];  // per tile: stream elements the tile kernel will see
     // per tile, in paint order across batches: the last candidate that can emit anything, and the
     // last one that is nothing but an opaque Solid (backdrop-only fill, alpha 0xff).  If they
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     __shared__ uint32_t s_last_kept[kStripTiles];
     __shared__ uint32_t s_last_solid[kStripTiles];
     __shared__ uint32_t s_solid_rgba[kStripTiles];
-    __shared__ uint32_t s_qbase[3];
+    __shared__ uint32_t s_qbase[5];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = LaneId();
@@ -281,6 +282,8 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
         P.ctr_next->light_count = 0;
         P.ctr_next->overflow = 0;
     }
+    unsigned long long tb[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (dead code unless kProfile)
+    if (kProfile) tb[0] = wall_clock64();
     if (tid < kStripTiles) {
         s_est[tid] = 0;
         s_last_kept[tid] = 0;
@@ -290,13 +293,15 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     __syncthreads();
 
     const uint8_t *scene = P.scene;
-    const uint32_t n_items = LoadU32(scene);
-    const uint32_t items_ix = LoadU32(scene + 4);
+    // wave-uniform values are pinned to SGPRs (readfirstlane): the record pointers and loop
+    // bounds derived from them then live on the scalar unit instead of in 64-bit VGPR pairs
+    const uint32_t n_items = __builtin_amdgcn_readfirstlane(LoadU32(scene));
+    const uint32_t items_ix = __builtin_amdgcn_readfirstlane(LoadU32(scene + 4));
     // This strip row owns arena[sr_base[b] .. sr_base[b+1]): the host sized it for the worst
     // case (every chunk of every candidate survives), so records are bump-allocated without
     // atomics and without a counting pass.
-    uint32_t cursor = P.sr_base[blockIdx.x];
-    const uint32_t region_end = P.sr_base[blockIdx.x + 1];
+    uint32_t cursor = __builtin_amdgcn_readfirstlane(P.sr_base[blockIdx.x]);
+    const uint32_t region_end = __builtin_amdgcn_readfirstlane(P.sr_base[blockIdx.x + 1]);
     uint32_t head = 0;       // first record of this strip row
     uint32_t prev_rec = 0;   // record whose `next` field is still open
 
@@ -325,6 +330,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
         uint32_t nb = 0;
         uint32_t cpos = 0;
         if (more) cpos = BlockRank<kBinWaves>(cand, s_part, &nb);
+        nb = __builtin_amdgcn_readfirstlane(nb);
         if (more && ncand + nb <= kBatch) {
             // append and keep scanning
             if (cand) {
@@ -339,6 +345,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
             continue;  // (nb > kBatch cannot happen: a scan step tests kBatch items)
         }
         __syncthreads();  // the appended candidates are visible
+        if (kProfile && tb[1] == 0) tb[1] = wall_clock64();  // first record starts (item scan done)
 
         // ---- candidate headers + chunk-stream offsets ---------------------------------
         uint32_t nch = 0;
@@ -387,6 +394,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
         }
         uint32_t total_ch;
         const uint32_t choff = BlockExclusiveScan<kBinWaves>(nch, s_part, &total_ch);
+        total_ch = __builtin_amdgcn_readfirstlane(total_ch);
         if (tid < ncand) s_choff[tid] = choff;
         if (tid == 0) s_choff[ncand] = total_ch;
 
@@ -414,142 +422,185 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
         if (head == 0) head = rec;
         prev_rec = rec;
         __syncthreads();  // s_choff, s_c* visible to every wave
+        if (kProfile && tb[2] == 0) tb[2] = wall_clock64();  // headers + scan done
 
-        // ---- each wave takes a contiguous 1/kBinWaves of the chunk stream ----------------------
-        // Chunks whose box cannot reach the strip row are dropped; the segments of the others
-        // are expanded 4 chunks x 16 segments per step, voted (phase 1), and the survivors
-        // are compacted -- all inside the wave: ballots and mbcnt ranks, no workgroup barrier.
-        {
-            const uint32_t q_lo = static_cast<uint32_t>((static_cast<uint64_t>(total_ch) * wave) / kBinWaves);
-            const uint32_t q_hi = static_cast<uint32_t>((static_cast<uint64_t>(total_ch) * (wave + 1)) / kBinWaves);
-            const uint32_t ext_base = q_lo * kChunkSegs;  // first segment slot of this wave's extent
-            uint32_t vcount = 0;
-            for (uint32_t e0 = q_lo; e0 < q_hi; e0 += 64) {
-                const uint32_t e = e0 + lane;
-                bool sv = false;
-                uint32_t pk = 0;
-                if (e < q_hi) {
-                    const uint32_t c = FindOwner(s_choff, ncand, e);
+        // ---- chunk stream -> surviving chunks -> segment votes ---------------------------------
+        // Block rounds of 256 chunks: chunks whose box cannot reach the strip row are dropped and
+        // the survivors get consecutive indices (paint order).  Every surviving chunk OWNS
+        // kChunkSegs segment slots (slot = chunk_index * kChunkSegs + segment_in_chunk), so the
+        // expansion needs no compaction at all: each lane votes one segment (phase 1), writes
+        // its slot's meta word (0 = no vote) and, if voted, the segment -- and the four waves
+        // simply split the round's elements evenly.
+        uint32_t sbase = 0;  // surviving chunks so far
+        constexpr uint32_t kCPL = 4;  // chunks tested per lane per round: fewer rounds, fewer barriers
+        for (uint32_t r0 = 0; r0 < total_ch; r0 += kBinThreads * kCPL) {
+            const uint32_t eb = r0 + kCPL * tid;  // this lane's consecutive chunks (stream order)
+            uint32_t svb = 0;
+            uint32_t pk[kCPL];
+            unsigned long long t_r0 = 0;
+            if (kProfile) t_r0 = wall_clock64();
+            if (eb < total_ch) {
+                uint32_t c = FindOwner(s_choff, ncand, eb);
+                uint32_t cc[kCPL];
+                float4 bb[kCPL];
+#pragma unroll
+                for (uint32_t u = 0; u < kCPL; ++u) {
+                    const uint32_t e = eb + u;
+                    while (c + 1 < ncand && s_choff[c + 1] <= e) ++c;  // owners only move forward
+                    cc[u] = c;
                     const uint32_t j = e - s_choff[c];
-                    const uint32_t ctag = s_ctag[c];
-                    pk = (c << 24) | j;
+                    pk[u] = (c << 24) | j;
+                    bb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < total_ch && s_ctag[c] != kItemLine) bb[u] = P.chunk_bbox[s_cchunk[c] + j];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kCPL; ++u) {
+                    if (eb + u >= total_ch) continue;
+                    const uint32_t ctag = s_ctag[cc[u]];
+                    bool sv;
                     if (ctag == kItemLine) {
                         sv = true;
-                    } else {
-                        const float4 bb = P.chunk_bbox[s_cchunk[c] + j];
-                        if (ctag == kItemFill) {  // necessary part of :264-265 for any segment of the chunk
-                            sv = bb.w >= fy0 && bb.y < fy1 && bb.x < fsx1;
-                        } else {  // necessary part of :378-379
-                            const float hw = s_chw[c];
-                            sv = bb.w > fsy0 - hw && bb.y < fsy1 + hw && bb.z > fsx0 - hw && bb.x < fsx1 + hw;
-                        }
+                    } else if (ctag == kItemFill) {  // necessary part of :264-265 for any segment of the chunk
+                        sv = bb[u].w >= fy0 && bb[u].y < fy1 && bb[u].x < fsx1;
+                    } else {  // necessary part of :378-379
+                        const float hw = s_chw[cc[u]];
+                        sv = bb[u].w > fsy0 - hw && bb[u].y < fsy1 + hw && bb[u].z > fsx0 - hw && bb[u].x < fsx1 + hw;
                     }
+                    if (sv) svb |= 1u << u;
                 }
-                const uint64_t svm = __ballot(sv);
-                const uint32_t ns = static_cast<uint32_t>(__popcll(svm));
-                if (ns == 0) continue;
-                WaveSync();
-                if (sv) s_surv[wave][RankBelow(svm)] = pk;
-                WaveSync();
-                for (uint32_t f0 = 0; f0 < ns * kChunkSegs; f0 += 64) {
-                    const uint32_t f = f0 + lane;
-                    bool vote = false;
-                    uint32_t vc = 0;
-                    float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (f < ns * kChunkSegs) {
-                        const uint32_t spk = s_surv[wave][f / kChunkSegs];
-                        vc = spk >> 24;
-                        const uint32_t k = (spk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
-                        if (k < s_cnseg[vc]) {
-                            const uint32_t ctag = s_ctag[vc];
-                            const uint8_t *pts = scene + s_cpts[vc];
-                            if (ctag == kItemFill) {
-                                const uint32_t k1 = (k + 1 == s_cnpt[vc]) ? 0u : k + 1;
-                                const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
-                                const float2 b = LoadF2(pts + static_cast<size_t>(k1) * 8);
-                                seg = make_float4(a.x, a.y, b.x, b.y);
-                                vote = VoteFill(seg, y0, sx0);
-                            } else if (ctag == kItemPoly) {
-                                const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
-                                const float2 b = LoadF2(pts + static_cast<size_t>(k + 1) * 8);
-                                seg = make_float4(a.x, a.y, b.x, b.y);
-                                const int y_test = sy0 + static_cast<int>(((k & 31u) >> 4) * kTileH);
-                                vote = VotePoly(seg, s_chw[vc], y_test, sx0, sy0);
-                            } else {  // line
-                                const float2 a = LoadF2(pts);
-                                const float2 b = LoadF2(pts + 8);
-                                seg = make_float4(a.x, a.y, b.x, b.y);
-                                vote = true;
-                            }
-                        }
-                    }
-                    const uint64_t vm = __ballot(vote);
-                    if (vote) {
-                        // Per tile of the strip: (a) can this segment emit a command there -- the
-                        // x/box pre-conditions of phase 2 (:334, :349-350, :416-417); (b) for fills,
-                        // the backdrop term of :326-333, which the reference accumulates per tile over
-                        // EVERY voted segment of the row, is summed once per (item, tile) here.
+            }
+            uint32_t ns;
+            uint32_t srank = BlockExclusiveScan<kBinWaves>(static_cast<uint32_t>(__popc(svb)), s_part, &ns);
+            ns = __builtin_amdgcn_readfirstlane(ns);
+            if (kProfile) { tb[8] += wall_clock64() - t_r0; tb[10] += 1; }  // chunk-test part of the round
+            if (ns == 0) continue;  // uniform
+#pragma unroll
+            for (uint32_t u = 0; u < kCPL; ++u)
+                if ((svb >> u) & 1u) (&s_surv[0][0])[srank++] = pk[u];
+            __syncthreads();
+            unsigned long long t_e0 = 0;
+            if (kProfile) t_e0 = wall_clock64();
+            const uint32_t n_el = ns * kChunkSegs;
+            for (uint32_t f0 = wave * 64u; f0 < n_el; f0 += kBinThreads) {
+                const uint32_t f = f0 + lane;
+                bool vote = false;
+                uint32_t vc = 0;
+                float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < n_el) {
+                    const uint32_t spk = (&s_surv[0][0])[f / kChunkSegs];
+                    vc = spk >> 24;
+                    const uint32_t k = (spk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
+                    if (k < s_cnseg[vc]) {
                         const uint32_t ctag = s_ctag[vc];
-                        const uint32_t hm = s_cmask[vc];
-                        uint32_t M = 0;
-                        const float xmin = fminf(seg.x, seg.z), ymin = fminf(seg.y, seg.w);
-                        const float xmax = fmaxf(seg.x, seg.z), ymax = fmaxf(seg.y, seg.w);
+                        const uint8_t *pts = scene + s_cpts[vc];
                         if (ctag == kItemFill) {
-                            // xmin < fx1 and xmax > fx0 against integer tile edges: exact in integers
-                            const int fl = static_cast<int>(floorf(fmaxf(fminf(xmin, 1048576.0f), -1048576.0f)));
-                            const int ce = static_cast<int>(ceilf(fmaxf(fminf(xmax, 1048576.0f), -1048576.0f)));
-                            const int t_lo = max(0, (fl - sx0) >> 4);                 // first t with x0+16 > xmin
-                            const int t_hi = min(15, ((ce - sx0 + 15) >> 4) - 1);      // last t with x0 < xmax
-                            if (t_hi >= t_lo) M = ((2u << t_hi) - 1u) & ~((1u << t_lo) - 1u);
-                            if (ymin <= fy0) {
-                                // backdrop: sign(line(x0, y0)) == sign(a) holds on a suffix of the tiles
-                                // (every rounding in a*x0 + y0*b + c is monotone in x0), so one bisection
-                                // finds the first tile; there s00 is the same expression, i.e. sign(a).
-                                const float a = seg.w - seg.y;
-                                const float b = seg.x - seg.z;
-                                const float cc = -(a * seg.x + b * seg.y);
-                                const float sa = Sgn(a);
-                                const float yb = fy0 * b;
-                                if (sa != 0.0f) {
-                                    int lo = 0, hi = 16;  // first t in [0,16] where the predicate holds
-                                    while (lo < hi) {
-                                        const int mid = (lo + hi) >> 1;
-                                        const float fxm = static_cast<float>(sx0 + mid * static_cast<int>(kTileW));
-                                        if (Sgn(a * fxm + yb + cc) == sa) hi = mid; else lo = mid + 1;
-                                    }
-                                    if (lo < 16) atomicAdd(&s_ct[vc * kStripTiles + lo], static_cast<uint32_t>(-static_cast<int>(sa)) << kCtShift);
-                                }
-                            }
+                            const uint32_t k1 = (k + 1 == s_cnpt[vc]) ? 0u : k + 1;
+                            const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
+                            const float2 b = LoadF2(pts + static_cast<size_t>(k1) * 8);
+                            seg = make_float4(a.x, a.y, b.x, b.y);
+                            vote = VoteFill(seg, y0, sx0);
                         } else if (ctag == kItemPoly) {
-                            const float hw = s_chw[vc];
-                            if (ymax > fy0 - hw && ymin < fy1 + hw) {
-#pragma unroll 4
-                                for (uint32_t t = 0; t < kStripTiles; ++t) {
-                                    const float fx0 = static_cast<float>(sx0 + static_cast<int>(t * kTileW));
-                                    const float fx1 = static_cast<float>(sx0 + static_cast<int>((t + 1) * kTileW));
-                                    if (xmax > fx0 - hw && xmin < fx1 + hw) M |= 1u << t;
-                                }
-                            }
-                        } else {
-                            M = 0xffffu;  // a line is tested by every tile its bbox hits (:223-247)
+                            const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
+                            const float2 b = LoadF2(pts + static_cast<size_t>(k + 1) * 8);
+                            seg = make_float4(a.x, a.y, b.x, b.y);
+                            const int y_test = sy0 + static_cast<int>(((k & 31u) >> 4) * kTileH);
+                            vote = VotePoly(seg, s_chw[vc], y_test, sx0, sy0);
+                        } else {  // line
+                            const float2 a = LoadF2(pts);
+                            const float2 b = LoadF2(pts + 8);
+                            seg = make_float4(a.x, a.y, b.x, b.y);
+                            vote = true;
                         }
-                        M &= hm;
-                        for (uint32_t m = M; m; m &= m - 1) atomicAdd(&s_ct[vc * kStripTiles + __builtin_ctz(m)], 1u);
-                        const uint32_t pos = ext_base + vcount + RankBelow(vm);
-                        segs[pos] = seg;
-                        meta[pos] = M | (vc << 16);
                     }
-                    vcount += static_cast<uint32_t>(__popcll(vm));
+                }
+                uint32_t mword = 0;
+                if (f < n_el) {
+                    const uint32_t slot = sbase * kChunkSegs + f;
+                    if (vote) {
+                // Per tile of the strip: (a) can this segment emit a command there -- the
+                // x/box pre-conditions of phase 2 (:334, :349-350, :416-417); (b) for fills,
+                // the backdrop term of :326-333, which the reference accumulates per tile over
+                // EVERY voted segment of the row, is summed once per (item, tile) here.
+                const uint32_t ctag = s_ctag[vc];
+                const uint32_t hm = s_cmask[vc];
+                uint32_t M = 0;
+                const float xmin = fminf(seg.x, seg.z), ymin = fminf(seg.y, seg.w);
+                const float xmax = fmaxf(seg.x, seg.z), ymax = fmaxf(seg.y, seg.w);
+                if (ctag == kItemFill) {
+                    // xmin < fx1 and xmax > fx0 against integer tile edges: exact in integers
+                    const int fl = static_cast<int>(floorf(fmaxf(fminf(xmin, 1048576.0f), -1048576.0f)));
+                    const int ce = static_cast<int>(ceilf(fmaxf(fminf(xmax, 1048576.0f), -1048576.0f)));
+                    const int t_lo = max(0, (fl - sx0) >> 4);                 // first t with x0+16 > xmin
+                    const int t_hi = min(15, ((ce - sx0 + 15) >> 4) - 1);      // last t with x0 < xmax
+                    if (t_hi >= t_lo) M = ((2u << t_hi) - 1u) & ~((1u << t_lo) - 1u);
+                    if (ymin <= fy0) {
+                        // backdrop: sign(line(x0, y0)) == sign(a) holds on a suffix of the tiles
+                        // (every rounding in a*x0 + y0*b + c is monotone in x0), so one bisection
+                        // finds the first tile; there s00 is the same expression, i.e. sign(a).
+                        const float a = seg.w - seg.y;
+                        const float b = seg.x - seg.z;
+                        const float cc = -(a * seg.x + b * seg.y);
+                        const float sa = Sgn(a);
+                        const float yb = fy0 * b;
+                        if (sa != 0.0f) {
+                            int lo = 0, hi = 16;  // first t in [0,16] where the predicate holds
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                const float fxm = static_cast<float>(sx0 + mid * static_cast<int>(kTileW));
+                                if (Sgn(a * fxm + yb + cc) == sa) hi = mid; else lo = mid + 1;
+                            }
+                            if (lo < 16) atomicAdd(&s_ct[vc * kStripTiles + lo], static_cast<uint32_t>(-static_cast<int>(sa)) << kCtShift);
+                        }
+                    }
+                } else if (ctag == kItemPoly) {
+                    const float hw = s_chw[vc];
+                    if (ymax > fy0 - hw && ymin < fy1 + hw) {
+#pragma unroll 4
+                        for (uint32_t t = 0; t < kStripTiles; ++t) {
+                            const float fx0 = static_cast<float>(sx0 + static_cast<int>(t * kTileW));
+                            const float fx1 = static_cast<float>(sx0 + static_cast<int>((t + 1) * kTileW));
+                            if (xmax > fx0 - hw && xmin < fx1 + hw) M |= 1u << t;
+                        }
+                    }
+                } else {
+                    M = 0xffffu;  // a line is tested by every tile its bbox hits (:223-247)
+                }
+                M &= hm;
+                        segs[slot] = seg;
+                        mword = M | (vc << 16) | 0x80000000u;  // bit 31: a voted segment lives here
+                    }
+                    meta[slot] = mword;
+                }
+                // relevant-segment counts per (candidate, tile).  Neighbouring lanes hold segments
+                // of the same item hitting the same tiles, so per-lane LDS atomics would serialise
+                // 64-fold; instead, for each distinct candidate of the wave, sixteen ballots count
+                // the lanes per tile and lane t adds tile t's count once.
+                {
+                    const uint32_t mm = mword & 0xffffu;
+                    uint64_t rem = __ballot(mm != 0);
+                    while (rem) {
+                        const uint32_t v = __shfl(vc, static_cast<int>(__builtin_ctzll(rem)), 64);
+                        const bool in_grp = mm != 0 && vc == v;
+                        uint32_t mycnt = 0;
+#pragma unroll
+                        for (uint32_t t = 0; t < kStripTiles; ++t) {
+                            const uint64_t bt = __ballot(in_grp && ((mm >> t) & 1u));
+                            if (lane == t) mycnt = static_cast<uint32_t>(__popcll(bt));
+                        }
+                        if (lane < kStripTiles && mycnt) atomicAdd(&s_ct[v * kStripTiles + lane], mycnt);
+                        rem &= ~__ballot(in_grp);
+                    }
                 }
             }
-            if (lane == 0) {
-                hdr[4 + wave] = vcount;                // segments in this wave's extent
-                hdr[4 + kBinWaves + wave] = ext_base;  // first slot of the extent
-            }
+            sbase += ns;
+            __syncthreads();  // s_surv is rewritten by the next round
+            if (kProfile) { tb[9] += wall_clock64() - t_e0; tb[11] += n_el; }  // expansion part
         }
+        if (tid == 0) hdr[3] = sbase * kChunkSegs;  // slots the tile kernel has to scan
         __syncthreads();  // every wave's s_ct contributions are in
+        if (kProfile) { tb[3] = wall_clock64(); tb[6] += total_ch; }  // segment stream done
 
-        // ---- candidate records, per-(candidate, tile) table, mask table, per-tile estimate ---
+        // ---- candidate records, per-(candidate, tile) table, mask table ------------------------
         if (tid < mask_dwords) {
             uint32_t w0 = 0;
             if (tid < ncand) {
@@ -557,25 +608,27 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
                 // segment, a non-zero backdrop (Solid / DrawFill), or a circle
                 uint32_t hm = 0;
                 int run = 0;  // backdrop steps were recorded at the first tile they apply to
-                uint32_t *ctw = ct_tab + kCtDwords * tid;
                 const uint32_t cm = s_cmask[tid];
-#pragma unroll 4
-                for (uint32_t t = 0; t < kStripTiles; ++t) {
-                    const uint32_t raw = s_ct[tid * kStripTiles + t];
-                    const uint32_t cnt = raw & kCtCountMask;
-                    run += static_cast<int>(raw) >> kCtShift;
-                    ctw[t] = (static_cast<uint32_t>(run) << kCtShift) | cnt;
-                    const bool pseudo = tag == kItemCircle || (tag == kItemFill && run != 0);
-                    const uint32_t n_el = cnt ? cnt : (pseudo ? 1u : 0u);
-                    if (n_el && ((cm >> t) & 1u) && tag != 0) {
-                        hm |= 1u << t;
-                        atomicAdd(&s_est[t], n_el);
-                        const uint32_t key = s_cidx[tid] + 1u;  // paint order
-                        atomicMax(&s_last_kept[t], key);
-                        if (tag == kItemFill && cnt == 0 && (rgba & 0xff000000u) == 0xff000000u) {
-                            atomicMax(&s_last_solid[t], key);
-                        }
+                const bool opaque = (rgba & 0xff000000u) == 0xff000000u;
+                uint4 *ctw = reinterpret_cast<uint4 *>(ct_tab + kCtDwords * tid);
+#pragma unroll 1
+                for (uint32_t q = 0; q < 4; ++q) {
+                    uint32_t ct[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k) {
+                        const uint32_t t = 4 * q + k;
+                        const uint32_t raw = s_ct[tid * kStripTiles + t];
+                        const uint32_t cnt = raw & kCtCountMask;
+                        run += static_cast<int>(raw) >> kCtShift;
+                        ct[k] = (static_cast<uint32_t>(run) << kCtShift) | cnt;
+                        const bool pseudo = tag == kItemCircle || (tag == kItemFill && run != 0);
+                        uint32_t n_el = cnt ? cnt : (pseudo ? 1u : 0u);
+                        if (!((cm >> t) & 1u) || tag == 0) n_el = 0;
+                        if (n_el) hm |= 1u << t;
+                        // for the per-tile pass below: elements | "is nothing but an opaque Solid" << 31
+                        s_ct[tid * kStripTiles + t] = n_el | ((n_el && tag == kItemFill && cnt == 0 && opaque) ? 0x80000000u : 0u);
                     }
+                    ctw[q] = make_uint4(ct[0], ct[1], ct[2], ct[3]);
                 }
                 w0 = tag | (hm << 16);
                 const uint32_t rg = P.lut_srgb2lin[rgba & 0xffu] | (P.lut_srgb2lin[(rgba >> 8) & 0xffu] << 16);
@@ -583,22 +636,47 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
                 uint4 *cr = reinterpret_cast<uint4 *>(cand_rec + kCandDwords * tid);
                 cr[0] = make_uint4(w0, rgba, aux0, aux1);
                 cr[1] = make_uint4(s_cidx[tid], 0u, rg, ba);
+                s_cpts[tid] = rgba;  // (points offsets are no longer needed) colour for the solid test
             }
             mask_tab[tid] = w0;
         }
         __syncthreads();
-        if (tid < ncand) {
-            // colour of the newest opaque-solid candidate of each tile (this batch may own it)
-            const uint32_t key = s_cidx[tid] + 1u;
-            const uint32_t w0 = mask_tab[tid];
-            const uint32_t rgba_c = cand_rec[kCandDwords * tid + 1];
-            if ((w0 & 0xffffu) == kItemFill && (rgba_c & 0xff000000u) == 0xff000000u)
-                for (uint32_t m = w0 >> 16; m; m &= m - 1) {
-                    const uint32_t t = __builtin_ctz(m);
-                    if (s_last_solid[t] == key) s_solid_rgba[t] = rgba_c;
+        // ---- per tile, in paint order: elements queued, last candidate that can emit, last one
+        //      that is nothing but an opaque Solid.  thread = (tile, slice of the candidates)
+        {
+            const uint32_t t = tid & (kStripTiles - 1u), sl = tid >> 4;
+            uint32_t est_p = 0, lk = 0, ls = 0;
+            for (uint32_t c = sl; c < ncand; c += kThreads / kStripTiles) {
+                const uint32_t v = s_ct[c * kStripTiles + t];
+                if (v) {
+                    est_p += v & 0x7fffffffu;
+                    lk = c + 1u;
+                    if (v >> 31) ls = c + 1u;
                 }
+            }
+            uint32_t *part = &s_surv[0][0];  // (free during finalisation) [3][16 slices][16 tiles]
+            part[sl * kStripTiles + t] = est_p;
+            part[256 + sl * kStripTiles + t] = lk;
+            part[512 + sl * kStripTiles + t] = ls;
+            __syncthreads();
+            if (tid < kStripTiles) {
+                uint32_t est = 0, lkm = 0, lsm = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < kThreads / kStripTiles; ++q) {
+                    est += part[q * kStripTiles + tid];
+                    lkm = max(lkm, part[256 + q * kStripTiles + tid]);
+                    lsm = max(lsm, part[512 + q * kStripTiles + tid]);
+                }
+                s_est[tid] += est;
+                if (lkm) s_last_kept[tid] = s_cidx[lkm - 1u] + 1u;  // records come in paint order
+                if (lsm) {
+                    s_last_solid[tid] = s_cidx[lsm - 1u] + 1u;
+                    s_solid_rgba[tid] = s_cpts[lsm - 1u];
+                }
+            }
         }
         __syncthreads();  // s_c* arrays are rewritten by the next record
+        if (kProfile) tb[4] = wall_clock64();  // record finalised
         ncand = 0;
         if (!more) break;
         if (cand) {  // the scan step that did not fit opens the next record
@@ -631,29 +709,34 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     const uint32_t queued = vheavy | heavy | light;
     // command-list slots of the queued tiles: an element emits at most 2 commands + its item's
     // closing command, plus End -- one atomic per strip row on the list arena
-    if (tid == 0 && queued) {
+    // command-list slots of the queued tiles (an element emits at most 2 commands + its item's
+    // closing command, plus End) and the three queue positions: four atomics in flight at once
+    if (tid == 3 && queued) {
         uint32_t total = 0;
-        uint32_t off[kStripTiles];
-#pragma unroll
-        for (uint32_t t = 0; t < kStripTiles; ++t) {
-            off[t] = total;
-            if ((queued >> t) & 1u) total += 3u * s_est[t] + 1u;
-        }
-        const uint32_t base = atomicAdd(&P.ctr_cur->ptcl_top, total);
-        const bool fits = base + total <= P.ptcl_cap && base + total >= base;
-        if (!fits) P.ctr_cur->overflow = 1;
 #pragma unroll
         for (uint32_t t = 0; t < kStripTiles; ++t)
-            if ((queued >> t) & 1u)
-                P.tile_ptcl[row_rel * P.tiles_x + strip * kStripTiles + t] = fits ? base + off[t] : 0xffffffffu;
-        if (!fits) s_est[0] = 0xffffffffu;  // poison: queue nothing from this strip row
+            if ((queued >> t) & 1u) total += 3u * s_est[t] + 1u;
+        s_qbase[3] = atomicAdd(&P.ctr_cur->ptcl_top, total);
+        s_qbase[4] = total;
     }
-    __syncthreads();
-    if (s_est[0] == 0xffffffffu) vheavy = heavy = light = 0;
     if (tid == 0 && vheavy) s_qbase[0] = atomicAdd(&P.ctr_cur->vheavy_count, static_cast<uint32_t>(__popc(vheavy)));
     if (tid == 1 && heavy) s_qbase[1] = atomicAdd(&P.ctr_cur->heavy_count, static_cast<uint32_t>(__popc(heavy)));
     if (tid == 2 && light) s_qbase[2] = atomicAdd(&P.ctr_cur->light_count, static_cast<uint32_t>(__popc(light)));
     __syncthreads();
+    bool fits = true;
+    if (queued) {
+        const uint32_t base = s_qbase[3], total = s_qbase[4];
+        fits = base + total <= P.ptcl_cap && base + total >= base;
+        if (!fits && tid == 0) P.ctr_cur->overflow = 1;  // the host grows the arena and re-renders
+        if (tid < kStripTiles && ((queued >> tid) & 1u)) {
+            uint32_t off = 0;
+            for (uint32_t t = 0; t < tid; ++t)
+                if ((queued >> t) & 1u) off += 3u * s_est[t] + 1u;
+            P.tile_ptcl[row_rel * P.tiles_x + strip * kStripTiles + tid] = fits ? base + off : 0u;
+        }
+    }
+    // (on overflow the tiles are still queued, with lists at slot 0: in bounds, garbage pixels,
+    //  and pm_sync re-renders the frame with a larger arena)
     if (tid < kStripTiles) {
         // three queues, by expected list length: the fine kernel starts with the longest
         const uint32_t tile = row_rel * P.tiles_x + strip * kStripTiles + tid;
@@ -664,6 +747,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
     }
     // tiles with nothing to draw are background: no item touches them, or every touching
     // item lost all its segments in phase 1 (the reference writes Bail/white for them)
+    if (kProfile) tb[5] = wall_clock64();  // queues + list slots done
     const uint32_t clear = ~queued & valid;  // background (white) or one opaque colour
     if (tid < tiles_here)  // what this kernel decided per tile: 0 = queued, else the tile's colour
         P.tile_state[row_rel * P.tiles_x + strip * kStripTiles + tid] =
@@ -689,6 +773,11 @@ __global__ __launch_bounds__(kBinThreads) void pm_bin_kernel(FrameParams P) {
                 }
             }
         }
+    }
+    if (kProfile && P.dbg_bin && tid == 0) {
+        unsigned long long *d = P.dbg_bin + 12ull * blockIdx.x;
+        tb[7] = wall_clock64();
+        for (int k = 0; k < 12; ++k) d[k] = tb[k];
     }
 }
 
@@ -963,7 +1052,6 @@ __device__ __forceinline__ void Interpret1(const Cmd *cmds, uint32_t n, float px
 
 struct CoarseLds {
     uint32_t ring[kRing];     // indices of the record's segments relevant to this tile
-    uint32_t ext[2 * kBinWaves];  // extent table of the record (counts, first slots)
     uint8_t hidx[kThreads];   // candidates of the record that hit this tile (indices)
     uint32_t htag[kWaveCands];
     uint32_t hrgba[kWaveCands];
@@ -1023,7 +1111,6 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
         while (rec != 0) {
             // header and mask table sit next to each other: all loads are in flight together
             const uint4 hdr = *reinterpret_cast<const uint4 *>(P.arena + rec);
-            const uint32_t ext_word = (lane < 2u * kBinWaves) ? P.arena[rec + 4u + lane] : 0u;  // extent table
             const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * lane);
             const uint32_t next = hdr.x;
             const uint32_t ncand = hdr.y;
@@ -1032,14 +1119,10 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
             const uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
             const float4 *segs = reinterpret_cast<const float4 *>(ct_tab + kCtDwords * ncand);
             const uint32_t *meta = reinterpret_cast<const uint32_t *>(segs + kChunkSegs * hdr.z);
-            // Worklist of the segments that matter to THIS tile: the record's segment metas
-            // (one extent per binning wave, in paint order) are scanned linearly, 4 per
-            // lane per step with independent loads, and the slots of those carrying this
-            // tile's bit are kept, in order, in a small LDS ring.
-            WaveSync();
-            if (lane < 2u * kBinWaves) L.ext[lane] = ext_word;  // [0,16) counts, [16,32) first slots
-            WaveSync();
-            uint32_t ext = 0;       // extent being scanned
+            // Worklist of the segments that matter to THIS tile: the record's segment slots are
+            // scanned linearly (2 meta words per lane per step, independent loads) and the slots
+            // carrying this tile's bit are kept, in paint order, in a small LDS ring.
+            const uint32_t n_slots = hdr.w;
             uint32_t scan_pos = 0;  // next segment to scan
             uint32_t ring_cnt = 0;  // relevant segments found so far (ring write position)
             uint32_t rel_done = 0;  // relevant segments owned by earlier candidate passes
@@ -1134,14 +1217,9 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
                         if (wm) {
                             const uint32_t my_need = wants ? (L.hwoff[c] + (e - L.hoff[c]) + 1u) : 0u;
                             const uint32_t need = __shfl(my_need, 63 - __builtin_clzll(wm), 64);
-                            while (ring_cnt < need && ext < static_cast<uint32_t>(kBinWaves)) {
-                                const uint32_t cnt_x = L.ext[ext];
-                                const uint32_t st_x = L.ext[kBinWaves + ext];
-                                if (scan_pos >= cnt_x) {
-                                    ++ext;
-                                    scan_pos = 0;
-                                    continue;
-                                }
+                            while (ring_cnt < need && scan_pos < n_slots) {
+                                const uint32_t cnt_x = n_slots;
+                                const uint32_t st_x = 0;
                                 const uint32_t i0 = scan_pos + 2u * lane;
                                 uint2 mv = make_uint2(0u, 0u);
                                 if (i0 < cnt_x) mv = *reinterpret_cast<const uint2 *>(meta + st_x + i0);
@@ -1514,7 +1592,10 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_b
 }
 
 void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream) {
-    hipLaunchKernelGGL(pm_bin_kernel, dim3(n_striprows), dim3(kBinThreads), 0, stream, p);
+    if (p.dbg_bin)
+        hipLaunchKernelGGL(pm_bin_kernel<true>, dim3(n_striprows), dim3(kBinThreads), 0, stream, p);
+    else
+        hipLaunchKernelGGL(pm_bin_kernel<false>, dim3(n_striprows), dim3(kBinThreads), 0, stream, p);
 }
 
 void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream) {

@@ -168,6 +168,16 @@ def _time_tiles(self, max_slots: int = 1 << 20) -> np.ndarray:
 Renderer.time_tiles = _time_tiles
 
 
+def _time_bins(self, max_rows: int = 1 << 20) -> np.ndarray:
+    out = np.zeros((max_rows, 12), np.uint64)
+    n = C.c_size_t(0)
+    _lib.check(self._lib.pm_debug_time_bins(self._h, out.ctypes.data, max_rows, C.byref(n)), "pm_debug_time_bins")
+    return out[: n.value]
+
+
+Renderer.time_bins = _time_bins
+
+
 def init_test_scene(buf: np.ndarray) -> None:
     """The reference's one FFI symbol (include/piet_metal.h:3): Tiger at scale 8."""
     lib = _lib.load()

@@ -1,0 +1,38 @@
+"""Developer profiling: where does pm_bin_kernel's time go at Tiger 4K?"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import piet_metal_amd as pm
+wl = pm.workloads.tiger(3840, 2160)
+r = pm.Renderer(0)
+r.resize(wl.width, wl.height)
+r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+for _ in range(3): r.render()
+r.sync()
+t = r.time_bins().astype(np.int64)
+us = 1e-2
+t0 = t[:, 0].min()
+dur = (t[:, 7] - t[:, 0]) * us
+print(f"WGs {len(t)} kernel span {(t[:,7].max()-t0)*us:.1f} us; WG duration mean {dur.mean():.2f} p50 {np.median(dur):.2f} p90 {np.percentile(dur,90):.2f} max {dur.max():.2f}")
+print(f"start spread: last WG starts at {(t[:,0].max()-t0)*us:.1f} us")
+has = t[:, 1] > 0
+print(f"WGs with a record: {has.sum()}")
+def ph(a, b, m): 
+    d = (t[m, b] - t[m, a]) * us
+    return f"mean {d.mean():.2f} p90 {np.percentile(d,90):.2f} max {d.max():.2f}"
+m = has
+print("item scan      :", ph(0, 1, m))
+print("headers+scan   :", ph(1, 2, m))
+print("segment stream :", ph(2, 3, m), "(last record)")
+print("finalise       :", ph(3, 4, m))
+print("queues         :", ph(4, 5, m))
+print("clear+exit     :", ph(5, 7, m))
+e = ~has
+d = (t[e, 7] - t[e, 0]) * us
+print(f"WGs without candidates: {e.sum()}, duration mean {d.mean():.2f} max {d.max():.2f}")
+ch = t[:, 6]
+worst = np.argsort(-dur)[:6]
+for i in worst: print(f"  WG {i} chunks {ch[i]} dur {dur[i]:.1f} start {(t[i,0]-t0)*us:.1f} phases {[(t[i,k+1]-t[i,k])*us if t[i,k+1]>0 and t[i,k]>0 else None for k in (0,1,2,3,4)]}")
+print("heavy WG detail: chunk-test time, expansion time, rounds, elements")
+for i in worst: print(f"  WG {i}: chunk rounds {t[i,10]} test {t[i,8]*us:.1f} us, expansion {t[i,9]*us:.1f} us for {t[i,11]} elements ({t[i,11]/256:.1f} block steps) -> {t[i,9]*us/max(1,t[i,11]/256):.2f} us/step")
+tot_el = t[:, 11].sum(); print("total elements", tot_el, "total chunks", ch.sum())
