@@ -7,6 +7,12 @@
 //                                           pm_flatten_and_encode (PietRenderer.m:203-205)
 //   -drawInMTKView:                      -> pm_render      (PietRenderer.m:59-103)
 //
+// Frames are pipelined like the reference's command queue ([commandBuffer commit] never waits,
+// PietRenderer.m:102): three frame slots (own arena, queues, command lists, framebuffer) and
+// two HIP streams -- binning of frame N+1 runs while the tile kernels of frame N are still
+// busy; events order slot reuse.  A frame rendered into a caller-owned buffer
+// (pm_render_to) runs its three kernels back to back on the caller's stream instead.
+//
 // There is deliberately no CPU rendering path in this library: without a gfx950
 // device pm_create fails with PM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
@@ -120,9 +126,33 @@ void BuildLuts(Luts *l) {
 
 }  // namespace
 
+
+namespace {
+constexpr int kSlots = 3;
+}
+
+struct FrameSlot {
+    uint8_t *d_fb = nullptr;  // this slot's framebuffer (pm_render); pm_render_to uses the caller's
+    uint32_t *d_arena = nullptr;
+    uint32_t *d_striprow = nullptr;
+    uint32_t *d_queue = nullptr;
+    uint32_t *d_tile_state = nullptr;
+    uint32_t *d_tile_ptcl = nullptr;
+    uint32_t *d_tile_ncmd = nullptr;
+    pm::Cmd *d_ptcl = nullptr;
+    uint32_t ptcl_cap = 0;  // commands
+    pm::Counters *d_ctr = nullptr;  // two: a frame's binning kernel zeroes the one the slot's next frame uses
+    uint32_t parity = 0;
+    hipEvent_t ev_bin = nullptr, ev_fine = nullptr;
+    bool in_flight = false;   // ev_fine was recorded for a frame using this slot
+    pm::FrameParams params{};
+    hipStream_t tile_stream = nullptr;  // stream the slot's last tile kernels ran on
+};
+
 struct pm_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // tile kernels (coarse + fine); "the" context stream
+    hipStream_t bin_stream = nullptr;  // binning kernel of the next frame
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
 
@@ -134,60 +164,57 @@ struct pm_ctx {
     uint32_t n_items = 0;
     std::vector<uint8_t> item_meta;  // copy of header + bboxes + items (arena sizing)
     uint32_t *d_chunk_base = nullptr;  // scene index: first chunk of every item (+ total)
-    float4 *d_chunk_bbox = nullptr;    // scene index: bounding box of every 16-segment chunk
+    float4 *d_chunk_bbox = nullptr;    // scene index: bounding box of every chunk of segments
     size_t chunk_base_cap = 0, chunk_bbox_cap = 0;
     uint32_t n_chunks = 0;
 
     // viewport
     uint32_t width = 0, height = 0, tiles_x = 0, tiles_y = 0, strips_x = 0;
     uint32_t row0 = 0, row1 = 0;
-    bool band_set = false;
-    uint8_t *d_fb = nullptr;
     size_t fb_stride = 0;
     size_t fb_bytes = 0;
 
-    // binning state
-    uint32_t *d_arena = nullptr;
-    uint32_t arena_cap = 0;
-    uint32_t *d_striprow = nullptr;
+    // binning state shared by the slots
     uint32_t *d_sr_base = nullptr;  // private arena region of every strip row
-    uint32_t *d_queue = nullptr;
-    uint32_t *d_tile_state = nullptr;
-    uint32_t *d_tile_ptcl = nullptr;
-    uint32_t *d_tile_ncmd = nullptr;
-    pm::Cmd *d_ptcl = nullptr;  // per-tile command lists
-    uint32_t ptcl_cap = 0;      // commands
-    pm::Counters *d_ctr = nullptr;  // [2]
-    uint32_t frame = 0;
+    uint32_t arena_cap = 0;         // dwords per slot
     bool arena_dirty = true;
+
+    FrameSlot slot[kSlots];
+    uint32_t frame = 0;
+    int last_slot = -1;  // slot of the most recently submitted frame
 
     // tables
     uint32_t *d_lut_srgb2lin = nullptr;
     uint32_t *d_lut_unorm2h = nullptr;
     uint8_t *d_lut_lin2srgb = nullptr;
-
-    pm::FrameParams last_params{};
-    hipStream_t last_stream = nullptr;
-    bool have_frame = false;
 };
 
 namespace {
 
 uint32_t BandRows(const pm_ctx *c) { return c->row1 - c->row0; }
+size_t BandTiles(const pm_ctx *c) { return std::max<size_t>(static_cast<size_t>(BandRows(c)) * c->tiles_x, 1); }
+
+int SyncAll(pm_ctx *c) {
+    PM_TRY(hipStreamSynchronize(c->bin_stream));
+    PM_TRY(hipStreamSynchronize(c->stream));
+    for (auto &s : c->slot)
+        if (s.in_flight && s.tile_stream && s.tile_stream != c->stream) PM_TRY(hipStreamSynchronize(s.tile_stream));
+    return PM_OK;
+}
 
 void FreeViewport(pm_ctx *c) {
-    if (c->d_fb) (void)hipFree(c->d_fb);
-    if (c->d_striprow) (void)hipFree(c->d_striprow);
-    if (c->d_queue) (void)hipFree(c->d_queue);
-    if (c->d_tile_state) (void)hipFree(c->d_tile_state);
-    if (c->d_tile_ptcl) (void)hipFree(c->d_tile_ptcl);
-    if (c->d_tile_ncmd) (void)hipFree(c->d_tile_ncmd);
-    c->d_tile_state = nullptr;
-    c->d_tile_ptcl = nullptr;
-    c->d_tile_ncmd = nullptr;
-    c->d_fb = nullptr;
-    c->d_striprow = nullptr;
-    c->d_queue = nullptr;
+    for (auto &s : c->slot) {
+        if (s.d_fb) (void)hipFree(s.d_fb);
+        if (s.d_striprow) (void)hipFree(s.d_striprow);
+        if (s.d_queue) (void)hipFree(s.d_queue);
+        if (s.d_tile_state) (void)hipFree(s.d_tile_state);
+        if (s.d_tile_ptcl) (void)hipFree(s.d_tile_ptcl);
+        if (s.d_tile_ncmd) (void)hipFree(s.d_tile_ncmd);
+        s.d_fb = nullptr;
+        s.d_striprow = s.d_queue = s.d_tile_state = s.d_tile_ptcl = s.d_tile_ncmd = nullptr;
+        s.in_flight = false;
+    }
+    c->last_slot = -1;
 }
 
 int AllocViewport(pm_ctx *c) {
@@ -195,14 +222,16 @@ int AllocViewport(pm_ctx *c) {
     const uint32_t rows = BandRows(c);
     c->fb_stride = static_cast<size_t>(c->width) * 4;
     c->fb_bytes = c->fb_stride * static_cast<size_t>(rows) * pm::kTileH;
-    PM_TRY(hipMalloc(&c->d_fb, std::max<size_t>(c->fb_bytes, 16)));
-    PM_TRY(hipMalloc(&c->d_striprow, std::max<size_t>(static_cast<size_t>(rows) * c->strips_x, 1) * sizeof(uint32_t)));
-    PM_TRY(hipMalloc(&c->d_queue, 3 * std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));  // three class queues
-    PM_TRY(hipMalloc(&c->d_tile_state, std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));
-    PM_TRY(hipMalloc(&c->d_tile_ptcl, std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));
-    PM_TRY(hipMalloc(&c->d_tile_ncmd, std::max<size_t>(static_cast<size_t>(rows) * c->tiles_x, 1) * sizeof(uint32_t)));
+    const size_t tiles = BandTiles(c);
+    for (auto &s : c->slot) {
+        PM_TRY(hipMalloc(&s.d_fb, std::max<size_t>(c->fb_bytes, 16)));
+        PM_TRY(hipMalloc(&s.d_striprow, std::max<size_t>(static_cast<size_t>(rows) * c->strips_x, 1) * sizeof(uint32_t)));
+        PM_TRY(hipMalloc(&s.d_queue, 3 * tiles * sizeof(uint32_t)));  // three class queues
+        PM_TRY(hipMalloc(&s.d_tile_state, tiles * sizeof(uint32_t)));
+        PM_TRY(hipMalloc(&s.d_tile_ptcl, tiles * sizeof(uint32_t)));
+        PM_TRY(hipMalloc(&s.d_tile_ncmd, tiles * sizeof(uint32_t)));
+    }
     c->arena_dirty = true;
-    c->have_frame = false;
     return PM_OK;
 }
 
@@ -269,8 +298,9 @@ void StripRowBounds(const pm_ctx *c, std::vector<uint64_t> *need) {
 }
 
 int EnsureArena(pm_ctx *c) {
-    if (!c->arena_dirty && c->d_arena) return PM_OK;
+    if (!c->arena_dirty && c->slot[0].d_arena) return PM_OK;
     if (c->item_meta.empty() || c->tiles_x == 0) return PM_OK;  // nothing to size against yet
+    PM_TRY(SyncAll(c) == PM_OK ? hipSuccess : hipErrorUnknown);
     std::vector<uint64_t> need;
     StripRowBounds(c, &need);
     std::vector<uint32_t> base(need.size() + 1);
@@ -284,29 +314,31 @@ int EnsureArena(pm_ctx *c) {
         }
     }
     base[need.size()] = static_cast<uint32_t>(total);
-    if (!c->d_arena || total > c->arena_cap) {
-        if (c->d_arena) (void)hipFree(c->d_arena);
-        c->d_arena = nullptr;
-        PM_TRY(hipMalloc(&c->d_arena, total * sizeof(uint32_t)));
-        c->arena_cap = static_cast<uint32_t>(total);
+    for (auto &s : c->slot) {
+        if (!s.d_arena || total > c->arena_cap) {
+            if (s.d_arena) (void)hipFree(s.d_arena);
+            s.d_arena = nullptr;
+            PM_TRY(hipMalloc(&s.d_arena, total * sizeof(uint32_t)));
+        }
+        if (!s.d_ptcl) {
+            // Command-list arena: lists are sized from what binning actually found, so there is no
+            // static bound; start generously (HBM is 288 GB) and let pm_sync grow it on overflow.
+            uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
+            cmds = std::min<uint64_t>(cmds, 0x7fffffffull);
+            PM_TRY(hipMalloc(&s.d_ptcl, cmds * sizeof(pm::Cmd)));
+            s.ptcl_cap = static_cast<uint32_t>(cmds);
+        }
     }
+    c->arena_cap = std::max<uint32_t>(c->arena_cap, static_cast<uint32_t>(total));
     if (c->d_sr_base) (void)hipFree(c->d_sr_base);
     c->d_sr_base = nullptr;
     PM_TRY(hipMalloc(&c->d_sr_base, base.size() * sizeof(uint32_t)));
     PM_TRY(hipMemcpy(c->d_sr_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (!c->d_ptcl) {
-        // Command-list arena: lists are sized from what binning actually found, so there is no
-        // static bound; start generously (HBM is 288 GB) and let pm_sync grow it on overflow.
-        uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
-        cmds = std::min<uint64_t>(cmds, 0x7fffffffull);
-        PM_TRY(hipMalloc(&c->d_ptcl, cmds * sizeof(pm::Cmd)));
-        c->ptcl_cap = static_cast<uint32_t>(cmds);
-    }
     c->arena_dirty = false;
     return PM_OK;
 }
 
-int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
+int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     if (!c->d_scene || c->scene_bytes < 8) {
         SetError("no scene resident (pm_upload_scene / pm_flatten_and_encode first)");
         return PM_ERR_INVALID;
@@ -317,6 +349,7 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     }
     int r = EnsureArena(c);
     if (r != PM_OK) return r;
+    std::memset(p, 0, sizeof(*p));
     p->scene = c->d_scene;
     p->scene_bytes = static_cast<uint32_t>(c->scene_bytes);
     p->width = c->width;
@@ -329,59 +362,76 @@ int BuildParams(pm_ctx *c, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     p->fb = fb;
     p->fb_stride = static_cast<uint32_t>(stride);
     p->fb_vec16 = ((reinterpret_cast<uintptr_t>(fb) & 15u) == 0 && (stride & 15u) == 0) ? 1u : 0u;
-    p->arena = c->d_arena;
+    p->arena = s->d_arena;
     p->arena_cap = c->arena_cap;
-    p->striprow_head = c->d_striprow;
     p->sr_base = c->d_sr_base;
-    p->queue = c->d_queue;
-    p->queue_cap = std::max<uint32_t>(BandRows(c) * c->tiles_x, 1u);
-    p->tile_state = c->d_tile_state;
-    p->ptcl = c->d_ptcl;
-    p->ptcl_cap = c->ptcl_cap;
-    p->tile_ptcl = c->d_tile_ptcl;
-    p->tile_ncmd = c->d_tile_ncmd;
-    p->ctr_cur = c->d_ctr + (c->frame & 1u);
-    p->ctr_next = c->d_ctr + ((c->frame + 1u) & 1u);
+    p->striprow_head = s->d_striprow;
+    p->queue = s->d_queue;
+    p->queue_cap = static_cast<uint32_t>(BandTiles(c));
+    p->tile_state = s->d_tile_state;
+    p->ptcl = s->d_ptcl;
+    p->ptcl_cap = s->ptcl_cap;
+    p->tile_ptcl = s->d_tile_ptcl;
+    p->tile_ncmd = s->d_tile_ncmd;
+    p->ctr_cur = s->d_ctr + s->parity;
+    p->ctr_next = s->d_ctr + (s->parity ^ 1u);
     p->chunk_base = c->d_chunk_base;
     p->chunk_bbox = c->d_chunk_bbox;
     p->lut_srgb2lin = c->d_lut_srgb2lin;
     p->lut_unorm2h = c->d_lut_unorm2h;
     p->lut_lin2srgb = c->d_lut_lin2srgb;
-    p->dbg_counts = nullptr;
-    p->dbg_solid = nullptr;
-    p->dbg_cmds = nullptr;
-    p->dbg_max = 0;
-    p->dbg_time = nullptr;
-    p->dbg_bin = nullptr;
     return PM_OK;
 }
 
-// Persistent grids: workgroups of 4 waves, one wave per tile (or per quarter tile).
-constexpr uint32_t kCoarseWgPerCu = 6;  // pm_coarse_kernel: latency-bound, small register footprint
+// Persistent grids: workgroups of 4 waves, one wave per tile (or per part of a tile).
+constexpr uint32_t kCoarseWgPerCu = 6;  // pm_coarse_kernel: latency-bound
 constexpr uint32_t kFineWgPerCu = 4;    // pm_fine_kernel: VALU-bound interpreter
 
 uint32_t CoarseGrid(const pm_ctx *c) {
-    const uint32_t tiles = BandRows(c) * c->tiles_x;
+    const uint32_t tiles = static_cast<uint32_t>(BandTiles(c));
     return std::max(1u, std::min((tiles + 3u) / 4u, static_cast<uint32_t>(c->n_cus) * kCoarseWgPerCu));
 }
 
 uint32_t FineGrid(const pm_ctx *c) {
-    const uint32_t tiles = BandRows(c) * c->tiles_x;
+    const uint32_t tiles = static_cast<uint32_t>(BandTiles(c));
     return std::max(1u, std::min(tiles, static_cast<uint32_t>(c->n_cus) * kFineWgPerCu));
 }
 
-int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t stream) {
-    pm::FrameParams p;
-    int r = BuildParams(c, fb, stride, &p);
-    if (r != PM_OK) return r;
-    pm::LaunchBin(p, BandRows(c) * c->strips_x, stream);
-    pm::LaunchCoarse(p, CoarseGrid(c), false, stream);
-    pm::LaunchFine(p, FineGrid(c), stream);
-    PM_TRY(hipGetLastError());
-    c->last_stream = stream;
-    c->last_params = p;
-    c->have_frame = true;
+void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t tile_stream) {
+    FrameSlot *s = &c->slot[si];
+    s->in_flight = true;
+    s->params = p;
+    s->tile_stream = tile_stream;
+    s->parity ^= 1u;
+    c->last_slot = si;
     c->frame += 1;
+}
+
+// One frame.  user_stream == nullptr: pipelined over (bin_stream, stream); otherwise all three
+// kernels run back to back on the caller's stream.
+int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream) {
+    const int si = static_cast<int>(c->frame % kSlots);
+    FrameSlot *s = &c->slot[si];
+    if (!fb) fb = s->d_fb;
+    pm::FrameParams p;
+    int r = BuildParams(c, s, fb, stride, &p);
+    if (r != PM_OK) return r;
+    hipStream_t sb = user_stream ? user_stream : c->bin_stream;
+    hipStream_t st = user_stream ? user_stream : c->stream;
+    if (s->in_flight) PM_TRY(hipStreamWaitEvent(sb, s->ev_fine, 0));  // previous user of this slot
+    // frames that target the same caller-owned buffer must not overlap each other
+    if (c->last_slot >= 0 && c->slot[c->last_slot].in_flight && c->slot[c->last_slot].params.fb == fb)
+        PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].ev_fine, 0));
+    pm::LaunchBin(p, BandRows(c) * c->strips_x, sb);
+    if (sb != st) {
+        PM_TRY(hipEventRecord(s->ev_bin, sb));
+        PM_TRY(hipStreamWaitEvent(st, s->ev_bin, 0));
+    }
+    pm::LaunchCoarse(p, CoarseGrid(c), false, st);
+    pm::LaunchFine(p, FineGrid(c), st);
+    PM_TRY(hipGetLastError());
+    PM_TRY(hipEventRecord(s->ev_fine, st));
+    Submitted(c, si, p, st);
     return PM_OK;
 }
 
@@ -456,7 +506,7 @@ int SetScene(pm_ctx *c, size_t bytes) {
     c->scene_bytes = bytes;
     c->n_items = n;
     c->arena_dirty = true;
-    c->have_frame = false;
+    c->last_slot = -1;
     return BuildSceneIndex(c);
 }
 
@@ -526,12 +576,15 @@ pm_ctx *pm_create(int device, int *err) {
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&c->bin_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
-    if ((e = hipMalloc(&c->d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
-    pm::Counters init[2];
-    std::memset(init, 0, sizeof(init));
-    if ((e = hipMemcpy(c->d_ctr, init, sizeof(init), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy(counters)");
+    for (auto &s : c->slot) {
+        if ((e = hipEventCreateWithFlags(&s.ev_bin, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&s.ev_fine, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipMalloc(&s.d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
+        if ((e = hipMemset(s.d_ctr, 0, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMemset(counters)");
+    }
     Luts *l = new (std::nothrow) Luts();
     if (!l) {
         *err = PM_ERR_CAPACITY;
@@ -559,12 +612,16 @@ pm_ctx *pm_create(int device, int *err) {
 void pm_destroy(pm_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream && c->bin_stream) (void)SyncAll(c);
     FreeViewport(c);
-    if (c->d_arena) (void)hipFree(c->d_arena);
+    for (auto &s : c->slot) {
+        if (s.d_arena) (void)hipFree(s.d_arena);
+        if (s.d_ptcl) (void)hipFree(s.d_ptcl);
+        if (s.d_ctr) (void)hipFree(s.d_ctr);
+        if (s.ev_bin) (void)hipEventDestroy(s.ev_bin);
+        if (s.ev_fine) (void)hipEventDestroy(s.ev_fine);
+    }
     if (c->d_sr_base) (void)hipFree(c->d_sr_base);
-    if (c->d_ptcl) (void)hipFree(c->d_ptcl);
-    if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->h_scene) (void)hipHostFree(c->h_scene);
     if (c->d_chunk_base) (void)hipFree(c->d_chunk_base);
@@ -574,6 +631,7 @@ void pm_destroy(pm_ctx *c) {
     if (c->d_lut_lin2srgb) (void)hipFree(c->d_lut_lin2srgb);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (c->bin_stream) (void)hipStreamDestroy(c->bin_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -581,7 +639,8 @@ void pm_destroy(pm_ctx *c) {
 int pm_resize(pm_ctx *c, uint32_t width, uint32_t height) {
     if (!c || width == 0 || height == 0 || width > 65535 || height > 65535) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
-    PM_TRY(hipStreamSynchronize(c->stream));
+    int r = SyncAll(c);
+    if (r != PM_OK) return r;
     c->width = width;
     c->height = height;
     c->tiles_x = (width + pm::kTileW - 1) / pm::kTileW;   // PietRenderer.m:63-64
@@ -589,17 +648,16 @@ int pm_resize(pm_ctx *c, uint32_t width, uint32_t height) {
     c->strips_x = (c->tiles_x + pm::kStripTiles - 1) / pm::kStripTiles;
     c->row0 = 0;
     c->row1 = c->tiles_y;
-    c->band_set = false;
     return AllocViewport(c);
 }
 
 int pm_set_band(pm_ctx *c, uint32_t tile_row0, uint32_t tile_row1) {
     if (!c || c->tiles_y == 0 || tile_row0 >= tile_row1 || tile_row1 > c->tiles_y) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
-    PM_TRY(hipStreamSynchronize(c->stream));
+    int r = SyncAll(c);
+    if (r != PM_OK) return r;
     c->row0 = tile_row0;
     c->row1 = tile_row1;
-    c->band_set = true;
     return AllocViewport(c);
 }
 
@@ -612,13 +670,16 @@ uint8_t *pm_scene_buffer(pm_ctx *c, size_t *cap) {
 int pm_scene_reserve(pm_ctx *c, size_t cap) {
     if (!c) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
-    PM_TRY(hipStreamSynchronize(c->stream));
+    int r = SyncAll(c);
+    if (r != PM_OK) return r;
     return ReserveScene(c, cap);
 }
 
 int pm_upload_scene(pm_ctx *c, size_t bytes) {
     if (!c || bytes > c->scene_cap || bytes < 8) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
+    int r = SyncAll(c);  // frames in flight still read the old scene
+    if (r != PM_OK) return r;
     PM_TRY(hipMemcpyAsync(c->d_scene, c->h_scene, bytes, hipMemcpyHostToDevice, c->stream));
     return SetScene(c, bytes);
 }
@@ -627,6 +688,10 @@ int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const
                           const double affine[6], float width_scale, size_t *scene_bytes, uint32_t *n_items) {
     if (!c || !affine || (n_paths && !paths) || (n_els && !els)) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
+    {
+        const int rs = SyncAll(c);  // frames in flight still read the old scene
+        if (rs != PM_OK) return rs;
+    }
     size_t bytes = 0;
     uint32_t items = 0;
     hipError_t he = hipSuccess;
@@ -664,49 +729,54 @@ int pm_download_scene(pm_ctx *c, uint8_t *dst, size_t cap, size_t *bytes) {
 int pm_render(pm_ctx *c) {
     if (!c) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
-    return Enqueue(c, c->d_fb, c->fb_stride, c->stream);
+    return Enqueue(c, nullptr, c->fb_stride, nullptr);
 }
 
 int pm_render_to(pm_ctx *c, void *dev_framebuffer, size_t stride_bytes, void *hip_stream) {
     if (!c || !dev_framebuffer || (stride_bytes & 3u) || stride_bytes < static_cast<size_t>(c->width) * 4) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    return Enqueue(c, static_cast<uint8_t *>(dev_framebuffer), stride_bytes, s);
+    return Enqueue(c, static_cast<uint8_t *>(dev_framebuffer), stride_bytes, hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream);
 }
 
 int pm_sync(pm_ctx *c) {
     if (!c) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
-    PM_TRY(hipStreamSynchronize(c->stream));
-    for (int attempt = 0; c->have_frame && attempt < 6; ++attempt) {
-        if (c->last_stream && c->last_stream != c->stream) PM_TRY(hipStreamSynchronize(c->last_stream));
-        pm::Counters k;
-        PM_TRY(hipMemcpy(&k, c->last_params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
-        if (!k.overflow) return PM_OK;
-        // the command-list arena was too small for this frame: grow it and render the frame again
-        const uint64_t want = std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(4ull * c->ptcl_cap, 2ull * k.ptcl_top));
-        if (want <= c->ptcl_cap) break;
-        (void)hipFree(c->d_ptcl);
-        c->d_ptcl = nullptr;
-        PM_TRY(hipMalloc(&c->d_ptcl, want * sizeof(pm::Cmd)));
-        c->ptcl_cap = static_cast<uint32_t>(want);
-        const int r = Enqueue(c, c->last_params.fb, c->last_params.fb_stride, c->last_stream ? c->last_stream : c->stream);
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        int r = SyncAll(c);
         if (r != PM_OK) return r;
-        PM_TRY(hipStreamSynchronize(c->last_stream ? c->last_stream : c->stream));
+        if (c->last_slot < 0) return PM_OK;
+        FrameSlot *s = &c->slot[c->last_slot];
+        pm::Counters k;
+        PM_TRY(hipMemcpy(&k, s->params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
+        if (!k.overflow) return PM_OK;
+        // the command-list arena was too small for this frame: grow it (all slots) and render
+        // the last frame again
+        const uint64_t want = std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(4ull * s->ptcl_cap, 2ull * k.ptcl_top));
+        if (want <= s->ptcl_cap) break;
+        for (auto &t : c->slot) {
+            if (t.d_ptcl) (void)hipFree(t.d_ptcl);
+            t.d_ptcl = nullptr;
+            PM_TRY(hipMalloc(&t.d_ptcl, want * sizeof(pm::Cmd)));
+            t.ptcl_cap = static_cast<uint32_t>(want);
+        }
+        const pm::FrameParams lp = s->params;
+        hipStream_t ts = s->tile_stream;
+        bool own_fb = false;
+        for (auto &t : c->slot) own_fb = own_fb || (lp.fb == t.d_fb);
+        r = Enqueue(c, own_fb ? nullptr : lp.fb, lp.fb_stride, (own_fb || ts == c->stream) ? nullptr : ts);
+        if (r != PM_OK) return r;
     }
-    if (c->have_frame) {
-        SetError("command-list arena overflow (frame needs more than 2^31 commands)");
-        return PM_ERR_CAPACITY;
-    }
-    return PM_OK;
+    SetError("command-list arena overflow (frame needs more than 2^31 commands)");
+    return PM_ERR_CAPACITY;
 }
 
 int pm_read_pixels(pm_ctx *c, uint8_t *dst, size_t dst_stride, int fmt) {
-    if (!c || !dst || !c->d_fb || dst_stride < static_cast<size_t>(c->width) * 4) return PM_ERR_INVALID;
+    if (!c || !dst || c->last_slot < 0 || dst_stride < static_cast<size_t>(c->width) * 4) return PM_ERR_INVALID;
     const int r = pm_sync(c);
     if (r != PM_OK) return r;
+    const FrameSlot *s = &c->slot[c->last_slot];
     const uint32_t rows = std::min(BandRows(c) * pm::kTileH, c->height - c->row0 * pm::kTileH);
-    PM_TRY(hipMemcpy2D(dst, dst_stride, c->d_fb, c->fb_stride, static_cast<size_t>(c->width) * 4, rows, hipMemcpyDeviceToHost));
+    PM_TRY(hipMemcpy2D(dst, dst_stride, s->params.fb, s->params.fb_stride, static_cast<size_t>(c->width) * 4, rows, hipMemcpyDeviceToHost));
     if (fmt == PM_FMT_BGRA8) {
         for (uint32_t y = 0; y < rows; ++y) {
             uint8_t *row = dst + static_cast<size_t>(y) * dst_stride;
@@ -720,7 +790,7 @@ void *pm_framebuffer_device_ptr(pm_ctx *c, size_t *stride_bytes, uint32_t *rows)
     if (!c) return nullptr;
     if (stride_bytes) *stride_bytes = c->fb_stride;
     if (rows) *rows = BandRows(c) * pm::kTileH;
-    return c->d_fb;
+    return c->slot[c->last_slot >= 0 ? c->last_slot : 0].d_fb;
 }
 
 void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes) {
@@ -733,19 +803,25 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
     if (!c || iters <= 0) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
     int r;
+    if ((r = SyncAll(c)) != PM_OK) return r;
     if (total_ms) {
-        PM_TRY(hipEventRecord(c->ev[0], c->stream));
+        // pipelined, as pm_render submits them: start on the binning stream, end on the tile stream
+        PM_TRY(hipEventRecord(c->ev[0], c->bin_stream));
         for (int i = 0; i < iters; ++i)
-            if ((r = Enqueue(c, c->d_fb, c->fb_stride, c->stream)) != PM_OK) return r;
+            if ((r = Enqueue(c, nullptr, c->fb_stride, nullptr)) != PM_OK) return r;
         PM_TRY(hipEventRecord(c->ev[1], c->stream));
         PM_TRY(hipEventSynchronize(c->ev[1]));
         PM_TRY(hipEventElapsedTime(total_ms, c->ev[0], c->ev[1]));
+        if ((r = SyncAll(c)) != PM_OK) return r;
     }
     if (bin_ms || coarse_ms || fine_ms) {
+        // one kernel at a time on one stream, each launch bracketed by events
         double a1 = 0, a2 = 0, a3 = 0;
         for (int i = 0; i < iters; ++i) {
+            const int si = static_cast<int>(c->frame % kSlots);
+            FrameSlot *s = &c->slot[si];
             pm::FrameParams p;
-            if ((r = BuildParams(c, c->d_fb, c->fb_stride, &p)) != PM_OK) return r;
+            if ((r = BuildParams(c, s, s->d_fb, c->fb_stride, &p)) != PM_OK) return r;
             PM_TRY(hipEventRecord(c->ev[0], c->stream));
             pm::LaunchBin(p, BandRows(c) * c->strips_x, c->stream);
             PM_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -753,11 +829,9 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             PM_TRY(hipEventRecord(c->ev[2], c->stream));
             pm::LaunchFine(p, FineGrid(c), c->stream);
             PM_TRY(hipEventRecord(c->ev[3], c->stream));
+            PM_TRY(hipEventRecord(s->ev_fine, c->stream));
             PM_TRY(hipEventSynchronize(c->ev[3]));
-            c->last_params = p;
-            c->last_stream = c->stream;
-            c->have_frame = true;
-            c->frame += 1;
+            Submitted(c, si, p, c->stream);
             float t1 = 0, t2 = 0, t3 = 0;
             PM_TRY(hipEventElapsedTime(&t1, c->ev[0], c->ev[1]));
             PM_TRY(hipEventElapsedTime(&t2, c->ev[1], c->ev[2]));
@@ -777,7 +851,8 @@ int pm_get_stats(pm_ctx *c, pm_stats *out) {
     if (!c || !out) return PM_ERR_INVALID;
     std::memset(out, 0, sizeof(*out));
     PM_TRY(hipSetDevice(c->device));
-    PM_TRY(hipStreamSynchronize(c->stream));
+    int r = SyncAll(c);
+    if (r != PM_OK) return r;
     out->tiles_x = c->tiles_x;
     out->tiles_y = c->tiles_y;
     out->band_row0 = c->row0;
@@ -785,9 +860,9 @@ int pm_get_stats(pm_ctx *c, pm_stats *out) {
     out->n_items = c->n_items;
     out->arena_cap_dwords = c->arena_cap;
     out->scene_bytes = static_cast<uint32_t>(c->scene_bytes);
-    if (c->have_frame) {
+    if (c->last_slot >= 0) {
         pm::Counters k;
-        PM_TRY(hipMemcpy(&k, c->last_params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
+        PM_TRY(hipMemcpy(&k, c->slot[c->last_slot].params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
         out->queued_tiles = k.vheavy_count + k.heavy_count + k.light_count;
         out->heavy_tiles = k.vheavy_count + k.heavy_count;
         out->arena_used_dwords = k.arena_top;
@@ -799,23 +874,24 @@ int pm_get_stats(pm_ctx *c, pm_stats *out) {
 
 int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *counts, uint32_t *solid, pm_cmd *cmds) {
     if (!c || !counts || !solid || (max_cmds_per_tile && !cmds)) return PM_ERR_INVALID;
-    if (!c->have_frame) {
+    if (c->last_slot < 0) {
         SetError("pm_debug_capture_ptcl needs a rendered frame");
         return PM_ERR_INVALID;
     }
     PM_TRY(hipSetDevice(c->device));
-    PM_TRY(hipStreamSynchronize(c->stream));
+    int r = pm_sync(c);
+    if (r != PM_OK) return r;
+    FrameSlot *s = &c->slot[c->last_slot];
     const size_t tiles = static_cast<size_t>(BandRows(c)) * c->tiles_x;
     uint32_t *d_counts = nullptr, *d_solid = nullptr;
     pm::Cmd *d_cmds = nullptr;
-    PM_TRY(hipMalloc(&d_counts, tiles * sizeof(uint32_t)));
-    PM_TRY(hipMalloc(&d_solid, tiles * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&d_counts, std::max<size_t>(tiles, 1) * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&d_solid, std::max<size_t>(tiles, 1) * sizeof(uint32_t)));
     PM_TRY(hipMalloc(&d_cmds, std::max<size_t>(tiles * max_cmds_per_tile, 1) * sizeof(pm::Cmd)));
-    // tiles the binning kernel cleared itself never reach the tile kernel: {Bail}, white
-    // tiles the binning kernel resolved itself never reach the tile kernel: {Bail} + its colour
+    // tiles the binning kernel resolved itself never reach the tile kernels: {Bail} + its colour
     std::vector<uint32_t> h_counts(tiles, 1u), h_solid(tiles, 0xffffffffu);
-    if (tiles) PM_TRY(hipMemcpy(h_solid.data(), c->d_tile_state, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::vector<pm::Cmd> h_cmds(tiles * max_cmds_per_tile);
+    if (tiles) PM_TRY(hipMemcpy(h_solid.data(), s->d_tile_state, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (size_t t = 0; t < tiles && max_cmds_per_tile; ++t) {
         h_cmds[t * max_cmds_per_tile].tag = pm::kCmdBail;
         std::memset(h_cmds[t * max_cmds_per_tile].body, 0, sizeof(h_cmds[0].body));
@@ -825,12 +901,12 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
     if (e == hipSuccess) e = hipMemcpy(d_solid, h_solid.data(), tiles * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && max_cmds_per_tile) e = hipMemcpy(d_cmds, h_cmds.data(), h_cmds.size() * sizeof(pm::Cmd), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        pm::FrameParams p = c->last_params;  // same arena / queue / counters as the last frame
+        pm::FrameParams p = s->params;  // same arena / queues / counters as the last frame
         p.dbg_counts = d_counts;
         p.dbg_solid = d_solid;
         p.dbg_cmds = d_cmds;
         p.dbg_max = max_cmds_per_tile;
-        pm::LaunchCoarse(p, CoarseGrid(c), true, c->stream);  // replays the last frame's queue
+        pm::LaunchCoarse(p, CoarseGrid(c), true, c->stream);  // replays the last frame's queues
         e = hipStreamSynchronize(c->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(counts, d_counts, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);
@@ -846,25 +922,27 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
 int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows) {
     if (!c || !out) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
-    PM_TRY(hipStreamSynchronize(c->stream));
+    int r = SyncAll(c);
+    if (r != PM_OK) return r;
     const size_t rows = static_cast<size_t>(BandRows(c)) * c->strips_x;
     if (n_rows) *n_rows = rows;
     if (rows > max_rows) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;
     PM_TRY(hipMalloc(&d, std::max<size_t>(rows, 1) * 12 * sizeof(unsigned long long)));
+    const int si = static_cast<int>(c->frame % kSlots);
+    FrameSlot *s = &c->slot[si];
     pm::FrameParams p;
-    int r = BuildParams(c, c->d_fb, c->fb_stride, &p);
+    r = BuildParams(c, s, s->d_fb, c->fb_stride, &p);
     if (r == PM_OK) {
         p.dbg_bin = d;
+        hipError_t e = hipSuccess;
         pm::LaunchBin(p, BandRows(c) * c->strips_x, c->stream);
         pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
         pm::LaunchFine(p, FineGrid(c), c->stream);
-        c->last_params = p;
-        c->last_params.dbg_bin = nullptr;
-        c->last_stream = c->stream;
-        c->have_frame = true;
-        c->frame += 1;
-        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipEventRecord(s->ev_fine, c->stream);
+        p.dbg_bin = nullptr;
+        Submitted(c, si, p, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e == hipSuccess) e = hipMemcpy(out, d, rows * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         if (e != hipSuccess) r = HipFail(e, "bin timeline");
     }
@@ -873,17 +951,19 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
 }
 
 int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_slots) {
-    if (!c || !out || !c->have_frame) return PM_ERR_INVALID;
+    if (!c || !out || c->last_slot < 0) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
-    PM_TRY(hipStreamSynchronize(c->stream));
+    int r = pm_sync(c);
+    if (r != PM_OK) return r;
+    FrameSlot *s = &c->slot[c->last_slot];
     pm::Counters k;
-    PM_TRY(hipMemcpy(&k, c->last_params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
+    PM_TRY(hipMemcpy(&k, s->params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
     const size_t slots = 16ull * k.vheavy_count + 4ull * k.heavy_count + k.light_count;
     if (n_slots) *n_slots = slots;
     if (slots > max_slots) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;
     PM_TRY(hipMalloc(&d, std::max<size_t>(slots, 1) * 4 * sizeof(unsigned long long)));
-    pm::FrameParams p = c->last_params;
+    pm::FrameParams p = s->params;
     p.dbg_time = d;
     pm::LaunchFine(p, FineGrid(c), c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);

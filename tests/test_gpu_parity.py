@@ -265,3 +265,34 @@ def test_back_to_back_frames_and_timing_api(pm, pmo, renderer):
     tm = renderer.time_frames(10)
     assert tm["total_ms"] > 0 and tm["bin_ms"] > 0 and tm["fine_ms"] > 0
     assert np.array_equal(renderer.read_pixels(), pmo.render(scene, 1024, 768))
+
+
+def test_pipelined_frames_every_slot_and_scene_switch(pm, pmo, renderer):
+    """Frames overlap across two streams and three frame slots: whichever slot the last
+    frame landed in must hold the right picture, also right after the scene changed
+    under frames still in flight."""
+    a, b = pmo.scene_cardioid(), pmo.scene_path_test()
+    renderer.resize(800, 832)
+    want_a, want_b = pmo.render(a, 800, 832), pmo.render(b, 800, 832)
+    renderer.set_scene_bytes(a)
+    for n in (1, 2, 3, 4, 7):
+        for _ in range(n):
+            renderer.render()
+        assert np.array_equal(renderer.read_pixels(), want_a), n
+    for _ in range(5):
+        renderer.render()
+    renderer.set_scene_bytes(b)  # no sync by the caller
+    for _ in range(4):
+        renderer.render()
+    assert np.array_equal(renderer.read_pixels(), want_b)
+    assert_ptcl_equal(renderer, pmo, b, 800, 832)
+    # a caller-owned framebuffer interleaved with pipelined frames
+    import torch
+
+    t = torch.zeros((832, 800, 4), dtype=torch.uint8, device="cuda:0")
+    renderer.render()
+    renderer.render_to(t, None)
+    renderer.render()
+    renderer.sync()
+    assert np.array_equal(t.cpu().numpy(), want_b)
+    assert np.array_equal(renderer.read_pixels(), want_b)
