@@ -9,8 +9,8 @@
 //
 // Frames are pipelined like the reference's command queue ([commandBuffer commit] never waits,
 // PietRenderer.m:102): three frame slots (own arena, queues, command lists, framebuffer) and
-// two HIP streams -- binning of frame N+1 runs while the tile kernels of frame N are still
-// busy; events order slot reuse.  A frame rendered into a caller-owned buffer
+// three HIP streams, one per kernel -- binning of frame N+2 and the coarse kernel of frame N+1
+// run while the fine kernel of frame N is still busy; events order the stages and slot reuse.  A frame rendered into a caller-owned buffer
 // (pm_render_to) runs its three kernels back to back on the caller's stream instead.
 //
 // There is deliberately no CPU rendering path in this library: without a gfx950
@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -128,7 +129,15 @@ void BuildLuts(Luts *l) {
 
 
 namespace {
-constexpr int kSlots = 3;
+constexpr int kMaxSlots = 16;
+constexpr int kMaxStreams = 4;
+constexpr int kDefaultBinStreams = 2, kDefaultCoarseStreams = 1, kDefaultFineStreams = 1;  // measured best on Tiger 4K
+
+int EnvInt(const char *name, int dflt, int lo, int hi) {
+    const char *v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    return std::max(lo, std::min(hi, std::atoi(v)));
+}
 }
 
 struct FrameSlot {
@@ -143,7 +152,7 @@ struct FrameSlot {
     uint32_t ptcl_cap = 0;  // commands
     pm::Counters *d_ctr = nullptr;  // two: a frame's binning kernel zeroes the one the slot's next frame uses
     uint32_t parity = 0;
-    hipEvent_t ev_bin = nullptr, ev_fine = nullptr;
+    hipEvent_t ev_bin = nullptr, ev_coarse = nullptr, ev_fine = nullptr;
     bool in_flight = false;   // ev_fine was recorded for a frame using this slot
     pm::FrameParams params{};
     hipStream_t tile_stream = nullptr;  // stream the slot's last tile kernels ran on
@@ -152,7 +161,9 @@ struct FrameSlot {
 struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // tile kernels (coarse + fine); "the" context stream
-    hipStream_t bin_stream = nullptr;  // binning kernel of the next frame
+    // frame N: binning on bin_streams[N % nb], coarse on coarse_streams[N % nc], fine on
+    // fine_streams[N % nf]; stream == fine_streams[0]
+    std::vector<hipStream_t> bin_streams, coarse_streams, fine_streams;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
 
@@ -179,7 +190,7 @@ struct pm_ctx {
     uint32_t arena_cap = 0;         // dwords per slot
     bool arena_dirty = true;
 
-    FrameSlot slot[kSlots];
+    std::vector<FrameSlot> slot;
     uint32_t frame = 0;
     int last_slot = -1;  // slot of the most recently submitted frame
 
@@ -195,8 +206,9 @@ uint32_t BandRows(const pm_ctx *c) { return c->row1 - c->row0; }
 size_t BandTiles(const pm_ctx *c) { return std::max<size_t>(static_cast<size_t>(BandRows(c)) * c->tiles_x, 1); }
 
 int SyncAll(pm_ctx *c) {
-    PM_TRY(hipStreamSynchronize(c->bin_stream));
-    PM_TRY(hipStreamSynchronize(c->stream));
+    for (hipStream_t q : c->bin_streams) PM_TRY(hipStreamSynchronize(q));
+    for (hipStream_t q : c->coarse_streams) PM_TRY(hipStreamSynchronize(q));
+    for (hipStream_t q : c->fine_streams) PM_TRY(hipStreamSynchronize(q));
     for (auto &s : c->slot)
         if (s.in_flight && s.tile_stream && s.tile_stream != c->stream) PM_TRY(hipStreamSynchronize(s.tile_stream));
     return PM_OK;
@@ -407,27 +419,32 @@ void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t tile_str
     c->frame += 1;
 }
 
-// One frame.  user_stream == nullptr: pipelined over (bin_stream, stream); otherwise all three
+// One frame.  user_stream == nullptr: pipelined over (bin_stream, coarse_stream, stream); otherwise all three
 // kernels run back to back on the caller's stream.
 int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream) {
-    const int si = static_cast<int>(c->frame % kSlots);
+    const int si = static_cast<int>(c->frame % c->slot.size());
     FrameSlot *s = &c->slot[si];
     if (!fb) fb = s->d_fb;
     pm::FrameParams p;
     int r = BuildParams(c, s, fb, stride, &p);
     if (r != PM_OK) return r;
-    hipStream_t sb = user_stream ? user_stream : c->bin_stream;
-    hipStream_t st = user_stream ? user_stream : c->stream;
+    hipStream_t sb = user_stream ? user_stream : c->bin_streams[c->frame % c->bin_streams.size()];
+    hipStream_t sc = user_stream ? user_stream : c->coarse_streams[c->frame % c->coarse_streams.size()];
+    hipStream_t st = user_stream ? user_stream : c->fine_streams[c->frame % c->fine_streams.size()];
     if (s->in_flight) PM_TRY(hipStreamWaitEvent(sb, s->ev_fine, 0));  // previous user of this slot
     // frames that target the same caller-owned buffer must not overlap each other
     if (c->last_slot >= 0 && c->slot[c->last_slot].in_flight && c->slot[c->last_slot].params.fb == fb)
         PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].ev_fine, 0));
     pm::LaunchBin(p, BandRows(c) * c->strips_x, sb);
-    if (sb != st) {
+    if (sb != sc) {
         PM_TRY(hipEventRecord(s->ev_bin, sb));
-        PM_TRY(hipStreamWaitEvent(st, s->ev_bin, 0));
+        PM_TRY(hipStreamWaitEvent(sc, s->ev_bin, 0));
     }
-    pm::LaunchCoarse(p, CoarseGrid(c), false, st);
+    pm::LaunchCoarse(p, CoarseGrid(c), false, sc);
+    if (sc != st) {
+        PM_TRY(hipEventRecord(s->ev_coarse, sc));
+        PM_TRY(hipStreamWaitEvent(st, s->ev_coarse, 0));
+    }
     pm::LaunchFine(p, FineGrid(c), st);
     PM_TRY(hipGetLastError());
     PM_TRY(hipEventRecord(s->ev_fine, st));
@@ -575,12 +592,22 @@ pm_ctx *pm_create(int device, int *err) {
     };
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-    if ((e = hipStreamCreateWithFlags(&c->bin_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+    // Depth of the frame pipeline (see the top of this file); tunable for experiments.
+    const int nb = EnvInt("PM_BIN_STREAMS", kDefaultBinStreams, 1, kMaxStreams);
+    const int nc = EnvInt("PM_COARSE_STREAMS", kDefaultCoarseStreams, 1, kMaxStreams);
+    const int nf = EnvInt("PM_FINE_STREAMS", kDefaultFineStreams, 1, kMaxStreams);
+    c->slot.resize(static_cast<size_t>(EnvInt("PM_SLOTS", nb + nc + nf, 2, kMaxSlots)));
+    for (int i = 0; i < nb + nc + nf; ++i) {
+        hipStream_t q = nullptr;
+        if ((e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
+        (i < nb ? c->bin_streams : i < nb + nc ? c->coarse_streams : c->fine_streams).push_back(q);
+    }
+    c->stream = c->fine_streams[0];
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
     for (auto &s : c->slot) {
         if ((e = hipEventCreateWithFlags(&s.ev_bin, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&s.ev_coarse, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipEventCreateWithFlags(&s.ev_fine, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipMalloc(&s.d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
         if ((e = hipMemset(s.d_ctr, 0, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMemset(counters)");
@@ -612,13 +639,14 @@ pm_ctx *pm_create(int device, int *err) {
 void pm_destroy(pm_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream && c->bin_stream) (void)SyncAll(c);
+    (void)SyncAll(c);
     FreeViewport(c);
     for (auto &s : c->slot) {
         if (s.d_arena) (void)hipFree(s.d_arena);
         if (s.d_ptcl) (void)hipFree(s.d_ptcl);
         if (s.d_ctr) (void)hipFree(s.d_ctr);
         if (s.ev_bin) (void)hipEventDestroy(s.ev_bin);
+        if (s.ev_coarse) (void)hipEventDestroy(s.ev_coarse);
         if (s.ev_fine) (void)hipEventDestroy(s.ev_fine);
     }
     if (c->d_sr_base) (void)hipFree(c->d_sr_base);
@@ -631,8 +659,9 @@ void pm_destroy(pm_ctx *c) {
     if (c->d_lut_lin2srgb) (void)hipFree(c->d_lut_lin2srgb);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
-    if (c->bin_stream) (void)hipStreamDestroy(c->bin_stream);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (hipStream_t q : c->bin_streams) (void)hipStreamDestroy(q);
+    for (hipStream_t q : c->coarse_streams) (void)hipStreamDestroy(q);
+    for (hipStream_t q : c->fine_streams) (void)hipStreamDestroy(q);
     delete c;
 }
 
@@ -806,9 +835,11 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
     if ((r = SyncAll(c)) != PM_OK) return r;
     if (total_ms) {
         // pipelined, as pm_render submits them: start on the binning stream, end on the tile stream
-        PM_TRY(hipEventRecord(c->ev[0], c->bin_stream));
+        PM_TRY(hipEventRecord(c->ev[0], c->stream));  // everything is idle: fires at once
         for (int i = 0; i < iters; ++i)
             if ((r = Enqueue(c, nullptr, c->fb_stride, nullptr)) != PM_OK) return r;
+        for (auto &s : c->slot)  // join: the end event follows the last frame of every stream
+            if (s.in_flight) PM_TRY(hipStreamWaitEvent(c->stream, s.ev_fine, 0));
         PM_TRY(hipEventRecord(c->ev[1], c->stream));
         PM_TRY(hipEventSynchronize(c->ev[1]));
         PM_TRY(hipEventElapsedTime(total_ms, c->ev[0], c->ev[1]));
@@ -818,7 +849,7 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
         // one kernel at a time on one stream, each launch bracketed by events
         double a1 = 0, a2 = 0, a3 = 0;
         for (int i = 0; i < iters; ++i) {
-            const int si = static_cast<int>(c->frame % kSlots);
+            const int si = static_cast<int>(c->frame % c->slot.size());
             FrameSlot *s = &c->slot[si];
             pm::FrameParams p;
             if ((r = BuildParams(c, s, s->d_fb, c->fb_stride, &p)) != PM_OK) return r;
@@ -929,7 +960,7 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
     if (rows > max_rows) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;
     PM_TRY(hipMalloc(&d, std::max<size_t>(rows, 1) * 12 * sizeof(unsigned long long)));
-    const int si = static_cast<int>(c->frame % kSlots);
+    const int si = static_cast<int>(c->frame % c->slot.size());
     FrameSlot *s = &c->slot[si];
     pm::FrameParams p;
     r = BuildParams(c, s, s->d_fb, c->fb_stride, &p);
