@@ -154,11 +154,16 @@ int pm_read_pixels(pm_ctx *c, uint8_t *dst, size_t dst_stride, int fmt);
 void *pm_framebuffer_device_ptr(pm_ctx *c, size_t *stride_bytes, uint32_t *rows);
 void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes);
 
-/* Time `iters` back-to-back frames with HIP events on the ctx stream.
- * total_ms = whole batch; bin/coarse/fine_ms = average per-launch duration of the three
- * frame kernels (pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel) measured in a separate
- * event-bracketed pass (any pointer may be NULL). */
+/* Time `iters` frames with HIP events (any pointer may be NULL).
+ * total_ms = the whole batch submitted back to back through the frame pipeline, as pm_render
+ * does; bin/coarse/fine_ms = average per-launch duration of the three frame kernels
+ * (pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel), each ALONE on the GPU: a second pass
+ * of `iters` frames serialized on one stream, every launch bracketed by events. */
 int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms);
+/* Same, but the per-kernel durations are taken INSIDE the pipelined batch: every launch is
+ * bracketed by events on the stream it runs on while frames overlap (iters <= 4096).  These
+ * are the durations a kernel trace of pm_render traffic shows. */
+int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms);
 
 typedef struct {
     uint32_t tiles_x, tiles_y;    /* tile grid of the viewport */

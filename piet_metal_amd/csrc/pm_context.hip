@@ -421,7 +421,7 @@ void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t tile_str
 
 // One frame.  user_stream == nullptr: pipelined over (bin_stream, coarse_stream, stream); otherwise all three
 // kernels run back to back on the caller's stream.
-int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream) {
+int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipEvent_t *tev = nullptr) {
     const int si = static_cast<int>(c->frame % c->slot.size());
     FrameSlot *s = &c->slot[si];
     if (!fb) fb = s->d_fb;
@@ -435,17 +435,23 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream) {
     // frames that target the same caller-owned buffer must not overlap each other
     if (c->last_slot >= 0 && c->slot[c->last_slot].in_flight && c->slot[c->last_slot].params.fb == fb)
         PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].ev_fine, 0));
+    if (tev) PM_TRY(hipEventRecord(tev[0], sb));
     pm::LaunchBin(p, BandRows(c) * c->strips_x, sb);
+    if (tev) PM_TRY(hipEventRecord(tev[1], sb));
     if (sb != sc) {
         PM_TRY(hipEventRecord(s->ev_bin, sb));
         PM_TRY(hipStreamWaitEvent(sc, s->ev_bin, 0));
     }
+    if (tev) PM_TRY(hipEventRecord(tev[2], sc));
     pm::LaunchCoarse(p, CoarseGrid(c), false, sc);
+    if (tev) PM_TRY(hipEventRecord(tev[3], sc));
     if (sc != st) {
         PM_TRY(hipEventRecord(s->ev_coarse, sc));
         PM_TRY(hipStreamWaitEvent(st, s->ev_coarse, 0));
     }
+    if (tev) PM_TRY(hipEventRecord(tev[4], st));
     pm::LaunchFine(p, FineGrid(c), st);
+    if (tev) PM_TRY(hipEventRecord(tev[5], st));
     PM_TRY(hipGetLastError());
     PM_TRY(hipEventRecord(s->ev_fine, st));
     Submitted(c, si, p, st);
@@ -876,6 +882,45 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
         if (fine_ms) *fine_ms = static_cast<float>(a3 / iters);
     }
     return pm_sync(c);
+}
+
+int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms) {
+    if (!c || iters <= 0 || iters > 4096) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = SyncAll(c)) != PM_OK) return r;
+    std::vector<hipEvent_t> tev(static_cast<size_t>(iters) * 6, nullptr);
+    hipError_t e = hipSuccess;
+    for (auto &v : tev)
+        if (e == hipSuccess) e = hipEventCreate(&v);
+    r = PM_OK;
+    if (e != hipSuccess) r = HipFail(e, "hipEventCreate");
+    if (r == PM_OK) e = hipEventRecord(c->ev[0], c->stream);
+    for (int i = 0; i < iters && r == PM_OK; ++i) r = Enqueue(c, nullptr, c->fb_stride, nullptr, &tev[static_cast<size_t>(i) * 6]);
+    if (r == PM_OK) {
+        for (auto &s : c->slot)
+            if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.ev_fine, 0);
+        if (e == hipSuccess) e = hipEventRecord(c->ev[1], c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(c->ev[1]);
+        if (e == hipSuccess) r = SyncAll(c);
+        double acc[3] = {0, 0, 0};
+        for (int i = 0; i < iters && e == hipSuccess && r == PM_OK; ++i)
+            for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+                float t = 0;
+                e = hipEventElapsedTime(&t, tev[static_cast<size_t>(i) * 6 + 2 * k], tev[static_cast<size_t>(i) * 6 + 2 * k + 1]);
+                acc[k] += t;
+            }
+        float tt = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&tt, c->ev[0], c->ev[1]);
+        if (e != hipSuccess) r = HipFail(e, "pipelined timing");
+        if (total_ms) *total_ms = tt;
+        if (bin_ms) *bin_ms = static_cast<float>(acc[0] / iters);
+        if (coarse_ms) *coarse_ms = static_cast<float>(acc[1] / iters);
+        if (fine_ms) *fine_ms = static_cast<float>(acc[2] / iters);
+    }
+    for (auto &v : tev)
+        if (v) (void)hipEventDestroy(v);
+    return r == PM_OK ? pm_sync(c) : r;
 }
 
 int pm_get_stats(pm_ctx *c, pm_stats *out) {

@@ -1,0 +1,38 @@
+#!/bin/bash
+# Round profile (run on the GPU box through gpurun):  tools/prof_round.sh <tag>
+#   1. bench.py (default flags) -> gpurun_out/<tag>/bench.json
+#   2. rocprofv3 --kernel-trace --stats of the same command -> kernel_stats.csv
+#   3. PMC passes (FETCH_SIZE, WRITE_SIZE, then SQ counters), each in its own run with
+#      --kernel-trace only, -> pmc_passN.csv + pmc_summary.json
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $ROOT/bench.py"
+timeout 600 $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 1500 $OUT/bench.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --no-cpu-baseline > $OUT/trace.log 2>&1
+f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -8 $OUT/kernel_stats.csv
+find $OUT/trace -name "*kernel_trace.csv" -size +30M -delete
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- $BENCH --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
+  f=$(find $OUT/pmc$i -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && cp $f $OUT/pmc_pass$i.csv || tail -5 $OUT/pmc$i.log
+done
+python - $OUT <<'PY'
+import csv, sys, collections, glob, json, os
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(os.path.join(out, "pmc_pass*.csv"))):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].strip()
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summ = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"launches": len(next(iter(d.values())))} for k, d in agg.items() if "pm_" in k}
+json.dump(summ, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+print(json.dumps(summ, indent=1))
+PY
+rm -rf $OUT/trace $OUT/pmc[0-9]
+ls -la $OUT
