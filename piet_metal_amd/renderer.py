@@ -161,7 +161,7 @@ class Renderer:
 
 
 def _time_tiles(self, max_slots: int = 1 << 20) -> np.ndarray:
-    """Developer profiling: per-slot timeline of the tile kernel, rows =
+    """Developer profiling: per-slot timeline of pm_fine_kernel, rows =
     (start, end, tile | quarter << 31, wave << 32 | commands)."""
     out = np.zeros((max_slots, 4), np.uint64)
     n = C.c_size_t(0)

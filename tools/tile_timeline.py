@@ -1,4 +1,4 @@
-"""Developer profiling: where does pm_tile_kernel's time go at Tiger 4K?"""
+"""Developer profiling: where does pm_fine_kernel's time go at Tiger 4K?"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
