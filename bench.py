@@ -95,6 +95,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump", default=None, help="rank 0 saves the last gathered frame as .npy (tests)")
     args = ap.parse_args()
 
     import torch
@@ -110,9 +111,18 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X: there is no CPU fallback for the product path", file=sys.stderr)
         return 2
+    # Rehearsal of the N>1 path on a 1-GPU box (tests/test_gpu_parity.py): every rank on
+    # device 0 and gloo as the transport.  The driver's multi-GPU runs never set these.
+    if os.environ.get("PM_BENCH_SHARE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("PM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     if world > 1:
-        pmd.init_process_group("nccl")
+        if backend == "nccl":
+            pmd.init_process_group("nccl")
+        else:
+            os.environ["LOCAL_RANK"] = str(local)
+            pmd.init_process_group(backend)
         import torch.distributed as dist
 
     wl = stacked_tigers(pm, world)
@@ -213,6 +223,14 @@ def main() -> int:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pm, pm.workloads.tiger(3840, 2160))
         print(json.dumps(out), flush=True)
+    if args.dump and rank == 0:
+        import numpy as np
+
+        img = full if world > 1 else band[: wl.height]
+        if world == 1:
+            r.render_to(band, stream)
+            torch.cuda.synchronize()
+        np.save(args.dump, img.cpu().numpy())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

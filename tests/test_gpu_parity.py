@@ -296,3 +296,29 @@ def test_pipelined_frames_every_slot_and_scene_switch(pm, pmo, renderer):
     renderer.sync()
     assert np.array_equal(t.cpu().numpy(), want_b)
     assert np.array_equal(renderer.read_pixels(), want_b)
+
+
+def test_bench_two_rank_path_rehearsal_on_one_gpu(pm, pmo, tmp_path):
+    """bench.py's N>1 path (bands via pm_set_band + pm_render_to on torch's stream, gather to
+    rank 0) with both ranks on this box's one GPU and gloo as transport: the gathered frame
+    must equal the oracle's render of the stacked scene, and rank 0 prints the JSON line."""
+    import subprocess
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    dump = tmp_path / "frame.npy"
+    env = dict(os.environ, PM_BENCH_SHARE_DEVICE="1", PM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dump", str(dump)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    js = json.loads(line)
+    assert js["n_gpus"] == 2 and js["scaling"] == "weak" and js["value"] > 0 and js["config"]["viewport"] == [3840, 4320]
+    wl = bench.stacked_tigers(pm, 2)
+    scene, _ = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
+    got = np.load(dump)
+    assert got.shape == (4320, 3840, 4)
+    assert np.array_equal(got, pmo.render(scene, 3840, 4320))
