@@ -1034,7 +1034,9 @@ int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_sl
     FrameSlot *s = &c->slot[c->last_slot];
     pm::Counters k;
     PM_TRY(hipMemcpy(&k, s->params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
-    const size_t slots = 16ull * k.vheavy_count + 4ull * k.heavy_count + k.light_count;
+    const bool dense = k.vheavy_count + k.heavy_count >= FineGrid(c) * 4u;  // as pm_fine_kernel decides
+    const size_t slots = dense ? static_cast<size_t>(k.vheavy_count) + k.heavy_count + k.light_count
+                               : 16ull * k.vheavy_count + 4ull * k.heavy_count + k.light_count;
     if (n_slots) *n_slots = slots;
     if (slots > max_slots) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;

@@ -1488,8 +1488,13 @@ __global__ __launch_bounds__(kThreads) void pm_fine_kernel(FrameParams P) {
     const uint32_t n_a = P.ctr_cur->vheavy_count, n_b = P.ctr_cur->heavy_count, n_c = P.ctr_cur->light_count;
     const uint32_t wave_global = blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWaves;
-    // slots: 16 per very heavy tile (one pixel row per wave), 4 per heavy tile, 1 per light tile
-    const uint32_t s_a = 16u * n_a, s_b = 4u * n_b;
+    // slots: 16 per very heavy tile (one pixel row per wave), 4 per heavy tile, 1 per light tile.
+    // Splitting a tile buys latency when few long lists set the span of the launch; with more
+    // long lists than waves it only costs work (the y-only math is no longer shared by 4
+    // pixels), so dense frames render every tile with one wave.
+    const bool dense = n_a + n_b >= n_waves;
+    const uint32_t sh_a = dense ? 0u : 4u, sh_b = dense ? 0u : 2u;
+    const uint32_t s_a = n_a << sh_a, s_b = n_b << sh_b;
     const uint32_t n_slots = s_a + s_b + n_c;
     const uint8_t *lut = P.lut_lin2srgb;
     auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {  // linear -> sRGB + unorm8 (:563-565)
@@ -1504,13 +1509,13 @@ __global__ __launch_bounds__(kThreads) void pm_fine_kernel(FrameParams P) {
         // rows of the tile this wave renders: [row0, row0 + nrows)
         uint32_t tile, row0, nrows;
         if (slot < s_a) {
-            tile = P.queue[slot >> 4];
-            row0 = slot & 15u;
-            nrows = 1;
+            tile = P.queue[slot >> sh_a];
+            nrows = 16u >> sh_a;
+            row0 = (slot & ((1u << sh_a) - 1u)) * nrows;
         } else if (slot < s_a + s_b) {
-            tile = P.queue[P.queue_cap + ((slot - s_a) >> 2)];
-            row0 = 4u * ((slot - s_a) & 3u);
-            nrows = 4;
+            tile = P.queue[P.queue_cap + ((slot - s_a) >> sh_b)];
+            nrows = 16u >> sh_b;
+            row0 = ((slot - s_a) & ((1u << sh_b) - 1u)) * nrows;
         } else {
             tile = P.queue[2u * P.queue_cap + (slot - s_a - s_b)];
             row0 = 0;
