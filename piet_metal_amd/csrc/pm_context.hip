@@ -257,6 +257,7 @@ int ValidateScene(const uint8_t *meta, size_t meta_len, size_t scene_bytes, uint
     const uint64_t bbox_end = 8ull + 8ull * n;
     const uint64_t items_end = static_cast<uint64_t>(items_ix) + 32ull * n;
     if (bbox_end > scene_bytes || items_end > scene_bytes || items_ix < bbox_end) return PM_ERR_SCENE;
+    if (items_ix & 7u) return PM_ERR_SCENE;  // the encoder keeps everything 8-byte aligned (src/lib.rs:113-130)
     if (items_end > meta_len) return PM_ERR_SCENE;
     for (uint32_t i = 0; i < n; ++i) {
         const uint8_t *it = meta + items_ix + 32ull * i;
@@ -364,6 +365,8 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     std::memset(p, 0, sizeof(*p));
     p->scene = c->d_scene;
     p->scene_bytes = static_cast<uint32_t>(c->scene_bytes);
+    p->n_items = c->n_items;
+    std::memcpy(&p->items_ix, c->item_meta.data() + 4, 4);
     p->width = c->width;
     p->height = c->height;
     p->tiles_x = c->tiles_x;
@@ -1005,6 +1008,7 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
     if (rows > max_rows) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;
     PM_TRY(hipMalloc(&d, std::max<size_t>(rows, 1) * 12 * sizeof(unsigned long long)));
+    PM_TRY(hipMemset(d, 0, std::max<size_t>(rows, 1) * 12 * sizeof(unsigned long long)));
     const int si = static_cast<int>(c->frame % c->slot.size());
     FrameSlot *s = &c->slot[si];
     pm::FrameParams p;

@@ -65,6 +65,7 @@ constexpr uint32_t kCtCountMask = (1u << kCtShift) - 1u;
 struct FrameParams {
     const uint8_t *scene;
     uint32_t scene_bytes;
+    uint32_t n_items, items_ix;  // the scene header (SimpleGroup), validated on the host
     uint32_t width, height;
     uint32_t tiles_x, tiles_y;
     uint32_t row0, row1;  // band of tile rows rendered by this context

@@ -187,6 +187,24 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_p
     return base + incl - v;
 }
 
+// bit k of an 8-bit value -> bit 4k
+__device__ __forceinline__ uint32_t SpreadNibbles(uint32_t x) {
+    x = (x | (x << 12)) & 0x000f000fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x;
+}
+// cross-lane moves inside groups of 4 / 8 lanes (DPP: no LDS traffic)
+__device__ __forceinline__ uint32_t DppQuadXor1(uint32_t v) {  // quad_perm [1,0,3,2]
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ uint32_t DppQuadXor2(uint32_t v) {  // quad_perm [2,3,0,1]
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x4E, 0xf, 0xf, true));
+}
+__device__ __forceinline__ uint32_t DppHalfMirror(uint32_t v) {  // row_half_mirror: lane i <-> 7 - i of each 8
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x141, 0xf, 0xf, true));
+}
+
 // Largest c in [0, n) with off[c] <= e (off ascending, off[0] == 0, n >= 1).
 __device__ __forceinline__ uint32_t FindOwner(const uint32_t *off, uint32_t n, uint32_t e) {
     uint32_t lo = 0, hi = n;
@@ -236,8 +254,50 @@ __global__ void pm_index_kernel(const uint8_t *scene, uint32_t n_items, const ui
 // K1: binning, one workgroup per strip row
 // =====================================================================================
 
+namespace {
+
+// The kernel arguments, one dword per lane.  pm_bin_kernel is short of SGPRs: left to the
+// compiler, every late use of a FrameParams field becomes its own s_load + s_waitcnt (each a
+// 0.2 us scalar round trip, a dozen of them before the first useful load).  Instead the
+// whole struct is fetched with ONE vector load at entry and fields are picked out with
+// v_readlane -- no memory traffic, no waits.
+struct ParamRegs {
+    uint32_t w[(sizeof(FrameParams) / 4 + 63) / 64];
+};
+
+__device__ __forceinline__ ParamRegs LoadParams(const FrameParams &P) {
+    static_assert(sizeof(FrameParams) % 4 == 0, "FrameParams is read dword-wise");
+    ParamRegs r;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&P);
+    const uint32_t lane = LaneId();
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(r.w) / 4; ++k) {
+        const uint32_t ix = k * 64u + lane;
+        r.w[k] = ix < sizeof(FrameParams) / 4 ? src[ix] : 0u;
+    }
+    return r;
+}
+
+template <size_t kOff>
+__device__ __forceinline__ uint32_t ParamU32(const ParamRegs &r) {
+    static_assert(kOff % 4 == 0 && kOff < sizeof(FrameParams), "field offset");
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(r.w[kOff / 256]), static_cast<int>((kOff / 4) & 63)));
+}
+
+template <typename T, size_t kOff>
+__device__ __forceinline__ T ParamPtr(const ParamRegs &r) {
+    const uint64_t lo = ParamU32<kOff>(r), hi = ParamU32<kOff + 4>(r);
+    return reinterpret_cast<T>(lo | (hi << 32));
+}
+
+#define PM_PU(field) ParamU32<offsetof(FrameParams, field)>(PR)
+#define PM_PP(field) ParamPtr<decltype(FrameParams::field), offsetof(FrameParams, field)>(PR)
+
+}  // namespace
+
 template <bool kProfile>
 __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
+    const ParamRegs PR = LoadParams(P);
     __shared__ uint32_t s_part[kBinWaves];
     __shared__ uint32_t s_cidx[kThreads];   // candidate item index
     __shared__ uint32_t s_cmask[kThreads];  // candidate per-tile hit mask (16 bits)
@@ -248,7 +308,10 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     __shared__ float s_chw[kThreads];       // 0.5*width + 0.5 for polylines
     __shared__ uint32_t s_cchunk[kThreads]; // first chunk-table entry of the item
     __shared__ uint32_t s_choff[kThreads + 1];  // chunk-stream offsets
-    __shared__ uint32_t s_ct[kThreads * kStripTiles];  // per (candidate, tile): backdrop steps << 20 | relevant segments
+    // per (candidate, tile): backdrop steps << 20 | relevant segments.  Row stride 17: a thread per
+    // candidate walking its row, and 16 lanes adding to one row, are both free of bank conflicts.
+    constexpr uint32_t kCtStride = kStripTiles + 1;
+    __shared__ uint32_t s_ct[kThreads * kCtStride];
     __shared__ uint32_t s_surv[kBinWaves][256];  // [0][..]: surviving chunks of one round (c << 24 | j); later scratch  // surviving chunks of one wave round: c << 24 | j
     __shared__ uint32_t s_est[kStripTiles];  // per tile: stream elements the tile kernel will see
     // per tile, in paint order across batches: the last candidate that can emit anything, and the
@@ -258,13 +321,15 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     __shared__ uint32_t s_last_solid[kStripTiles];
     __shared__ uint32_t s_solid_rgba[kStripTiles];
     __shared__ uint32_t s_qbase[5];
+    __shared__ uint32_t s_crgba[kThreads], s_caux0[kThreads], s_caux1[kThreads];  // candidate colour / payload
+    __shared__ uint32_t s_lut[256];  // sRGB->linear half bits | a/255 half bits << 16
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = LaneId();
     const uint32_t wave = tid >> 6;
-    const uint32_t strip = blockIdx.x % P.strips_x;
-    const uint32_t row_rel = blockIdx.x / P.strips_x;
-    const uint32_t ty = P.row0 + row_rel;
+    const uint32_t strip = blockIdx.x % PM_PU(strips_x);
+    const uint32_t row_rel = blockIdx.x / PM_PU(strips_x);
+    const uint32_t ty = PM_PU(row0) + row_rel;
     const int sx0 = static_cast<int>(strip * kGroupW);
     const int y0 = static_cast<int>(ty * kTileH);
     const int sy0 = y0 & ~static_cast<int>(kGroupH - 1);
@@ -275,15 +340,25 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     if (blockIdx.x == 0 && tid == 0) {
         // The counters of the NEXT frame (the other parity) are idle now: reset them
         // here so that no separate memset launch is needed.
-        P.ctr_next->arena_top = 0;
-        P.ctr_next->ptcl_top = 0;
-        P.ctr_next->vheavy_count = 0;
-        P.ctr_next->heavy_count = 0;
-        P.ctr_next->light_count = 0;
-        P.ctr_next->overflow = 0;
+        PM_PP(ctr_next)->arena_top = 0;
+        PM_PP(ctr_next)->ptcl_top = 0;
+        PM_PP(ctr_next)->vheavy_count = 0;
+        PM_PP(ctr_next)->heavy_count = 0;
+        PM_PP(ctr_next)->light_count = 0;
+        PM_PP(ctr_next)->overflow = 0;
     }
-    unsigned long long tb[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (dead code unless kProfile)
-    if (kProfile) tb[0] = wall_clock64();
+    // Developer timeline (kProfile builds only): thread 0 stores the clock straight to memory, so
+    // that the profiled kernel keeps the register allocation of the production one.
+    // slots: 0 entry, 1 item scan done, 2 first record's headers done, 3 last segment stream done,
+    //        4 last record finalised, 5 queues done, 6 chunks tested (count), 7 exit
+    auto stamp = [&](uint32_t k) {
+        if (kProfile) {
+            if (tid == 0) PM_PP(dbg_bin)[12ull * blockIdx.x + k] = wall_clock64();
+        }
+    };
+    bool prof_first = true;
+    uint32_t prof_chunks = 0;
+    stamp(0);
     if (tid < kStripTiles) {
         s_est[tid] = 0;
         s_last_kept[tid] = 0;
@@ -292,30 +367,36 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     }
     __syncthreads();
 
-    const uint8_t *scene = P.scene;
+    const uint8_t *scene = PM_PP(scene);
     // wave-uniform values are pinned to SGPRs (readfirstlane): the record pointers and loop
     // bounds derived from them then live on the scalar unit instead of in 64-bit VGPR pairs
-    const uint32_t n_items = __builtin_amdgcn_readfirstlane(LoadU32(scene));
-    const uint32_t items_ix = __builtin_amdgcn_readfirstlane(LoadU32(scene + 4));
+    const uint32_t n_items = PM_PU(n_items), items_ix = PM_PU(items_ix);  // kernel arguments: no load on the critical path
     // This strip row owns arena[sr_base[b] .. sr_base[b+1]): the host sized it for the worst
     // case (every chunk of every candidate survives), so records are bump-allocated without
     // atomics and without a counting pass.
-    uint32_t cursor = __builtin_amdgcn_readfirstlane(P.sr_base[blockIdx.x]);
-    const uint32_t region_end = __builtin_amdgcn_readfirstlane(P.sr_base[blockIdx.x + 1]);
+    uint32_t cursor = __builtin_amdgcn_readfirstlane(PM_PP(sr_base)[blockIdx.x]);
+    const uint32_t region_end = __builtin_amdgcn_readfirstlane(PM_PP(sr_base)[blockIdx.x + 1]);
     uint32_t head = 0;       // first record of this strip row
     uint32_t prev_rec = 0;   // record whose `next` field is still open
 
     // Records hold up to kBatch CANDIDATES (not items): item bboxes are scanned kBatch at a time
     // and the survivors accumulate; a record is cut only when the next scan step would not fit.
     // Most strip rows therefore produce a single record.
+    // Every dependent global access costs 1-2 us here, so the scan keeps the NEXT step's bboxes
+    // in flight while it ranks the current ones.
     uint32_t ncand = 0;
+    uint2 bb_next = make_uint2(0u, 0u);
+    if (tid < n_items) bb_next = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(tid) * 8);
+    // the two colour tables ride along with the first bbox load (finalisation reads them from LDS)
+    s_lut[tid] = PM_PP(lut_srgb2lin)[tid] | (PM_PP(lut_unorm2h)[tid] << 16);
     for (uint32_t ib = 0;; ib += kBatch) {
         const bool more = ib < n_items;  // uniform
         const uint32_t i = ib + tid;
         bool cand = false;
         uint32_t mask = 0;
+        const uint2 bb = bb_next;
+        if (i + kBatch < n_items) bb_next = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(i + kBatch) * 8);
         if (more && tid < kBatch && i < n_items) {
-            const uint2 bb = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(i) * 8);
             const int bx = static_cast<int>(bb.x & 0xffffu), by = static_cast<int>(bb.x >> 16);
             const int bz = static_cast<int>(bb.y & 0xffffu), bw = static_cast<int>(bb.y >> 16);
             // the tile `hit` test of PietRender.metal:214, y part + strip-wide x part
@@ -345,38 +426,54 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             continue;  // (nb > kBatch cannot happen: a scan step tests kBatch items)
         }
         __syncthreads();  // the appended candidates are visible
-        if (kProfile && tb[1] == 0) tb[1] = wall_clock64();  // first record starts (item scan done)
+        if (kProfile && prof_first) stamp(1);  // first record starts (item scan done)
 
         // ---- candidate headers + chunk-stream offsets ---------------------------------
         uint32_t nch = 0;
-        uint32_t tag = 0, rgba = 0, aux0 = 0, aux1 = 0;
         if (tid < ncand) {
+            uint32_t tag = 0, rgba = 0, aux0 = 0, aux1 = 0;
             const uint32_t idx = s_cidx[tid];
             const uint8_t *item = scene + items_ix + static_cast<size_t>(idx) * kItemSize;
-            tag = LoadU32(item) & 0xffffu;
+            // the first 20 bytes of the item, its bbox and its chunk-table entry: all loads are
+            // issued before any of them is looked at (one round trip instead of a tag-dependent two)
+            uint2 w01v, w23v, ibbv;
+            uint32_t w4v;
+            const uint2 w01 = *reinterpret_cast<const uint2 *>(item);
+            const uint2 w23 = *reinterpret_cast<const uint2 *>(item + 8);
+            const uint32_t w4 = LoadU32(item + 16);
+            const uint2 ibb = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(idx) * 8);
+            uint32_t cbase = PM_PP(chunk_base)[idx];
+            {   // keep the compiler from sinking any of these loads into the tag branches below
+                uint32_t a0 = w01.x, a1 = w01.y, a2 = w23.x, a3 = w23.y, a4 = w4, a5 = ibb.x, a6 = ibb.y;
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(cbase));
+                w01v = make_uint2(a0, a1);
+                w23v = make_uint2(a2, a3);
+                w4v = a4;
+                ibbv = make_uint2(a5, a6);
+            }
+            tag = w01v.x & 0xffffu;
             uint32_t pts = 0, npt = 0, nseg = 0;
             float hw = 0.0f;
             if (tag == kItemCircle) {
-                const uint2 bb = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(idx) * 8);
-                aux0 = bb.x;
-                aux1 = bb.y;
+                aux0 = ibbv.x;
+                aux1 = ibbv.y;
             } else if (tag == kItemLine) {
-                rgba = LoadU32(item + 8);
-                aux0 = LoadU32(item + 12);  // width bits
+                rgba = w23v.x;
+                aux0 = w23v.y;  // width bits
                 pts = items_ix + idx * static_cast<uint32_t>(kItemSize) + 16;  // start,end live in the item
                 nseg = 1;
                 nch = 1;  // never culled at strip level (PietRender.metal:223-247)
             } else if (tag == kItemFill) {
-                rgba = LoadU32(item + 8);
-                npt = LoadU32(item + 12);
-                pts = LoadU32(item + 16);
+                rgba = w23v.x;
+                npt = w23v.y;
+                pts = w4v;
                 nseg = FillSegs(npt);
                 nch = (nseg + kChunkSegs - 1) / kChunkSegs;
             } else if (tag == kItemPoly) {
-                rgba = LoadU32(item + 4);
-                aux0 = LoadU32(item + 8);  // width bits
-                npt = LoadU32(item + 12);
-                pts = LoadU32(item + 16);
+                rgba = w01v.y;
+                aux0 = w23v.x;  // width bits
+                npt = w23v.y;
+                pts = w4v;
                 hw = 0.5f * __uint_as_float(aux0) + 0.5f;
                 nseg = PolySegs(npt);
                 nch = (nseg + kChunkSegs - 1) / kChunkSegs;
@@ -384,13 +481,16 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                 tag = 0;
             }
             s_ctag[tid] = tag;
+            s_crgba[tid] = rgba;
+            s_caux0[tid] = aux0;
+            s_caux1[tid] = aux1;
             s_cpts[tid] = pts;
             s_cnpt[tid] = npt;
             s_cnseg[tid] = nseg;
             s_chw[tid] = hw;
-            s_cchunk[tid] = P.chunk_base[idx];
-            uint4 *z = reinterpret_cast<uint4 *>(&s_ct[tid * kStripTiles]);
-            z[0] = z[1] = z[2] = z[3] = make_uint4(0u, 0u, 0u, 0u);
+            s_cchunk[tid] = cbase;
+#pragma unroll
+            for (uint32_t t = 0; t < kStripTiles; ++t) s_ct[tid * kCtStride + t] = 0;
         }
         uint32_t total_ch;
         const uint32_t choff = BlockExclusiveScan<kBinWaves>(nch, s_part, &total_ch);
@@ -403,18 +503,18 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         const uint32_t rec = cursor;
         const uint32_t size = kRecHdrDwords + mask_dwords + (kCandDwords + kCtDwords) * ncand + 5u * kChunkSegs * total_ch;
         if (rec + size > region_end) {  // cannot happen unless the host bound is wrong
-            if (tid == 0) P.ctr_cur->overflow = 1;
+            if (tid == 0) PM_PP(ctr_cur)->overflow = 1;
             break;
         }
         cursor += size;
-        uint32_t *hdr = P.arena + rec;
+        uint32_t *hdr = PM_PP(arena) + rec;
         uint32_t *mask_tab = hdr + kRecHdrDwords;
         uint32_t *cand_rec = mask_tab + mask_dwords;
         uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
         float4 *segs = reinterpret_cast<float4 *>(ct_tab + kCtDwords * ncand);
         uint32_t *meta = reinterpret_cast<uint32_t *>(segs + kChunkSegs * total_ch);
         if (tid == 0) {
-            if (prev_rec) P.arena[prev_rec] = rec;
+            if (prev_rec) PM_PP(arena)[prev_rec] = rec;
             hdr[0] = 0;  // next
             hdr[1] = ncand;
             hdr[2] = total_ch;
@@ -422,7 +522,8 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         if (head == 0) head = rec;
         prev_rec = rec;
         __syncthreads();  // s_choff, s_c* visible to every wave
-        if (kProfile && tb[2] == 0) tb[2] = wall_clock64();  // headers + scan done
+        if (kProfile && prof_first) stamp(2);  // headers + scan done
+        prof_first = false;
 
         // ---- chunk stream -> surviving chunks -> segment votes ---------------------------------
         // Block rounds of 256 chunks: chunks whose box cannot reach the strip row are dropped and
@@ -435,10 +536,9 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         constexpr uint32_t kCPL = 4;  // chunks tested per lane per round: fewer rounds, fewer barriers
         for (uint32_t r0 = 0; r0 < total_ch; r0 += kBinThreads * kCPL) {
             const uint32_t eb = r0 + kCPL * tid;  // this lane's consecutive chunks (stream order)
+            if (kProfile && r0 == 0) stamp(8);
             uint32_t svb = 0;
             uint32_t pk[kCPL];
-            unsigned long long t_r0 = 0;
-            if (kProfile) t_r0 = wall_clock64();
             if (eb < total_ch) {
                 uint32_t c = FindOwner(s_choff, ncand, eb);
                 uint32_t cc[kCPL];
@@ -451,7 +551,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                     const uint32_t j = e - s_choff[c];
                     pk[u] = (c << 24) | j;
                     bb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < total_ch && s_ctag[c] != kItemLine) bb[u] = P.chunk_bbox[s_cchunk[c] + j];
+                    if (e < total_ch && s_ctag[c] != kItemLine) bb[u] = PM_PP(chunk_bbox)[s_cchunk[c] + j];
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < kCPL; ++u) {
@@ -472,15 +572,14 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             uint32_t ns;
             uint32_t srank = BlockExclusiveScan<kBinWaves>(static_cast<uint32_t>(__popc(svb)), s_part, &ns);
             ns = __builtin_amdgcn_readfirstlane(ns);
-            if (kProfile) { tb[8] += wall_clock64() - t_r0; tb[10] += 1; }  // chunk-test part of the round
+            if (kProfile && r0 == 0) stamp(9);
             if (ns == 0) continue;  // uniform
 #pragma unroll
             for (uint32_t u = 0; u < kCPL; ++u)
                 if ((svb >> u) & 1u) (&s_surv[0][0])[srank++] = pk[u];
             __syncthreads();
-            unsigned long long t_e0 = 0;
-            if (kProfile) t_e0 = wall_clock64();
             const uint32_t n_el = ns * kChunkSegs;
+            if (kProfile && r0 == 0) stamp(10);
             for (uint32_t f0 = wave * 64u; f0 < n_el; f0 += kBinThreads) {
                 const uint32_t f = f0 + lane;
                 bool vote = false;
@@ -549,7 +648,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                                 const float fxm = static_cast<float>(sx0 + mid * static_cast<int>(kTileW));
                                 if (Sgn(a * fxm + yb + cc) == sa) hi = mid; else lo = mid + 1;
                             }
-                            if (lo < 16) atomicAdd(&s_ct[vc * kStripTiles + lo], static_cast<uint32_t>(-static_cast<int>(sa)) << kCtShift);
+                            if (lo < 16) atomicAdd(&s_ct[vc * kCtStride + lo], static_cast<uint32_t>(-static_cast<int>(sa)) << kCtShift);
                         }
                     }
                 } else if (ctag == kItemPoly) {
@@ -571,34 +670,37 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                     }
                     meta[slot] = mword;
                 }
-                // relevant-segment counts per (candidate, tile).  Neighbouring lanes hold segments
-                // of the same item hitting the same tiles, so per-lane LDS atomics would serialise
-                // 64-fold; instead, for each distinct candidate of the wave, sixteen ballots count
-                // the lanes per tile and lane t adds tile t's count once.
+                // relevant-segment counts per (candidate, tile).  The 8 lanes of a chunk share one
+                // candidate: spread the 16 tile bits to 16 nibbles (64 bits), add the 8 lanes with
+                // three DPP steps (8 <= 15 fits a nibble), and let lane j of the chunk add the counts
+                // of tiles 2j and 2j+1 -- ~40 instructions instead of 16 ballots per distinct candidate.
                 {
+                    static_assert(kChunkSegs == 8, "one chunk = 8 lanes");
                     const uint32_t mm = mword & 0xffffu;
-                    uint64_t rem = __ballot(mm != 0);
-                    while (rem) {
-                        const uint32_t v = __shfl(vc, static_cast<int>(__builtin_ctzll(rem)), 64);
-                        const bool in_grp = mm != 0 && vc == v;
-                        uint32_t mycnt = 0;
-#pragma unroll
-                        for (uint32_t t = 0; t < kStripTiles; ++t) {
-                            const uint64_t bt = __ballot(in_grp && ((mm >> t) & 1u));
-                            if (lane == t) mycnt = static_cast<uint32_t>(__popcll(bt));
-                        }
-                        if (lane < kStripTiles && mycnt) atomicAdd(&s_ct[v * kStripTiles + lane], mycnt);
-                        rem &= ~__ballot(in_grp);
+                    uint32_t lo8 = SpreadNibbles(mm & 0xffu), hi8 = SpreadNibbles(mm >> 8);
+                    lo8 += DppQuadXor1(lo8); hi8 += DppQuadXor1(hi8);
+                    lo8 += DppQuadXor2(lo8); hi8 += DppQuadXor2(hi8);
+                    lo8 += DppHalfMirror(lo8); hi8 += DppHalfMirror(hi8);
+                    const uint32_t j = lane & 7u;
+                    const uint32_t two = (((j < 4u) ? lo8 : hi8) >> (8u * (j & 3u))) & 0xffu;
+                    if (f < n_el && two) {
+                        uint32_t *row = &s_ct[vc * kCtStride + 2u * j];
+                        if (two & 15u) atomicAdd(row, two & 15u);
+                        if (two >> 4) atomicAdd(row + 1, two >> 4);
                     }
                 }
             }
+            if (kProfile && r0 == 0) {
+                stamp(11);
+                if (tid == 0) PM_PP(dbg_bin)[12ull * blockIdx.x + 6] = n_el;  // (slot 6: elements of round 0)
+            }
             sbase += ns;
             __syncthreads();  // s_surv is rewritten by the next round
-            if (kProfile) { tb[9] += wall_clock64() - t_e0; tb[11] += n_el; }  // expansion part
         }
         if (tid == 0) hdr[3] = sbase * kChunkSegs;  // slots the tile kernel has to scan
         __syncthreads();  // every wave's s_ct contributions are in
-        if (kProfile) { tb[3] = wall_clock64(); tb[6] += total_ch; }  // segment stream done
+        stamp(3);  // segment stream done
+        if (kProfile) prof_chunks += total_ch;
 
         // ---- candidate records, per-(candidate, tile) table, mask table ------------------------
         if (tid < mask_dwords) {
@@ -609,6 +711,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                 uint32_t hm = 0;
                 int run = 0;  // backdrop steps were recorded at the first tile they apply to
                 const uint32_t cm = s_cmask[tid];
+                const uint32_t tag = s_ctag[tid], rgba = s_crgba[tid];
                 const bool opaque = (rgba & 0xff000000u) == 0xff000000u;
                 uint4 *ctw = reinterpret_cast<uint4 *>(ct_tab + kCtDwords * tid);
 #pragma unroll 1
@@ -617,7 +720,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
 #pragma unroll
                     for (uint32_t k = 0; k < 4; ++k) {
                         const uint32_t t = 4 * q + k;
-                        const uint32_t raw = s_ct[tid * kStripTiles + t];
+                        const uint32_t raw = s_ct[tid * kCtStride + t];
                         const uint32_t cnt = raw & kCtCountMask;
                         run += static_cast<int>(raw) >> kCtShift;
                         ct[k] = (static_cast<uint32_t>(run) << kCtShift) | cnt;
@@ -626,15 +729,15 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                         if (!((cm >> t) & 1u) || tag == 0) n_el = 0;
                         if (n_el) hm |= 1u << t;
                         // for the per-tile pass below: elements | "is nothing but an opaque Solid" << 31
-                        s_ct[tid * kStripTiles + t] = n_el | ((n_el && tag == kItemFill && cnt == 0 && opaque) ? 0x80000000u : 0u);
+                        s_ct[tid * kCtStride + t] = n_el | ((n_el && tag == kItemFill && cnt == 0 && opaque) ? 0x80000000u : 0u);
                     }
                     ctw[q] = make_uint4(ct[0], ct[1], ct[2], ct[3]);
                 }
                 w0 = tag | (hm << 16);
-                const uint32_t rg = P.lut_srgb2lin[rgba & 0xffu] | (P.lut_srgb2lin[(rgba >> 8) & 0xffu] << 16);
-                const uint32_t ba = P.lut_srgb2lin[(rgba >> 16) & 0xffu] | (P.lut_unorm2h[rgba >> 24] << 16);
+                const uint32_t rg = (s_lut[rgba & 0xffu] & 0xffffu) | (s_lut[(rgba >> 8) & 0xffu] << 16);
+                const uint32_t ba = (s_lut[(rgba >> 16) & 0xffu] & 0xffffu) | (s_lut[rgba >> 24] & 0xffff0000u);
                 uint4 *cr = reinterpret_cast<uint4 *>(cand_rec + kCandDwords * tid);
-                cr[0] = make_uint4(w0, rgba, aux0, aux1);
+                cr[0] = make_uint4(w0, rgba, s_caux0[tid], s_caux1[tid]);
                 cr[1] = make_uint4(s_cidx[tid], 0u, rg, ba);
                 s_cpts[tid] = rgba;  // (points offsets are no longer needed) colour for the solid test
             }
@@ -647,7 +750,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             const uint32_t t = tid & (kStripTiles - 1u), sl = tid >> 4;
             uint32_t est_p = 0, lk = 0, ls = 0;
             for (uint32_t c = sl; c < ncand; c += kThreads / kStripTiles) {
-                const uint32_t v = s_ct[c * kStripTiles + t];
+                const uint32_t v = s_ct[c * kCtStride + t];
                 if (v) {
                     est_p += v & 0x7fffffffu;
                     lk = c + 1u;
@@ -676,7 +779,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             }
         }
         __syncthreads();  // s_c* arrays are rewritten by the next record
-        if (kProfile) tb[4] = wall_clock64();  // record finalised
+        stamp(4);  // record finalised
         ncand = 0;
         if (!more) break;
         if (cand) {  // the scan step that did not fit opens the next record
@@ -686,13 +789,13 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         ncand = nb;
     }
     if (tid == 0) {
-        P.striprow_head[blockIdx.x] = head;
-        atomicAdd(&P.ctr_cur->arena_top, cursor - P.sr_base[blockIdx.x]);  // dwords used (stats only)
+        PM_PP(striprow_head)[blockIdx.x] = head;
+        atomicAdd(&PM_PP(ctr_cur)->arena_top, cursor - PM_PP(sr_base)[blockIdx.x]);  // dwords used (stats only)
     }
 
     // ---- queue the tiles with something to draw, clear the others ------------------------
     __syncthreads();
-    const uint32_t tiles_here = min(kStripTiles, P.tiles_x - strip * kStripTiles);
+    const uint32_t tiles_here = min(kStripTiles, PM_PU(tiles_x) - strip * kStripTiles);
     const uint32_t valid = (1u << tiles_here) - 1u;
     uint32_t vheavy = 0, heavy = 0, light = 0, solid = 0;
 #pragma unroll
@@ -711,46 +814,22 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     // closing command, plus End -- one atomic per strip row on the list arena
     // command-list slots of the queued tiles (an element emits at most 2 commands + its item's
     // closing command, plus End) and the three queue positions: four atomics in flight at once
+    uint32_t qres = 0, qtotal = 0;  // the atomics' results stay in registers until they are needed
     if (tid == 3 && queued) {
-        uint32_t total = 0;
 #pragma unroll
         for (uint32_t t = 0; t < kStripTiles; ++t)
-            if ((queued >> t) & 1u) total += 3u * s_est[t] + 1u;
-        s_qbase[3] = atomicAdd(&P.ctr_cur->ptcl_top, total);
-        s_qbase[4] = total;
+            if ((queued >> t) & 1u) qtotal += 3u * s_est[t] + 1u;
+        qres = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, qtotal);
     }
-    if (tid == 0 && vheavy) s_qbase[0] = atomicAdd(&P.ctr_cur->vheavy_count, static_cast<uint32_t>(__popc(vheavy)));
-    if (tid == 1 && heavy) s_qbase[1] = atomicAdd(&P.ctr_cur->heavy_count, static_cast<uint32_t>(__popc(heavy)));
-    if (tid == 2 && light) s_qbase[2] = atomicAdd(&P.ctr_cur->light_count, static_cast<uint32_t>(__popc(light)));
-    __syncthreads();
-    bool fits = true;
-    if (queued) {
-        const uint32_t base = s_qbase[3], total = s_qbase[4];
-        fits = base + total <= P.ptcl_cap && base + total >= base;
-        if (!fits && tid == 0) P.ctr_cur->overflow = 1;  // the host grows the arena and re-renders
-        if (tid < kStripTiles && ((queued >> tid) & 1u)) {
-            uint32_t off = 0;
-            for (uint32_t t = 0; t < tid; ++t)
-                if ((queued >> t) & 1u) off += 3u * s_est[t] + 1u;
-            P.tile_ptcl[row_rel * P.tiles_x + strip * kStripTiles + tid] = fits ? base + off : 0u;
-        }
-    }
-    // (on overflow the tiles are still queued, with lists at slot 0: in bounds, garbage pixels,
-    //  and pm_sync re-renders the frame with a larger arena)
-    if (tid < kStripTiles) {
-        // three queues, by expected list length: the fine kernel starts with the longest
-        const uint32_t tile = row_rel * P.tiles_x + strip * kStripTiles + tid;
-        const uint32_t below = (1u << tid) - 1u;
-        if ((vheavy >> tid) & 1u) P.queue[s_qbase[0] + __popc(vheavy & below)] = tile;
-        if ((heavy >> tid) & 1u) P.queue[P.queue_cap + s_qbase[1] + __popc(heavy & below)] = tile;
-        if ((light >> tid) & 1u) P.queue[2u * P.queue_cap + s_qbase[2] + __popc(light & below)] = tile;
-    }
+    if (tid == 0 && vheavy) qres = atomicAdd(&PM_PP(ctr_cur)->vheavy_count, static_cast<uint32_t>(__popc(vheavy)));
+    if (tid == 1 && heavy) qres = atomicAdd(&PM_PP(ctr_cur)->heavy_count, static_cast<uint32_t>(__popc(heavy)));
+    if (tid == 2 && light) qres = atomicAdd(&PM_PP(ctr_cur)->light_count, static_cast<uint32_t>(__popc(light)));
+    // (the four atomics are in flight while the background tiles are cleared)
     // tiles with nothing to draw are background: no item touches them, or every touching
     // item lost all its segments in phase 1 (the reference writes Bail/white for them)
-    if (kProfile) tb[5] = wall_clock64();  // queues + list slots done
     const uint32_t clear = ~queued & valid;  // background (white) or one opaque colour
     if (tid < tiles_here)  // what this kernel decided per tile: 0 = queued, else the tile's colour
-        P.tile_state[row_rel * P.tiles_x + strip * kStripTiles + tid] =
+        PM_PP(tile_state)[row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid] =
             ((clear >> tid) & 1u) ? (((solid >> tid) & 1u) ? s_solid_rgba[tid] : 0xffffffffu) : 0u;
     if (clear) {
         // 16 pixel rows x 1024 B: thread -> (row = it*4 + wave, 16 B = 4 px at lane*4)
@@ -762,23 +841,46 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             for (uint32_t it = 0; it < kTileH / kBinWaves; ++it) {
                 const uint32_t r = it * kBinWaves + wave;
                 const uint32_t py = static_cast<uint32_t>(y0) + r;
-                if (py < P.height && px < P.width) {
-                    uint8_t *dst = P.fb + static_cast<size_t>(row_rel * kTileH + r) * P.fb_stride + static_cast<size_t>(px) * 4;
-                    if (px + 4 <= P.width && P.fb_vec16) {
+                if (py < PM_PU(height) && px < PM_PU(width)) {
+                    uint8_t *dst = PM_PP(fb) + static_cast<size_t>(row_rel * kTileH + r) * PM_PU(fb_stride) + static_cast<size_t>(px) * 4;
+                    if (px + 4 <= PM_PU(width) && PM_PU(fb_vec16)) {
                         *reinterpret_cast<uint4 *>(dst) = make_uint4(col, col, col, col);
                     } else {
-                        for (uint32_t k = 0; k < 4 && px + k < P.width; ++k)
+                        for (uint32_t k = 0; k < 4 && px + k < PM_PU(width); ++k)
                             reinterpret_cast<uint32_t *>(dst)[k] = col;
                     }
                 }
             }
         }
     }
-    if (kProfile && P.dbg_bin && tid == 0) {
-        unsigned long long *d = P.dbg_bin + 12ull * blockIdx.x;
-        tb[7] = wall_clock64();
-        for (int k = 0; k < 12; ++k) d[k] = tb[k];
+    if (tid < 4) s_qbase[tid] = qres;
+    if (tid == 3) s_qbase[4] = qtotal;
+    __syncthreads();
+    bool fits = true;
+    if (queued) {
+        const uint32_t base = s_qbase[3], total = s_qbase[4];
+        fits = base + total <= PM_PU(ptcl_cap) && base + total >= base;
+        if (!fits && tid == 0) PM_PP(ctr_cur)->overflow = 1;  // the host grows the arena and re-renders
+        if (tid < kStripTiles && ((queued >> tid) & 1u)) {
+            uint32_t off = 0;
+            for (uint32_t t = 0; t < tid; ++t)
+                if ((queued >> t) & 1u) off += 3u * s_est[t] + 1u;
+            PM_PP(tile_ptcl)[row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid] = fits ? base + off : 0u;
+        }
     }
+    // (on overflow the tiles are still queued, with lists at slot 0: in bounds, garbage pixels,
+    //  and pm_sync re-renders the frame with a larger arena)
+    if (tid < kStripTiles) {
+        // three queues, by expected list length: the fine kernel starts with the longest
+        const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid;
+        const uint32_t below = (1u << tid) - 1u;
+        if ((vheavy >> tid) & 1u) PM_PP(queue)[s_qbase[0] + __popc(vheavy & below)] = tile;
+        if ((heavy >> tid) & 1u) PM_PP(queue)[PM_PU(queue_cap) + s_qbase[1] + __popc(heavy & below)] = tile;
+        if ((light >> tid) & 1u) PM_PP(queue)[2u * PM_PU(queue_cap) + s_qbase[2] + __popc(light & below)] = tile;
+    }
+    stamp(5);  // queues + list slots done
+    (void)prof_chunks;
+    stamp(7);
 }
 
 // =====================================================================================

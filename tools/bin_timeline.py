@@ -33,6 +33,16 @@ print(f"WGs without candidates: {e.sum()}, duration mean {d.mean():.2f} max {d.m
 ch = t[:, 6]
 worst = np.argsort(-dur)[:6]
 for i in worst: print(f"  WG {i} chunks {ch[i]} dur {dur[i]:.1f} start {(t[i,0]-t0)*us:.1f} phases {[(t[i,k+1]-t[i,k])*us if t[i,k+1]>0 and t[i,k]>0 else None for k in (0,1,2,3,4)]}")
-print("heavy WG detail: chunk-test time, expansion time, rounds, elements")
-for i in worst: print(f"  WG {i}: chunk rounds {t[i,10]} test {t[i,8]*us:.1f} us, expansion {t[i,9]*us:.1f} us for {t[i,11]} elements ({t[i,11]/256:.1f} block steps) -> {t[i,9]*us/max(1,t[i,11]/256):.2f} us/step")
-tot_el = t[:, 11].sum(); print("total elements", tot_el, "total chunks", ch.sum())
+print("total chunks", ch.sum())
+print(f"sum of WG durations {dur.sum():.0f} us -> {dur.sum()/1024:.1f} us of the machine at 1024 resident WGs")
+for lo, hi in [(0, 8), (8, 12), (12, 20), (20, 30), (30, 45), (45, 1000)]:
+    m2 = (dur >= lo) & (dur < hi)
+    print(f"  WGs with {lo}-{hi} us: {m2.sum()} -> {dur[m2].sum():.0f} us total")
+print("round 0 of the segment stream (WGs with >= 512 elements in it):")
+big = (t[:, 6] >= 512) & (t[:, 11] > 0)
+for nm, a, b in [("headers done -> round start", 2, 8), ("chunk tests + scan", 8, 9), ("survivor list + barrier", 9, 10), ("expansion (wave 0)", 10, 11)]:
+    d = (t[big, b] - t[big, a]) * us
+    print(f"   {nm:28s} mean {d.mean():.2f} p90 {np.percentile(d, 90):.2f} max {d.max():.2f}")
+el = t[big, 6]
+d = (t[big, 11] - t[big, 10]) * us
+print(f"   {big.sum()} WGs, elements mean {el.mean():.0f}; expansion per 256-element step: {(d / np.ceil(el / 256)).mean():.2f} us")
