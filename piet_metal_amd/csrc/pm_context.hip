@@ -187,6 +187,9 @@ struct pm_ctx {
 
     // binning state shared by the slots
     uint32_t *d_sr_base = nullptr;  // private arena region of every strip row
+    uint2 *d_band_bbox = nullptr;   // items that reach the band (bbox, scene index), paint order
+    uint32_t *d_band_item = nullptr;
+    uint32_t n_band_items = 0;
     uint32_t arena_cap = 0;         // dwords per slot
     bool arena_dirty = true;
 
@@ -347,6 +350,33 @@ int EnsureArena(pm_ctx *c) {
     c->d_sr_base = nullptr;
     PM_TRY(hipMalloc(&c->d_sr_base, base.size() * sizeof(uint32_t)));
     PM_TRY(hipMemcpy(c->d_sr_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // the items whose bbox reaches the band (rows: bw >= y0 && by < y1, PietRender.metal:198/:214)
+    {
+        const uint8_t *meta = c->item_meta.data();
+        std::vector<uint2> bbs;
+        std::vector<uint32_t> ids;
+        const uint32_t y0 = c->row0 * pm::kTileH, y1 = c->row1 * pm::kTileH;
+        for (uint32_t i = 0; i < c->n_items; ++i) {
+            uint32_t w[2];
+            std::memcpy(w, meta + 8 + 8ull * i, 8);
+            const uint32_t bx = w[0] & 0xffffu, by = w[0] >> 16, bw = w[1] >> 16;
+            if (bw >= y0 && by < y1 && bx < c->strips_x * pm::kGroupW) {
+                bbs.push_back(make_uint2(w[0], w[1]));
+                ids.push_back(i);
+            }
+        }
+        if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
+        if (c->d_band_item) (void)hipFree(c->d_band_item);
+        c->d_band_bbox = nullptr;
+        c->d_band_item = nullptr;
+        c->n_band_items = static_cast<uint32_t>(ids.size());
+        PM_TRY(hipMalloc(&c->d_band_bbox, std::max<size_t>(ids.size(), 1) * sizeof(uint2)));
+        PM_TRY(hipMalloc(&c->d_band_item, std::max<size_t>(ids.size(), 1) * sizeof(uint32_t)));
+        if (!ids.empty()) {
+            PM_TRY(hipMemcpy(c->d_band_bbox, bbs.data(), ids.size() * sizeof(uint2), hipMemcpyHostToDevice));
+            PM_TRY(hipMemcpy(c->d_band_item, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+    }
     c->arena_dirty = false;
     return PM_OK;
 }
@@ -390,6 +420,9 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->tile_ncmd = s->d_tile_ncmd;
     p->ctr_cur = s->d_ctr + s->parity;
     p->ctr_next = s->d_ctr + (s->parity ^ 1u);
+    p->band_bbox = c->d_band_bbox;
+    p->band_item = c->d_band_item;
+    p->n_band_items = c->n_band_items;
     p->chunk_base = c->d_chunk_base;
     p->chunk_bbox = c->d_chunk_bbox;
     p->lut_srgb2lin = c->d_lut_srgb2lin;
@@ -659,6 +692,8 @@ void pm_destroy(pm_ctx *c) {
         if (s.ev_fine) (void)hipEventDestroy(s.ev_fine);
     }
     if (c->d_sr_base) (void)hipFree(c->d_sr_base);
+    if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
+    if (c->d_band_item) (void)hipFree(c->d_band_item);
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->h_scene) (void)hipHostFree(c->h_scene);
     if (c->d_chunk_base) (void)hipFree(c->d_chunk_base);

@@ -86,6 +86,9 @@ struct FrameParams {
     uint32_t *tile_ncmd;      // [tiles] commands in the list (0: resolved to one colour)
     Counters *ctr_cur;
     Counters *ctr_next;
+    const uint2 *band_bbox;        // [n_band_items] bboxes of the items that reach this band, paint order
+    const uint32_t *band_item;     // [n_band_items] their scene indices
+    uint32_t n_band_items;
     const uint32_t *chunk_base;    // [n_items + 1]
     const float4 *chunk_bbox;      // [chunk_base[n_items]]
     const uint32_t *lut_srgb2lin;  // [256] binary16 bits of the sRGB EOTF

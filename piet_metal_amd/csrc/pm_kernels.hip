@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     const uint8_t *scene = PM_PP(scene);
     // wave-uniform values are pinned to SGPRs (readfirstlane): the record pointers and loop
     // bounds derived from them then live on the scalar unit instead of in 64-bit VGPR pairs
-    const uint32_t n_items = PM_PU(n_items), items_ix = PM_PU(items_ix);  // kernel arguments: no load on the critical path
+    const uint32_t items_ix = PM_PU(items_ix);  // kernel argument: no load on the critical path
     // This strip row owns arena[sr_base[b] .. sr_base[b+1]): the host sized it for the worst
     // case (every chunk of every candidate survives), so records are bump-allocated without
     // atomics and without a counting pass.
@@ -385,18 +385,33 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     // Every dependent global access costs 1-2 us here, so the scan keeps the NEXT step's bboxes
     // in flight while it ranks the current ones.
     uint32_t ncand = 0;
+    // The scan runs over the items whose bbox reaches this context's band of tile rows (a
+    // paint-ordered subset the host lists once per scene / viewport; with one GPU it is every
+    // item in view), not over the whole scene: with the rows sharded over N GPUs each rank
+    // looks at its own share only.
+    const uint32_t n_band = PM_PU(n_band_items);
+    const uint2 *band_bbox = PM_PP(band_bbox);
+    const uint32_t *band_item = PM_PP(band_item);
     uint2 bb_next = make_uint2(0u, 0u);
-    if (tid < n_items) bb_next = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(tid) * 8);
+    uint32_t it_next = 0;
+    if (tid < n_band) {
+        bb_next = band_bbox[tid];
+        it_next = band_item[tid];
+    }
     // the two colour tables ride along with the first bbox load (finalisation reads them from LDS)
     s_lut[tid] = PM_PP(lut_srgb2lin)[tid] | (PM_PP(lut_unorm2h)[tid] << 16);
     for (uint32_t ib = 0;; ib += kBatch) {
-        const bool more = ib < n_items;  // uniform
-        const uint32_t i = ib + tid;
+        const bool more = ib < n_band;  // uniform
+        const uint32_t j = ib + tid;
         bool cand = false;
         uint32_t mask = 0;
         const uint2 bb = bb_next;
-        if (i + kBatch < n_items) bb_next = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(i + kBatch) * 8);
-        if (more && tid < kBatch && i < n_items) {
+        const uint32_t i = it_next;  // scene index of band item j
+        if (j + kBatch < n_band) {
+            bb_next = band_bbox[j + kBatch];
+            it_next = band_item[j + kBatch];
+        }
+        if (more && tid < kBatch && j < n_band) {
             const int bx = static_cast<int>(bb.x & 0xffffu), by = static_cast<int>(bb.x >> 16);
             const int bz = static_cast<int>(bb.y & 0xffffu), bw = static_cast<int>(bb.y >> 16);
             // the tile `hit` test of PietRender.metal:214, y part + strip-wide x part
