@@ -12,13 +12,20 @@ namespace pm {
 // Per-frame counters; two copies alternate between frames so that frame N's binning
 // kernel can reset frame N+1's copy (no memset launch on the critical path).
 struct Counters {
-    uint32_t arena_top;    // bump pointer into the arena, in dwords
-    uint32_t heavy_count;  // tiles in queue B (long lists: 4 waves per tile)
-    uint32_t overflow;     // set if the arena ran out
-    uint32_t light_count;  // tiles in queue C (one wave per tile)
-    uint32_t ptcl_top;     // bump pointer into the command-list arena, in commands
-    uint32_t vheavy_count; // tiles in queue A (very long lists: 16 waves per tile)
-    uint32_t pad[2];
+    // Every strip row of a frame adds to these with returning atomics.  The L2 executes
+    // same-cache-line atomics one after the other (~90 per us measured), so each hot counter
+    // lives on its own 128-byte line.
+    uint32_t ptcl_top;      // bump pointer into the command-list arena, in commands
+    uint32_t pad0[31];
+    uint32_t vheavy_count;  // tiles in queue A (very long lists: 16 waves per tile)
+    uint32_t pad1[31];
+    uint32_t heavy_count;   // tiles in queue B (long lists: 4 waves per tile)
+    uint32_t pad2[31];
+    uint32_t light_count;   // tiles in queue C (one wave per tile)
+    uint32_t pad3[31];
+    uint32_t arena_top;     // dwords of binning records written (statistics)
+    uint32_t overflow;      // set if the command-list arena ran out
+    uint32_t pad4[30];
 };
 
 // Arena record written by pm_bin_kernel for one (strip row, batch of <=256 items):

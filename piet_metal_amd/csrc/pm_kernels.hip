@@ -825,11 +825,11 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     heavy &= valid;
     light &= valid;
     const uint32_t queued = vheavy | heavy | light;
-    // command-list slots of the queued tiles: an element emits at most 2 commands + its item's
-    // closing command, plus End -- one atomic per strip row on the list arena
     // command-list slots of the queued tiles (an element emits at most 2 commands + its item's
-    // closing command, plus End) and the three queue positions: four atomics in flight at once
-    uint32_t qres = 0, qtotal = 0;  // the atomics' results stay in registers until they are needed
+    // closing command, plus End) and the three queue positions: four atomics in flight at once.
+    // vmcnt is per wave and counts loads and stores alike: wave 0 waits for its atomics BEFORE
+    // it issues any clearing store, while waves 1-3 clear at once.
+    uint32_t qres = 0, qtotal = 0;
     if (tid == 3 && queued) {
 #pragma unroll
         for (uint32_t t = 0; t < kStripTiles; ++t)
@@ -839,7 +839,10 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     if (tid == 0 && vheavy) qres = atomicAdd(&PM_PP(ctr_cur)->vheavy_count, static_cast<uint32_t>(__popc(vheavy)));
     if (tid == 1 && heavy) qres = atomicAdd(&PM_PP(ctr_cur)->heavy_count, static_cast<uint32_t>(__popc(heavy)));
     if (tid == 2 && light) qres = atomicAdd(&PM_PP(ctr_cur)->light_count, static_cast<uint32_t>(__popc(light)));
-    // (the four atomics are in flight while the background tiles are cleared)
+    if (queued) {  // uniform
+        if (tid < 4) s_qbase[tid] = qres;
+        if (tid == 3) s_qbase[4] = qtotal;
+    }
     // tiles with nothing to draw are background: no item touches them, or every touching
     // item lost all its segments in phase 1 (the reference writes Bail/white for them)
     const uint32_t clear = ~queued & valid;  // background (white) or one opaque colour
@@ -868,8 +871,6 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             }
         }
     }
-    if (tid < 4) s_qbase[tid] = qres;
-    if (tid == 3) s_qbase[4] = qtotal;
     __syncthreads();
     bool fits = true;
     if (queued) {
