@@ -144,7 +144,7 @@ struct FrameSlot {
     uint8_t *d_fb = nullptr;  // this slot's framebuffer (pm_render); pm_render_to uses the caller's
     uint32_t *d_arena = nullptr;
     uint32_t *d_striprow = nullptr;
-    uint32_t *d_queue = nullptr;
+    uint4 *d_queue = nullptr;
     uint32_t *d_tile_state = nullptr;
     uint32_t *d_tile_ptcl = nullptr;
     uint32_t *d_tile_ncmd = nullptr;
@@ -226,7 +226,8 @@ void FreeViewport(pm_ctx *c) {
         if (s.d_tile_ptcl) (void)hipFree(s.d_tile_ptcl);
         if (s.d_tile_ncmd) (void)hipFree(s.d_tile_ncmd);
         s.d_fb = nullptr;
-        s.d_striprow = s.d_queue = s.d_tile_state = s.d_tile_ptcl = s.d_tile_ncmd = nullptr;
+        s.d_queue = nullptr;
+        s.d_striprow = s.d_tile_state = s.d_tile_ptcl = s.d_tile_ncmd = nullptr;
         s.in_flight = false;
     }
     c->last_slot = -1;
@@ -241,7 +242,7 @@ int AllocViewport(pm_ctx *c) {
     for (auto &s : c->slot) {
         PM_TRY(hipMalloc(&s.d_fb, std::max<size_t>(c->fb_bytes, 16)));
         PM_TRY(hipMalloc(&s.d_striprow, std::max<size_t>(static_cast<size_t>(rows) * c->strips_x, 1) * sizeof(uint32_t)));
-        PM_TRY(hipMalloc(&s.d_queue, 3 * tiles * sizeof(uint32_t)));  // three class queues
+        PM_TRY(hipMalloc(&s.d_queue, 3 * tiles * sizeof(uint4)));  // three class queues
         PM_TRY(hipMalloc(&s.d_tile_state, tiles * sizeof(uint32_t)));
         PM_TRY(hipMalloc(&s.d_tile_ptcl, tiles * sizeof(uint32_t)));
         PM_TRY(hipMalloc(&s.d_tile_ncmd, tiles * sizeof(uint32_t)));

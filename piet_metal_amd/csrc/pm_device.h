@@ -84,7 +84,7 @@ struct FrameParams {
     uint32_t arena_cap;   // dwords
     const uint32_t *sr_base;  // [n_striprows + 1] private arena region of every strip row
     uint32_t *striprow_head;
-    uint32_t *queue;
+    uint4 *queue;             // three class queues of {tile, first command slot, first record, commands}
     uint32_t queue_cap;
     uint32_t *tile_state;     // [tiles of the band] 0 = queued for the tile kernels, else resolved colour
     Cmd *ptcl;                // per-tile command lists (24-byte records, TestApp/GenTypes.h:430-495)

@@ -873,6 +873,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     }
     __syncthreads();
     bool fits = true;
+    uint32_t list_slot = 0;
     if (queued) {
         const uint32_t base = s_qbase[3], total = s_qbase[4];
         fits = base + total <= PM_PU(ptcl_cap) && base + total >= base;
@@ -881,7 +882,8 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             uint32_t off = 0;
             for (uint32_t t = 0; t < tid; ++t)
                 if ((queued >> t) & 1u) off += 3u * s_est[t] + 1u;
-            PM_PP(tile_ptcl)[row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid] = fits ? base + off : 0u;
+            list_slot = fits ? base + off : 0u;
+            PM_PP(tile_ptcl)[row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid] = list_slot;
         }
     }
     // (on overflow the tiles are still queued, with lists at slot 0: in bounds, garbage pixels,
@@ -890,9 +892,12 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         // three queues, by expected list length: the fine kernel starts with the longest
         const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid;
         const uint32_t below = (1u << tid) - 1u;
-        if ((vheavy >> tid) & 1u) PM_PP(queue)[s_qbase[0] + __popc(vheavy & below)] = tile;
-        if ((heavy >> tid) & 1u) PM_PP(queue)[PM_PU(queue_cap) + s_qbase[1] + __popc(heavy & below)] = tile;
-        if ((light >> tid) & 1u) PM_PP(queue)[2u * PM_PU(queue_cap) + s_qbase[2] + __popc(light & below)] = tile;
+        // a queue entry is everything the tile kernels need to start: {tile, first command slot,
+        // first binning record of the strip row, commands written (filled in by pm_coarse_kernel)}
+        const uint4 entry = make_uint4(tile, list_slot, head, 0u);
+        if ((vheavy >> tid) & 1u) PM_PP(queue)[s_qbase[0] + __popc(vheavy & below)] = entry;
+        if ((heavy >> tid) & 1u) PM_PP(queue)[PM_PU(queue_cap) + s_qbase[1] + __popc(heavy & below)] = entry;
+        if ((light >> tid) & 1u) PM_PP(queue)[2u * PM_PU(queue_cap) + s_qbase[2] + __popc(light & below)] = entry;
     }
     stamp(5);  // queues + list slots done
     (void)prof_chunks;
@@ -1206,10 +1211,12 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
     for (uint32_t pass = 0; pass * n_waves < n_total; ++pass) {
         const uint32_t slot = pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
         if (slot >= n_total) continue;
-        const uint32_t tile = (slot < n_a) ? P.queue[slot]
-                              : (slot < n_a + n_b) ? P.queue[P.queue_cap + (slot - n_a)]
-                                                   : P.queue[2u * P.queue_cap + (slot - n_a - n_b)];
-        Cmd *const out_cmds = P.ptcl + P.tile_ptcl[tile];  // this tile's private command slots
+        uint4 *const qentry = P.queue + ((slot < n_a) ? slot
+                                         : (slot < n_a + n_b) ? P.queue_cap + (slot - n_a)
+                                                              : 2u * P.queue_cap + (slot - n_a - n_b));
+        const uint4 qe = *qentry;
+        const uint32_t tile = qe.x;
+        Cmd *const out_cmds = P.ptcl + qe.y;  // this tile's private command slots
         const uint32_t tx = tile % P.tiles_x;
         const uint32_t ty_rel = tile / P.tiles_x;
         const uint32_t ty = P.row0 + ty_rel;
@@ -1219,13 +1226,12 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
         const float fx1 = static_cast<float>(x0 + static_cast<int>(kTileW));
         const float fy1 = static_cast<float>(y0 + static_cast<int>(kTileH));
         const uint32_t tbit = tx & (kStripTiles - 1);
-        const uint32_t sr = ty_rel * P.strips_x + tx / kStripTiles;
 
         uint32_t solid_color = 0xffffffffu;  // TileEncoder::solidColor (:74)
         uint32_t n_pending = 0;              // commands written to the tile's list so far
         uint32_t list_len = 0;               // logical list length since tileBegin (capture)
 
-        uint32_t rec = P.striprow_head[sr];
+        uint32_t rec = qe.z;  // (= striprow_head[sr])
         while (rec != 0) {
             // header and mask table sit next to each other: all loads are in flight together
             const uint4 hdr = *reinterpret_cast<const uint4 *>(P.arena + rec);
@@ -1555,7 +1561,10 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
         }
 
         // ---- TileEncoder::end() (:144-151): Bail tiles are finished here (composite :34-44) ----
-        if (lane == 0) P.tile_ncmd[tile] = solid_color ? 0u : n_pending;
+        if (lane == 0) {
+            P.tile_ncmd[tile] = solid_color ? 0u : n_pending;
+            qentry->w = solid_color ? 0u : n_pending;  // what pm_fine_kernel reads
+        }
         if (solid_color != 0) {
             // the tile is one opaque colour, bytes as stored: 64 lanes x 16 B = the whole tile
             const uint32_t pxi = static_cast<uint32_t>(x0) + (lane & 3u) * 4u;
@@ -1615,36 +1624,61 @@ __global__ __launch_bounds__(kThreads) void pm_fine_kernel(FrameParams P) {
     const uint32_t s_a = n_a << sh_a, s_b = n_b << sh_b;
     const uint32_t n_slots = s_a + s_b + n_c;
     const uint8_t *lut = P.lut_lin2srgb;
-    auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {  // linear -> sRGB + unorm8 (:563-565)
+    // linear -> sRGB + unorm8 (:563-565): the 65,536-entry table of decision D2.  (A compact
+    // LDS-resident form of the table was measured slower: this kernel is bound by instruction
+    // issue, and twelve byte loads per lane are fewer instructions than twelve decodes.)
+    auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {
         return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, r)]) |
                (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
                (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, b)]) << 16) | 0xff000000u;
     };
-
-    for (uint32_t pass = 0; pass * n_waves < n_slots; ++pass) {
-        const uint32_t slot = pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
-        if (slot >= n_slots) continue;
-        // rows of the tile this wave renders: [row0, row0 + nrows)
-        uint32_t tile, row0, nrows;
+    // slot -> queue entry index and the rows of the tile this wave renders: [row0, row0 + nrows)
+    auto slot_entry = [&](uint32_t slot, uint32_t &row0, uint32_t &nrows) -> uint32_t {
         if (slot < s_a) {
-            tile = P.queue[slot >> sh_a];
             nrows = 16u >> sh_a;
             row0 = (slot & ((1u << sh_a) - 1u)) * nrows;
-        } else if (slot < s_a + s_b) {
-            tile = P.queue[P.queue_cap + ((slot - s_a) >> sh_b)];
+            return slot >> sh_a;
+        }
+        if (slot < s_a + s_b) {
             nrows = 16u >> sh_b;
             row0 = ((slot - s_a) & ((1u << sh_b) - 1u)) * nrows;
-        } else {
-            tile = P.queue[2u * P.queue_cap + (slot - s_a - s_b)];
-            row0 = 0;
-            nrows = 16;
+            return P.queue_cap + ((slot - s_a) >> sh_b);
         }
+        row0 = 0;
+        nrows = 16;
+        return 2u * P.queue_cap + (slot - s_a - s_b);
+    };
+    auto pass_slot = [&](uint32_t pass) -> uint32_t {
+        return pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
+    };
+
+    // The queue entry {tile, first command slot, -, commands} of the NEXT slot is fetched while
+    // the current tile is interpreted: one exposed round trip per tile (the command list) instead
+    // of three dependent ones.
+    uint32_t slot = pass_slot(0);
+    uint4 qe = make_uint4(0u, 0u, 0u, 0u);
+    {
+        uint32_t r0_, nr_;
+        if (slot < n_slots) qe = P.queue[slot_entry(slot, r0_, nr_)];
+    }
+    for (uint32_t pass = 0; pass * n_waves < n_slots; ++pass) {
+        const uint32_t cur_slot = slot;
+        const uint4 cur = qe;
+        slot = pass_slot(pass + 1u);
+        {
+            uint32_t r0_, nr_;
+            if ((pass + 1u) * n_waves < n_slots && slot < n_slots) qe = P.queue[slot_entry(slot, r0_, nr_)];
+        }
+        if (cur_slot >= n_slots) continue;
+        uint32_t row0, nrows;
+        (void)slot_entry(cur_slot, row0, nrows);
+        const uint32_t tile = cur.x;
         const bool quarter = nrows != 16u;  // one pixel per lane (lanes beyond nrows*16 idle)
         unsigned long long t_begin = 0;
         if (P.dbg_time) t_begin = wall_clock64();
-        const uint32_t n_cmd = P.tile_ncmd[tile];
+        const uint32_t n_cmd = cur.w;
         if (n_cmd != 0) {  // 0: the coarse kernel found one opaque colour and wrote it
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(P.ptcl + P.tile_ptcl[tile]);
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(P.ptcl + cur.y);
             const uint32_t tx = tile % P.tiles_x;
             const uint32_t ty_rel = tile / P.tiles_x;
             const uint32_t x0 = tx * kTileW;
@@ -1696,7 +1730,7 @@ __global__ __launch_bounds__(kThreads) void pm_fine_kernel(FrameParams P) {
             }
         }
         if (P.dbg_time && lane == 0) {
-            unsigned long long *d = P.dbg_time + 4ull * slot;
+            unsigned long long *d = P.dbg_time + 4ull * cur_slot;
             d[0] = t_begin;
             d[1] = wall_clock64();
             d[2] = tile | (quarter ? 0x80000000u : 0u);
