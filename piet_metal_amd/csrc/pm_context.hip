@@ -150,6 +150,8 @@ struct FrameSlot {
     uint32_t *d_tile_ncmd = nullptr;
     pm::Cmd *d_ptcl = nullptr;
     uint32_t ptcl_cap = 0;  // commands
+    uint2 *d_row_bbox = nullptr;  // per-tile-row item lists of this slot's frame (large scenes)
+    uint32_t *d_row_item = nullptr;
     pm::Counters *d_ctr = nullptr;  // two: a frame's binning kernel zeroes the one the slot's next frame uses
     uint32_t parity = 0;
     hipEvent_t ev_bin = nullptr, ev_coarse = nullptr, ev_fine = nullptr;
@@ -190,6 +192,9 @@ struct pm_ctx {
     uint2 *d_band_bbox = nullptr;   // items that reach the band (bbox, scene index), paint order
     uint32_t *d_band_item = nullptr;
     uint32_t n_band_items = 0;
+    uint32_t *d_row_base = nullptr;  // per-tile-row item lists (large scenes): offsets
+    uint32_t row_total = 0;
+    bool use_row_lists = false;
     uint32_t arena_cap = 0;         // dwords per slot
     bool arena_dirty = true;
 
@@ -341,6 +346,8 @@ int EnsureArena(pm_ctx *c) {
             // Command-list arena: lists are sized from what binning actually found, so there is no
             // static bound; start generously (HBM is 288 GB) and let pm_sync grow it on overflow.
             uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
+            if (const char *v = std::getenv("PM_PTCL_INITIAL_CMDS"))  // tests: force the overflow -> grow -> re-render path
+                cmds = std::max<uint64_t>(64, std::strtoull(v, nullptr, 10));
             cmds = std::min<uint64_t>(cmds, 0x7fffffffull);
             PM_TRY(hipMalloc(&s.d_ptcl, cmds * sizeof(pm::Cmd)));
             s.ptcl_cap = static_cast<uint32_t>(cmds);
@@ -376,6 +383,45 @@ int EnsureArena(pm_ctx *c) {
         if (!ids.empty()) {
             PM_TRY(hipMemcpy(c->d_band_bbox, bbs.data(), ids.size() * sizeof(uint2), hipMemcpyHostToDevice));
             PM_TRY(hipMemcpy(c->d_band_item, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        // Large scenes: every tile row gets its own item list each frame (pm_rowcull_kernel); the
+        // host only sizes the lists, with the kernel's predicate.
+        const int min_items = EnvInt("PM_ROW_LIST_MIN_ITEMS", 2048, 0, 1 << 30);
+        c->use_row_lists = static_cast<int>(ids.size()) >= min_items && !ids.empty();
+        for (auto &s : c->slot) {
+            if (s.d_row_bbox) (void)hipFree(s.d_row_bbox);
+            if (s.d_row_item) (void)hipFree(s.d_row_item);
+            s.d_row_bbox = nullptr;
+            s.d_row_item = nullptr;
+        }
+        if (c->d_row_base) (void)hipFree(c->d_row_base);
+        c->d_row_base = nullptr;
+        if (c->use_row_lists) {
+            const uint32_t rows = BandRows(c);
+            std::vector<uint32_t> rb(rows + 1, 0u);
+            for (const uint2 &b : bbs) {
+                const uint32_t by = b.x >> 16, bw = b.y >> 16;
+                const uint32_t r_lo = std::max(by / pm::kTileH, c->row0), r_hi = std::min(bw / pm::kTileH, c->row1 - 1);
+                for (uint32_t r = r_lo; r <= r_hi && r_hi >= r_lo; ++r) rb[r - c->row0 + 1] += 1;
+            }
+            uint64_t run = 0;
+            for (uint32_t r = 0; r < rows; ++r) {
+                const uint32_t n_r = rb[r + 1];
+                rb[r] = static_cast<uint32_t>(run);
+                run += n_r;
+            }
+            if (run > 0xfffffff0ull) {
+                SetError("per-row item lists beyond 2^32 entries");
+                return PM_ERR_CAPACITY;
+            }
+            rb[rows] = static_cast<uint32_t>(run);
+            c->row_total = static_cast<uint32_t>(run);
+            PM_TRY(hipMalloc(&c->d_row_base, rb.size() * sizeof(uint32_t)));
+            PM_TRY(hipMemcpy(c->d_row_base, rb.data(), rb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            for (auto &s : c->slot) {
+                PM_TRY(hipMalloc(&s.d_row_bbox, std::max<uint64_t>(run, 1) * sizeof(uint2)));
+                PM_TRY(hipMalloc(&s.d_row_item, std::max<uint64_t>(run, 1) * sizeof(uint32_t)));
+            }
         }
     }
     c->arena_dirty = false;
@@ -424,6 +470,10 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->band_bbox = c->d_band_bbox;
     p->band_item = c->d_band_item;
     p->n_band_items = c->n_band_items;
+    p->use_row_lists = c->use_row_lists ? 1u : 0u;
+    p->row_base = c->d_row_base;
+    p->row_bbox = s->d_row_bbox;
+    p->row_item = s->d_row_item;
     p->chunk_base = c->d_chunk_base;
     p->chunk_bbox = c->d_chunk_bbox;
     p->lut_srgb2lin = c->d_lut_srgb2lin;
@@ -687,6 +737,8 @@ void pm_destroy(pm_ctx *c) {
     for (auto &s : c->slot) {
         if (s.d_arena) (void)hipFree(s.d_arena);
         if (s.d_ptcl) (void)hipFree(s.d_ptcl);
+        if (s.d_row_bbox) (void)hipFree(s.d_row_bbox);
+        if (s.d_row_item) (void)hipFree(s.d_row_item);
         if (s.d_ctr) (void)hipFree(s.d_ctr);
         if (s.ev_bin) (void)hipEventDestroy(s.ev_bin);
         if (s.ev_coarse) (void)hipEventDestroy(s.ev_coarse);
@@ -695,6 +747,7 @@ void pm_destroy(pm_ctx *c) {
     if (c->d_sr_base) (void)hipFree(c->d_sr_base);
     if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
     if (c->d_band_item) (void)hipFree(c->d_band_item);
+    if (c->d_row_base) (void)hipFree(c->d_row_base);
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->h_scene) (void)hipHostFree(c->h_scene);
     if (c->d_chunk_base) (void)hipFree(c->d_chunk_base);

@@ -96,6 +96,11 @@ struct FrameParams {
     const uint2 *band_bbox;        // [n_band_items] bboxes of the items that reach this band, paint order
     const uint32_t *band_item;     // [n_band_items] their scene indices
     uint32_t n_band_items;
+    // large scenes: per-tile-row item lists written each frame by pm_rowcull_kernel
+    uint32_t use_row_lists;
+    const uint32_t *row_base;      // [band rows + 1] list offsets (host-computed sizes)
+    uint2 *row_bbox;               // [row_base[rows]]
+    uint32_t *row_item;
     const uint32_t *chunk_base;    // [n_items + 1]
     const float4 *chunk_bbox;      // [chunk_base[n_items]]
     const uint32_t *lut_srgb2lin;  // [256] binary16 bits of the sRGB EOTF

@@ -251,6 +251,43 @@ __global__ void pm_index_kernel(const uint8_t *scene, uint32_t n_items, const ui
 }
 
 // =====================================================================================
+// K1a: per-tile-row item lists (large scenes only), one workgroup per tile row
+// =====================================================================================
+//
+// With thousands of items every strip-row workgroup of pm_bin_kernel would scan every bbox of
+// the band (PietRender.metal:191-208 does exactly that per threadgroup).  The row part of that
+// test does not depend on the strip, so for large scenes it is done once per tile row here and
+// the strip rows of the row scan the (much shorter) row list instead.  Lists keep paint order;
+// their sizes are known to the host from the same predicate, so row r writes exactly
+// row_base[r+1] - row_base[r] entries.
+__global__ __launch_bounds__(kBinThreads) void pm_rowcull_kernel(FrameParams P) {
+    __shared__ uint32_t s_part[kBinWaves];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t row_rel = blockIdx.x;
+    const int y0 = static_cast<int>((P.row0 + row_rel) * kTileH);
+    uint32_t out = P.row_base[row_rel];
+    for (uint32_t jb = 0; jb < P.n_band_items; jb += kBinThreads) {
+        const uint32_t j = jb + tid;
+        bool hit = false;
+        uint2 bb = make_uint2(0u, 0u);
+        uint32_t it = 0;
+        if (j < P.n_band_items) {
+            bb = P.band_bbox[j];
+            it = P.band_item[j];
+            const int by = static_cast<int>(bb.x >> 16), bw = static_cast<int>(bb.y >> 16);
+            hit = bw >= y0 && by < y0 + static_cast<int>(kTileH);  // row part of :198 / :214
+        }
+        uint32_t total;
+        const uint32_t pos = BlockRank<kBinWaves>(hit, s_part, &total);
+        if (hit) {
+            P.row_bbox[out + pos] = bb;
+            P.row_item[out + pos] = it;
+        }
+        out += total;
+    }
+}
+
+// =====================================================================================
 // K1: binning, one workgroup per strip row
 // =====================================================================================
 
@@ -389,9 +426,16 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     // paint-ordered subset the host lists once per scene / viewport; with one GPU it is every
     // item in view), not over the whole scene: with the rows sharded over N GPUs each rank
     // looks at its own share only.
-    const uint32_t n_band = PM_PU(n_band_items);
+    uint32_t n_band = PM_PU(n_band_items);
     const uint2 *band_bbox = PM_PP(band_bbox);
     const uint32_t *band_item = PM_PP(band_item);
+    if (PM_PU(use_row_lists)) {  // large scene: this tile row's list from pm_rowcull_kernel
+        const uint32_t *rb = PM_PP(row_base);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane(rb[row_rel]);
+        n_band = __builtin_amdgcn_readfirstlane(rb[row_rel + 1]) - lo;
+        band_bbox = PM_PP(row_bbox) + lo;
+        band_item = PM_PP(row_item) + lo;
+    }
     uint2 bb_next = make_uint2(0u, 0u);
     uint32_t it_next = 0;
     if (tid < n_band) {
@@ -882,12 +926,12 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             uint32_t off = 0;
             for (uint32_t t = 0; t < tid; ++t)
                 if ((queued >> t) & 1u) off += 3u * s_est[t] + 1u;
-            list_slot = fits ? base + off : 0u;
+            list_slot = fits ? base + off : 0xffffffffu;  // no room: the tile kernels skip the tile
             PM_PP(tile_ptcl)[row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid] = list_slot;
         }
     }
-    // (on overflow the tiles are still queued, with lists at slot 0: in bounds, garbage pixels,
-    //  and pm_sync re-renders the frame with a larger arena)
+    // (on overflow the tiles are still queued but marked "no list": the tile kernels skip them,
+    //  the frame has holes, and pm_sync re-renders it with a larger arena)
     if (tid < kStripTiles) {
         // three queues, by expected list length: the fine kernel starts with the longest
         const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid;
@@ -1216,6 +1260,10 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
                                                               : 2u * P.queue_cap + (slot - n_a - n_b));
         const uint4 qe = *qentry;
         const uint32_t tile = qe.x;
+        if (qe.y == 0xffffffffu) {  // the command-list arena overflowed (pm_sync re-renders the frame)
+            if (lane == 0) qentry->w = 0;
+            continue;
+        }
         Cmd *const out_cmds = P.ptcl + qe.y;  // this tile's private command slots
         const uint32_t tx = tile % P.tiles_x;
         const uint32_t ty_rel = tile / P.tiles_x;
@@ -1749,6 +1797,7 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_b
 }
 
 void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream) {
+    if (p.use_row_lists) hipLaunchKernelGGL(pm_rowcull_kernel, dim3(p.row1 - p.row0), dim3(kBinThreads), 0, stream, p);
     if (p.dbg_bin)
         hipLaunchKernelGGL(pm_bin_kernel<true>, dim3(n_striprows), dim3(kBinThreads), 0, stream, p);
     else

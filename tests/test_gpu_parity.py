@@ -322,3 +322,64 @@ def test_bench_two_rank_path_rehearsal_on_one_gpu(pm, pmo, tmp_path):
     got = np.load(dump)
     assert got.shape == (4320, 3840, 4)
     assert np.array_equal(got, pmo.render(scene, 3840, 4320))
+
+
+def test_command_list_arena_overflow_grows_and_rerenders(pm, pmo, monkeypatch):
+    """Lists are sized from what binning finds, so the arena can run out: pm_sync must notice,
+    grow it and render the frame again (also with several frames in flight)."""
+    monkeypatch.setenv("PM_PTCL_INITIAL_CMDS", "2048")
+    r = pm.Renderer(0)
+    try:
+        wl = pm.workloads.tiger(960, 540)
+        r.resize(wl.width, wl.height)
+        r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        scene = r.download_scene()
+        want = pmo.render(scene, 960, 540)
+        for _ in range(5):
+            r.render()
+        assert np.array_equal(r.read_pixels(), want)
+        st = r.stats()
+        assert st["overflow"] == 0 and st["ptcl_used_cmds"] > 2048
+        for _ in range(3):
+            r.render()
+        assert np.array_equal(r.read_pixels(), want)
+    finally:
+        r.close()
+
+
+def test_cli_renders_svg_to_png(pm, pmo, tmp_path):
+    from piet_metal_amd import cli
+
+    out = str(tmp_path / "tiger.png")
+    assert cli.main(["tiger", out, "--width", "640", "--height", "400"]) == 0
+    wl = pm.workloads.tiger(640, 400)
+    scene, _ = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
+    assert np.array_equal(cli.read_png_rgba(out), pmo.render(scene, 640, 400))
+
+
+def test_per_row_item_lists_large_scene_path(pm, pmo, monkeypatch):
+    """Scenes with thousands of items bin through per-tile-row item lists
+    (pm_rowcull_kernel); forced on here for small scenes, full frame and bands."""
+    monkeypatch.setenv("PM_ROW_LIST_MIN_ITEMS", "1")
+    r = pm.Renderer(0)
+    try:
+        wl = pm.workloads.tiger(1000, 700)
+        r.resize(wl.width, wl.height)
+        r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        scene = r.download_scene()
+        want = pmo.render(scene, 1000, 700)
+        for _ in range(3):
+            r.render()
+        assert np.array_equal(r.read_pixels(), want)
+        assert_ptcl_equal(r, pmo, scene, 1000, 700)
+        r.set_band(10, 31)
+        r.render()
+        assert np.array_equal(r.read_pixels(), want[160:496])
+        for seed in (21, 22):
+            scene = encode_ops(pm, random_ops(seed, 400, extent=700.0))
+            r.resize(700, 500)
+            r.set_scene_bytes(scene)
+            r.render()
+            assert np.array_equal(r.read_pixels(), pmo.render(scene, 700, 500)), seed
+    finally:
+        r.close()

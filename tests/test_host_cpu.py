@@ -340,3 +340,15 @@ def test_workload_generators_are_deterministic(pm):
     assert len(g.paths.paths) == 4 * 138
     assert pm.workloads.band_rows(135, 8, 0) == (0, 17) and pm.workloads.band_rows(135, 8, 7) == (119, 135)
     assert sum(b - a for a, b in (pm.workloads.band_rows(135, 8, r) for r in range(8))) == 135
+
+
+def test_png_writer_round_trip(tmp_path):
+    from piet_metal_amd import cli
+
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, size=(37, 53, 4), dtype=np.uint8)
+    p = str(tmp_path / "x.png")
+    cli.write_png(p, img)
+    assert np.array_equal(cli.read_png_rgba(p), img)
+    with pytest.raises(ValueError):
+        cli.write_png(p, img[:, :, :3])
