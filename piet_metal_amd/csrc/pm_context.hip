@@ -189,6 +189,7 @@ struct pm_ctx {
 
     // binning state shared by the slots
     uint32_t *d_sr_base = nullptr;  // private arena region of every strip row
+    uint32_t sr_empty_dwords = 0;   // size of a region no item reaches
     uint2 *d_band_bbox = nullptr;   // items that reach the band (bbox, scene index), paint order
     uint32_t *d_band_item = nullptr;
     uint32_t n_band_items = 0;
@@ -336,6 +337,8 @@ int EnsureArena(pm_ctx *c) {
         }
     }
     base[need.size()] = static_cast<uint32_t>(total);
+    // what StripRowBounds gives a strip row before any item adds to it
+    c->sr_empty_dwords = static_cast<uint32_t>((static_cast<uint64_t>(pm::kRecHdrDwords + 3u) * ((c->n_items + 255u) / 256u) + 3u) & ~3ull);
     for (auto &s : c->slot) {
         if (!s.d_arena || total > c->arena_cap) {
             if (s.d_arena) (void)hipFree(s.d_arena);
@@ -457,6 +460,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->arena = s->d_arena;
     p->arena_cap = c->arena_cap;
     p->sr_base = c->d_sr_base;
+    p->sr_empty_dwords = c->sr_empty_dwords;
     p->striprow_head = s->d_striprow;
     p->queue = s->d_queue;
     p->queue_cap = static_cast<uint32_t>(BandTiles(c));

@@ -83,6 +83,7 @@ struct FrameParams {
     uint32_t *arena;
     uint32_t arena_cap;   // dwords
     const uint32_t *sr_base;  // [n_striprows + 1] private arena region of every strip row
+    uint32_t sr_empty_dwords; // size of a region no item's bbox reaches
     uint32_t *striprow_head;
     uint4 *queue;             // three class queues of {tile, first command slot, first record, commands}
     uint32_t queue_cap;

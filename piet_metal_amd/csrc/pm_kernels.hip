@@ -436,6 +436,9 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         band_bbox = PM_PP(row_bbox) + lo;
         band_item = PM_PP(row_item) + lo;
     }
+    // The host sized this strip row's arena region from the same bbox predicate: a region that
+    // only holds the fixed header allowance means no item can land here -- nothing to scan.
+    if (region_end - cursor == PM_PU(sr_empty_dwords)) n_band = 0;
     uint2 bb_next = make_uint2(0u, 0u);
     uint32_t it_next = 0;
     if (tid < n_band) {
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         it_next = band_item[tid];
     }
     // the two colour tables ride along with the first bbox load (finalisation reads them from LDS)
-    s_lut[tid] = PM_PP(lut_srgb2lin)[tid] | (PM_PP(lut_unorm2h)[tid] << 16);
+    if (n_band) s_lut[tid] = PM_PP(lut_srgb2lin)[tid] | (PM_PP(lut_unorm2h)[tid] << 16);
     for (uint32_t ib = 0;; ib += kBatch) {
         const bool more = ib < n_band;  // uniform
         const uint32_t j = ib + tid;

@@ -383,3 +383,31 @@ def test_per_row_item_lists_large_scene_path(pm, pmo, monkeypatch):
             assert np.array_equal(r.read_pixels(), pmo.render(scene, 700, 500)), seed
     finally:
         r.close()
+
+
+def test_maximum_viewports(pm, pmo):
+    """The reference caps the grid at 256 x 256 tiles (PietShaderTypes.h:24-32); here the grid
+    is dynamic up to the u16 bbox range.  A huge viewport must show the same picture in the
+    region a small one covers, and be background elsewhere."""
+    r = pm.Renderer(0)
+    try:
+        scene = pmo.scene_cardioid()
+        want = pmo.render(scene, 2048, 1536)
+        r.resize(16384, 12288)  # 1024 x 768 tiles, 805 Mpix
+        r.set_scene_bytes(scene)
+        r.render()
+        r.render()
+        got = r.read_pixels()
+        assert got.shape == (12288, 16384, 4)
+        assert np.array_equal(got[:1536, :2048], want)
+        assert (got[1536:] == 255).all() and (got[:1536, 2048:] == 255).all()
+        del got
+        # the widest viewport the u16 bboxes allow, one and a half tile rows tall
+        r.resize(65535, 24)
+        r.set_scene_bytes(scene)
+        r.render()
+        got = r.read_pixels()
+        assert np.array_equal(got[:, :2048], want[:24])
+        assert (got[:, 2048:] == 255).all()
+    finally:
+        r.close()
