@@ -200,11 +200,11 @@ def main() -> int:
         # algorithmic bytes of one launch of the dominant kernel = one frame of this
         # rank's band: scene read once + every RGBA8 pixel written once
         b_alg = scene_bytes + 4 * band_px
-        kernels = {"pm_bin_kernel": tm["bin_ms"], "pm_coarse_kernel": tm["coarse_ms"], "pm_fine_kernel": tm["fine_ms"]}
+        kernels = {"pm_bin_kernel": tm["bin_ms"], "pm_coarse_kernel": tm["coarse_ms"], "pm_fine_kernel": tm["fine_ms"], "pm_clear_kernel": tm["clear_ms"]}
         dom = max(kernels, key=kernels.get)
         dom_ms = kernels[dom]
         achieved = b_alg / (dom_ms * 1e-3) / 1e9
-        alone_ms = {"pm_bin_kernel": alone["bin_ms"], "pm_coarse_kernel": alone["coarse_ms"], "pm_fine_kernel": alone["fine_ms"]}
+        alone_ms = {"pm_bin_kernel": alone["bin_ms"], "pm_coarse_kernel": alone["coarse_ms"], "pm_fine_kernel": alone["fine_ms"], "pm_clear_kernel": alone["clear_ms"]}
         latency_ms = sum(alone_ms.values())
         pipelined_ms = tm["total_ms"] / tm["iters"]
         traffic = None

@@ -156,14 +156,15 @@ void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes);
 
 /* Time `iters` frames with HIP events (any pointer may be NULL).
  * total_ms = the whole batch submitted back to back through the frame pipeline, as pm_render
- * does; bin/coarse/fine_ms = average per-launch duration of the three frame kernels
- * (pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel), each ALONE on the GPU: a second pass
+ * does; bin/coarse/fine/clear_ms = average per-launch duration of the frame kernels
+ * (pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel, pm_clear_kernel), each ALONE on the GPU: a second pass
  * of `iters` frames serialized on one stream, every launch bracketed by events. */
-int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms);
+int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms, float *clear_ms);
 /* Same, but the per-kernel durations are taken INSIDE the pipelined batch: every launch is
  * bracketed by events on the stream it runs on while frames overlap (iters <= 4096).  These
  * are the durations a kernel trace of pm_render traffic shows. */
-int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms);
+int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms,
+                             float *clear_ms);
 
 typedef struct {
     uint32_t tiles_x, tiles_y;    /* tile grid of the viewport */

@@ -154,7 +154,7 @@ struct FrameSlot {
     uint32_t *d_row_item = nullptr;
     pm::Counters *d_ctr = nullptr;  // two: a frame's binning kernel zeroes the one the slot's next frame uses
     uint32_t parity = 0;
-    hipEvent_t ev_bin = nullptr, ev_coarse = nullptr, ev_fine = nullptr;
+    hipEvent_t ev_bin = nullptr, ev_clear = nullptr, ev_coarse = nullptr, ev_fine = nullptr;
     bool in_flight = false;   // ev_fine was recorded for a frame using this slot
     pm::FrameParams params{};
     hipStream_t tile_stream = nullptr;  // stream the slot's last tile kernels ran on
@@ -166,7 +166,7 @@ struct pm_ctx {
     // frame N: binning on bin_streams[N % nb], coarse on coarse_streams[N % nc], fine on
     // fine_streams[N % nf]; stream == fine_streams[0]
     std::vector<hipStream_t> bin_streams, coarse_streams, fine_streams;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
 
     // scene
@@ -522,10 +522,15 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     hipStream_t sb = user_stream ? user_stream : c->bin_streams[c->frame % c->bin_streams.size()];
     hipStream_t sc = user_stream ? user_stream : c->coarse_streams[c->frame % c->coarse_streams.size()];
     hipStream_t st = user_stream ? user_stream : c->fine_streams[c->frame % c->fine_streams.size()];
-    if (s->in_flight) PM_TRY(hipStreamWaitEvent(sb, s->ev_fine, 0));  // previous user of this slot
+    if (s->in_flight) {  // previous user of this slot
+        PM_TRY(hipStreamWaitEvent(sb, s->ev_fine, 0));
+        PM_TRY(hipStreamWaitEvent(sb, s->ev_clear, 0));
+    }
     // frames that target the same caller-owned buffer must not overlap each other
-    if (c->last_slot >= 0 && c->slot[c->last_slot].in_flight && c->slot[c->last_slot].params.fb == fb)
+    if (c->last_slot >= 0 && c->slot[c->last_slot].in_flight && c->slot[c->last_slot].params.fb == fb) {
         PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].ev_fine, 0));
+        PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].ev_clear, 0));
+    }
     if (tev) PM_TRY(hipEventRecord(tev[0], sb));
     pm::LaunchBin(p, BandRows(c) * c->strips_x, sb);
     if (tev) PM_TRY(hipEventRecord(tev[1], sb));
@@ -533,6 +538,11 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
         PM_TRY(hipEventRecord(s->ev_bin, sb));
         PM_TRY(hipStreamWaitEvent(sc, s->ev_bin, 0));
     }
+    // the resolved tiles' pixels: behind binning on its stream, next to the tile kernels
+    if (tev) PM_TRY(hipEventRecord(tev[6], sb));
+    pm::LaunchClear(p, BandRows(c) * c->strips_x, sb);
+    if (tev) PM_TRY(hipEventRecord(tev[7], sb));
+    PM_TRY(hipEventRecord(s->ev_clear, sb));
     if (tev) PM_TRY(hipEventRecord(tev[2], sc));
     pm::LaunchCoarse(p, CoarseGrid(c), false, sc);
     if (tev) PM_TRY(hipEventRecord(tev[3], sc));
@@ -704,6 +714,7 @@ pm_ctx *pm_create(int device, int *err) {
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
     for (auto &s : c->slot) {
         if ((e = hipEventCreateWithFlags(&s.ev_bin, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&s.ev_clear, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipEventCreateWithFlags(&s.ev_coarse, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipEventCreateWithFlags(&s.ev_fine, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipMalloc(&s.d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
@@ -745,6 +756,7 @@ void pm_destroy(pm_ctx *c) {
         if (s.d_row_item) (void)hipFree(s.d_row_item);
         if (s.d_ctr) (void)hipFree(s.d_ctr);
         if (s.ev_bin) (void)hipEventDestroy(s.ev_bin);
+        if (s.ev_clear) (void)hipEventDestroy(s.ev_clear);
         if (s.ev_coarse) (void)hipEventDestroy(s.ev_coarse);
         if (s.ev_fine) (void)hipEventDestroy(s.ev_fine);
     }
@@ -930,7 +942,7 @@ void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes) {
     return c->d_scene;
 }
 
-int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms) {
+int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms, float *clear_ms) {
     if (!c || iters <= 0) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
     int r;
@@ -941,15 +953,18 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
         for (int i = 0; i < iters; ++i)
             if ((r = Enqueue(c, nullptr, c->fb_stride, nullptr)) != PM_OK) return r;
         for (auto &s : c->slot)  // join: the end event follows the last frame of every stream
-            if (s.in_flight) PM_TRY(hipStreamWaitEvent(c->stream, s.ev_fine, 0));
+            if (s.in_flight) {
+                PM_TRY(hipStreamWaitEvent(c->stream, s.ev_fine, 0));
+                PM_TRY(hipStreamWaitEvent(c->stream, s.ev_clear, 0));
+            }
         PM_TRY(hipEventRecord(c->ev[1], c->stream));
         PM_TRY(hipEventSynchronize(c->ev[1]));
         PM_TRY(hipEventElapsedTime(total_ms, c->ev[0], c->ev[1]));
         if ((r = SyncAll(c)) != PM_OK) return r;
     }
-    if (bin_ms || coarse_ms || fine_ms) {
+    if (bin_ms || coarse_ms || fine_ms || clear_ms) {
         // one kernel at a time on one stream, each launch bracketed by events
-        double a1 = 0, a2 = 0, a3 = 0;
+        double a1 = 0, a2 = 0, a3 = 0, a4 = 0;
         for (int i = 0; i < iters; ++i) {
             const int si = static_cast<int>(c->frame % c->slot.size());
             FrameSlot *s = &c->slot[si];
@@ -962,48 +977,57 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             PM_TRY(hipEventRecord(c->ev[2], c->stream));
             pm::LaunchFine(p, FineGrid(c), c->stream);
             PM_TRY(hipEventRecord(c->ev[3], c->stream));
+            pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
+            PM_TRY(hipEventRecord(c->ev[4], c->stream));
             PM_TRY(hipEventRecord(s->ev_fine, c->stream));
-            PM_TRY(hipEventSynchronize(c->ev[3]));
+            PM_TRY(hipEventRecord(s->ev_clear, c->stream));
+            PM_TRY(hipEventSynchronize(c->ev[4]));
             Submitted(c, si, p, c->stream);
-            float t1 = 0, t2 = 0, t3 = 0;
+            float t1 = 0, t2 = 0, t3 = 0, t4 = 0;
             PM_TRY(hipEventElapsedTime(&t1, c->ev[0], c->ev[1]));
             PM_TRY(hipEventElapsedTime(&t2, c->ev[1], c->ev[2]));
             PM_TRY(hipEventElapsedTime(&t3, c->ev[2], c->ev[3]));
+            PM_TRY(hipEventElapsedTime(&t4, c->ev[3], c->ev[4]));
             a1 += t1;
             a2 += t2;
             a3 += t3;
+            a4 += t4;
         }
         if (bin_ms) *bin_ms = static_cast<float>(a1 / iters);
         if (coarse_ms) *coarse_ms = static_cast<float>(a2 / iters);
         if (fine_ms) *fine_ms = static_cast<float>(a3 / iters);
+        if (clear_ms) *clear_ms = static_cast<float>(a4 / iters);
     }
     return pm_sync(c);
 }
 
-int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms) {
+int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms,
+                             float *clear_ms) {
     if (!c || iters <= 0 || iters > 4096) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
     int r;
     if ((r = SyncAll(c)) != PM_OK) return r;
-    std::vector<hipEvent_t> tev(static_cast<size_t>(iters) * 6, nullptr);
+    std::vector<hipEvent_t> tev(static_cast<size_t>(iters) * 8, nullptr);
     hipError_t e = hipSuccess;
     for (auto &v : tev)
         if (e == hipSuccess) e = hipEventCreate(&v);
     r = PM_OK;
     if (e != hipSuccess) r = HipFail(e, "hipEventCreate");
     if (r == PM_OK) e = hipEventRecord(c->ev[0], c->stream);
-    for (int i = 0; i < iters && r == PM_OK; ++i) r = Enqueue(c, nullptr, c->fb_stride, nullptr, &tev[static_cast<size_t>(i) * 6]);
+    for (int i = 0; i < iters && r == PM_OK; ++i) r = Enqueue(c, nullptr, c->fb_stride, nullptr, &tev[static_cast<size_t>(i) * 8]);
     if (r == PM_OK) {
-        for (auto &s : c->slot)
+        for (auto &s : c->slot) {
             if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.ev_fine, 0);
+            if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.ev_clear, 0);
+        }
         if (e == hipSuccess) e = hipEventRecord(c->ev[1], c->stream);
         if (e == hipSuccess) e = hipEventSynchronize(c->ev[1]);
         if (e == hipSuccess) r = SyncAll(c);
-        double acc[3] = {0, 0, 0};
+        double acc[4] = {0, 0, 0, 0};
         for (int i = 0; i < iters && e == hipSuccess && r == PM_OK; ++i)
-            for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+            for (int k = 0; k < 4 && e == hipSuccess; ++k) {
                 float t = 0;
-                e = hipEventElapsedTime(&t, tev[static_cast<size_t>(i) * 6 + 2 * k], tev[static_cast<size_t>(i) * 6 + 2 * k + 1]);
+                e = hipEventElapsedTime(&t, tev[static_cast<size_t>(i) * 8 + 2 * k], tev[static_cast<size_t>(i) * 8 + 2 * k + 1]);
                 acc[k] += t;
             }
         float tt = 0;
@@ -1013,6 +1037,7 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
         if (bin_ms) *bin_ms = static_cast<float>(acc[0] / iters);
         if (coarse_ms) *coarse_ms = static_cast<float>(acc[1] / iters);
         if (fine_ms) *fine_ms = static_cast<float>(acc[2] / iters);
+        if (clear_ms) *clear_ms = static_cast<float>(acc[3] / iters);
     }
     for (auto &v : tev)
         if (v) (void)hipEventDestroy(v);
@@ -1110,9 +1135,11 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
         p.dbg_bin = d;
         hipError_t e = hipSuccess;
         pm::LaunchBin(p, BandRows(c) * c->strips_x, c->stream);
+        pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
         pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
         pm::LaunchFine(p, FineGrid(c), c->stream);
         if (e == hipSuccess) e = hipEventRecord(s->ev_fine, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(s->ev_clear, c->stream);
         p.dbg_bin = nullptr;
         Submitted(c, si, p, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

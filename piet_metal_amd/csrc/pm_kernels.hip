@@ -891,33 +891,13 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         if (tid == 3) s_qbase[4] = qtotal;
     }
     // tiles with nothing to draw are background: no item touches them, or every touching
-    // item lost all its segments in phase 1 (the reference writes Bail/white for them)
+    // item lost all its segments in phase 1 (the reference writes Bail/white for them).  Their
+    // pixels are written by pm_clear_kernel from tile_state: 25 MB of stores per 4K frame that
+    // would otherwise stall these latency-bound workgroups in bursts.
     const uint32_t clear = ~queued & valid;  // background (white) or one opaque colour
     if (tid < tiles_here)  // what this kernel decided per tile: 0 = queued, else the tile's colour
         PM_PP(tile_state)[row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid] =
             ((clear >> tid) & 1u) ? (((solid >> tid) & 1u) ? s_solid_rgba[tid] : 0xffffffffu) : 0u;
-    if (clear) {
-        // 16 pixel rows x 1024 B: thread -> (row = it*4 + wave, 16 B = 4 px at lane*4)
-        const uint32_t t = lane >> 2;  // tile of these 4 pixels
-        if ((clear >> t) & 1u) {
-            const uint32_t col = ((solid >> t) & 1u) ? s_solid_rgba[t] : 0xffffffffu;
-            const uint32_t px = static_cast<uint32_t>(sx0) + lane * 4u;
-#pragma unroll
-            for (uint32_t it = 0; it < kTileH / kBinWaves; ++it) {
-                const uint32_t r = it * kBinWaves + wave;
-                const uint32_t py = static_cast<uint32_t>(y0) + r;
-                if (py < PM_PU(height) && px < PM_PU(width)) {
-                    uint8_t *dst = PM_PP(fb) + static_cast<size_t>(row_rel * kTileH + r) * PM_PU(fb_stride) + static_cast<size_t>(px) * 4;
-                    if (px + 4 <= PM_PU(width) && PM_PU(fb_vec16)) {
-                        *reinterpret_cast<uint4 *>(dst) = make_uint4(col, col, col, col);
-                    } else {
-                        for (uint32_t k = 0; k < 4 && px + k < PM_PU(width); ++k)
-                            reinterpret_cast<uint32_t *>(dst)[k] = col;
-                    }
-                }
-            }
-        }
-    }
     __syncthreads();
     bool fits = true;
     uint32_t list_slot = 0;
@@ -949,6 +929,38 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     stamp(5);  // queues + list slots done
     (void)prof_chunks;
     stamp(7);
+}
+
+// =====================================================================================
+// K1b: pixels of the tiles binning resolved (background or one opaque colour) -- the composite
+// of PietRender.metal:34-44 for tiles that never reach the tile kernels.  Pure store bandwidth;
+// runs next to pm_coarse_kernel / pm_fine_kernel, which write the other tiles.
+// =====================================================================================
+__global__ __launch_bounds__(kBinThreads) void pm_clear_kernel(FrameParams P) {
+    const uint32_t lane = LaneId(), wave = threadIdx.x >> 6;
+    const uint32_t strip = blockIdx.x % P.strips_x;
+    const uint32_t row_rel = blockIdx.x / P.strips_x;
+    const uint32_t t = lane >> 2;  // tile of this lane's 4 pixels
+    const uint32_t tx = strip * kStripTiles + t;
+    if (tx >= P.tiles_x) return;
+    const uint32_t col = P.tile_state[row_rel * P.tiles_x + tx];
+    if (col == 0) return;  // queued: the tile kernels write it
+    const uint32_t px = strip * kGroupW + lane * 4u;
+    const uint32_t y0 = (P.row0 + row_rel) * kTileH;
+    // 16 pixel rows x 1024 B per strip row: thread -> (row = it*4 + wave, 16 B = 4 px at lane*4)
+#pragma unroll
+    for (uint32_t it = 0; it < kTileH / kBinWaves; ++it) {
+        const uint32_t r = it * kBinWaves + wave;
+        const uint32_t py = y0 + r;
+        if (py < P.height && px < P.width) {
+            uint8_t *dst = P.fb + static_cast<size_t>(row_rel * kTileH + r) * P.fb_stride + static_cast<size_t>(px) * 4;
+            if (px + 4 <= P.width && P.fb_vec16) {
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(col, col, col, col);
+            } else {
+                for (uint32_t k = 0; k < 4 && px + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = col;
+            }
+        }
+    }
 }
 
 // =====================================================================================
@@ -1805,6 +1817,10 @@ void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream) {
         hipLaunchKernelGGL(pm_bin_kernel<true>, dim3(n_striprows), dim3(kBinThreads), 0, stream, p);
     else
         hipLaunchKernelGGL(pm_bin_kernel<false>, dim3(n_striprows), dim3(kBinThreads), 0, stream, p);
+}
+
+void LaunchClear(const FrameParams &p, uint32_t n_striprows, hipStream_t stream) {
+    hipLaunchKernelGGL(pm_clear_kernel, dim3(n_striprows), dim3(kBinThreads), 0, stream, p);
 }
 
 void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream) {

@@ -131,14 +131,15 @@ class Renderer:
         """total_ms: `iters` frames through the frame pipeline.  bin/coarse/fine_ms: average
         launch duration of the three kernels -- each alone on the GPU (default), or inside
         the overlapping pipelined batch (pipelined=True)."""
-        tot, k1, k2, k3 = C.c_float(0), C.c_float(0), C.c_float(0), C.c_float(0)
+        tot, k1, k2, k3, k4 = C.c_float(0), C.c_float(0), C.c_float(0), C.c_float(0), C.c_float(0)
         pk = per_kernel
         fn = self._lib.pm_time_frames_pipelined if pipelined else self._lib.pm_time_frames
         _lib.check(
-            fn(self._h, iters, C.byref(tot), C.byref(k1) if pk else None, C.byref(k2) if pk else None, C.byref(k3) if pk else None),
+            fn(self._h, iters, C.byref(tot), C.byref(k1) if pk else None, C.byref(k2) if pk else None, C.byref(k3) if pk else None,
+               C.byref(k4) if pk else None),
             "pm_time_frames",
         )
-        return {"total_ms": tot.value, "bin_ms": k1.value, "coarse_ms": k2.value, "fine_ms": k3.value, "iters": iters}
+        return {"total_ms": tot.value, "bin_ms": k1.value, "coarse_ms": k2.value, "fine_ms": k3.value, "clear_ms": k4.value, "iters": iters}
 
     def stats(self) -> dict:
         s = _lib.Stats()

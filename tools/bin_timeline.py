@@ -46,3 +46,9 @@ for nm, a, b in [("headers done -> round start", 2, 8), ("chunk tests + scan", 8
 el = t[big, 6]
 d = (t[big, 11] - t[big, 10]) * us
 print(f"   {big.sum()} WGs, elements mean {el.mean():.0f}; expansion per 256-element step: {(d / np.ceil(el / 256)).mean():.2f} us")
+e = (t[:, 1] == 0) & (t[:, 11] > 0)
+if e.any():
+    print("strip rows without candidates, tail:")
+    for nm, a, b in [("entry -> tail", 0, 8), ("barrier", 8, 9), ("masks + clear stores issued", 9, 10), ("barrier", 10, 11), ("queue writes -> exit", 11, 7)]:
+        d = (t[e, b] - t[e, a]) * us
+        print(f"   {nm:30s} mean {d.mean():.2f} p90 {np.percentile(d, 90):.2f} max {d.max():.2f}")
