@@ -32,9 +32,9 @@ struct Counters {
 //   [0] next record offset (0 = end)   [1] ncand   [2] chunks streamed (sizes segs/meta)
 //   [3] segment slots in use (= surviving chunks x kChunkSegs)
 //   mask table: ncand dwords { tag | hitmask16 << 16 }, padded to a multiple of 4
-//       (one 16-byte load per lane of the tile kernel covers 256 candidates); a hit
+//       (one 16-byte load per lane of the coarse kernel covers 256 candidates); a hit
 //       bit survives only where the candidate can emit a command
-//   ncand x 8 dwords: { tag | hitmask16 << 16, rgba, aux0, aux1, seg_off, seg_cnt, rg, ba }
+//   ncand x 8 dwords: { tag | hitmask16 << 16, rgba, aux0, aux1, item index, 0, rg, ba }
 //       aux0/aux1 = bbox words (circle) or width bits (line, polyline)
 //       rg/ba = the colour already through unpack_unorm4x8_srgb_to_half (4 x binary16)
 //   ncand x 16 dwords: per tile of the strip { backdrop << 20 | relevant segments }
@@ -49,20 +49,20 @@ struct Counters {
 // the worst case, so the binning kernel allocates with plain arithmetic: no atomics, no
 // counting pass.
 //
-// Tile queue: tiles whose segment stream is long are pushed from the front
-// (queue[0 .. heavy_count)), the others from the back (queue[cap-1-i]); the tile
-// kernel hands slots out front first through `cursor`, so the expensive tiles start
-// first and the cheap ones fill the tail.
+// Tile queues: three class queues (very long / long / short lists, by the number of stream
+// elements binning counted for the tile) of 16-byte entries {tile, first command slot, first
+// binning record of the strip row, commands written}; the tile kernels walk them statically,
+// longest first, so the expensive tiles start first and the cheap ones fill the tail.
 //
 // Scene index (built once per scene upload by pm_index_kernel, like the ShortBbox
-// array the encoder builds at encode time): segments are grouped in chunks of 16
+// array the encoder builds at encode time): segments are grouped in chunks of kChunkSegs
 // consecutive segments of one Fill / StrokePolyLine item; chunk_bbox holds each
 // chunk's float bounding box {xmin, ymin, xmax, ymax}; chunk_base[i] is the first
 // chunk of item i (chunk_base[n_items] = total).  The binning kernel streams only
 // the chunks whose box can reach its strip row.
 constexpr uint32_t kChunkSegs = 8;
 constexpr uint32_t kArenaBase = 4;     // offset 0 means "none"
-constexpr int kBinWaves = 4;                          // waves of one binning workgroup (one extent each)
+constexpr int kBinWaves = 4;           // waves of one binning workgroup
 constexpr uint32_t kRecHdrDwords = 4;
 constexpr uint32_t kCandDwords = 8;
 constexpr uint32_t kCtDwords = 16;           // per candidate: one word per tile of the strip

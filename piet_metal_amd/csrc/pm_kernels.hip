@@ -6,37 +6,38 @@
 //   renderKernel TestApp/PietRender.metal:457-566  (+ stroke/renderDf :49-60)
 //   composite    TestApp/PietRender.metal:16-44
 //
-// Decomposition (NOT the reference's thread-per-tile / 256 MiB tile buffer):
+// Decomposition (NOT the reference's thread-per-tile / 256 MiB tile buffer) -- one kernel per
+// level of parallelism, chained by events over the frame pipeline of pm_context.hip:
 //
-//   pm_index_kernel (once per scene) float bounding box of every chunk of 16
-//       consecutive segments -- the segment-level analogue of the ShortBbox array
-//       the encoder already builds per item.
-//   pm_bin_kernel   one 256-thread workgroup per strip row (16 tiles x 1 tile).
-//       - item bboxes vs strip row: wave64 ballots + prefix ranks compact the
-//         candidate items in paint order;
-//       - the chunks of all candidates form one flat stream; chunks whose box
-//         cannot reach the strip row are dropped, the segments of the others are
-//         expanded lane-parallel and each lane evaluates the reference's "phase 1"
-//         segment vote (PietRender.metal:258-295 fills, :374-399 polylines);
-//         votes are compacted in order and the surviving segments (16 B each) are
-//         appended to a bump-allocated arena record in HBM;
-//       - tiles no item touches are cleared to the background right here with
-//         16-byte coalesced stores; the others are pushed on a tile queue.
-//   pm_tile_kernel  persistent; ONE WAVE PER TILE, no workgroup barriers.
-//       - candidates are filtered by a per-tile hit bit, their surviving segments
-//         again form one flat stream; each lane runs the reference's "phase 2"
-//         test for (tile, segment) (:302-357, :406-440) and emits 0..3 commands;
-//         ballots / mbcnt prefix ranks give every command its slot in an
-//         LDS-resident command list (never written to HBM);
-//       - the wave then interprets the list (renderKernel) for the tile's 256
-//         pixels, 4 horizontally adjacent pixels per lane: everything that only
-//         depends on y (segment window, the two divides of the area integral,
-//         FillEdge) is computed once per lane, colour blending runs as packed
-//         half2 math, and each lane finishes with one 16-byte store;
-//       - accumulators are binary16 exactly where the source declares `half`,
-//         commands are applied in list order (half accumulation is order
-//         dependent), opaque-solid detection (TileEncoder::encodeSolid/end) is
-//         tracked per tile so Bail tiles are written as one constant.
+//   pm_index_kernel   (once per scene) float bounding box of every chunk of 8 consecutive
+//       segments -- the segment-level analogue of the ShortBbox array the encoder builds per item.
+//   pm_rowcull_kernel (large scenes only) per tile row, the paint-ordered list of items whose
+//       bbox reaches the row.
+//   pm_bin_kernel     one 256-thread workgroup per strip row (16 tiles x 1 tile).
+//       - item bboxes vs strip row: wave64 ballots + prefix ranks compact the candidate items in
+//         paint order;
+//       - the chunks of all candidates form one flat stream; chunks whose box cannot reach the
+//         strip row are dropped; every surviving chunk owns 8 segment slots of an arena record
+//         and each lane evaluates the reference's "phase 1" segment vote for one slot
+//         (PietRender.metal:258-295 fills, :374-399 polylines), the 16-bit mask of tiles the
+//         segment can matter to, and for fills the backdrop step;
+//       - per (item, tile) counts and backdrops, the TileEncoder solid rule per tile, the
+//         command-list space of every tile and its place in one of three class queues.
+//   pm_clear_kernel   pixels of the tiles binning resolved (background / one opaque colour).
+//   pm_coarse_kernel  persistent; ONE WAVE PER QUEUED TILE, no workgroup barriers.
+//       - candidates are filtered by a per-tile hit bit; the record's slots carrying the tile's
+//         bit are gathered in paint order; each lane runs the reference's "phase 2" test for
+//         (tile, segment) (:302-357, :406-440) and emits 0..3 commands; ballots / mbcnt prefix
+//         ranks give every command its slot in the tile's command list in HBM (the reference's
+//         24-byte Cmd records);
+//       - opaque-solid detection (TileEncoder::encodeSolid/end) restarts the list; Bail tiles are
+//         written as one constant here.
+//   pm_fine_kernel    persistent; interprets a tile's command list (renderKernel) for its 256
+//       pixels with 1, 4 or 16 waves by list length.  Everything that only depends on y
+//       (segment window, the two divides of the area integral, FillEdge) is computed once per
+//       lane, colour blending runs as packed half2 math, and each lane finishes with one
+//       16-byte store.  Accumulators are binary16 exactly where the source declares `half`;
+//       commands are applied in list order (half accumulation is order dependent).
 //
 // Compile with -ffp-contract=off: every source-level f32/f16 operation is one
 // IEEE rounding, as in the oracle.
@@ -48,7 +49,7 @@ namespace pm {
 
 namespace {
 
-constexpr int kThreads = 256;   // tile kernel workgroup
+constexpr int kThreads = 256;   // coarse / fine kernel workgroup
 constexpr int kWaves = kThreads / 64;
 constexpr int kBinThreads = 64 * kBinWaves;  // binning workgroup: its waves share one strip row's segment stream
 constexpr uint32_t kBatch = 256;   // candidate items per binning batch
