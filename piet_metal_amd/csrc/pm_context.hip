@@ -155,7 +155,8 @@ struct FrameSlot {
     pm::Counters *d_ctr = nullptr;  // two: a frame's binning kernel zeroes the one the slot's next frame uses
     uint32_t parity = 0;
     hipEvent_t ev_bin = nullptr, ev_clear = nullptr, ev_coarse = nullptr, ev_fine = nullptr;
-    bool in_flight = false;   // ev_fine was recorded for a frame using this slot
+    bool in_flight = false;   // a frame using this slot was submitted; w_fine / w_clear mark its end
+    hipEvent_t w_fine = nullptr, w_clear = nullptr;  // (the slot's own events, or a timing pass's)
     pm::FrameParams params{};
     hipStream_t tile_stream = nullptr;  // stream the slot's last tile kernels ran on
 };
@@ -166,7 +167,7 @@ struct pm_ctx {
     // frame N: binning on bin_streams[N % nb], coarse on coarse_streams[N % nc], fine on
     // fine_streams[N % nf]; stream == fine_streams[0]
     std::vector<hipStream_t> bin_streams, coarse_streams, fine_streams;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
 
     // scene
@@ -510,8 +511,10 @@ void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t tile_str
     c->frame += 1;
 }
 
-// One frame.  user_stream == nullptr: pipelined over (bin_stream, coarse_stream, stream); otherwise all three
-// kernels run back to back on the caller's stream.
+// One frame.  user_stream == nullptr: pipelined over the context's streams; otherwise all
+// kernels run back to back on the caller's stream.  tev (timing passes): eight events
+// {begin, end} x {bin, clear, coarse, fine} carried by the dispatches themselves, so that a
+// timed frame puts exactly the same packets on the queues as an untimed one.
 int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipEvent_t *tev = nullptr) {
     const int si = static_cast<int>(c->frame % c->slot.size());
     FrameSlot *s = &c->slot[si];
@@ -522,39 +525,36 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     hipStream_t sb = user_stream ? user_stream : c->bin_streams[c->frame % c->bin_streams.size()];
     hipStream_t sc = user_stream ? user_stream : c->coarse_streams[c->frame % c->coarse_streams.size()];
     hipStream_t st = user_stream ? user_stream : c->fine_streams[c->frame % c->fine_streams.size()];
+    hipEvent_t e_bin = s->ev_bin, e_clear = s->ev_clear, e_coarse = s->ev_coarse, e_fine = s->ev_fine;
+    hipEvent_t none[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t *t = tev ? tev : none;
     if (s->in_flight) {  // previous user of this slot
-        PM_TRY(hipStreamWaitEvent(sb, s->ev_fine, 0));
-        PM_TRY(hipStreamWaitEvent(sb, s->ev_clear, 0));
+        PM_TRY(hipStreamWaitEvent(sb, s->w_fine, 0));
+        PM_TRY(hipStreamWaitEvent(sb, s->w_clear, 0));
     }
     // frames that target the same caller-owned buffer must not overlap each other
-    if (c->last_slot >= 0 && c->slot[c->last_slot].in_flight && c->slot[c->last_slot].params.fb == fb) {
-        PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].ev_fine, 0));
-        PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].ev_clear, 0));
+    if (c->last_slot >= 0 && c->last_slot != si && c->slot[c->last_slot].in_flight && c->slot[c->last_slot].params.fb == fb) {
+        PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].w_fine, 0));
+        PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].w_clear, 0));
     }
-    if (tev) PM_TRY(hipEventRecord(tev[0], sb));
-    pm::LaunchBin(p, BandRows(c) * c->strips_x, sb);
-    if (tev) PM_TRY(hipEventRecord(tev[1], sb));
+    pm::LaunchBin(p, BandRows(c) * c->strips_x, sb, t[0], t[1]);
     if (sb != sc) {
-        PM_TRY(hipEventRecord(s->ev_bin, sb));
-        PM_TRY(hipStreamWaitEvent(sc, s->ev_bin, 0));
+        PM_TRY(hipEventRecord(e_bin, sb));
+        PM_TRY(hipStreamWaitEvent(sc, e_bin, 0));
     }
     // the resolved tiles' pixels: behind binning on its stream, next to the tile kernels
-    if (tev) PM_TRY(hipEventRecord(tev[6], sb));
-    pm::LaunchClear(p, BandRows(c) * c->strips_x, sb);
-    if (tev) PM_TRY(hipEventRecord(tev[7], sb));
-    PM_TRY(hipEventRecord(s->ev_clear, sb));
-    if (tev) PM_TRY(hipEventRecord(tev[2], sc));
-    pm::LaunchCoarse(p, CoarseGrid(c), false, sc);
-    if (tev) PM_TRY(hipEventRecord(tev[3], sc));
+    pm::LaunchClear(p, BandRows(c) * c->strips_x, sb, t[2], t[3]);
+    PM_TRY(hipEventRecord(e_clear, sb));
+    pm::LaunchCoarse(p, CoarseGrid(c), false, sc, t[4], t[5]);
     if (sc != st) {
-        PM_TRY(hipEventRecord(s->ev_coarse, sc));
-        PM_TRY(hipStreamWaitEvent(st, s->ev_coarse, 0));
+        PM_TRY(hipEventRecord(e_coarse, sc));
+        PM_TRY(hipStreamWaitEvent(st, e_coarse, 0));
     }
-    if (tev) PM_TRY(hipEventRecord(tev[4], st));
-    pm::LaunchFine(p, FineGrid(c), st);
-    if (tev) PM_TRY(hipEventRecord(tev[5], st));
+    pm::LaunchFine(p, FineGrid(c), st, t[6], t[7]);
     PM_TRY(hipGetLastError());
-    PM_TRY(hipEventRecord(s->ev_fine, st));
+    PM_TRY(hipEventRecord(e_fine, st));
+    s->w_fine = e_fine;
+    s->w_clear = e_clear;
     Submitted(c, si, p, st);
     return PM_OK;
 }
@@ -954,8 +954,8 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             if ((r = Enqueue(c, nullptr, c->fb_stride, nullptr)) != PM_OK) return r;
         for (auto &s : c->slot)  // join: the end event follows the last frame of every stream
             if (s.in_flight) {
-                PM_TRY(hipStreamWaitEvent(c->stream, s.ev_fine, 0));
-                PM_TRY(hipStreamWaitEvent(c->stream, s.ev_clear, 0));
+                PM_TRY(hipStreamWaitEvent(c->stream, s.w_fine, 0));
+                PM_TRY(hipStreamWaitEvent(c->stream, s.w_clear, 0));
             }
         PM_TRY(hipEventRecord(c->ev[1], c->stream));
         PM_TRY(hipEventSynchronize(c->ev[1]));
@@ -970,24 +970,22 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             FrameSlot *s = &c->slot[si];
             pm::FrameParams p;
             if ((r = BuildParams(c, s, s->d_fb, c->fb_stride, &p)) != PM_OK) return r;
-            PM_TRY(hipEventRecord(c->ev[0], c->stream));
-            pm::LaunchBin(p, BandRows(c) * c->strips_x, c->stream);
-            PM_TRY(hipEventRecord(c->ev[1], c->stream));
-            pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
-            PM_TRY(hipEventRecord(c->ev[2], c->stream));
-            pm::LaunchFine(p, FineGrid(c), c->stream);
-            PM_TRY(hipEventRecord(c->ev[3], c->stream));
-            pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
-            PM_TRY(hipEventRecord(c->ev[4], c->stream));
+            // each dispatch carries its own begin / end events: pure kernel durations
+            pm::LaunchBin(p, BandRows(c) * c->strips_x, c->stream, c->ev[0], c->ev[1]);
+            pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream, c->ev[2], c->ev[3]);
+            pm::LaunchFine(p, FineGrid(c), c->stream, c->ev[4], c->ev[5]);
+            pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream, c->ev[6], c->ev[7]);
             PM_TRY(hipEventRecord(s->ev_fine, c->stream));
             PM_TRY(hipEventRecord(s->ev_clear, c->stream));
-            PM_TRY(hipEventSynchronize(c->ev[4]));
+            s->w_fine = s->ev_fine;
+            s->w_clear = s->ev_clear;
+            PM_TRY(hipStreamSynchronize(c->stream));
             Submitted(c, si, p, c->stream);
             float t1 = 0, t2 = 0, t3 = 0, t4 = 0;
             PM_TRY(hipEventElapsedTime(&t1, c->ev[0], c->ev[1]));
-            PM_TRY(hipEventElapsedTime(&t2, c->ev[1], c->ev[2]));
-            PM_TRY(hipEventElapsedTime(&t3, c->ev[2], c->ev[3]));
-            PM_TRY(hipEventElapsedTime(&t4, c->ev[3], c->ev[4]));
+            PM_TRY(hipEventElapsedTime(&t2, c->ev[2], c->ev[3]));
+            PM_TRY(hipEventElapsedTime(&t3, c->ev[4], c->ev[5]));
+            PM_TRY(hipEventElapsedTime(&t4, c->ev[6], c->ev[7]));
             a1 += t1;
             a2 += t2;
             a3 += t3;
@@ -1017,13 +1015,13 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
     for (int i = 0; i < iters && r == PM_OK; ++i) r = Enqueue(c, nullptr, c->fb_stride, nullptr, &tev[static_cast<size_t>(i) * 8]);
     if (r == PM_OK) {
         for (auto &s : c->slot) {
-            if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.ev_fine, 0);
-            if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.ev_clear, 0);
+            if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.w_fine, 0);
+            if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.w_clear, 0);
         }
         if (e == hipSuccess) e = hipEventRecord(c->ev[1], c->stream);
         if (e == hipSuccess) e = hipEventSynchronize(c->ev[1]);
         if (e == hipSuccess) r = SyncAll(c);
-        double acc[4] = {0, 0, 0, 0};
+        double acc[4] = {0, 0, 0, 0};  // bin, clear, coarse, fine
         for (int i = 0; i < iters && e == hipSuccess && r == PM_OK; ++i)
             for (int k = 0; k < 4 && e == hipSuccess; ++k) {
                 float t = 0;
@@ -1035,10 +1033,11 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
         if (e != hipSuccess) r = HipFail(e, "pipelined timing");
         if (total_ms) *total_ms = tt;
         if (bin_ms) *bin_ms = static_cast<float>(acc[0] / iters);
-        if (coarse_ms) *coarse_ms = static_cast<float>(acc[1] / iters);
-        if (fine_ms) *fine_ms = static_cast<float>(acc[2] / iters);
-        if (clear_ms) *clear_ms = static_cast<float>(acc[3] / iters);
+        if (clear_ms) *clear_ms = static_cast<float>(acc[1] / iters);
+        if (coarse_ms) *coarse_ms = static_cast<float>(acc[2] / iters);
+        if (fine_ms) *fine_ms = static_cast<float>(acc[3] / iters);
     }
+    (void)SyncAll(c);
     for (auto &v : tev)
         if (v) (void)hipEventDestroy(v);
     return r == PM_OK ? pm_sync(c) : r;
@@ -1140,6 +1139,8 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
         pm::LaunchFine(p, FineGrid(c), c->stream);
         if (e == hipSuccess) e = hipEventRecord(s->ev_fine, c->stream);
         if (e == hipSuccess) e = hipEventRecord(s->ev_clear, c->stream);
+        s->w_fine = s->ev_fine;
+        s->w_clear = s->ev_clear;
         p.dbg_bin = nullptr;
         Submitted(c, si, p, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -120,9 +120,11 @@ struct FrameParams {
 
 void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks, float4 *chunk_bbox,
                  hipStream_t stream);
-void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream);
-void LaunchClear(const FrameParams &p, uint32_t n_striprows, hipStream_t stream);
-void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream);
-void LaunchFine(const FrameParams &p, uint32_t grid, hipStream_t stream);
+// (t0, t1): optional timing events carried by the dispatch itself
+void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void LaunchClear(const FrameParams &p, uint32_t n_striprows, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream, hipEvent_t t0 = nullptr,
+                  hipEvent_t t1 = nullptr);
+void LaunchFine(const FrameParams &p, uint32_t grid, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 }  // namespace pm
