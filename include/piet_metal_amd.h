@@ -166,6 +166,11 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
 int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms,
                              float *clear_ms);
 
+/* Latency of ONE frame with nothing else in flight: begin of its first kernel to end of its
+ * last one, from the dispatches' own timestamps; median and minimum over `iters` frames
+ * (SURVEY.md 8d's t_frame; PietRenderer.m has no timing at all). */
+int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms);
+
 typedef struct {
     uint32_t tiles_x, tiles_y;    /* tile grid of the viewport */
     uint32_t band_row0, band_row1;

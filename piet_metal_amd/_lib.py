@@ -104,6 +104,7 @@ SIGNATURES = {
     "pm_framebuffer_device_ptr": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "pm_scene_device_ptr": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "pm_time_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pm_frame_latency": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_time_frames_pipelined": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "pm_debug_capture_ptcl": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1045,6 +1045,37 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
     return r == PM_OK ? pm_sync(c) : r;
 }
 
+int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms) {
+    if (!c || iters <= 0 || iters > 4096) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = SyncAll(c)) != PM_OK) return r;
+    hipEvent_t tev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (auto &v : tev)
+        if (e == hipSuccess) e = hipEventCreate(&v);
+    std::vector<float> lat;
+    r = e == hipSuccess ? PM_OK : HipFail(e, "hipEventCreate");
+    for (int i = 0; i < iters && r == PM_OK; ++i) {
+        // one frame through the pipeline's streams, nothing else in flight: first kernel's
+        // begin to last kernel's end (SURVEY 8d's t_frame), from the dispatches' own timestamps
+        r = Enqueue(c, nullptr, c->fb_stride, nullptr, tev);
+        if (r == PM_OK) r = SyncAll(c);
+        float t_fine = 0, t_clear = 0;
+        if (r == PM_OK && hipEventElapsedTime(&t_fine, tev[0], tev[7]) == hipSuccess &&
+            hipEventElapsedTime(&t_clear, tev[0], tev[3]) == hipSuccess)
+            lat.push_back(std::max(t_fine, t_clear));
+    }
+    for (auto &v : tev)
+        if (v) (void)hipEventDestroy(v);
+    if (r != PM_OK) return r;
+    if (lat.empty()) return PM_ERR_HIP;
+    std::sort(lat.begin(), lat.end());
+    if (median_ms) *median_ms = lat[lat.size() / 2];
+    if (min_ms) *min_ms = lat.front();
+    return pm_sync(c);
+}
+
 int pm_get_stats(pm_ctx *c, pm_stats *out) {
     if (!c || !out) return PM_ERR_INVALID;
     std::memset(out, 0, sizeof(*out));

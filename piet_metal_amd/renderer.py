@@ -141,6 +141,12 @@ class Renderer:
         )
         return {"total_ms": tot.value, "bin_ms": k1.value, "coarse_ms": k2.value, "fine_ms": k3.value, "clear_ms": k4.value, "iters": iters}
 
+    def frame_latency(self, iters: int = 100) -> dict:
+        """One frame at a time: first kernel's begin to last kernel's end (median / min, ms)."""
+        med, mn = C.c_float(0), C.c_float(0)
+        _lib.check(self._lib.pm_frame_latency(self._h, iters, C.byref(med), C.byref(mn)), "pm_frame_latency")
+        return {"median_ms": med.value, "min_ms": mn.value, "iters": iters}
+
     def stats(self) -> dict:
         s = _lib.Stats()
         _lib.check(self._lib.pm_get_stats(self._h, C.byref(s)), "pm_get_stats")

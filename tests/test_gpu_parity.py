@@ -411,3 +411,12 @@ def test_maximum_viewports(pm, pmo):
         assert (got[:, 2048:] == 255).all()
     finally:
         r.close()
+
+
+def test_frame_latency_api(pm, pmo, renderer):
+    scene = pmo.scene_cardioid()
+    renderer.resize(1024, 768)
+    renderer.set_scene_bytes(scene)
+    lat = renderer.frame_latency(20)
+    assert 0 < lat["min_ms"] <= lat["median_ms"] < 50
+    assert np.array_equal(renderer.read_pixels(), pmo.render(scene, 1024, 768))
