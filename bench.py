@@ -238,7 +238,7 @@ def main() -> int:
                 "frame_latency_frac": round(b_alg / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "frame_pipelined_ms": round(pipelined_ms, 5),
                 "frame_pipelined_frac": round(b_alg / (pipelined_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "kernels_ms / kernel_ms: per-launch HIP-event durations inside the pipelined batch (frames overlap on 4 streams, as in the timed region; what rocprofv3 --kernel-trace shows); kernels_alone_ms: the same kernels with frames serialized on one stream; frame_latency_ms: one frame with nothing else in flight, first kernel begin to last kernel end (median of 100; SURVEY 8d's t_frame); the path is latency/VALU bound, not HBM bound (DESIGN.md)",
+                "note": "kernels_ms / kernel_ms: per-launch durations inside the overlapping batch (four frames in flight on four streams, as in the timed region), from events carried by the dispatches -- what rocprofv3 --kernel-trace shows; kernels_alone_ms: the same kernels with frames serialized on one stream; frame_latency_ms: one frame with nothing else in flight, first kernel begin to last kernel end (median of 100; SURVEY 8d's t_frame); the path is latency/VALU bound, not HBM bound (DESIGN.md)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -7,13 +7,16 @@
 //                                           pm_flatten_and_encode (PietRenderer.m:203-205)
 //   -drawInMTKView:                      -> pm_render      (PietRenderer.m:59-103)
 //
-// Frames are pipelined like the reference's command queue ([commandBuffer commit] never waits,
-// PietRenderer.m:102): five frame slots (own arena, queues, command lists, framebuffer) and
-// four HIP streams -- two alternate for binning (+ the clear kernel behind it), one runs the
-// coarse kernels, one the fine kernels; events order the stages of a frame and the reuse of a
-// slot, so binning of frames N+2, N+3 and the coarse kernel of frame N+1 run while the fine
-// kernel of frame N is still busy.  A frame rendered into a caller-owned buffer (pm_render_to)
-// runs its kernels back to back on the caller's stream instead.
+// Frames overlap like the reference's command buffers ([commandBuffer commit] never waits,
+// PietRenderer.m:102): frame N runs its four kernels back to back on stream N % 4 and owns
+// frame slot N % 4 (arena, queues, command lists, framebuffer), so frames in flight share no
+// mutable state and need no cross-stream events; the in-order queues do the ordering.  At 4K
+// every kernel alone leaves most of the chip idle (its span is set by its longest dependent
+// chain), and four frames side by side fill it.  Measured alternatives: one stream per kernel
+// stage chained by events (each cross-stream dependency costs 10-15 us to release the next
+// dispatch) was 5 % slower; more than four streams (ROCm's default number of hardware queues)
+// was slower still.  A frame rendered into a caller-owned buffer (pm_render_to) runs on the
+// caller's stream.
 //
 // There is deliberately no CPU rendering path in this library: without a gfx950
 // device pm_create fails with PM_ERR_NO_DEVICE.
@@ -132,8 +135,7 @@ void BuildLuts(Luts *l) {
 
 namespace {
 constexpr int kMaxSlots = 16;
-constexpr int kMaxStreams = 4;
-constexpr int kDefaultBinStreams = 2, kDefaultCoarseStreams = 1, kDefaultFineStreams = 1;  // measured best on Tiger 4K
+constexpr int kDefaultFrameStreams = 4;  // = ROCm's default hardware queues; measured best on Tiger 4K
 
 int EnvInt(const char *name, int dflt, int lo, int hi) {
     const char *v = std::getenv(name);
@@ -156,19 +158,16 @@ struct FrameSlot {
     uint32_t *d_row_item = nullptr;
     pm::Counters *d_ctr = nullptr;  // two: a frame's binning kernel zeroes the one the slot's next frame uses
     uint32_t parity = 0;
-    hipEvent_t ev_bin = nullptr, ev_clear = nullptr, ev_coarse = nullptr, ev_fine = nullptr;
-    bool in_flight = false;   // a frame using this slot was submitted; w_fine / w_clear mark its end
-    hipEvent_t w_fine = nullptr, w_clear = nullptr;  // (the slot's own events, or a timing pass's)
+    hipEvent_t ev_done = nullptr;  // end of the slot's last frame
+    bool in_flight = false;        // a frame using this slot was submitted; ev_done marks its end
     pm::FrameParams params{};
-    hipStream_t tile_stream = nullptr;  // stream the slot's last tile kernels ran on
+    hipStream_t frame_stream = nullptr;  // stream the slot's last frame ran on
 };
 
 struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // tile kernels (coarse + fine); "the" context stream
-    // frame N: binning on bin_streams[N % nb], coarse on coarse_streams[N % nc], fine on
-    // fine_streams[N % nf]; stream == fine_streams[0]
-    std::vector<hipStream_t> bin_streams, coarse_streams, fine_streams;
+    std::vector<hipStream_t> streams;  // frame N runs on streams[N % n]; stream == streams[0]
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
 
@@ -218,11 +217,9 @@ uint32_t BandRows(const pm_ctx *c) { return c->row1 - c->row0; }
 size_t BandTiles(const pm_ctx *c) { return std::max<size_t>(static_cast<size_t>(BandRows(c)) * c->tiles_x, 1); }
 
 int SyncAll(pm_ctx *c) {
-    for (hipStream_t q : c->bin_streams) PM_TRY(hipStreamSynchronize(q));
-    for (hipStream_t q : c->coarse_streams) PM_TRY(hipStreamSynchronize(q));
-    for (hipStream_t q : c->fine_streams) PM_TRY(hipStreamSynchronize(q));
+    for (hipStream_t q : c->streams) PM_TRY(hipStreamSynchronize(q));
     for (auto &s : c->slot)
-        if (s.in_flight && s.tile_stream && s.tile_stream != c->stream) PM_TRY(hipStreamSynchronize(s.tile_stream));
+        if (s.in_flight && s.frame_stream) PM_TRY(hipStreamSynchronize(s.frame_stream));  // (a caller's stream)
     return PM_OK;
 }
 
@@ -503,20 +500,20 @@ uint32_t FineGrid(const pm_ctx *c) {
     return std::max(1u, std::min(tiles, static_cast<uint32_t>(c->n_cus) * kFineWgPerCu));
 }
 
-void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t tile_stream) {
+void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t frame_stream) {
     FrameSlot *s = &c->slot[si];
     s->in_flight = true;
     s->params = p;
-    s->tile_stream = tile_stream;
+    s->frame_stream = frame_stream;
     s->parity ^= 1u;
     c->last_slot = si;
     c->frame += 1;
 }
 
-// One frame.  user_stream == nullptr: pipelined over the context's streams; otherwise all
-// kernels run back to back on the caller's stream.  tev (timing passes): eight events
-// {begin, end} x {bin, clear, coarse, fine} carried by the dispatches themselves, so that a
-// timed frame puts exactly the same packets on the queues as an untimed one.
+// One frame: its kernels back to back on one in-order stream -- the context's stream
+// frame % n, or the caller's.  tev (timing passes): eight events {begin, end} x {bin, clear,
+// coarse, fine} carried by the dispatches themselves, so that a timed frame puts exactly the
+// same packets on the queue as an untimed one.
 int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipEvent_t *tev = nullptr) {
     const int si = static_cast<int>(c->frame % c->slot.size());
     FrameSlot *s = &c->slot[si];
@@ -524,40 +521,25 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     pm::FrameParams p;
     int r = BuildParams(c, s, fb, stride, &p);
     if (r != PM_OK) return r;
-    hipStream_t sb = user_stream ? user_stream : c->bin_streams[c->frame % c->bin_streams.size()];
-    hipStream_t sc = user_stream ? user_stream : c->coarse_streams[c->frame % c->coarse_streams.size()];
-    hipStream_t st = user_stream ? user_stream : c->fine_streams[c->frame % c->fine_streams.size()];
-    hipEvent_t e_bin = s->ev_bin, e_clear = s->ev_clear, e_coarse = s->ev_coarse, e_fine = s->ev_fine;
+    hipStream_t q = user_stream ? user_stream : c->streams[c->frame % c->streams.size()];
     hipEvent_t none[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t *t = tev ? tev : none;
-    if (s->in_flight) {  // previous user of this slot
-        PM_TRY(hipStreamWaitEvent(sb, s->w_fine, 0));
-        PM_TRY(hipStreamWaitEvent(sb, s->w_clear, 0));
-    }
+    // the slot's previous frame (same stream unless the caller's streams are involved or the
+    // slot count differs from the stream count: then the event orders the reuse)
+    if (s->in_flight && s->frame_stream != q) PM_TRY(hipStreamWaitEvent(q, s->ev_done, 0));
     // frames that target the same caller-owned buffer must not overlap each other
-    if (c->last_slot >= 0 && c->last_slot != si && c->slot[c->last_slot].in_flight && c->slot[c->last_slot].params.fb == fb) {
-        PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].w_fine, 0));
-        PM_TRY(hipStreamWaitEvent(sb, c->slot[c->last_slot].w_clear, 0));
+    if (c->last_slot >= 0 && c->last_slot != si) {
+        const FrameSlot &l = c->slot[c->last_slot];
+        if (l.in_flight && l.params.fb == fb && l.frame_stream != q) PM_TRY(hipStreamWaitEvent(q, l.ev_done, 0));
     }
-    pm::LaunchBin(p, BandRows(c) * c->strips_x, sb, t[0], t[1]);
-    if (sb != sc) {
-        PM_TRY(hipEventRecord(e_bin, sb));
-        PM_TRY(hipStreamWaitEvent(sc, e_bin, 0));
-    }
-    // the resolved tiles' pixels: behind binning on its stream, next to the tile kernels
-    pm::LaunchClear(p, BandRows(c) * c->strips_x, sb, t[2], t[3]);
-    PM_TRY(hipEventRecord(e_clear, sb));
-    pm::LaunchCoarse(p, CoarseGrid(c), false, sc, t[4], t[5]);
-    if (sc != st) {
-        PM_TRY(hipEventRecord(e_coarse, sc));
-        PM_TRY(hipStreamWaitEvent(st, e_coarse, 0));
-    }
-    pm::LaunchFine(p, FineGrid(c), st, t[6], t[7]);
+    const uint32_t n_striprows = BandRows(c) * c->strips_x;
+    pm::LaunchBin(p, n_striprows, q, t[0], t[1]);
+    pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // the resolved tiles' pixels (needs tile_state)
+    pm::LaunchCoarse(p, CoarseGrid(c), false, q, t[4], t[5]);
+    pm::LaunchFine(p, FineGrid(c), q, t[6], t[7]);
     PM_TRY(hipGetLastError());
-    PM_TRY(hipEventRecord(e_fine, st));
-    s->w_fine = e_fine;
-    s->w_clear = e_clear;
-    Submitted(c, si, p, st);
+    PM_TRY(hipEventRecord(s->ev_done, q));
+    Submitted(c, si, p, q);
     return PM_OK;
 }
 
@@ -701,24 +683,19 @@ pm_ctx *pm_create(int device, int *err) {
     };
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(e, "hipSetDevice");
-    // Depth of the frame pipeline (see the top of this file); tunable for experiments.
-    const int nb = EnvInt("PM_BIN_STREAMS", kDefaultBinStreams, 1, kMaxStreams);
-    const int nc = EnvInt("PM_COARSE_STREAMS", kDefaultCoarseStreams, 1, kMaxStreams);
-    const int nf = EnvInt("PM_FINE_STREAMS", kDefaultFineStreams, 1, kMaxStreams);
-    c->slot.resize(static_cast<size_t>(EnvInt("PM_SLOTS", nb + nc + nf + 1, 2, kMaxSlots)));  // measured: 5 beats 4 and 6 by 5 %
-    for (int i = 0; i < nb + nc + nf; ++i) {
+    // Frames in flight (see the top of this file); tunable for experiments.
+    const int n_streams = EnvInt("PM_FRAME_STREAMS", kDefaultFrameStreams, 1, kMaxSlots);
+    c->slot.resize(static_cast<size_t>(EnvInt("PM_SLOTS", n_streams, 1, kMaxSlots)));
+    for (int i = 0; i < n_streams; ++i) {
         hipStream_t q = nullptr;
         if ((e = hipStreamCreateWithFlags(&q, hipStreamNonBlocking)) != hipSuccess) return fail(e, "hipStreamCreate");
-        (i < nb ? c->bin_streams : i < nb + nc ? c->coarse_streams : c->fine_streams).push_back(q);
+        c->streams.push_back(q);
     }
-    c->stream = c->fine_streams[0];
+    c->stream = c->streams[0];
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
     for (auto &s : c->slot) {
-        if ((e = hipEventCreateWithFlags(&s.ev_bin, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-        if ((e = hipEventCreateWithFlags(&s.ev_clear, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-        if ((e = hipEventCreateWithFlags(&s.ev_coarse, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
-        if ((e = hipEventCreateWithFlags(&s.ev_fine, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
+        if ((e = hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipMalloc(&s.d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
         if ((e = hipMemset(s.d_ctr, 0, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMemset(counters)");
     }
@@ -757,10 +734,7 @@ void pm_destroy(pm_ctx *c) {
         if (s.d_row_bbox) (void)hipFree(s.d_row_bbox);
         if (s.d_row_item) (void)hipFree(s.d_row_item);
         if (s.d_ctr) (void)hipFree(s.d_ctr);
-        if (s.ev_bin) (void)hipEventDestroy(s.ev_bin);
-        if (s.ev_clear) (void)hipEventDestroy(s.ev_clear);
-        if (s.ev_coarse) (void)hipEventDestroy(s.ev_coarse);
-        if (s.ev_fine) (void)hipEventDestroy(s.ev_fine);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
     if (c->d_sr_base) (void)hipFree(c->d_sr_base);
     if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
@@ -775,9 +749,7 @@ void pm_destroy(pm_ctx *c) {
     if (c->d_lut_lin2srgb) (void)hipFree(c->d_lut_lin2srgb);
     for (auto &ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
-    for (hipStream_t q : c->bin_streams) (void)hipStreamDestroy(q);
-    for (hipStream_t q : c->coarse_streams) (void)hipStreamDestroy(q);
-    for (hipStream_t q : c->fine_streams) (void)hipStreamDestroy(q);
+    for (hipStream_t q : c->streams) (void)hipStreamDestroy(q);
     delete c;
 }
 
@@ -905,10 +877,11 @@ int pm_sync(pm_ctx *c) {
             t.ptcl_cap = static_cast<uint32_t>(want);
         }
         const pm::FrameParams lp = s->params;
-        hipStream_t ts = s->tile_stream;
+        hipStream_t ts = s->frame_stream;
         bool own_fb = false;
         for (auto &t : c->slot) own_fb = own_fb || (lp.fb == t.d_fb);
-        r = Enqueue(c, own_fb ? nullptr : lp.fb, lp.fb_stride, (own_fb || ts == c->stream) ? nullptr : ts);
+        const bool ours = std::find(c->streams.begin(), c->streams.end(), ts) != c->streams.end();
+        r = Enqueue(c, own_fb ? nullptr : lp.fb, lp.fb_stride, (own_fb || ours) ? nullptr : ts);
         if (r != PM_OK) return r;
     }
     SetError("command-list arena overflow (frame needs more than 2^31 commands)");
@@ -956,8 +929,7 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             if ((r = Enqueue(c, nullptr, c->fb_stride, nullptr)) != PM_OK) return r;
         for (auto &s : c->slot)  // join: the end event follows the last frame of every stream
             if (s.in_flight) {
-                PM_TRY(hipStreamWaitEvent(c->stream, s.w_fine, 0));
-                PM_TRY(hipStreamWaitEvent(c->stream, s.w_clear, 0));
+                PM_TRY(hipStreamWaitEvent(c->stream, s.ev_done, 0));
             }
         PM_TRY(hipEventRecord(c->ev[1], c->stream));
         PM_TRY(hipEventSynchronize(c->ev[1]));
@@ -977,10 +949,7 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream, c->ev[2], c->ev[3]);
             pm::LaunchFine(p, FineGrid(c), c->stream, c->ev[4], c->ev[5]);
             pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream, c->ev[6], c->ev[7]);
-            PM_TRY(hipEventRecord(s->ev_fine, c->stream));
-            PM_TRY(hipEventRecord(s->ev_clear, c->stream));
-            s->w_fine = s->ev_fine;
-            s->w_clear = s->ev_clear;
+            PM_TRY(hipEventRecord(s->ev_done, c->stream));
             PM_TRY(hipStreamSynchronize(c->stream));
             Submitted(c, si, p, c->stream);
             float t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -1017,8 +986,7 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
     for (int i = 0; i < iters && r == PM_OK; ++i) r = Enqueue(c, nullptr, c->fb_stride, nullptr, &tev[static_cast<size_t>(i) * 8]);
     if (r == PM_OK) {
         for (auto &s : c->slot) {
-            if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.w_fine, 0);
-            if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.w_clear, 0);
+            if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.ev_done, 0);
         }
         if (e == hipSuccess) e = hipEventRecord(c->ev[1], c->stream);
         if (e == hipSuccess) e = hipEventSynchronize(c->ev[1]);
@@ -1170,10 +1138,7 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
         pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
         pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
         pm::LaunchFine(p, FineGrid(c), c->stream);
-        if (e == hipSuccess) e = hipEventRecord(s->ev_fine, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(s->ev_clear, c->stream);
-        s->w_fine = s->ev_fine;
-        s->w_clear = s->ev_clear;
+        if (e == hipSuccess) e = hipEventRecord(s->ev_done, c->stream);
         p.dbg_bin = nullptr;
         Submitted(c, si, p, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
