@@ -5,12 +5,12 @@ fraction of the dominant kernel and the CPU oracle timed beside it.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame of the hot path -- pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel
-(tileKernel + renderKernel + composite of the reference) -- over the scene already
+A "step" is one frame of the hot path -- pm_bin_kernel, pm_clear_kernel, pm_coarse_kernel,
+pm_fine_kernel (tileKernel + renderKernel + composite of the reference) -- over the scene already
 resident in HBM (flatten/encode happens once per scene, like the reference encodes once
 per resize, PietRenderer.m:145).  Frames are submitted back to back without waiting,
-as the reference commits command buffers (PietRenderer.m:102): consecutive frames
-overlap in the frame pipeline, so `value` is frames completed per second x pixels;
+as the reference commits command buffers (PietRenderer.m:102): up to four frames are in
+flight on four in-order streams, so `value` is frames completed per second x pixels;
 the latency of one frame alone is reported next to it (roofline.frame_latency_ms).
 
 N = 1 : one 3840x2160 Tiger frame per step.
@@ -191,6 +191,7 @@ def main() -> int:
     tm = r.time_frames(max(10, min(args.steps, 2000)), pipelined=True)
     alone = r.time_frames(20)
     lat = r.frame_latency(100)
+    n_overlapped, n_serial = args.warmup + args.steps + tm["iters"], alone["iters"] + lat["iters"]
     st = r.stats()
     band_px = wl.width * rows
     total_px = wl.width * wl.height
@@ -233,6 +234,10 @@ def main() -> int:
                 "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(dom_ms, 5),
                 "kernels_ms": {k: round(v, 5) for k, v in kernels.items()},
                 "kernels_alone_ms": {k: round(v, 5) for k, v in alone_ms.items()},
+                # what `rocprofv3 --kernel-trace --stats` of this command averages per kernel: the
+                # overlapping launches (warm-up + timed steps + the timed batch) at the in-flight
+                # duration, the serialized ones (alone pass + latency pass) at the alone duration
+                "trace_average_ms": {k: round((n_overlapped * kernels[k] + n_serial * alone_ms[k]) / (n_overlapped + n_serial), 5) for k in kernels},
                 "alone_frac": round(b_alg / (max(alone_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "frame_latency_ms": round(latency_ms, 5), "frame_latency_min_ms": round(lat["min_ms"], 5),
                 "frame_latency_frac": round(b_alg / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
