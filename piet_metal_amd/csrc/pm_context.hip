@@ -168,6 +168,7 @@ struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // tile kernels (coarse + fine); "the" context stream
     std::vector<hipStream_t> streams;  // frame N runs on streams[N % n]; stream == streams[0]
+    uint32_t coarse_wg_per_cu = 6, fine_wg_per_cu = 4;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
 
@@ -487,17 +488,17 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
 }
 
 // Persistent grids: workgroups of 4 waves, one wave per tile (or per part of a tile).
-constexpr uint32_t kCoarseWgPerCu = 6;  // pm_coarse_kernel: latency-bound
-constexpr uint32_t kFineWgPerCu = 4;    // pm_fine_kernel: VALU-bound interpreter
+// (per CU: 6 workgroups for pm_coarse_kernel, 4 for pm_fine_kernel by default -- with four frames in
+//  flight anything from 2 to 8 measures within 2 %)
 
 uint32_t CoarseGrid(const pm_ctx *c) {
     const uint32_t tiles = static_cast<uint32_t>(BandTiles(c));
-    return std::max(1u, std::min((tiles + 3u) / 4u, static_cast<uint32_t>(c->n_cus) * kCoarseWgPerCu));
+    return std::max(1u, std::min((tiles + 3u) / 4u, static_cast<uint32_t>(c->n_cus) * c->coarse_wg_per_cu));
 }
 
 uint32_t FineGrid(const pm_ctx *c) {
     const uint32_t tiles = static_cast<uint32_t>(BandTiles(c));
-    return std::max(1u, std::min(tiles, static_cast<uint32_t>(c->n_cus) * kFineWgPerCu));
+    return std::max(1u, std::min(tiles, static_cast<uint32_t>(c->n_cus) * c->fine_wg_per_cu));
 }
 
 void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t frame_stream) {
@@ -692,6 +693,8 @@ pm_ctx *pm_create(int device, int *err) {
         c->streams.push_back(q);
     }
     c->stream = c->streams[0];
+    c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 6, 1, 16));
+    c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 4, 1, 16));
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
     for (auto &s : c->slot) {
