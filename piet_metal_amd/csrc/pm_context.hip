@@ -191,7 +191,8 @@ struct pm_ctx {
     size_t fb_bytes = 0;
 
     // binning state shared by the slots
-    uint32_t *d_sr_base = nullptr;  // private arena region of every strip row
+    uint4 *d_sr_desc = nullptr;     // strip rows some item reaches: {strip row, arena region begin, end, 0}
+    uint32_t n_sr_active = 0;
     uint32_t sr_empty_dwords = 0;   // size of a region no item reaches
     uint2 *d_band_bbox = nullptr;   // items that reach the band (bbox, scene index), paint order
     uint32_t *d_band_item = nullptr;
@@ -358,10 +359,22 @@ int EnsureArena(pm_ctx *c) {
         }
     }
     c->arena_cap = std::max<uint32_t>(c->arena_cap, static_cast<uint32_t>(total));
-    if (c->d_sr_base) (void)hipFree(c->d_sr_base);
-    c->d_sr_base = nullptr;
-    PM_TRY(hipMalloc(&c->d_sr_base, base.size() * sizeof(uint32_t)));
-    PM_TRY(hipMemcpy(c->d_sr_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // The strip rows some item's bbox reaches get a workgroup of pm_bin_kernel each; the others are
+    // background for as long as this scene and viewport last: their tile_state is set to white
+    // once, here.  (An empty list still launches one workgroup: it resets the frame counters.)
+    std::vector<uint4> desc;
+    for (size_t i = 0; i < need.size(); ++i)
+        if (((need[i] + 3u) & ~3ull) != c->sr_empty_dwords) desc.push_back(make_uint4(static_cast<uint32_t>(i), base[i], base[i + 1], 0u));
+    if (desc.empty()) desc.push_back(make_uint4(0u, base[0], need.empty() ? base[0] : base[1], 0u));
+    c->n_sr_active = static_cast<uint32_t>(desc.size());
+    if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
+    c->d_sr_desc = nullptr;
+    PM_TRY(hipMalloc(&c->d_sr_desc, desc.size() * sizeof(uint4)));
+    PM_TRY(hipMemcpy(c->d_sr_desc, desc.data(), desc.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    for (auto &s : c->slot) {
+        PM_TRY(hipMemset(s.d_tile_state, 0xff, BandTiles(c) * sizeof(uint32_t)));
+        PM_TRY(hipMemset(s.d_striprow, 0, std::max<size_t>(need.size(), 1) * sizeof(uint32_t)));
+    }
     // the items whose bbox reaches the band (rows: bw >= y0 && by < y1, PietRender.metal:198/:214)
     {
         const uint8_t *meta = c->item_meta.data();
@@ -460,7 +473,8 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->fb_vec16 = ((reinterpret_cast<uintptr_t>(fb) & 15u) == 0 && (stride & 15u) == 0) ? 1u : 0u;
     p->arena = s->d_arena;
     p->arena_cap = c->arena_cap;
-    p->sr_base = c->d_sr_base;
+    p->sr_desc = c->d_sr_desc;
+    p->n_sr_active = c->n_sr_active;
     p->sr_empty_dwords = c->sr_empty_dwords;
     p->striprow_head = s->d_striprow;
     p->queue = s->d_queue;
@@ -534,7 +548,7 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
         if (l.in_flight && l.params.fb == fb && l.frame_stream != q) PM_TRY(hipStreamWaitEvent(q, l.ev_done, 0));
     }
     const uint32_t n_striprows = BandRows(c) * c->strips_x;
-    pm::LaunchBin(p, n_striprows, q, t[0], t[1]);
+    pm::LaunchBin(p, q, t[0], t[1]);
     pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // the resolved tiles' pixels (needs tile_state)
     pm::LaunchCoarse(p, CoarseGrid(c), false, q, t[4], t[5]);
     pm::LaunchFine(p, FineGrid(c), q, t[6], t[7]);
@@ -739,7 +753,7 @@ void pm_destroy(pm_ctx *c) {
         if (s.d_ctr) (void)hipFree(s.d_ctr);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
-    if (c->d_sr_base) (void)hipFree(c->d_sr_base);
+    if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
     if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
     if (c->d_band_item) (void)hipFree(c->d_band_item);
     if (c->d_row_base) (void)hipFree(c->d_row_base);
@@ -948,7 +962,7 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             pm::FrameParams p;
             if ((r = BuildParams(c, s, s->d_fb, c->fb_stride, &p)) != PM_OK) return r;
             // each dispatch carries its own begin / end events: pure kernel durations
-            pm::LaunchBin(p, BandRows(c) * c->strips_x, c->stream, c->ev[0], c->ev[1]);
+            pm::LaunchBin(p, c->stream, c->ev[0], c->ev[1]);
             pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream, c->ev[2], c->ev[3]);
             pm::LaunchFine(p, FineGrid(c), c->stream, c->ev[4], c->ev[5]);
             pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream, c->ev[6], c->ev[7]);
@@ -1137,7 +1151,7 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
     if (r == PM_OK) {
         p.dbg_bin = d;
         hipError_t e = hipSuccess;
-        pm::LaunchBin(p, BandRows(c) * c->strips_x, c->stream);
+        pm::LaunchBin(p, c->stream);
         pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
         pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
         pm::LaunchFine(p, FineGrid(c), c->stream);

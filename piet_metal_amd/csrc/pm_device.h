@@ -82,7 +82,8 @@ struct FrameParams {
     uint32_t fb_vec16;    // 1 if fb and stride are 16-byte aligned
     uint32_t *arena;
     uint32_t arena_cap;   // dwords
-    const uint32_t *sr_base;  // [n_striprows + 1] private arena region of every strip row
+    const uint4 *sr_desc;     // [n_sr_active] {strip row, its private arena region begin, end, 0}
+    uint32_t n_sr_active;     // strip rows some item reaches = workgroups of pm_bin_kernel
     uint32_t sr_empty_dwords; // size of a region no item's bbox reaches
     uint32_t *striprow_head;
     uint4 *queue;             // three class queues of {tile, first command slot, first record, commands}
@@ -121,7 +122,7 @@ struct FrameParams {
 void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks, float4 *chunk_bbox,
                  hipStream_t stream);
 // (t0, t1): optional timing events carried by the dispatch itself
-void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void LaunchClear(const FrameParams &p, uint32_t n_striprows, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream, hipEvent_t t0 = nullptr,
                   hipEvent_t t1 = nullptr);

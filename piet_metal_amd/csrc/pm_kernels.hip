@@ -366,8 +366,13 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = LaneId();
     const uint32_t wave = tid >> 6;
-    const uint32_t strip = blockIdx.x % PM_PU(strips_x);
-    const uint32_t row_rel = blockIdx.x / PM_PU(strips_x);
+    // Workgroup -> strip row: the host lists the strip rows some item's bbox reaches (it sized
+    // their arena regions from the same predicate); the others are background for the whole
+    // life of the scene and never get a workgroup.  One 16-byte load: {strip row, region, end}.
+    const uint4 srd = PM_PP(sr_desc)[blockIdx.x];
+    const uint32_t sr = __builtin_amdgcn_readfirstlane(srd.x);
+    const uint32_t strip = sr % PM_PU(strips_x);
+    const uint32_t row_rel = sr / PM_PU(strips_x);
     const uint32_t ty = PM_PU(row0) + row_rel;
     const int sx0 = static_cast<int>(strip * kGroupW);
     const int y0 = static_cast<int>(ty * kTileH);
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     //        4 last record finalised, 5 queues done, 6 chunks tested (count), 7 exit
     auto stamp = [&](uint32_t k) {
         if (kProfile) {
-            if (tid == 0) PM_PP(dbg_bin)[12ull * blockIdx.x + k] = wall_clock64();
+            if (tid == 0) PM_PP(dbg_bin)[12ull * sr + k] = wall_clock64();
         }
     };
     bool prof_first = true;
@@ -413,8 +418,9 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     // This strip row owns arena[sr_base[b] .. sr_base[b+1]): the host sized it for the worst
     // case (every chunk of every candidate survives), so records are bump-allocated without
     // atomics and without a counting pass.
-    uint32_t cursor = __builtin_amdgcn_readfirstlane(PM_PP(sr_base)[blockIdx.x]);
-    const uint32_t region_end = __builtin_amdgcn_readfirstlane(PM_PP(sr_base)[blockIdx.x + 1]);
+    uint32_t cursor = __builtin_amdgcn_readfirstlane(srd.y);
+    const uint32_t region_begin = cursor;
+    const uint32_t region_end = __builtin_amdgcn_readfirstlane(srd.z);
     uint32_t head = 0;       // first record of this strip row
     uint32_t prev_rec = 0;   // record whose `next` field is still open
 
@@ -756,7 +762,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             }
             if (kProfile && r0 == 0) {
                 stamp(11);
-                if (tid == 0) PM_PP(dbg_bin)[12ull * blockIdx.x + 6] = n_el;  // (slot 6: elements of round 0)
+                if (tid == 0) PM_PP(dbg_bin)[12ull * sr + 6] = n_el;  // (slot 6: elements of round 0)
             }
             sbase += ns;
             __syncthreads();  // s_surv is rewritten by the next round
@@ -853,8 +859,8 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         ncand = nb;
     }
     if (tid == 0) {
-        PM_PP(striprow_head)[blockIdx.x] = head;
-        atomicAdd(&PM_PP(ctr_cur)->arena_top, cursor - PM_PP(sr_base)[blockIdx.x]);  // dwords used (stats only)
+        PM_PP(striprow_head)[sr] = head;
+        atomicAdd(&PM_PP(ctr_cur)->arena_top, cursor - region_begin);  // dwords used (stats only)
     }
 
     // ---- queue the tiles with something to draw, clear the others ------------------------
@@ -1824,7 +1830,8 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_b
             hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                       \
     } while (0)
 
-void LaunchBin(const FrameParams &p, uint32_t n_striprows, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
+void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
+    const uint32_t n_striprows = p.n_sr_active;
     if (p.use_row_lists) hipLaunchKernelGGL(pm_rowcull_kernel, dim3(p.row1 - p.row0), dim3(kBinThreads), 0, stream, p);
     if (p.dbg_bin)
         PM_LAUNCH(pm_bin_kernel<true>, dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);

@@ -10,6 +10,7 @@ r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
 for _ in range(3): r.render()
 r.sync()
 t = r.time_bins().astype(np.int64)
+t = t[t[:, 0] > 0]  # strip rows no item reaches never get a workgroup
 us = 1e-2
 t0 = t[:, 0].min()
 dur = (t[:, 7] - t[:, 0]) * us
