@@ -359,7 +359,6 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     __shared__ uint32_t s_last_kept[kStripTiles];
     __shared__ uint32_t s_last_solid[kStripTiles];
     __shared__ uint32_t s_solid_rgba[kStripTiles];
-    __shared__ uint32_t s_qbase[5];
     __shared__ uint32_t s_crgba[kThreads], s_caux0[kThreads], s_caux1[kThreads];  // candidate colour / payload
     __shared__ uint32_t s_lut[256];  // sRGB->linear half bits | a/255 half bits << 16
 
@@ -863,76 +862,62 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         atomicAdd(&PM_PP(ctr_cur)->arena_top, cursor - region_begin);  // dwords used (stats only)
     }
 
-    // ---- queue the tiles with something to draw, clear the others ------------------------
-    __syncthreads();
+    // ---- queue the tiles with something to draw, mark the others --------------------------
+    // One wave is enough: lane t owns tile t of the strip row; the class masks are ballots, the
+    // command-list offsets a wave scan, and the atomics' results travel by v_readlane.
+    __syncthreads();  // s_est, s_last_* of the last record are in
+    if (wave != 0) return;
     const uint32_t tiles_here = min(kStripTiles, PM_PU(tiles_x) - strip * kStripTiles);
-    const uint32_t valid = (1u << tiles_here) - 1u;
-    uint32_t vheavy = 0, heavy = 0, light = 0, solid = 0;
-#pragma unroll
-    for (uint32_t t = 0; t < kStripTiles; ++t) {
-        const uint32_t est = s_est[t];
-        if (est != 0 && s_last_kept[t] == s_last_solid[t]) solid |= 1u << t;  // {Solid(opaque)} -> Bail
-        else if (est > kVeryHeavyStream) vheavy |= 1u << t;
-        else if (est > kHeavyStream) heavy |= 1u << t;
-        else if (est != 0) light |= 1u << t;
-    }
-    vheavy &= valid;
-    heavy &= valid;
-    light &= valid;
+    const bool tile_lane = lane < tiles_here;
+    const uint32_t est = tile_lane ? s_est[lane] : 0u;
+    // {Solid(opaque)} -> Bail: the tile is one opaque colour (TileEncoder::end, :144-151)
+    const bool is_solid = est != 0 && s_last_kept[lane & (kStripTiles - 1u)] == s_last_solid[lane & (kStripTiles - 1u)];
+    const bool is_queued = est != 0 && !is_solid;
+    const uint32_t vheavy = static_cast<uint32_t>(__ballot(is_queued && est > kVeryHeavyStream));
+    const uint32_t heavy = static_cast<uint32_t>(__ballot(is_queued && est > kHeavyStream && est <= kVeryHeavyStream));
+    const uint32_t light = static_cast<uint32_t>(__ballot(is_queued && est <= kHeavyStream));
     const uint32_t queued = vheavy | heavy | light;
-    // command-list slots of the queued tiles (an element emits at most 2 commands + its item's
-    // closing command, plus End) and the three queue positions: four atomics in flight at once.
-    // vmcnt is per wave and counts loads and stores alike: wave 0 waits for its atomics BEFORE
-    // it issues any clearing store, while waves 1-3 clear at once.
-    uint32_t qres = 0, qtotal = 0;
-    if (tid == 3 && queued) {
-#pragma unroll
-        for (uint32_t t = 0; t < kStripTiles; ++t)
-            if ((queued >> t) & 1u) qtotal += 3u * s_est[t] + 1u;
-        qres = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, qtotal);
-    }
-    if (tid == 0 && vheavy) qres = atomicAdd(&PM_PP(ctr_cur)->vheavy_count, static_cast<uint32_t>(__popc(vheavy)));
-    if (tid == 1 && heavy) qres = atomicAdd(&PM_PP(ctr_cur)->heavy_count, static_cast<uint32_t>(__popc(heavy)));
-    if (tid == 2 && light) qres = atomicAdd(&PM_PP(ctr_cur)->light_count, static_cast<uint32_t>(__popc(light)));
+    // command-list slots of a queued tile: an element emits at most 2 commands + its item's
+    // closing command, plus End
+    const uint32_t slots = is_queued ? 3u * est + 1u : 0u;
+    const uint32_t slots_incl = WaveInclusiveScan(slots);
+    const uint32_t qtotal = __shfl(slots_incl, 63, 64);
+    // list space and the three queue positions: four atomics in flight at once
+    uint32_t qres = 0;
     if (queued) {  // uniform
-        if (tid < 4) s_qbase[tid] = qres;
-        if (tid == 3) s_qbase[4] = qtotal;
+        if (lane == 3) qres = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, qtotal);
+        if (lane == 0 && vheavy) qres = atomicAdd(&PM_PP(ctr_cur)->vheavy_count, static_cast<uint32_t>(__popc(vheavy)));
+        if (lane == 1 && heavy) qres = atomicAdd(&PM_PP(ctr_cur)->heavy_count, static_cast<uint32_t>(__popc(heavy)));
+        if (lane == 2 && light) qres = atomicAdd(&PM_PP(ctr_cur)->light_count, static_cast<uint32_t>(__popc(light)));
     }
     // tiles with nothing to draw are background: no item touches them, or every touching
     // item lost all its segments in phase 1 (the reference writes Bail/white for them).  Their
     // pixels are written by pm_clear_kernel from tile_state: 25 MB of stores per 4K frame that
     // would otherwise stall these latency-bound workgroups in bursts.
-    const uint32_t clear = ~queued & valid;  // background (white) or one opaque colour
-    if (tid < tiles_here)  // what this kernel decided per tile: 0 = queued, else the tile's colour
-        PM_PP(tile_state)[row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid] =
-            ((clear >> tid) & 1u) ? (((solid >> tid) & 1u) ? s_solid_rgba[tid] : 0xffffffffu) : 0u;
-    __syncthreads();
-    bool fits = true;
-    uint32_t list_slot = 0;
+    const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + lane;
+    if (tile_lane)  // what this kernel decided per tile: 0 = queued, else the tile's colour
+        PM_PP(tile_state)[tile] = is_queued ? 0u : (is_solid ? s_solid_rgba[lane] : 0xffffffffu);
     if (queued) {
-        const uint32_t base = s_qbase[3], total = s_qbase[4];
-        fits = base + total <= PM_PU(ptcl_cap) && base + total >= base;
-        if (!fits && tid == 0) PM_PP(ctr_cur)->overflow = 1;  // the host grows the arena and re-renders
-        if (tid < kStripTiles && ((queued >> tid) & 1u)) {
-            uint32_t off = 0;
-            for (uint32_t t = 0; t < tid; ++t)
-                if ((queued >> t) & 1u) off += 3u * s_est[t] + 1u;
-            list_slot = fits ? base + off : 0xffffffffu;  // no room: the tile kernels skip the tile
-            PM_PP(tile_ptcl)[row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid] = list_slot;
+        const uint32_t q_a = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), 0));
+        const uint32_t q_b = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), 1));
+        const uint32_t q_c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), 2));
+        const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), 3));
+        const bool fits = base + qtotal <= PM_PU(ptcl_cap) && base + qtotal >= base;
+        // (on overflow the tiles are still queued but marked "no list": the tile kernels skip
+        //  them, the frame has holes, and pm_sync re-renders it with a larger arena)
+        if (!fits && lane == 0) PM_PP(ctr_cur)->overflow = 1;
+        if (is_queued) {
+            const uint32_t list_slot = fits ? base + (slots_incl - slots) : 0xffffffffu;
+            PM_PP(tile_ptcl)[tile] = list_slot;
+            // three queues, by expected list length: the fine kernel starts with the longest.  A
+            // queue entry is everything the tile kernels need to start: {tile, first command
+            // slot, first binning record of the strip row, commands written (pm_coarse_kernel)}
+            const uint4 entry = make_uint4(tile, list_slot, head, 0u);
+            const uint32_t below = (1u << lane) - 1u;
+            if ((vheavy >> lane) & 1u) PM_PP(queue)[q_a + __popc(vheavy & below)] = entry;
+            if ((heavy >> lane) & 1u) PM_PP(queue)[PM_PU(queue_cap) + q_b + __popc(heavy & below)] = entry;
+            if ((light >> lane) & 1u) PM_PP(queue)[2u * PM_PU(queue_cap) + q_c + __popc(light & below)] = entry;
         }
-    }
-    // (on overflow the tiles are still queued but marked "no list": the tile kernels skip them,
-    //  the frame has holes, and pm_sync re-renders it with a larger arena)
-    if (tid < kStripTiles) {
-        // three queues, by expected list length: the fine kernel starts with the longest
-        const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + tid;
-        const uint32_t below = (1u << tid) - 1u;
-        // a queue entry is everything the tile kernels need to start: {tile, first command slot,
-        // first binning record of the strip row, commands written (filled in by pm_coarse_kernel)}
-        const uint4 entry = make_uint4(tile, list_slot, head, 0u);
-        if ((vheavy >> tid) & 1u) PM_PP(queue)[s_qbase[0] + __popc(vheavy & below)] = entry;
-        if ((heavy >> tid) & 1u) PM_PP(queue)[PM_PU(queue_cap) + s_qbase[1] + __popc(heavy & below)] = entry;
-        if ((light >> tid) & 1u) PM_PP(queue)[2u * PM_PU(queue_cap) + s_qbase[2] + __popc(light & below)] = entry;
     }
     stamp(5);  // queues + list slots done
     (void)prof_chunks;

@@ -30,7 +30,7 @@ print("queues         :", ph(4, 5, m))
 print("clear+exit     :", ph(5, 7, m))
 e = ~has
 d = (t[e, 7] - t[e, 0]) * us
-print(f"WGs without candidates: {e.sum()}, duration mean {d.mean():.2f} max {d.max():.2f}")
+if e.any(): print(f"WGs without candidates: {e.sum()}, duration mean {d.mean():.2f} max {d.max():.2f}")
 ch = t[:, 6]
 worst = np.argsort(-dur)[:6]
 for i in worst: print(f"  WG {i} chunks {ch[i]} dur {dur[i]:.1f} start {(t[i,0]-t0)*us:.1f} phases {[(t[i,k+1]-t[i,k])*us if t[i,k+1]>0 and t[i,k]>0 else None for k in (0,1,2,3,4)]}")
