@@ -168,6 +168,7 @@ struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // tile kernels (coarse + fine); "the" context stream
     std::vector<hipStream_t> streams;  // frame N runs on streams[N % n]; stream == streams[0]
+    uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
     uint32_t coarse_wg_per_cu = 6, fine_wg_per_cu = 4;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
@@ -489,6 +490,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->band_bbox = c->d_band_bbox;
     p->band_item = c->d_band_item;
     p->n_band_items = c->n_band_items;
+    p->split_mode = c->split_mode;
     p->use_row_lists = c->use_row_lists ? 1u : 0u;
     p->row_base = c->d_row_base;
     p->row_bbox = s->d_row_bbox;
@@ -708,6 +710,7 @@ pm_ctx *pm_create(int device, int *err) {
     }
     c->stream = c->streams[0];
     c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 6, 1, 16));
+    c->split_mode = static_cast<uint32_t>(EnvInt("PM_FINE_SPLIT", 1, 0, 2));
     c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 4, 1, 16));
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -1174,9 +1177,10 @@ int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_sl
     FrameSlot *s = &c->slot[c->last_slot];
     pm::Counters k;
     PM_TRY(hipMemcpy(&k, s->params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
-    const bool dense = k.vheavy_count + k.heavy_count >= FineGrid(c) * 4u;  // as pm_fine_kernel decides
+    // as pm_fine_kernel decides
+    const bool dense = k.vheavy_count + k.heavy_count >= FineGrid(c) * 4u || c->split_mode == 0;
     const size_t slots = dense ? static_cast<size_t>(k.vheavy_count) + k.heavy_count + k.light_count
-                               : 16ull * k.vheavy_count + 4ull * k.heavy_count + k.light_count;
+                               : (c->split_mode == 1 ? 4ull : 16ull) * k.vheavy_count + 4ull * k.heavy_count + k.light_count;
     if (n_slots) *n_slots = slots;
     if (slots > max_slots) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;

@@ -98,6 +98,7 @@ struct FrameParams {
     const uint2 *band_bbox;        // [n_band_items] bboxes of the items that reach this band, paint order
     const uint32_t *band_item;     // [n_band_items] their scene indices
     uint32_t n_band_items;
+    uint32_t split_mode;           // fine kernel: 0 = one wave per tile always, 1 = at most 4 waves, 2 = 1/4/16 by class
     // large scenes: per-tile-row item lists written each frame by pm_rowcull_kernel
     uint32_t use_row_lists;
     const uint32_t *row_base;      // [band rows + 1] list offsets (host-computed sizes)

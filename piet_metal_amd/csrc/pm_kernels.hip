@@ -1671,12 +1671,13 @@ __global__ __launch_bounds__(kThreads) void pm_fine_kernel(FrameParams P) {
     const uint32_t n_a = P.ctr_cur->vheavy_count, n_b = P.ctr_cur->heavy_count, n_c = P.ctr_cur->light_count;
     const uint32_t wave_global = blockIdx.x * kWaves + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * kWaves;
-    // slots: 16 per very heavy tile (one pixel row per wave), 4 per heavy tile, 1 per light tile.
+    // slots: 4 per tile with a long list (16 for the very long ones in split mode 2), 1 per light tile.
     // Splitting a tile buys latency when few long lists set the span of the launch; with more
     // long lists than waves it only costs work (the y-only math is no longer shared by 4
     // pixels), so dense frames render every tile with one wave.
-    const bool dense = n_a + n_b >= n_waves;
-    const uint32_t sh_a = dense ? 0u : 4u, sh_b = dense ? 0u : 2u;
+    const bool dense = n_a + n_b >= n_waves || P.split_mode == 0;
+    const bool split4_only = P.split_mode == 1;  // (default) never 16 waves per tile: measured no faster than 4
+    const uint32_t sh_a = dense ? 0u : (split4_only ? 2u : 4u), sh_b = dense ? 0u : 2u;
     const uint32_t s_a = n_a << sh_a, s_b = n_b << sh_b;
     const uint32_t n_slots = s_a + s_b + n_c;
     const uint8_t *lut = P.lut_lin2srgb;
