@@ -68,14 +68,23 @@ __device__ __forceinline__ uint32_t RankBelow(uint64_t mask) {
                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
 }
 
+// Inclusive prefix sum over the 64 lanes in six DPP adds (no LDS crossbar): Hillis-Steele inside
+// each row of 16 lanes (row_shr 1, 2, 4, 8), then the row totals ripple with row_bcast15 /
+// row_bcast31 (the sequence LLVM's atomic optimizer emits for gfx9).
 __device__ __forceinline__ uint32_t WaveInclusiveScan(uint32_t v) {
-    const uint32_t lane = LaneId();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= static_cast<uint32_t>(d)) v += t;
-    }
-    return v;
+    int x = static_cast<int>(v);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
+    return static_cast<uint32_t>(x);
+}
+
+// Value of lane 63 (the total after an inclusive scan) as a wave-uniform scalar.
+__device__ __forceinline__ uint32_t WaveLast(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
 }
 
 // Compiler-level ordering of LDS traffic inside one wave (the LDS itself executes a
@@ -881,7 +890,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     // closing command, plus End
     const uint32_t slots = is_queued ? 3u * est + 1u : 0u;
     const uint32_t slots_incl = WaveInclusiveScan(slots);
-    const uint32_t qtotal = __shfl(slots_incl, 63, 64);
+    const uint32_t qtotal = WaveLast(slots_incl);
     // list space and the three queue positions: four atomics in flight at once
     uint32_t qres = 0;
     if (queued) {  // uniform
@@ -1315,7 +1324,7 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
                 if (4u * lane + k < ncand && ((mw[k] >> (16 + tbit)) & 1u)) hbits |= 1u << k;
             const uint32_t hcount = __popc(hbits);
             const uint32_t hincl = WaveInclusiveScan(hcount);
-            const uint32_t nhit = __shfl(hincl, 63, 64);
+            const uint32_t nhit = WaveLast(hincl);
             if (nhit == 0) {
                 rec = next;
                 continue;
@@ -1359,8 +1368,8 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
                         L.hoff[lane] = incl - v;
                         L.hwoff[lane] = rel_done + rincl - r;  // first relevant segment of the candidate
                     }
-                    stream_len = __shfl(incl, 63, 64);
-                    pass_rel = __shfl(rincl, 63, 64);
+                    stream_len = WaveLast(incl);
+                    pass_rel = WaveLast(rincl);
                     if (lane == 0) L.hoff[nh] = stream_len;
                 }
                 WaveSync();
@@ -1414,7 +1423,7 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
 #pragma unroll
                                 for (uint32_t q = 0; q < 2; ++q)
                                     if ((rb >> q) & 1u) L.ring[(wp++) & (kRing - 1u)] = st_x + i0 + q;
-                                ring_cnt += __shfl(rincl, 63, 64);
+                                ring_cnt += WaveLast(rincl);
                                 scan_pos += 128u;
                             }
                             WaveSync();
