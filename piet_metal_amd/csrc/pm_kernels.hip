@@ -82,6 +82,25 @@ __device__ __forceinline__ uint32_t WaveInclusiveScan(uint32_t v) {
     return static_cast<uint32_t>(x);
 }
 
+// Inclusive prefix maximum (unsigned), same DPP ladder; 0 is the identity.
+__device__ __forceinline__ uint32_t WaveInclusiveMax(uint32_t v) {
+    int x = static_cast<int>(v);
+    auto mx = [](int a, int b) { return static_cast<int>(max(static_cast<uint32_t>(a), static_cast<uint32_t>(b))); };
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
+    return static_cast<uint32_t>(x);
+}
+
+// Value of the highest lane set in a (non-empty, wave-uniform) ballot mask, as a scalar.
+__device__ __forceinline__ uint32_t WaveAtHighest(uint32_t v, uint64_t mask) {
+    const int l = __builtin_amdgcn_readfirstlane(63 - __builtin_clzll(mask));
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), l));
+}
+
 // Value of lane 63 (the total after an inclusive scan) as a wave-uniform scalar.
 __device__ __forceinline__ uint32_t WaveLast(uint32_t v) {
     return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
@@ -1247,6 +1266,7 @@ struct CoarseLds {
     uint32_t hrg[kWaveCands];
     uint32_t hba[kWaveCands];
     uint32_t hoff[kWaveCands + 1];
+    uint32_t own[64];            // stream position of a round -> candidate that starts there
     int backdrop[kWaveCands];
     uint32_t any[kWaveCands];
 };
@@ -1375,8 +1395,21 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
                 WaveSync();
 
                 // ---- stream rounds: phase-2 tests -> ordered commands --------------------------
+                uint32_t own_carry = 0;  // owner of the last element of the previous round
                 for (uint32_t e0 = 0; e0 < stream_len; e0 += 64) {
                     const uint32_t e = e0 + lane;
+                    // Owner of every element without a search: each candidate marks the stream
+                    // position where it starts, a prefix maximum spreads the marks (owners only
+                    // grow along the stream).
+                    L.own[lane] = 0;
+                    WaveSync();
+                    if (lane < nh) {
+                        const uint32_t p = L.hoff[lane] - e0;
+                        if (p < 64u) L.own[p] = lane;
+                    }
+                    WaveSync();
+                    const uint32_t owner = max(WaveInclusiveMax(L.own[lane]), own_carry);
+                    own_carry = WaveLast(owner);
                     uint32_t n_em = 0;   // commands of this stream element (0..2)
                     Cmd c0, c1;
                     c0.tag = 0; c1.tag = 0;
@@ -1384,7 +1417,7 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
                     bool draws = false;  // any of this lane's commands clears solidColor
                     uint32_t c = 0, ctag = 0;
                     if (e < stream_len) {
-                        c = FindOwner(L.hoff, nh, e);
+                        c = owner;
                         const uint32_t k = e - L.hoff[c];
                         is_last = (k + 1 == L.hcnt[c]);
                         ctag = L.htag[c];
@@ -1405,7 +1438,7 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
                         const uint64_t wm = __ballot(wants);
                         if (wm) {
                             const uint32_t my_need = wants ? (L.hwoff[c] + (e - L.hoff[c]) + 1u) : 0u;
-                            const uint32_t need = __shfl(my_need, 63 - __builtin_clzll(wm), 64);
+                            const uint32_t need = WaveAtHighest(my_need, wm);
                             while (ring_cnt < need && scan_pos < n_slots) {
                                 const uint32_t cnt_x = n_slots;
                                 const uint32_t st_x = 0;
@@ -1563,8 +1596,8 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
                     const uint64_t ms = __ballot(opaque_solid);
                     const uint64_t md = __ballot(draws);
                     int last_solid = -1, last_draw = -1;
-                    if (ms) last_solid = __shfl(static_cast<int>(pos + n_em), 63 - __builtin_clzll(ms), 64);
-                    if (md) last_draw = __shfl(static_cast<int>(pos + lane_total) - 1, 63 - __builtin_clzll(md), 64);
+                    if (ms) last_solid = static_cast<int>(WaveAtHighest(pos + n_em, ms));
+                    if (md) last_draw = static_cast<int>(WaveAtHighest(pos + lane_total, md)) - 1;
 
                     uint32_t base;        // list slot of round position 0 (may be "negative")
                     uint32_t first_kept;  // round positions below this are dropped
@@ -1616,7 +1649,7 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
                     }
                     n_pending = base + round_total;
                     list_len += round_total - first_kept;
-                    if (last_solid >= 0) solid_color = __shfl(fin.body[0], 63 - __builtin_clzll(ms), 64);
+                    if (last_solid >= 0) solid_color = WaveAtHighest(fin.body[0], ms);
                     if (last_draw > last_solid) solid_color = 0;  // encodeCircle/Line/Stroke/DrawFill (:81,:90,:99,:124)
                     WaveSync();
                 }
