@@ -99,7 +99,7 @@ def random_ops(seed, n, extent=700.0):
         k = rng.integers(0, 4)
         rgba = int(rng.integers(0, 1 << 32))
         if rng.random() < 0.5:
-            rgba |= 0xFF  # opaque
+            rgba |= 0xFF000000  # opaque (alpha is the top byte, unpack_unorm4x8)
         if k == 0:
             ops.append(("circle", float(rng.uniform(0, extent)), float(rng.uniform(0, extent)), float(rng.uniform(1, 40))))
         elif k == 1:
