@@ -94,8 +94,8 @@ def cpu_baseline(pm, wl_single, seconds_budget: float = 12.0):
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--gather", action="store_true", help="N>1: gather the bands to rank 0 inside every timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default=None, help="rank 0 saves the last gathered frame as .npy (tests)")
