@@ -420,3 +420,25 @@ def test_frame_latency_api(pm, pmo, renderer):
     lat = renderer.frame_latency(20)
     assert 0 < lat["min_ms"] <= lat["median_ms"] < 50
     assert np.array_equal(renderer.read_pixels(), pmo.render(scene, 1024, 768))
+
+
+@pytest.mark.parametrize("streams,slots", [(1, 1), (1, 3), (2, 5), (3, 2)])
+def test_other_pipeline_depths(pm, pmo, monkeypatch, streams, slots):
+    """PM_FRAME_STREAMS / PM_SLOTS other than the default 4 / 4: slot reuse across streams is
+    ordered by events, the pictures do not change."""
+    monkeypatch.setenv("PM_FRAME_STREAMS", str(streams))
+    monkeypatch.setenv("PM_SLOTS", str(slots))
+    r = pm.Renderer(0)
+    try:
+        scene = pmo.scene_cardioid()
+        r.resize(640, 480)
+        r.set_scene_bytes(scene)
+        want = pmo.render(scene, 640, 480)
+        for n in (1, 2, 5, 9):
+            for _ in range(n):
+                r.render()
+            assert np.array_equal(r.read_pixels(), want), n
+        tm = r.time_frames(5, pipelined=True)
+        assert tm["total_ms"] > 0 and tm["fine_ms"] > 0
+    finally:
+        r.close()
