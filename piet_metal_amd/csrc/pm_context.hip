@@ -8,7 +8,7 @@
 //   -drawInMTKView:                      -> pm_render      (PietRenderer.m:59-103)
 //
 // Frames overlap like the reference's command buffers ([commandBuffer commit] never waits,
-// PietRenderer.m:102): frame N runs its four kernels back to back on stream N % 4 and owns
+// PietRenderer.m:102): frame N runs its three kernels back to back on stream N % 4 and owns
 // frame slot N % 4 (arena, queues, command lists, framebuffer), so frames in flight share no
 // mutable state and need no cross-stream events; the in-order queues do the ordering.  At 4K
 // every kernel alone leaves most of the chip idle (its span is set by its longest dependent
@@ -168,6 +168,7 @@ struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // tile kernels (coarse + fine); "the" context stream
     std::vector<hipStream_t> streams;  // frame N runs on streams[N % n]; stream == streams[0]
+    bool fold_clear = true;  // pm_fine_kernel's launch also writes the resolved tiles (no pm_clear_kernel launch)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
     uint32_t coarse_wg_per_cu = 6, fine_wg_per_cu = 4;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -446,6 +447,8 @@ int EnsureArena(pm_ctx *c) {
     return PM_OK;
 }
 
+uint32_t FineGrid(const pm_ctx *c);
+
 int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     if (!c->d_scene || c->scene_bytes < 8) {
         SetError("no scene resident (pm_upload_scene / pm_flatten_and_encode first)");
@@ -491,6 +494,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->band_item = c->d_band_item;
     p->n_band_items = c->n_band_items;
     p->split_mode = c->split_mode;
+    p->fine_grid = FineGrid(c);
     p->use_row_lists = c->use_row_lists ? 1u : 0u;
     p->row_base = c->d_row_base;
     p->row_bbox = s->d_row_bbox;
@@ -551,9 +555,9 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     }
     const uint32_t n_striprows = BandRows(c) * c->strips_x;
     pm::LaunchBin(p, q, t[0], t[1]);
-    pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // the resolved tiles' pixels (needs tile_state)
+    if (!c->fold_clear) pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // the resolved tiles' pixels (needs tile_state)
     pm::LaunchCoarse(p, CoarseGrid(c), false, q, t[4], t[5]);
-    pm::LaunchFine(p, FineGrid(c), q, t[6], t[7]);
+    pm::LaunchFine(p, c->fold_clear ? n_striprows : 0u, q, t[6], t[7]);  // (+ the resolved tiles' pixels)
     PM_TRY(hipGetLastError());
     PM_TRY(hipEventRecord(s->ev_done, q));
     Submitted(c, si, p, q);
@@ -711,6 +715,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->stream = c->streams[0];
     c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 6, 1, 16));
     c->split_mode = static_cast<uint32_t>(EnvInt("PM_FINE_SPLIT", 1, 0, 2));
+    c->fold_clear = EnvInt("PM_FOLD_CLEAR", 1, 0, 1) != 0;
     c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 4, 1, 16));
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -967,8 +972,8 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             // each dispatch carries its own begin / end events: pure kernel durations
             pm::LaunchBin(p, c->stream, c->ev[0], c->ev[1]);
             pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream, c->ev[2], c->ev[3]);
-            pm::LaunchFine(p, FineGrid(c), c->stream, c->ev[4], c->ev[5]);
-            pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream, c->ev[6], c->ev[7]);
+            pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->stream, c->ev[4], c->ev[5]);
+            if (!c->fold_clear) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream, c->ev[6], c->ev[7]);
             PM_TRY(hipEventRecord(s->ev_done, c->stream));
             PM_TRY(hipStreamSynchronize(c->stream));
             Submitted(c, si, p, c->stream);
@@ -976,7 +981,7 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             PM_TRY(hipEventElapsedTime(&t1, c->ev[0], c->ev[1]));
             PM_TRY(hipEventElapsedTime(&t2, c->ev[2], c->ev[3]));
             PM_TRY(hipEventElapsedTime(&t3, c->ev[4], c->ev[5]));
-            PM_TRY(hipEventElapsedTime(&t4, c->ev[6], c->ev[7]));
+            if (!c->fold_clear) PM_TRY(hipEventElapsedTime(&t4, c->ev[6], c->ev[7]));
             a1 += t1;
             a2 += t2;
             a3 += t3;
@@ -1014,6 +1019,7 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
         double acc[4] = {0, 0, 0, 0};  // bin, clear, coarse, fine
         for (int i = 0; i < iters && e == hipSuccess && r == PM_OK; ++i)
             for (int k = 0; k < 4 && e == hipSuccess; ++k) {
+                if (k == 1 && c->fold_clear) continue;  // no separate clear launch
                 float t = 0;
                 e = hipEventElapsedTime(&t, tev[static_cast<size_t>(i) * 8 + 2 * k], tev[static_cast<size_t>(i) * 8 + 2 * k + 1]);
                 acc[k] += t;
@@ -1051,7 +1057,7 @@ int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms) {
         if (r == PM_OK) r = SyncAll(c);
         float t_fine = 0, t_clear = 0;
         if (r == PM_OK && hipEventElapsedTime(&t_fine, tev[0], tev[7]) == hipSuccess &&
-            hipEventElapsedTime(&t_clear, tev[0], tev[3]) == hipSuccess)
+            (c->fold_clear || hipEventElapsedTime(&t_clear, tev[0], tev[3]) == hipSuccess))
             lat.push_back(std::max(t_fine, t_clear));
     }
     for (auto &v : tev)
@@ -1155,9 +1161,9 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
         p.dbg_bin = d;
         hipError_t e = hipSuccess;
         pm::LaunchBin(p, c->stream);
-        pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
+        if (!c->fold_clear) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
         pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
-        pm::LaunchFine(p, FineGrid(c), c->stream);
+        pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->stream);
         if (e == hipSuccess) e = hipEventRecord(s->ev_done, c->stream);
         p.dbg_bin = nullptr;
         Submitted(c, si, p, c->stream);
@@ -1187,7 +1193,7 @@ int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_sl
     PM_TRY(hipMalloc(&d, std::max<size_t>(slots, 1) * 4 * sizeof(unsigned long long)));
     pm::FrameParams p = s->params;
     p.dbg_time = d;
-    pm::LaunchFine(p, FineGrid(c), c->stream);
+    pm::LaunchFine(p, 0u, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d, slots * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(d);

@@ -98,6 +98,7 @@ struct FrameParams {
     const uint2 *band_bbox;        // [n_band_items] bboxes of the items that reach this band, paint order
     const uint32_t *band_item;     // [n_band_items] their scene indices
     uint32_t n_band_items;
+    uint32_t fine_grid;            // persistent workgroups of pm_fine_kernel (blocks beyond it clear strip rows)
     uint32_t split_mode;           // fine kernel: 0 = one wave per tile always, 1 = at most 4 waves, 2 = 1/4/16 by class
     // large scenes: per-tile-row item lists written each frame by pm_rowcull_kernel
     uint32_t use_row_lists;
@@ -127,6 +128,7 @@ void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0 = nullptr
 void LaunchClear(const FrameParams &p, uint32_t n_striprows, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t stream, hipEvent_t t0 = nullptr,
                   hipEvent_t t1 = nullptr);
-void LaunchFine(const FrameParams &p, uint32_t grid, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+// clear_blocks: strip rows whose resolved tiles the launch also writes (0: pm_clear_kernel did)
+void LaunchFine(const FrameParams &p, uint32_t clear_blocks, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 }  // namespace pm

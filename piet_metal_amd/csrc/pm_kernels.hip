@@ -957,10 +957,10 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
 // of PietRender.metal:34-44 for tiles that never reach the tile kernels.  Pure store bandwidth;
 // runs next to pm_coarse_kernel / pm_fine_kernel, which write the other tiles.
 // =====================================================================================
-__global__ __launch_bounds__(kBinThreads) void pm_clear_kernel(FrameParams P) {
+__device__ __forceinline__ void ClearStripRow(const FrameParams &P, uint32_t striprow) {
     const uint32_t lane = LaneId(), wave = threadIdx.x >> 6;
-    const uint32_t strip = blockIdx.x % P.strips_x;
-    const uint32_t row_rel = blockIdx.x / P.strips_x;
+    const uint32_t strip = striprow % P.strips_x;
+    const uint32_t row_rel = striprow / P.strips_x;
     const uint32_t t = lane >> 2;  // tile of this lane's 4 pixels
     const uint32_t tx = strip * kStripTiles + t;
     if (tx >= P.tiles_x) return;
@@ -983,6 +983,8 @@ __global__ __launch_bounds__(kBinThreads) void pm_clear_kernel(FrameParams P) {
         }
     }
 }
+
+__global__ __launch_bounds__(kBinThreads) void pm_clear_kernel(FrameParams P) { ClearStripRow(P, blockIdx.x); }
 
 // =====================================================================================
 // K2: per-tile command lists (tile-level half of tileKernel), one wave per tile
@@ -1709,10 +1711,17 @@ __global__ __launch_bounds__(kThreads) void pm_fine_kernel(FrameParams P) {
     __shared__ Cmd s_cmds[kWaves][kFineChunk];
     Cmd *const cmds = s_cmds[threadIdx.x >> 6];
 
+    // Workgroups beyond the persistent grid write the pixels of the tiles binning resolved (see
+    // pm_clear_kernel): pure stores that fill the SIMDs this kernel's long tail leaves idle, and
+    // one launch less per frame.
+    if (blockIdx.x >= P.fine_grid) {
+        ClearStripRow(P, blockIdx.x - P.fine_grid);
+        return;
+    }
     const uint32_t lane = LaneId();
     const uint32_t n_a = P.ctr_cur->vheavy_count, n_b = P.ctr_cur->heavy_count, n_c = P.ctr_cur->light_count;
     const uint32_t wave_global = blockIdx.x * kWaves + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * kWaves;
+    const uint32_t n_waves = P.fine_grid * kWaves;
     // slots: 4 per tile with a long list (16 for the very long ones in split mode 2), 1 per light tile.
     // Splitting a tile buys latency when few long lists set the span of the launch; with more
     // long lists than waves it only costs work (the y-only math is no longer shared by 4
@@ -1878,8 +1887,8 @@ void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t
         PM_LAUNCH(pm_coarse_kernel<false>, dim3(grid), dim3(kThreads), stream, t0, t1, p);
 }
 
-void LaunchFine(const FrameParams &p, uint32_t grid, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
-    PM_LAUNCH(pm_fine_kernel, dim3(grid), dim3(kThreads), stream, t0, t1, p);
+void LaunchFine(const FrameParams &p, uint32_t clear_blocks, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
+    PM_LAUNCH(pm_fine_kernel, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
 }
 
 #undef PM_LAUNCH
