@@ -5,8 +5,8 @@ fraction of the dominant kernel and the CPU oracle timed beside it.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame of the hot path -- pm_bin_kernel, pm_clear_kernel, pm_coarse_kernel,
-pm_fine_kernel (tileKernel + renderKernel + composite of the reference) -- over the scene already
+A "step" is one frame of the hot path -- pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel
+(tileKernel + renderKernel + composite of the reference) -- over the scene already
 resident in HBM (flatten/encode happens once per scene, like the reference encodes once
 per resize, PietRenderer.m:145).  Frames are submitted back to back without waiting,
 as the reference commits command buffers (PietRenderer.m:102): up to four frames are in

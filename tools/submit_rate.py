@@ -1,4 +1,4 @@
-"""How fast can the host submit frames?  (pm_render = 4 launches + 1 event record)"""
+"""How fast can the host submit frames?  (pm_render = 3 launches + 1 event record)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import piet_metal_amd as pm
