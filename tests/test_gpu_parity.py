@@ -442,3 +442,28 @@ def test_other_pipeline_depths(pm, pmo, monkeypatch, streams, slots):
         assert tm["total_ms"] > 0 and tm["fine_ms"] > 0
     finally:
         r.close()
+
+
+def test_config5_full_size_properties(pm, pmo, renderer):
+    """BASELINE config 5 at full size on one GPU (5 x 5 Tigers, 8192^2, 7 600 items: the
+    per-row item lists are in use): the eight 64-row bands of the 8-GPU split reproduce the
+    full frame, rendering is idempotent, and two tile rows are checked against the oracle."""
+    wl = pm.workloads.config5_tiger_grid()
+    renderer.resize(wl.width, wl.height)
+    nbytes, nitems = renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    assert nitems == 7600
+    scene = renderer.download_scene()
+    renderer.render()
+    full = renderer.read_pixels()
+    renderer.render()
+    renderer.render()
+    assert np.array_equal(full, renderer.read_pixels())
+    for rank in (0, 3, 7):
+        r0, r1 = pm.workloads.band_rows(512, 8, rank)
+        assert (r0, r1) == (64 * rank, 64 * rank + 64)
+        renderer.set_band(r0, r1)
+        renderer.render()
+        assert np.array_equal(renderer.read_pixels(), full[r0 * 16 : r1 * 16]), rank
+    P = pmo.Ptcl(scene, wl.width, wl.height)
+    assert np.array_equal(full[200 * 16 : 202 * 16], P.render_rows(200, 202))
+    P.close()
