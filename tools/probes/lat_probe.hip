@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/bin/lat_probe tools/probes/lat_probe.hip
 // Developer probe: dependent-load round-trip time on MI355X, one wave alone vs a full grid.
 #include <hip/hip_runtime.h>
 #include <cstdio>
