@@ -212,13 +212,26 @@ def main() -> int:
             alone_ms.pop("pm_clear_kernel")
         latency_ms = lat["median_ms"]
         pipelined_ms = tm["total_ms"] / tm["iters"]
-        traffic = None
+        traffic, issue = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and world == 1:
             try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                prof = json.load(open(tpath))
+                traffic = prof.get(dom, {}).get("hbm_bytes_per_launch")
+                # The bound this path actually runs against: VALU issue.  A CDNA4 SIMD issues one
+                # wave64 VALU instruction per 4 cycles; instruction counts are the SQ counters of
+                # the committed rocprofv3 PMC passes (profiles/), one launch of each kernel = one frame.
+                insts = sum(prof[k]["valu_insts_per_launch"] for k in kernels if "valu_insts_per_launch" in prof.get(k, {}))
+                props = torch.cuda.get_device_properties(local)
+                n_simd = props.multi_processor_count * 4
+                clock_ghz = getattr(props, "clock_rate", 2400000) / 1e6
+                if insts:
+                    floor_ms = insts * 4 / n_simd / (clock_ghz * 1e9) * 1e3
+                    issue = {"bound": "valu-issue", "valu_wave_insts_per_frame": insts, "simds": n_simd, "cycles_per_inst": 4,
+                             "clock_ghz": round(clock_ghz, 3), "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / ms_per_step, 4),
+                             "source": prof.get("_source")}
             except Exception:
-                traffic = None
+                traffic, issue = None, None
         out = {
             "metric": "Mpixels/s, Ghostscript Tiger 3840x2160 (fills+strokes)",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -249,6 +262,8 @@ def main() -> int:
                 "note": "kernels_ms / kernel_ms: per-launch durations inside the overlapping batch (four frames in flight on four streams, as in the timed region), from events carried by the dispatches -- what rocprofv3 --kernel-trace shows; kernels_alone_ms: the same kernels with frames serialized on one stream; frame_latency_ms: one frame with nothing else in flight, first kernel begin to last kernel end (median of 100; SURVEY 8d's t_frame); the path is latency/VALU bound, not HBM bound (DESIGN.md)",
             },
         }
+        if issue is not None:
+            out["issue_roofline"] = issue
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pm, pm.workloads.tiger(3840, 2160))
         print(json.dumps(out), flush=True)

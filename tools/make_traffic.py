@@ -17,5 +17,7 @@ for k, d in summ.items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         out[name] = {"hbm_bytes_per_launch": int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024),
                      "fetch_size_kib": round(d["FETCH_SIZE"], 1), "write_size_kib": round(d["WRITE_SIZE"], 1)}
+        if "SQ_INSTS_VALU" in d:  # wave-instructions per launch (SQ counters of the same summary)
+            out[name]["valu_insts_per_launch"] = int(d["SQ_INSTS_VALU"])
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out, indent=1))
