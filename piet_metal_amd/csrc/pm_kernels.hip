@@ -1276,7 +1276,7 @@ struct CoarseLds {
 }  // namespace
 
 template <bool kCapture>
-__global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
+__global__ __launch_bounds__(kThreads, 5) void pm_coarse_kernel(FrameParams P) {
     __shared__ CoarseLds s_lds[kWaves];
     CoarseLds &L = s_lds[threadIdx.x >> 6];
 
@@ -1707,7 +1707,7 @@ __global__ __launch_bounds__(kThreads) void pm_coarse_kernel(FrameParams P) {
 // waves per tile (4 pixel rows each, 1 pixel per lane, Fill runs evaluated 4 at a time).
 // The list is staged through LDS in chunks with coalesced loads; interpreter state stays
 // in registers across chunks.
-__global__ __launch_bounds__(kThreads) void pm_fine_kernel(FrameParams P) {
+__global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     __shared__ Cmd s_cmds[kWaves][kFineChunk];
     Cmd *const cmds = s_cmds[threadIdx.x >> 6];
 
