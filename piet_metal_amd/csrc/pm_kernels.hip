@@ -50,6 +50,14 @@ namespace pm {
 
 namespace {
 
+// waves per SIMD the register allocation of the tile kernels aims at (5 = 96 VGPRs: no spills;
+// 6 = 80 VGPRs spills to scratch)
+#ifndef PM_COARSE_WPS
+#define PM_COARSE_WPS 5
+#endif
+#ifndef PM_FINE_WPS
+#define PM_FINE_WPS 5
+#endif
 constexpr int kThreads = 256;   // coarse / fine kernel workgroup
 constexpr int kWaves = kThreads / 64;
 constexpr int kBinThreads = 64 * kBinWaves;  // binning workgroup: its waves share one strip row's segment stream
@@ -1276,7 +1284,7 @@ struct CoarseLds {
 }  // namespace
 
 template <bool kCapture>
-__global__ __launch_bounds__(kThreads, 5) void pm_coarse_kernel(FrameParams P) {
+__global__ __launch_bounds__(kThreads, PM_COARSE_WPS) void pm_coarse_kernel(FrameParams P) {
     __shared__ CoarseLds s_lds[kWaves];
     CoarseLds &L = s_lds[threadIdx.x >> 6];
 
@@ -1707,7 +1715,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_coarse_kernel(FrameParams P) {
 // waves per tile (4 pixel rows each, 1 pixel per lane, Fill runs evaluated 4 at a time).
 // The list is staged through LDS in chunks with coalesced loads; interpreter state stays
 // in registers across chunks.
-__global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
+__global__ __launch_bounds__(kThreads, PM_FINE_WPS) void pm_fine_kernel(FrameParams P) {
     __shared__ Cmd s_cmds[kWaves][kFineChunk];
     Cmd *const cmds = s_cmds[threadIdx.x >> 6];
 
