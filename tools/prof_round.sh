@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round profile (run on the GPU box through gpurun):  tools/prof_round.sh <tag>
 #   1. bench.py (default flags) -> gpurun_out/<tag>/bench.json
-#   2. rocprofv3 --kernel-trace --stats of the same command -> kernel_stats.csv
+#   2. rocprofv3 --kernel-trace --stats of the same command -> kernel_stats.csv (+ that run's own
+#      JSON line -> bench_traced.json)
 #   3. PMC passes (FETCH_SIZE, WRITE_SIZE, then SQ counters), each in its own run with
 #      --kernel-trace only, -> pmc_passN.csv + pmc_summary.json
 set -u
@@ -12,7 +13,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py"
 timeout 600 $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 1500 $OUT/bench.json
+# the traced run's own JSON line is kept next to the stats: same process, same launches
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --no-cpu-baseline > $OUT/trace.log 2>&1
+grep '^{"metric"' $OUT/trace.log | tail -1 > $OUT/bench_traced.json
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -8 $OUT/kernel_stats.csv
 find $OUT/trace -name "*kernel_trace.csv" -size +30M -delete
 i=0
