@@ -1,11 +1,11 @@
 """Randomised parity sweep (GPU box): random scenes x random viewports x random bands,
 GPU pixels (and, for a subset, per-tile command lists) against the oracle.
 
-    python tools/fuzz_parity.py [first_seed] [count]
+    python tests/dev/fuzz_parity.py [first_seed] [count]
 """
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import piet_metal_amd as pm
 from oracle import pmo

@@ -1,7 +1,7 @@
 """Developer check (GPU box): product vs oracle on a few scenes, with diagnostics."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import piet_metal_amd as pm
 from oracle import pmo
 
