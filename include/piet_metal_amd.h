@@ -157,7 +157,8 @@ void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes);
 /* Time `iters` frames with HIP events (any pointer may be NULL).
  * total_ms = the whole batch submitted back to back through the frame pipeline, as pm_render
  * does; bin/coarse/fine/clear_ms = average per-launch duration of the frame kernels
- * (pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel, pm_clear_kernel), each ALONE on the GPU: a second pass
+ * (pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel; pm_clear_kernel only with PM_FOLD_CLEAR=0,
+ * else its work is part of pm_fine_kernel's launch and clear_ms is 0), each ALONE on the GPU: a second pass
  * of `iters` frames serialized on one stream, every launch bracketed by events. */
 int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *coarse_ms, float *fine_ms, float *clear_ms);
 /* Same, but the per-kernel durations are taken INSIDE the pipelined batch: every launch is
