@@ -166,7 +166,7 @@ struct FrameSlot {
 
 struct pm_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;      // tile kernels (coarse + fine); "the" context stream
+    hipStream_t stream = nullptr;      // == streams[0]: scene upload, flatten, index, debug replays
     std::vector<hipStream_t> streams;  // frame N runs on streams[N % n]; stream == streams[0]
     bool fold_clear = true;  // pm_fine_kernel's launch also writes the resolved tiles (no pm_clear_kernel launch)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
