@@ -467,3 +467,34 @@ def test_config5_full_size_properties(pm, pmo, renderer):
     P = pmo.Ptcl(scene, wl.width, wl.height)
     assert np.array_equal(full[200 * 16 : 202 * 16], P.render_rows(200, 202))
     P.close()
+
+
+@pytest.mark.timeout(120)
+def test_non_finite_coordinates_do_not_hang(pm, renderer):
+    """The reference leaves NaN / infinite / huge coordinates undefined (float -> int casts in
+    tileKernel); here they must neither hang nor fault, and the context must stay usable."""
+    rng = np.random.default_rng(3)
+    bad = [np.nan, np.inf, -np.inf, 3.0e38, -3.0e38, 1.0e9]
+    buf = np.zeros(1 << 20, np.uint8)
+    e = pm.Encoder(buf)
+    n = 120
+    e.begin_group(n)
+    for i in range(n):
+        pts = rng.uniform(0, 400, (int(rng.integers(2, 9)), 2))
+        pts[int(rng.integers(0, len(pts))), int(rng.integers(0, 2))] = bad[i % len(bad)]
+        if i % 2:
+            e.polyline(pts, 0xFF3366CC, 3.0)
+        else:
+            e.fill(pts, 0xFF22AA44)
+    e.end_group()
+    renderer.resize(512, 512)
+    renderer.set_scene_bytes(buf[: e.bytes_used])
+    for _ in range(3):
+        renderer.render()
+    img = renderer.read_pixels()
+    assert img.shape == (512, 512, 4)
+    # still alive
+    scene = buf[: e.bytes_used].copy()
+    renderer.set_scene_bytes(scene)
+    renderer.render()
+    renderer.sync()
