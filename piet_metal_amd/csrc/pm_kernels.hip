@@ -1016,6 +1016,17 @@ struct PixelState {
     _Float16 sa[4];                        // half signedArea (:472)
 };
 
+// f32 -> binary16 of a value that is the result of f32 arithmetic.  The value is pinned in a
+// register first: otherwise instruction selection folds `half(a * b)` (and friends) into
+// v_fma_mixlo_f16, which rounds the exact result ONCE to binary16 -- not the f32 rounding followed
+// by the conversion that the source (and the reference's `half(...)` casts, decision D1) specify.
+// Measured on gfx950: 958 of 16.7 M random products differ (tools/probes/mix_probe.hip); a
+// 2 000-scene fuzz run found two pixels off by one because of it.
+__device__ __forceinline__ _Float16 ToHalf(float x) {
+    asm volatile("" : "+v"(x));
+    return static_cast<_Float16>(x);
+}
+
 __device__ __forceinline__ _Float16 HalfFromBits(uint32_t b) {
     const uint16_t u = static_cast<uint16_t>(b);
     return __builtin_bit_cast(_Float16, u);
@@ -1052,7 +1063,7 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0
                 for (int k = 0; k < 4; ++k) {
                     const float dx = (px0 + static_cast<float>(k)) - cx;
                     const float r = sqrtf(dx * dx + dy * dy);
-                    alpha[k] = static_cast<_Float16>(Sat(circle_r - r));
+                    alpha[k] = ToHalf(Sat(circle_r - r));
                 }
                 const half2_t zero = Splat(static_cast<_Float16>(0.0f));
                 half2_t a01, a23;
@@ -1083,7 +1094,7 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0
                 _Float16 alpha[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    alpha[k] = static_cast<_Float16>(Sat(half_width + 0.5f - st.df[k]));
+                    alpha[k] = ToHalf(Sat(half_width + 0.5f - st.df[k]));
                     st.df[k] = 1e9f;
                 }
                 Blend4(st, cmd.body[2], cmd.body[3], alpha);
@@ -1110,7 +1121,7 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0
                         const float c = fmaxf(b, 0.0f);
                         const float d = fmaxf(xmin, 0.0f);
                         const float area = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-                        st.sa[k] = st.sa[k] + static_cast<_Float16>(area * wd);
+                        st.sa[k] = st.sa[k] + ToHalf(area * wd);
                     }
                 }
                 break;
@@ -1119,7 +1130,7 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0
                 const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
                 const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) st.sa[k] = static_cast<_Float16>(static_cast<float>(st.sa[k]) + v);
+                for (int k = 0; k < 4; ++k) st.sa[k] = ToHalf(static_cast<float>(st.sa[k]) + v);
                 break;
             }
             case kCmdDrawFill: {  // :535-545
@@ -1128,7 +1139,7 @@ __device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const _Float16 a = st.sa[k] + bd;
-                    alpha[k] = static_cast<_Float16>(fminf(fabsf(static_cast<float>(a)), 1.0f));
+                    alpha[k] = ToHalf(fminf(fabsf(static_cast<float>(a)), 1.0f));
                     st.sa[k] = static_cast<_Float16>(0.0f);
                 }
                 Blend4(st, cmd.body[2], cmd.body[3], alpha);
@@ -1176,7 +1187,7 @@ __device__ __forceinline__ void Interpret1(const Cmd *cmds, uint32_t n, float px
                 const float cx = x0 + (x1 - x0) * 0.5f, cy = y0 + (y1 - y0) * 0.5f;
                 const float dx = px - cx, dy = py - cy;
                 const float r = sqrtf(dx * dx + dy * dy);
-                const _Float16 alpha = static_cast<_Float16>(Sat(fminf(cx - x0, cy - y0) - r));
+                const _Float16 alpha = ToHalf(Sat(fminf(cx - x0, cy - y0) - r));
                 const _Float16 zero = static_cast<_Float16>(0.0f);
                 st.r = st.r + (zero - st.r) * alpha;
                 st.g = st.g + (zero - st.g) * alpha;
@@ -1194,7 +1205,7 @@ __device__ __forceinline__ void Interpret1(const Cmd *cmds, uint32_t n, float px
                 break;
             }
             case kCmdStroke: {
-                const _Float16 alpha = static_cast<_Float16>(Sat(__uint_as_float(cmd.body[0]) + 0.5f - st.df));
+                const _Float16 alpha = ToHalf(Sat(__uint_as_float(cmd.body[0]) + 0.5f - st.df));
                 Blend1(st, cmd.body[2], cmd.body[3], alpha);
                 st.df = 1e9f;
                 break;
@@ -1236,7 +1247,7 @@ __device__ __forceinline__ void Interpret1(const Cmd *cmds, uint32_t n, float px
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < 4; ++u)  // accumulate in list order (half adds do not commute)
-                        if (live[u]) st.sa = st.sa + static_cast<_Float16>(contrib[u]);
+                        if (live[u]) st.sa = st.sa + ToHalf(contrib[u]);
                 }
                 i += run - 1u;
                 break;
@@ -1244,12 +1255,12 @@ __device__ __forceinline__ void Interpret1(const Cmd *cmds, uint32_t n, float px
             case kCmdFillEdge: {
                 const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
                 const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
-                st.sa = static_cast<_Float16>(static_cast<float>(st.sa) + v);
+                st.sa = ToHalf(static_cast<float>(st.sa) + v);
                 break;
             }
             case kCmdDrawFill: {
                 _Float16 alpha = st.sa + static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
-                alpha = static_cast<_Float16>(fminf(fabsf(static_cast<float>(alpha)), 1.0f));
+                alpha = ToHalf(fminf(fabsf(static_cast<float>(alpha)), 1.0f));
                 Blend1(st, cmd.body[2], cmd.body[3], alpha);
                 st.sa = static_cast<_Float16>(0.0f);
                 break;
