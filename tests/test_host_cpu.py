@@ -352,3 +352,59 @@ def test_png_writer_round_trip(tmp_path):
     assert np.array_equal(cli.read_png_rgba(p), img)
     with pytest.raises(ValueError):
         cli.write_png(p, img[:, :, :3])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_svg_path_grammar_random(pm, seed):
+    """Random path data in every spelling the grammar allows (absolute / relative, implicit
+    repeats, implicit lineto after moveto, smooth cubics, H/V, numbers glued by signs and dots,
+    exponents) through the C++ front-end and the independent Python parser: bit-exact f64."""
+    rng = np.random.default_rng(1000 + seed)
+
+    def fmt(v):
+        style = rng.integers(0, 4)
+        if style == 0:
+            return repr(float(np.round(v, 3)))
+        if style == 1:
+            return f"{v:.2e}"
+        if style == 2 and abs(v) < 1:
+            s = f"{abs(v):.3f}"[1:]  # ".123"
+            return ("-" if v < 0 else "") + s
+        return f"{v:.4f}".rstrip("0").rstrip(".") or "0"
+
+    def nums(k):
+        vals = [float(rng.uniform(-200, 200)) if rng.random() < 0.8 else float(rng.uniform(-1, 1)) for _ in range(k)]
+        out = ""
+        for v in vals:
+            s = fmt(v)
+            sep = rng.choice([" ", ",", " , ", ""]) if out else ""
+            if sep == "" and out and not (s[0] == "-" or (s[0] == "." and "." in out.split()[-1].split(",")[-1].lstrip("-") and "e" not in out.split()[-1].lower())):
+                sep = " "
+            out += sep + s
+        return out
+
+    tags = {"M": 0, "L": 1, "C": 3, "Z": 4}
+    docs = []
+    for _ in range(40):
+        d = "M" + nums(2)
+        if rng.random() < 0.4:
+            d += " " + nums(2 * int(rng.integers(1, 3)))  # implicit lineto after moveto
+        for _ in range(int(rng.integers(1, 9))):
+            c = rng.choice(list("LlHhVvCcSsZzMm"))
+            if c in "Zz":
+                d += c
+            else:
+                per = {"L": 2, "H": 1, "V": 1, "C": 6, "S": 4, "M": 2}[c.upper()]
+                rep_n = int(rng.integers(1, 3))
+                d += rng.choice(["", " "]) + c + nums(per * rep_n)
+        docs.append(d)
+    svg = "<svg>" + "".join(f'<path d="{d}" fill="#123456"/>' for d in docs) + "</svg>"
+    ps = pm.PathSet.from_svg(svg)
+    assert len(ps.paths) == len(docs)
+    for d, path in zip(docs, ps.paths):
+        want = py_parse_path(d)
+        got = ps.els[path["el_begin"] : path["el_end"]]
+        assert len(got) == len(want), d
+        for g, (t, coords) in zip(got, want):
+            assert g["tag"] == tags[t], d
+            assert g["p"][: len(coords)].tolist() == coords, d
