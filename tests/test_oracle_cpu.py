@@ -260,3 +260,38 @@ def test_thin_line_rule(pmo):
     tag, rgba_b0, rgba_b1, rgba_b2, rgba_b3, width = struct.unpack_from("<I4Bf", scene.tobytes(), 16)
     assert tag == 4 and abs(width - 0.7) < 1e-7
     assert rgba_b3 == int(255.0 * np.sqrt(np.float32(0.175) / np.float32(0.7)))  # 127
+
+
+def test_render_half_matches_independent_numpy_restatement(pm, pmo):
+    """oracle/pmo_render.c against tests/np_render.py, a second restatement of renderKernel and
+    of the colour tables written from the Metal source with numpy float32 / float16 arrays:
+    the three tables and every non-Bail tile of four scenes (incl. the Tiger), byte for byte."""
+    import np_render
+    from test_host_cpu import encode_ops, random_ops
+
+    a, b, c = pmo.luts()
+    tables = (np_render.lut_srgb_to_linear_half(), np_render.lut_unorm_to_half(), np_render.lut_linear_half_to_srgb8())
+    assert np.array_equal(a, tables[0].view(np.uint16))
+    assert np.array_equal(b, tables[1].view(np.uint16))
+    assert np.array_equal(c, tables[2])
+    scenes = [
+        (pmo.scene_path_test(), 256, 320),
+        (pmo.scene_cardioid(), 480, 352),
+        (encode_ops(pm, random_ops(77, 150, extent=300.0)), 320, 304),
+    ]
+    wl = pm.workloads.tiger(640, 360)
+    scenes.append((pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)[0], 640, 360))
+    checked = 0
+    for scene, w, h in scenes:
+        want = pmo.render(scene, w, h)
+        P = pmo.Ptcl(scene, w, h)
+        for ty in range(P.tiles_y):
+            for tx in range(P.tiles_x):
+                got = np_render.render_tile(P.cmds(tx, ty), tx, ty, tables)
+                if got is None:
+                    continue  # Bail: the composite's solid colour, not renderKernel's business
+                ref = want[16 * ty : 16 * ty + 16, 16 * tx : 16 * tx + 16]
+                assert np.array_equal(got[: ref.shape[0], : ref.shape[1]], ref), (tx, ty)
+                checked += 1
+        P.close()
+    assert checked > 800
