@@ -28,6 +28,18 @@ def sha(a) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def ptcl_sha(P) -> str:
+    """Per-tile command lists: for every tile in row-major order, the command count (u32) followed
+    by the 24-byte commands as the reference lays them out (TestApp/GenTypes.h:330-495)."""
+    hsh = hashlib.sha256()
+    for ty in range(P.tiles_y):
+        for tx in range(P.tiles_x):
+            c = np.ascontiguousarray(P.cmds(tx, ty), dtype=np.uint32)
+            hsh.update(np.uint32(len(c)).tobytes())
+            hsh.update(c.tobytes())
+    return hsh.hexdigest()
+
+
 def scene_entry(scene, w, h, with_image=True):
     P = pmo.Ptcl(scene, w, h)
     tot, mx = P.total_cmds()
@@ -40,6 +52,7 @@ def scene_entry(scene, w, h, with_image=True):
         e["half_vs_f32_max_lsb"] = int(np.abs(img.astype(int) - f32.astype(int)).max())
     solid = np.array([[P.solid(tx, ty) for tx in range(P.tiles_x)] for ty in range(P.tiles_y)], np.uint32)
     e["solid_sha256"] = sha(solid)
+    e["ptcl_sha256"] = ptcl_sha(P)
     P.close()
     return e
 

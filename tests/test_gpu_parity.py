@@ -186,6 +186,15 @@ def test_baseline_configs(pm, pmo, renderer, golden, cfg):
     got = renderer.read_pixels()
     assert sha(got) == golden[wl.name]["rgba_sha256"]          # committed pin
     assert np.array_equal(got, pmo.render(scene, wl.width, wl.height))  # live oracle
+    # the GPU's per-tile command lists against the committed pin (24-byte reference layout)
+    counts, _solid, cmds = renderer.capture_ptcl(golden[wl.name]["max_cmds_per_tile"])
+    hsh = hashlib.sha256()
+    for ty in range(counts.shape[0]):
+        for tx in range(counts.shape[1]):
+            n = int(counts[ty, tx])
+            hsh.update(np.uint32(n).tobytes())
+            hsh.update(np.ascontiguousarray(cmds[ty, tx, :n]).tobytes())
+    assert hsh.hexdigest() == golden[wl.name]["ptcl_sha256"]
     st = renderer.stats()
     assert st["overflow"] == 0 and st["arena_used_dwords"] <= st["arena_cap_dwords"]
 

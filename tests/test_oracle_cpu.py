@@ -29,6 +29,13 @@ def check_scene(pmo, golden, key, scene, with_image=True):
     assert sha(scene) == g["scene_sha256"]
     P = pmo.Ptcl(scene, w, h)
     assert list(P.total_cmds()) == [g["total_cmds"], g["max_cmds_per_tile"]]
+    hsh = hashlib.sha256()  # per-tile command lists, as tests/golden/make_golden.py hashes them
+    for ty in range(P.tiles_y):
+        for tx in range(P.tiles_x):
+            c = np.ascontiguousarray(P.cmds(tx, ty), dtype=np.uint32)
+            hsh.update(np.uint32(len(c)).tobytes())
+            hsh.update(c.tobytes())
+    assert hsh.hexdigest() == g["ptcl_sha256"]
     if with_image:
         img = P.render()
         assert sha(img) == g["rgba_sha256"]
