@@ -302,3 +302,44 @@ def test_render_half_matches_independent_numpy_restatement(pm, pmo):
                 checked += 1
         P.close()
     assert checked > 800
+
+
+def test_tile_lists_match_independent_python_restatement(pm, pmo):
+    """oracle/pmo_tile.c (lane simulation in C) against tests/np_tile.py, a second restatement of
+    tileKernel + TileEncoder written from the Metal source as Python objects per lane with numpy
+    float32 scalars: per-tile command lists word for word, solid colours, and -- through
+    tests/np_render.py -- the pixels of the whole independent pipeline, byte for byte."""
+    import np_render
+    import np_tile
+    from test_host_cpu import encode_ops, random_ops
+
+    tables = (np_render.lut_srgb_to_linear_half(), np_render.lut_unorm_to_half(), np_render.lut_linear_half_to_srgb8())
+    wl = pm.workloads.tiger(256, 144)
+    tiger = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)[0]
+    scenes = [
+        ("path_test", pmo.scene_path_test(), 512, 832, False),
+        ("cardioid", pmo.scene_cardioid(), 480, 352, True),
+        ("random77", encode_ops(pm, random_ops(77, 150, extent=300.0)), 320, 304, True),
+        ("random78", encode_ops(pm, random_ops(78, 200, extent=700.0)), 700, 500, False),
+        ("random79", encode_ops(pm, random_ops(79, 120, extent=120.0)), 130, 100, True),
+        ("tiger", tiger, 256, 144, True),
+    ]
+    for name, scene, w, h, pixels in scenes:
+        got = np_tile.tile_lists(scene.tobytes(), w, h)
+        P = pmo.Ptcl(scene, w, h)
+        want_img = pmo.render(scene, w, h) if pixels else None
+        for ty in range(P.tiles_y):
+            for tx in range(P.tiles_x):
+                oc = P.cmds(tx, ty)
+                g, solid = got[(tx, ty)]
+                assert solid == P.solid(tx, ty), (name, tx, ty)
+                assert len(oc) == len(g), (name, tx, ty)
+                if g[0, 0] == np_tile.BAIL:
+                    assert oc[0, 0] == np_tile.BAIL, (name, tx, ty)
+                else:
+                    assert np.array_equal(oc, g), (name, tx, ty)
+                if pixels and g[0, 0] != np_tile.BAIL:
+                    img = np_render.render_tile(g, tx, ty, tables)
+                    ref = want_img[16 * ty : 16 * ty + 16, 16 * tx : 16 * tx + 16]
+                    assert np.array_equal(img[: ref.shape[0], : ref.shape[1]], ref), (name, tx, ty)
+        P.close()
