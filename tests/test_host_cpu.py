@@ -92,14 +92,16 @@ def _oracle_encode(pmo, ops, cap=1 << 20):
     return buf[: e.free_space].copy()
 
 
-def random_ops(seed, n, extent=700.0):
+def random_ops(seed, n, extent=700.0, opaque_mask=0xFF):
+    """Random Encoder calls.  Colours are what the Encoder API takes, 0xRRGGBBAA (it stores them
+    byte-swapped, `rgba.to_be()`, src/lib.rs:181/:200/:213): half of the items are opaque."""
     rng = np.random.default_rng(seed)
     ops = []
     for _ in range(n):
         k = rng.integers(0, 4)
         rgba = int(rng.integers(0, 1 << 32))
         if rng.random() < 0.5:
-            rgba |= 0xFF000000  # opaque (alpha is the top byte, unpack_unorm4x8)
+            rgba |= opaque_mask  # opaque: alpha is the LOW byte of the API colour
         if k == 0:
             ops.append(("circle", float(rng.uniform(0, extent)), float(rng.uniform(0, extent)), float(rng.uniform(1, 40))))
         elif k == 1:
