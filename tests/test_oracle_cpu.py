@@ -343,3 +343,51 @@ def test_tile_lists_match_independent_python_restatement(pm, pmo):
                     ref = want_img[16 * ty : 16 * ty + 16, 16 * tx : 16 * tx + 16]
                     assert np.array_equal(img[: ref.shape[0], : ref.shape[1]], ref), (name, tx, ty)
         P.close()
+
+
+def test_scene_builder_matches_independent_python_restatement(pm, pmo):
+    """oracle/pmo_flatten.c + pmo_encoder.c (make_tiger's two passes on parsed paths) against
+    tests/np_scene.py, a second restatement from the Rust source: scene bytes, byte for byte."""
+    import np_scene
+    from piet_metal_amd import _lib
+
+    cases = [pm.workloads.tiger_reference(), pm.workloads.tiger(1920, 1080, fills_only=True), pm.workloads.tiger(3840, 2160),
+             pm.workloads.config4_blobs(80, 512)]
+    for wl in cases:
+        sp = pmo.scaled_paths(wl.paths.paths, wl.width_scale)
+        ref, _ = pmo.scene_from_paths(sp, wl.paths.els, wl.affine)
+        assert np.array_equal(np.frombuffer(np_scene.scene_from_paths(sp, wl.paths.els, wl.affine), np.uint8), ref), wl.name
+    # random path sets: every element kind (quads and closes are ignored by flatten.rs), several
+    # subpaths, fills / strokes / both, thin strokes, rotations
+    rng = np.random.default_rng(5)
+    for _case in range(25):
+        els, paths = [], []
+        for _ in range(int(rng.integers(1, 30))):
+            e0 = len(els)
+            for _sub in range(int(rng.integers(1, 4))):
+                p = rng.uniform(0, 500, 2)
+                els.append((_lib.PM_EL_MOVE, [p[0], p[1], 0, 0, 0, 0]))
+                for _seg in range(int(rng.integers(1, 6))):
+                    q = [p + rng.uniform(-80, 80, 2) for _ in range(3)]
+                    kind = int(rng.integers(0, 4))
+                    if kind == 0:
+                        els.append((_lib.PM_EL_LINE, [q[0][0], q[0][1], 0, 0, 0, 0])); p = q[0]
+                    elif kind == 1:
+                        els.append((_lib.PM_EL_QUAD, [q[0][0], q[0][1], q[1][0], q[1][1], 0, 0]))
+                    elif kind == 2:
+                        els.append((_lib.PM_EL_CURVE, [q[0][0], q[0][1], q[1][0], q[1][1], q[2][0], q[2][1]])); p = q[2]
+                    else:
+                        els.append((_lib.PM_EL_CLOSE, [0] * 6))
+            paths.append((e0, len(els), int(rng.integers(1, 4)), int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32)),
+                          float(rng.choice([0.05, 0.4, 1.0, 5.0]))))
+        E = np.zeros(len(els), pm.PathSet.EL_DTYPE)
+        for i, (t, p) in enumerate(els):
+            E["tag"][i] = t
+            E["p"][i] = p
+        P = np.array(paths, dtype=pm.PathSet.PATH_DTYPE)
+        s = float(rng.choice([0.5, 1.0, 3.3]))
+        th = float(rng.uniform(0, 6.28))
+        aff = (s * np.cos(th), s * np.sin(th), -s * np.sin(th), s * np.cos(th), float(rng.uniform(-20, 90)), float(rng.uniform(-20, 90)))
+        sp = pmo.scaled_paths(P, s)
+        ref, _ = pmo.scene_from_paths(sp, E, aff)
+        assert np.array_equal(np.frombuffer(np_scene.scene_from_paths(sp, E, aff), np.uint8), ref), _case
