@@ -547,11 +547,19 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     hipEvent_t *t = tev ? tev : none;
     // the slot's previous frame (same stream unless the caller's streams are involved or the
     // slot count differs from the stream count: then the event orders the reuse)
-    if (s->in_flight && s->frame_stream != q) PM_TRY(hipStreamWaitEvent(q, s->ev_done, 0));
+    // (no event is recorded per frame: one recorded on the other stream when the need arises
+    //  marks the end of everything submitted there so far, the slot's frame included)
+    if (s->in_flight && s->frame_stream != q) {
+        PM_TRY(hipEventRecord(s->ev_done, s->frame_stream));
+        PM_TRY(hipStreamWaitEvent(q, s->ev_done, 0));
+    }
     // frames that target the same caller-owned buffer must not overlap each other
     if (c->last_slot >= 0 && c->last_slot != si) {
-        const FrameSlot &l = c->slot[c->last_slot];
-        if (l.in_flight && l.params.fb == fb && l.frame_stream != q) PM_TRY(hipStreamWaitEvent(q, l.ev_done, 0));
+        FrameSlot &l = c->slot[c->last_slot];
+        if (l.in_flight && l.params.fb == fb && l.frame_stream != q) {
+            PM_TRY(hipEventRecord(l.ev_done, l.frame_stream));
+            PM_TRY(hipStreamWaitEvent(q, l.ev_done, 0));
+        }
     }
     const uint32_t n_striprows = BandRows(c) * c->strips_x;
     pm::LaunchBin(p, q, t[0], t[1]);
@@ -559,7 +567,6 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     pm::LaunchCoarse(p, CoarseGrid(c), false, q, t[4], t[5]);
     pm::LaunchFine(p, c->fold_clear ? n_striprows : 0u, q, t[6], t[7]);  // (+ the resolved tiles' pixels)
     PM_TRY(hipGetLastError());
-    PM_TRY(hipEventRecord(s->ev_done, q));
     Submitted(c, si, p, q);
     return PM_OK;
 }
@@ -953,7 +960,8 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
         for (int i = 0; i < iters; ++i)
             if ((r = Enqueue(c, nullptr, c->fb_stride, nullptr)) != PM_OK) return r;
         for (auto &s : c->slot)  // join: the end event follows the last frame of every stream
-            if (s.in_flight) {
+            if (s.in_flight && s.frame_stream != c->stream) {
+                PM_TRY(hipEventRecord(s.ev_done, s.frame_stream));
                 PM_TRY(hipStreamWaitEvent(c->stream, s.ev_done, 0));
             }
         PM_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -974,7 +982,6 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream, c->ev[2], c->ev[3]);
             pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->stream, c->ev[4], c->ev[5]);
             if (!c->fold_clear) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream, c->ev[6], c->ev[7]);
-            PM_TRY(hipEventRecord(s->ev_done, c->stream));
             PM_TRY(hipStreamSynchronize(c->stream));
             Submitted(c, si, p, c->stream);
             float t1 = 0, t2 = 0, t3 = 0, t4 = 0;
@@ -1011,7 +1018,9 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
     for (int i = 0; i < iters && r == PM_OK; ++i) r = Enqueue(c, nullptr, c->fb_stride, nullptr, &tev[static_cast<size_t>(i) * 8]);
     if (r == PM_OK) {
         for (auto &s : c->slot) {
-            if (s.in_flight && e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.ev_done, 0);
+            if (!s.in_flight || s.frame_stream == c->stream) continue;
+            if (e == hipSuccess) e = hipEventRecord(s.ev_done, s.frame_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.ev_done, 0);
         }
         if (e == hipSuccess) e = hipEventRecord(c->ev[1], c->stream);
         if (e == hipSuccess) e = hipEventSynchronize(c->ev[1]);
@@ -1164,7 +1173,6 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
         if (!c->fold_clear) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
         pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
         pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(s->ev_done, c->stream);
         p.dbg_bin = nullptr;
         Submitted(c, si, p, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
