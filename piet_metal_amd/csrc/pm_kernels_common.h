@@ -1,0 +1,275 @@
+// Shared by pm_bin.hip, pm_coarse.hip and pm_fine.hip -- hand-written HIP kernels for gfx950
+// (CDNA4, wave64): the compute path of
+// piet-metal re-designed for MI355X.
+//
+// Reference semantics being reproduced (bit-exact against oracle/):
+//   tileKernel   TestApp/PietRender.metal:160-454  (+ TileEncoder :69-157)
+//   renderKernel TestApp/PietRender.metal:457-566  (+ stroke/renderDf :49-60)
+//   composite    TestApp/PietRender.metal:16-44
+//
+// Decomposition (NOT the reference's thread-per-tile / 256 MiB tile buffer) -- one kernel per
+// level of parallelism, chained by events over the frame pipeline of pm_context.hip:
+//
+//   pm_index_kernel   (once per scene) float bounding box of every chunk of 8 consecutive
+//       segments -- the segment-level analogue of the ShortBbox array the encoder builds per item.
+//   pm_rowcull_kernel (large scenes only) per tile row, the paint-ordered list of items whose
+//       bbox reaches the row.
+//   pm_bin_kernel     one 256-thread workgroup per strip row (16 tiles x 1 tile).
+//       - item bboxes vs strip row: wave64 ballots + prefix ranks compact the candidate items in
+//         paint order;
+//       - the chunks of all candidates form one flat stream; chunks whose box cannot reach the
+//         strip row are dropped; every surviving chunk owns 8 segment slots of an arena record
+//         and each lane evaluates the reference's "phase 1" segment vote for one slot
+//         (PietRender.metal:258-295 fills, :374-399 polylines), the 16-bit mask of tiles the
+//         segment can matter to, and for fills the backdrop step;
+//       - per (item, tile) counts and backdrops, the TileEncoder solid rule per tile, the
+//         command-list space of every tile and its place in one of three class queues.
+//   pm_clear_kernel   pixels of the tiles binning resolved (background / one opaque colour).
+//   pm_coarse_kernel  persistent; ONE WAVE PER QUEUED TILE, no workgroup barriers.
+//       - candidates are filtered by a per-tile hit bit; the record's slots carrying the tile's
+//         bit are gathered in paint order; each lane runs the reference's "phase 2" test for
+//         (tile, segment) (:302-357, :406-440) and emits 0..3 commands; ballots / mbcnt prefix
+//         ranks give every command its slot in the tile's command list in HBM (the reference's
+//         24-byte Cmd records);
+//       - opaque-solid detection (TileEncoder::encodeSolid/end) restarts the list; Bail tiles are
+//         written as one constant here.
+//   pm_fine_kernel    persistent; interprets a tile's command list (renderKernel) for its 256
+//       pixels with 1, 4 or 16 waves by list length.  Everything that only depends on y
+//       (segment window, the two divides of the area integral, FillEdge) is computed once per
+//       lane, colour blending runs as packed half2 math, and each lane finishes with one
+//       16-byte store.  Accumulators are binary16 exactly where the source declares `half`;
+//       commands are applied in list order (half accumulation is order dependent).
+//
+// Compile with -ffp-contract=off: every source-level f32/f16 operation is one
+// IEEE rounding, as in the oracle.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <cstddef>
+
+#include "pm_device.h"
+
+namespace pm {
+
+namespace {
+
+// waves per SIMD the register allocation of the tile kernels aims at (5 = 96 VGPRs: no spills;
+// 6 = 80 VGPRs spills to scratch)
+#ifndef PM_COARSE_WPS
+#define PM_COARSE_WPS 5
+#endif
+#ifndef PM_FINE_WPS
+#define PM_FINE_WPS 5
+#endif
+constexpr int kThreads = 256;   // coarse / fine kernel workgroup
+constexpr int kWaves = kThreads / 64;
+constexpr int kBinThreads = 64 * kBinWaves;  // binning workgroup: its waves share one strip row's segment stream
+constexpr uint32_t kBatch = 256;   // candidate items per binning batch
+constexpr uint32_t kHeavyStream = 32;       // stream elements above which a tile is split over 4 waves
+constexpr uint32_t kVeryHeavyStream = 96;   // ... over 16 waves (one pixel row each)
+
+// ---------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t LaneId() { return __lane_id(); }
+
+__device__ __forceinline__ uint32_t RankBelow(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+// Inclusive prefix sum over the 64 lanes in six DPP adds (no LDS crossbar): Hillis-Steele inside
+// each row of 16 lanes (row_shr 1, 2, 4, 8), then the row totals ripple with row_bcast15 /
+// row_bcast31 (the sequence LLVM's atomic optimizer emits for gfx9).
+__device__ __forceinline__ uint32_t WaveInclusiveScan(uint32_t v) {
+    int x = static_cast<int>(v);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast31 -> rows 2, 3
+    return static_cast<uint32_t>(x);
+}
+
+// Inclusive prefix maximum (unsigned), same DPP ladder; 0 is the identity.
+__device__ __forceinline__ uint32_t WaveInclusiveMax(uint32_t v) {
+    int x = static_cast<int>(v);
+    auto mx = [](int a, int b) { return static_cast<int>(max(static_cast<uint32_t>(a), static_cast<uint32_t>(b))); };
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+    x = mx(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
+    return static_cast<uint32_t>(x);
+}
+
+// Value of the highest lane set in a (non-empty, wave-uniform) ballot mask, as a scalar.
+__device__ __forceinline__ uint32_t WaveAtHighest(uint32_t v, uint64_t mask) {
+    const int l = __builtin_amdgcn_readfirstlane(63 - __builtin_clzll(mask));
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), l));
+}
+
+// Value of lane 63 (the total after an inclusive scan) as a wave-uniform scalar.
+__device__ __forceinline__ uint32_t WaveLast(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), 63));
+}
+
+// Compiler-level ordering of LDS traffic inside one wave (the LDS itself executes a
+// wave's instructions in order); no instruction is emitted.
+__device__ __forceinline__ void WaveSync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+__device__ __forceinline__ float Sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+__device__ __forceinline__ float Sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+// "not all four corners strictly on one side" test used throughout tileKernel
+// (PietRender.metal:241, :289, :340, :349, :394, :431).
+__device__ __forceinline__ bool Straddles(float s00, float s01, float s10, float s11) {
+    return s00 * s01 + s00 * s10 + s00 * s11 < 3.0f;
+}
+
+__device__ __forceinline__ uint32_t LoadU32(const uint8_t *p) { return *reinterpret_cast<const uint32_t *>(p); }
+__device__ __forceinline__ float2 LoadF2(const uint8_t *p) { return *reinterpret_cast<const float2 *>(p); }
+
+// Segments of an item as the kernels count them.
+__device__ __forceinline__ uint32_t FillSegs(uint32_t npt) { return npt; }                      // implicitly closed (:262)
+__device__ __forceinline__ uint32_t PolySegs(uint32_t npt) { return npt >= 2 ? npt - 1 : 0; }  // open (:369)
+
+// ---------------------------------------------------------------------------------
+// phase-1 votes (strip level)
+// ---------------------------------------------------------------------------------
+
+// PietRender.metal:258-295.  y0 = the voting lane's tile row, sx0 = group strip x.
+__device__ __forceinline__ bool VoteFill(float4 s, int y0, int sx0) {
+    const float xmin = fminf(s.x, s.z), ymin = fminf(s.y, s.w);
+    const float xmax = fmaxf(s.x, s.z), ymax = fmaxf(s.y, s.w);
+    const float fy0 = static_cast<float>(y0);
+    const float fy1 = static_cast<float>(y0 + static_cast<int>(kTileH));
+    if (!(ymax >= fy0 && ymin < fy1 && xmin < static_cast<float>(sx0 + static_cast<int>(kGroupW)))) return false;
+    const float a = s.w - s.y;
+    const float b = s.x - s.z;
+    const float c = -(a * s.x + b * s.y);
+    const float left = a * static_cast<float>(sx0);
+    const float right = a * static_cast<float>(sx0 + static_cast<int>(kGroupW));
+    const float ytop = fmaxf(fy0, ymin);
+    const float ybot = fminf(fy1, ymax);
+    const float top = b * ytop;
+    const float bot = b * ybot;
+    const float s_top_left = Sgn(right - a * static_cast<float>(kTileW) + fy0 * b + c);
+    const float s00 = Sgn(top + left + c);
+    const float s01 = Sgn(top + right + c);
+    const float s10 = Sgn(bot + left + c);
+    const float s11 = Sgn(bot + right + c);
+    bool hit = (s_top_left == Sgn(a)) && (ymin <= fy0);
+    if (Straddles(s00, s01, s10, s11) && xmax > static_cast<float>(sx0)) hit = true;
+    return hit;
+}
+
+// PietRender.metal:374-399.  y_test = row of the lane that votes for this segment
+// (lane = segment index & 31, row = lane >> 4: quirk Q4), sx0/sy0 = group origin.
+__device__ __forceinline__ bool VotePoly(float4 s, float hw, int y_test, int sx0, int sy0) {
+    const float xmin = fminf(s.x, s.z), ymin = fminf(s.y, s.w);
+    const float xmax = fmaxf(s.x, s.z), ymax = fmaxf(s.y, s.w);
+    if (!(ymax > static_cast<float>(sy0) - hw && ymin < static_cast<float>(sy0 + static_cast<int>(kGroupH)) + hw &&
+          xmax > static_cast<float>(sx0) - hw && xmin < static_cast<float>(sx0 + static_cast<int>(kGroupW)) + hw))
+        return false;
+    const float a = s.w - s.y;
+    const float b = s.x - s.z;
+    const float c = -(a * s.x + b * s.y);
+    const float left = a * (static_cast<float>(sx0) - hw);
+    const float right = a * (static_cast<float>(sx0 + static_cast<int>(kGroupW)) + hw);
+    const float top = b * (static_cast<float>(y_test) - hw);
+    const float bot = b * (static_cast<float>(y_test + static_cast<int>(kTileH)) + hw);
+    const float s00 = Sgn(top + left + c);
+    const float s01 = Sgn(top + right + c);
+    const float s10 = Sgn(bot + left + c);
+    const float s11 = Sgn(bot + right + c);
+    return Straddles(s00, s01, s10, s11);
+}
+
+// Block-wide ordered rank of a predicate (NW waves).  s_part must hold NW words.
+// Contains two barriers.
+template <int NW>
+__device__ __forceinline__ uint32_t BlockRank(bool pred, uint32_t *s_part, uint32_t *total) {
+    const uint64_t m = __ballot(pred);
+    const uint32_t wave = threadIdx.x >> 6;
+    if (LaneId() == 0) s_part[wave] = static_cast<uint32_t>(__popcll(m));
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const uint32_t v = s_part[w];
+        if (w < static_cast<int>(wave)) base += v;
+        tot += v;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + RankBelow(m);
+}
+
+// Block-wide exclusive scan of arbitrary u32 values.  Two barriers.
+template <int NW>
+__device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_part, uint32_t *total) {
+    const uint32_t incl = WaveInclusiveScan(v);
+    const uint32_t wave = threadIdx.x >> 6;
+    if (LaneId() == 63) s_part[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const uint32_t x = s_part[w];
+        if (w < static_cast<int>(wave)) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// bit k of an 8-bit value -> bit 4k
+__device__ __forceinline__ uint32_t SpreadNibbles(uint32_t x) {
+    x = (x | (x << 12)) & 0x000f000fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x;
+}
+// cross-lane moves inside groups of 4 / 8 lanes (DPP: no LDS traffic)
+__device__ __forceinline__ uint32_t DppQuadXor1(uint32_t v) {  // quad_perm [1,0,3,2]
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ uint32_t DppQuadXor2(uint32_t v) {  // quad_perm [2,3,0,1]
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x4E, 0xf, 0xf, true));
+}
+__device__ __forceinline__ uint32_t DppHalfMirror(uint32_t v) {  // row_half_mirror: lane i <-> 7 - i of each 8
+    return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x141, 0xf, 0xf, true));
+}
+
+// Largest c in [0, n) with off[c] <= e (off ascending, off[0] == 0, n >= 1).
+__device__ __forceinline__ uint32_t FindOwner(const uint32_t *off, uint32_t n, uint32_t e) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+
+// Launch helper.  With (t0, t1) the dispatch itself carries the two events
+// (hipExtLaunchKernelGGL): their timestamps are the dispatch's own begin / end, what a
+// kernel trace shows, and no extra packet goes on the queue.
+#define PM_LAUNCH(kernel, grid, block, stream, t0, t1, ...)                                        \
+    do {                                                                                           \
+        if (t0)                                                                                    \
+            hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, t0, t1, 0, __VA_ARGS__);         \
+        else                                                                                       \
+            hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                       \
+    } while (0)
+
+}  // namespace
+
+}  // namespace pm

@@ -512,7 +512,7 @@ def test_non_finite_coordinates_do_not_hang(pm, renderer):
 @pytest.mark.parametrize("seed,n,extent,w,h", [(20206, 279, 400.0, 1424, 398), (20740, 417, 900.0, 1173, 1384)])
 def test_fuzz_regressions(pm, pmo, renderer, seed, n, extent, w, h):
     """Scenes a 2 000-scene fuzz run found one pixel off by one in: `half(area * wd)` had been
-    fused into v_fma_mixlo_f16, which rounds once instead of twice (ToHalf in pm_kernels.hip)."""
+    fused into v_fma_mixlo_f16, which rounds once instead of twice (ToHalf in pm_fine.hip)."""
     # (generated with the colour mask the fuzz tool had that day: mostly translucent items)
     scene = encode_ops(pm, random_ops(seed, n, extent=extent, opaque_mask=0xFF000000), cap=4 << 20)
     assert np.array_equal(gpu_render(renderer, scene, w, h), pmo.render(scene, w, h))
