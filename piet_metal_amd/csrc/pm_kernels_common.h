@@ -1,6 +1,5 @@
 // Shared by pm_bin.hip, pm_coarse.hip and pm_fine.hip -- hand-written HIP kernels for gfx950
-// (CDNA4, wave64): the compute path of
-// piet-metal re-designed for MI355X.
+// (CDNA4, wave64): the compute path of piet-metal re-designed for MI355X.
 //
 // Reference semantics being reproduced (bit-exact against oracle/):
 //   tileKernel   TestApp/PietRender.metal:160-454  (+ TileEncoder :69-157)
@@ -8,7 +7,7 @@
 //   composite    TestApp/PietRender.metal:16-44
 //
 // Decomposition (NOT the reference's thread-per-tile / 256 MiB tile buffer) -- one kernel per
-// level of parallelism, chained by events over the frame pipeline of pm_context.hip:
+// level of parallelism, launched back to back on the frame's stream by pm_context.hip:
 //
 //   pm_index_kernel   (once per scene) float bounding box of every chunk of 8 consecutive
 //       segments -- the segment-level analogue of the ShortBbox array the encoder builds per item.
@@ -24,7 +23,8 @@
 //         segment can matter to, and for fills the backdrop step;
 //       - per (item, tile) counts and backdrops, the TileEncoder solid rule per tile, the
 //         command-list space of every tile and its place in one of three class queues.
-//   pm_clear_kernel   pixels of the tiles binning resolved (background / one opaque colour).
+//   (clearing)        pixels of the tiles binning resolved (background / one opaque colour): extra
+//       workgroups of pm_fine_kernel's launch (or pm_clear_kernel with PM_FOLD_CLEAR=0).
 //   pm_coarse_kernel  persistent; ONE WAVE PER QUEUED TILE, no workgroup barriers.
 //       - candidates are filtered by a per-tile hit bit; the record's slots carrying the tile's
 //         bit are gathered in paint order; each lane runs the reference's "phase 2" test for
