@@ -411,42 +411,52 @@ __global__ __launch_bounds__(kThreads, PM_FINE_WPS) void pm_fine_kernel(FramePar
             const uint32_t pyi = y0 + prow;
             const bool lane_on = !quarter || (lane >> 4) < nrows;
             const float px0 = static_cast<float>(pxi), py = static_cast<float>(pyi);
-            PixelState1 s1;
-            s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
-            s1.df = 1e9f;
-            s1.sa = static_cast<_Float16>(0.0f);
-            PixelState st;
-            st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = Splat(static_cast<_Float16>(1.0f));
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                st.df[k] = 1e9f;
-                st.sa[k] = static_cast<_Float16>(0.0f);
-            }
-            for (uint32_t c0 = 0; c0 < n_cmd; c0 += kFineChunk) {
-                const uint32_t m = min(kFineChunk, n_cmd - c0);
+            uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
+            // stage the list through LDS in chunks (24-byte commands, 8-byte aligned: copied as
+            // 64-bit words, coalesced) and interpret; the interpreter state stays in registers
+            auto stage = [&](uint32_t c0, uint32_t m) {
                 WaveSync();
-                // 24-byte commands, 8-byte aligned: copy as 64-bit words, coalesced
                 const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
                 uint2 *l = reinterpret_cast<uint2 *>(cmds);
                 for (uint32_t w = lane; w < 3u * m; w += 64u) l[w] = g[w];
                 WaveSync();
-                if (quarter) Interpret1(cmds, m, px0, py, s1);
-                else Interpret(cmds, m, px0, py, st);
-            }
-            uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
-            if (quarter) {
+            };
+            if (quarter) {  // (the two pixel layouts keep their state in separate live ranges)
+                PixelState1 s1;
+                s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
+                s1.df = 1e9f;
+                s1.sa = static_cast<_Float16>(0.0f);
+                for (uint32_t c0 = 0; c0 < n_cmd; c0 += kFineChunk) {
+                    const uint32_t m = min(kFineChunk, n_cmd - c0);
+                    stage(c0, m);
+                    Interpret1(cmds, m, px0, py, s1);
+                }
                 if (lane_on && pyi < P.height && pxi < P.width) *reinterpret_cast<uint32_t *>(dst) = enc(s1.r, s1.g, s1.b);
-            } else if (pyi < P.height && pxi < P.width) {
-                uint4 out;
-                out.x = enc(st.r01.x, st.g01.x, st.b01.x);
-                out.y = enc(st.r01.y, st.g01.y, st.b01.y);
-                out.z = enc(st.r23.x, st.g23.x, st.b23.x);
-                out.w = enc(st.r23.y, st.g23.y, st.b23.y);
-                if (pxi + 4 <= P.width && P.fb_vec16) {
-                    *reinterpret_cast<uint4 *>(dst) = out;
-                } else {
-                    const uint32_t o[4] = {out.x, out.y, out.z, out.w};
-                    for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = o[k];
+            } else {
+                PixelState st;
+                st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = Splat(static_cast<_Float16>(1.0f));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    st.df[k] = 1e9f;
+                    st.sa[k] = static_cast<_Float16>(0.0f);
+                }
+                for (uint32_t c0 = 0; c0 < n_cmd; c0 += kFineChunk) {
+                    const uint32_t m = min(kFineChunk, n_cmd - c0);
+                    stage(c0, m);
+                    Interpret(cmds, m, px0, py, st);
+                }
+                if (pyi < P.height && pxi < P.width) {
+                    uint4 out;
+                    out.x = enc(st.r01.x, st.g01.x, st.b01.x);
+                    out.y = enc(st.r01.y, st.g01.y, st.b01.y);
+                    out.z = enc(st.r23.x, st.g23.x, st.b23.x);
+                    out.w = enc(st.r23.y, st.g23.y, st.b23.y);
+                    if (pxi + 4 <= P.width && P.fb_vec16) {
+                        *reinterpret_cast<uint4 *>(dst) = out;
+                    } else {
+                        const uint32_t o[4] = {out.x, out.y, out.z, out.w};
+                        for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = o[k];
+                    }
                 }
             }
         }
