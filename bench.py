@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """bench.py -- the metric BASELINE.json names: Mpixels/s on the Ghostscript Tiger at
-3840x2160 (fills + strokes, BASELINE config 3), 1/2/4/8 GPUs, with the HBM-roofline
+3840x2160 (fills + strokes, BASELINE config 3) on 1/2/4/8 GPUs, with the HBM-roofline
 fraction of the dominant kernel and the CPU oracle timed beside it.
 
     python bench.py --gpus N --steps K --warmup W
@@ -8,26 +8,32 @@ fraction of the dominant kernel and the CPU oracle timed beside it.
 A "step" is one frame of the hot path -- pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel
 (tileKernel + renderKernel + composite of the reference) -- over the scene already
 resident in HBM (flatten/encode happens once per scene, like the reference encodes once
-per resize, PietRenderer.m:145).  Frames are submitted back to back without waiting,
-as the reference commits command buffers (PietRenderer.m:102): up to four frames are in
-flight on four in-order streams, so `value` is frames completed per second x pixels;
-the latency of one frame alone is reported next to it (roofline.frame_latency_ms).
+per resize, PietRenderer.m:145; its cost is reported as scene.*).
 
-N = 1 : one 3840x2160 Tiger frame per step.
-N > 1 : weak scaling -- the viewport is 3840 x (2160*N) with one Tiger per 2160-row
-        band; rank r renders the tile rows of band r (the scene is replicated; the path
-        has no exchange step, so there is no collective in the timed region and every
-        band stays in its GPU's HBM, exactly as the frame does at N = 1).
-        value = all pixels of all ranks / time of the slowest rank.
-        The one collective of the design -- gathering the bands to rank 0 over RCCL/xGMI
-        for presentation -- is timed separately after the run and reported as
-        config.gather_ms (--gather puts it into every step instead).
+Two figures, both top level and both named:
+  value               W*H / t_frame, t_frame = ONE frame alone, first kernel begin to last
+                      kernel end, from the dispatches' own timestamps, median over the K timed
+                      steps' worth of frames (>= 100).  The contract metric.
+  sustained_mpix_s    W*H / (wall time of the K timed steps / K): frames submitted back to
+                      back without waiting, as the reference commits command buffers
+                      (PietRenderer.m:102); up to four frames overlap on four in-order streams.
+                      ms_per_step is this wall time per step.
+
+N > 1 (one process per GPU, torch.distributed.run): STRONG scaling of the same 3840x2160
+frame -- rank r renders a band of tile rows (cost-balanced cuts from measured band times),
+and every step ends with the one collective of the design: the bands are gathered straight
+into the final image on rank 0 (one grouped send/recv over RCCL/xGMI).  value is then
+W*H / t_frame_e2e with t_frame_e2e = one step alone, host-timed around render + gather +
+device sync, MAX over ranks; t_render (slowest rank's band), t_gather and the sustained
+end-to-end rate are reported next to it.  A "config5" block carries the same measurements
+for BASELINE config 5 (8192^2 grid of 25 Tigers), where the frame is big enough to shard.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -36,19 +42,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-
-
-def stacked_tigers(pm, n: int):
-    """n Tigers at the config-3 scale (10.8), one per 2160-row band."""
-    wl = pm.workloads.tiger(3840, 2160)
-    if n == 1:
-        return wl
-    scale = wl.width_scale
-    sets = [wl.paths.transformed((1.0, 0.0, 0.0, 1.0, 0.0, 2160.0 * k / scale)) for k in range(n)]
-    wl.paths = pm.PathSet.concat(sets)
-    wl.height = 2160 * n
-    wl.name = f"tiger_3840x2160_x{n}"
-    return wl
 
 
 def cpu_baseline(pm, wl_single, seconds_budget: float = 12.0):
@@ -91,12 +84,147 @@ def cpu_baseline(pm, wl_single, seconds_budget: float = 12.0):
     return out
 
 
+class Job:
+    """One workload on this rank's GPU: scene resident, band set, buffers for the gather."""
+
+    def __init__(self, pm, pmd, torch, dist, r, wl, rank, world, local, args):
+        self.pm, self.pmd, self.torch, self.dist = pm, pmd, torch, dist
+        self.r, self.wl, self.rank, self.world, self.local, self.args = r, wl, rank, world, local, args
+        t0 = time.perf_counter()
+        r.resize(wl.width, wl.height)
+        self.scene_bytes, self.n_items = r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        r.render()
+        r.sync()
+        self.first_frame_ms = (time.perf_counter() - t0) * 1e3  # fused: flatten + encode + index + arena + frame 1
+        self.scene_t = r.scene_timings()
+        self.cuts = None
+        self.layout = pmd.band_layout(wl.height, world)
+        self.band = self.full = self.pad = self.scratch = None
+        self.stream = torch.cuda.current_stream()
+        self.balance_log = []
+        if world > 1:
+            self._set_cuts([b[0] for b in self.layout] + [self.layout[-1][1]])
+            if not args.equal_bands:
+                for _ in range(3):
+                    ms = self._all_band_ms()
+                    self.balance_log.append({"cuts": list(self.cuts), "band_ms": [round(v, 4) for v in ms]})
+                    new = pmd.balanced_cuts(self.cuts, ms)
+                    if new == self.cuts:
+                        break
+                    self._set_cuts(new)
+            self._alloc()
+
+    # ---- bands -------------------------------------------------------------------------
+    def _set_cuts(self, cuts):
+        self.cuts = list(cuts)
+        self.layout = self.pmd.band_layout(self.wl.height, self.world, self.cuts)
+        r0, r1, _ = self.layout[self.rank]
+        self.r.set_band(r0, r1)
+
+    def _all_band_ms(self):
+        self.r.render()
+        self.r.sync()
+        mine = self.r.frame_latency(30)["median_ms"]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=f"cuda:{self.local}")
+        t[self.rank] = mine
+        self.dist.all_reduce(t)
+        return [float(v) for v in t.tolist()]
+
+    def _alloc(self):
+        torch, wl = self.torch, self.wl
+        dev = f"cuda:{self.local}"
+        r0, _r1, rows = self.layout[self.rank]
+        if self.rank == 0:
+            self.full = torch.zeros((wl.height, wl.width, 4), dtype=torch.uint8, device=dev)
+            self.band = self.full[r0 * 16 : r0 * 16 + rows]  # the root renders straight into the final image
+        else:
+            self.band = torch.zeros((max(rows, 1), wl.width, 4), dtype=torch.uint8, device=dev)
+
+    # ---- one step ----------------------------------------------------------------------
+    def step(self):
+        if self.world == 1:
+            self.r.render()
+            return
+        self.r.render_to(self.band, self.stream)  # caller-owned band on torch's stream: the gather follows in stream order
+        self.gather()
+
+    def gather(self):
+        if self.args.gather_impl == "allgather":
+            if self.pad is None:
+                rows = self.pmd.padded_band_rows(self.wl.height, self.world, self.cuts)
+                self.pad = self.torch.zeros((rows, self.wl.width, 4), dtype=self.torch.uint8, device=self.band.device)
+                self.scratch = self.torch.empty((self.world,) + tuple(self.pad.shape), dtype=self.torch.uint8, device=self.band.device)
+                if self.full is None:
+                    self.full = self.torch.zeros((self.wl.height, self.wl.width, 4), dtype=self.torch.uint8, device=self.band.device)
+            n = self.layout[self.rank][2]
+            self.pad[:n] = self.band[:n]
+            self.pmd.allgather_bands(self.pad, self.layout, self.wl.height, full=self.full, scratch=self.scratch)
+        else:
+            self.pmd.gather_bands(self.band, self.layout, self.wl.height, dst=0, full=self.full)
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.r.sync()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=f"cuda:{self.local}")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- measurements --------------------------------------------------------------------
+    def sustained(self, steps: int, warmup: int, precondition: int):
+        """(elapsed seconds of `steps` steps, MAX over ranks).  `precondition` untimed steps
+        bring clocks, queues and caches to the state a long run has before the counted warm-up."""
+        for _ in range(precondition):
+            self.step()
+        self.fence()
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.fence()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def lone_frame_host_ms(self, n: int) -> float:
+        """One step alone, host-timed around submit + device sync: median, MAX over ranks."""
+        ts = []
+        for _ in range(n):
+            self.fence()
+            t0 = time.perf_counter()
+            self.step()
+            self.r.sync()
+            self.torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return self.max_over_ranks(statistics.median(ts))
+
+    def gather_alone_ms(self, n: int) -> float:
+        if self.world == 1:
+            return 0.0
+        ts = []
+        for _ in range(n):
+            self.fence()
+            t0 = time.perf_counter()
+            self.gather()
+            self.torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return self.max_over_ranks(statistics.median(ts))
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--gather", action="store_true", help="N>1: gather the bands to rank 0 inside every timed step")
+    ap.add_argument("--equal-bands", action="store_true", help="N>1: near-equal tile-row split instead of cost-balanced cuts")
+    ap.add_argument("--gather-impl", choices=["sendrecv", "allgather"], default="sendrecv",
+                    help="N>1: grouped send/recv into the final image (default) or padded all-gather")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default=None, help="rank 0 saves the last gathered frame as .npy (tests)")
     args = ap.parse_args()
@@ -120,6 +248,7 @@ def main() -> int:
         local = 0
     backend = os.environ.get("PM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
+    dist = None
     if world > 1:
         if backend == "nccl":
             pmd.init_process_group("nccl")
@@ -127,161 +256,205 @@ def main() -> int:
             os.environ["LOCAL_RANK"] = str(local)
             pmd.init_process_group(backend)
         import torch.distributed as dist
+    staged = backend != "nccl" and world > 1  # gloo rehearsal: bands travel through host tensors
+    if staged:
+        _patch_for_host_transport(pmd, torch)
 
-    wl = stacked_tigers(pm, world)
     r = pm.Renderer(local)
-    r.resize(wl.width, wl.height)
-    scene_bytes, n_items = r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
-    layout = pmd.band_layout(wl.height, world)
-    r0, r1, rows = layout[rank]
-    if world > 1:
-        r.set_band(r0, r1)
-    pad_rows = pmd.padded_band_rows(wl.height, world)
-    band = torch.zeros((pad_rows, wl.width, 4), dtype=torch.uint8, device=f"cuda:{local}")
-    full = torch.empty((wl.height, wl.width, 4), dtype=torch.uint8, device=f"cuda:{local}") if (world > 1 and rank == 0) else None
-    stream = torch.cuda.current_stream()
-    do_gather = world > 1 and args.gather
+    wl = pm.workloads.tiger(3840, 2160)
+    job = Job(pm, pmd, torch, dist, r, wl, rank, world, local, args)
+    W, H = wl.width, wl.height
+    px = W * H
 
-    def gather_step():
-        r.render_to(band, stream)  # caller-owned band on torch's stream: the gather follows in stream order
-        pmd.gather_framebuffer(band, wl.height, dst=0, full=full)
-
-    def step():
-        if do_gather:
-            gather_step()
-        else:
-            r.render()
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        r.sync()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    gather_ms = None
-    if world > 1:  # the presentation gather, on its own: render into the band tensor + gather
-        for _ in range(2):
-            gather_step()
-        fence()
-        tg = time.perf_counter()
-        n_g = 10
-        for _ in range(n_g):
-            gather_step()
-        fence()
-        t = torch.tensor([(time.perf_counter() - tg) / n_g * 1e3], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        gather_ms = float(t.item())
-
-    # per-kernel durations with HIP events on the stream the kernels run on (ctx stream)
-    # (a) inside the pipelined batch, i.e. under the conditions of the timed region;
-    # (b) each kernel alone on the GPU (frames serialized on one stream)
-    tm = r.time_frames(max(10, min(args.steps, 2000)), pipelined=True)
-    alone = r.time_frames(20)
-    lat = r.frame_latency(100)
-    n_overlapped, n_serial = args.warmup + args.steps + tm["iters"], alone["iters"] + lat["iters"]
-    st = r.stats()
-    band_px = wl.width * rows
-    total_px = wl.width * wl.height
+    precondition = max(0, min(300, 3000 // max(1, world * world)))
+    elapsed = job.sustained(args.steps, args.warmup, precondition)
     ms_per_step = elapsed / args.steps * 1e3
-    value = total_px / (elapsed / args.steps) / 1e6
+    sustained = px / (elapsed / args.steps) / 1e6
+
+    n_lat = max(100, min(args.steps, 400))
+    t_frame_host = job.lone_frame_host_ms(min(n_lat, 100))
+    if world == 1:
+        lat = r.frame_latency(n_lat)
+        t_frame = lat["median_ms"]
+        t_render, t_gather = t_frame, 0.0
+        tm = r.time_frames(max(10, min(args.steps, 2000)), pipelined=True)
+        alone = r.time_frames(20)
+        n_overlapped, n_serial = precondition + args.warmup + args.steps + tm["iters"], alone["iters"] + lat["iters"] + min(n_lat, 100) + 1
+    else:
+        # band render alone (kernel timestamps), slowest rank; the gather alone; one whole step alone
+        job.r.render_to(job.band, job.stream)
+        job.fence()
+        lat = r.frame_latency(n_lat)
+        t_render = job.max_over_ranks(lat["median_ms"])
+        t_gather = job.gather_alone_ms(30)
+        t_frame = t_frame_host
+        tm = r.time_frames(max(10, min(args.steps, 500)), pipelined=True)
+        alone = r.time_frames(20)
+        n_overlapped = n_serial = 1
+    st = r.stats()
+    value = px / (t_frame * 1e-3) / 1e6
+
+    cfg5 = None
+    if not args.no_config5:
+        cfg5 = config5_block(pm, pmd, torch, dist, r, rank, world, local, args)
 
     if rank == 0:
-        # algorithmic bytes of one launch of the dominant kernel = one frame of this
-        # rank's band: scene read once + every RGBA8 pixel written once
-        b_alg = scene_bytes + 4 * band_px
+        rows = job.layout[rank][2]
+        b_alg = job.scene_bytes + 4 * W * rows  # this rank's launch: scene read once + its pixels written once
+        b_alg_frame = world * job.scene_bytes + 4 * px
         kernels = {"pm_bin_kernel": tm["bin_ms"], "pm_coarse_kernel": tm["coarse_ms"], "pm_fine_kernel": tm["fine_ms"], "pm_clear_kernel": tm["clear_ms"]}
-        dom = max(kernels, key=kernels.get)
-        dom_ms = kernels[dom]
-        achieved = b_alg / (dom_ms * 1e-3) / 1e9
         alone_ms = {"pm_bin_kernel": alone["bin_ms"], "pm_coarse_kernel": alone["coarse_ms"], "pm_fine_kernel": alone["fine_ms"], "pm_clear_kernel": alone["clear_ms"]}
         if kernels["pm_clear_kernel"] == 0:  # folded into pm_fine_kernel's launch
             kernels.pop("pm_clear_kernel")
             alone_ms.pop("pm_clear_kernel")
-        latency_ms = lat["median_ms"]
+        dom = max(kernels, key=kernels.get)
+        dom_ms = kernels[dom]
+        achieved = b_alg / (dom_ms * 1e-3) / 1e9
         pipelined_ms = tm["total_ms"] / tm["iters"]
-        traffic, issue = None, None
+        traffic, traffic_frame, issue = None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and world == 1:
             try:
                 prof = json.load(open(tpath))
                 traffic = prof.get(dom, {}).get("hbm_bytes_per_launch")
-                # The bound this path actually runs against: VALU issue.  A CDNA4 SIMD issues one
-                # wave64 VALU instruction per 4 cycles; instruction counts are the SQ counters of
-                # the committed rocprofv3 PMC passes (profiles/), one launch of each kernel = one frame.
+                per_kernel = [prof[k]["hbm_bytes_per_launch"] for k in kernels if "hbm_bytes_per_launch" in prof.get(k, {})]
+                if len(per_kernel) == len(kernels):
+                    traffic_frame = {"hbm_bytes_per_frame": int(sum(per_kernel)), "ratio_to_algorithmic": round(sum(per_kernel) / b_alg, 3)}
                 insts = sum(prof[k]["valu_insts_per_launch"] for k in kernels if "valu_insts_per_launch" in prof.get(k, {}))
                 props = torch.cuda.get_device_properties(local)
                 n_simd = props.multi_processor_count * 4
                 clock_ghz = getattr(props, "clock_rate", 2400000) / 1e6
                 if insts:
-                    floor_ms = insts * 4 / n_simd / (clock_ghz * 1e9) * 1e3
-                    issue = {"bound": "valu-issue", "valu_wave_insts_per_frame": insts, "simds": n_simd, "cycles_per_inst": 4,
-                             "clock_ghz": round(clock_ghz, 3), "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / ms_per_step, 4),
+                    # CDNA4 SIMDs are 32 lanes wide: a wave64 VALU instruction issues in 2 cycles
+                    # (MI355X_MICROARCH.md, per-instruction constants); counts = SQ_INSTS_VALU of
+                    # the committed PMC passes, one launch of each kernel = one frame
+                    floor_ms = insts * 2 / n_simd / (clock_ghz * 1e9) * 1e3
+                    issue = {"bound": "valu-issue", "valu_wave_insts_per_frame": insts, "simds": n_simd, "cycles_per_inst": 2,
+                             "clock_ghz": round(clock_ghz, 3), "floor_ms": round(floor_ms, 5),
+                             "frac_sustained": round(floor_ms / ms_per_step, 4), "frac_lone_frame": round(floor_ms / t_frame, 4),
                              "source": prof.get("_source")}
             except Exception:
-                traffic, issue = None, None
+                traffic, traffic_frame, issue = None, None, None
         out = {
-            "metric": "Mpixels/s, Ghostscript Tiger 3840x2160 (fills+strokes)",
+            "metric": "Mpixels/s, Ghostscript Tiger 3840x2160 (fills+strokes): W*H / t_frame",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "t_frame_ms": round(t_frame, 5),
+            "value_definition": ("W*H / t_frame; t_frame = one frame alone, first kernel begin to last kernel end, dispatch timestamps, median of "
+                                 f"{lat['iters']} (SURVEY.md 8d)") if world == 1 else
+                                ("W*H / t_frame_e2e; one step alone = band render + gather into the final image on rank 0 + device sync, host-timed, "
+                                 "median, MAX over ranks (includes launch and RCCL latency; compare with t_frame_host_ms at N=1)"),
+            "sustained_mpix_s": round(sustained, 1), "ms_per_step": round(ms_per_step, 5),
+            "sustained_definition": "W*H / (wall time of the K timed steps / K), steps submitted back to back, barrier + device sync on both sides, MAX over ranks"
+                                    + ("" if world == 1 else "; every step ends with the gather to rank 0"),
+            "t_frame_host_ms": round(t_frame_host, 5),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 geometry + f16 accumulators (as the reference)", "data": "synthetic: embedded Ghostscript_Tiger.svg, scale 10.8, flattened on device",
             "config": {
-                "workload": "BASELINE config 3: Ghostscript Tiger 3840x2160, fills + strokes" + ("" if world == 1 else f", one Tiger per 2160-row band x {world} (weak scaling)"),
-                "viewport": [wl.width, wl.height], "items": n_items, "scene_bytes": scene_bytes,
-                "parallelism": "1 GPU" if world == 1 else f"tile-row bands x{world}, scene replicated, " + ("RCCL gather of bands to rank 0 every step" if do_gather else "no collective in the timed region (bands stay resident, as the frame does at N=1)"),
-                "gather_ms": None if gather_ms is None else round(gather_ms, 4),
-                "queued_tiles_rank0": st["queued_tiles"],
+                "workload": "BASELINE config 3: Ghostscript Tiger 3840x2160, fills + strokes",
+                "viewport": [W, H], "items": job.n_items, "scene_bytes": job.scene_bytes,
+                "parallelism": "1 GPU" if world == 1 else f"tile-row bands x{world} ({'near-equal' if args.equal_bands else 'cost-balanced'} cuts), scene replicated, "
+                               f"{'grouped send/recv' if args.gather_impl == 'sendrecv' else 'padded all-gather'} of the bands into the final image on rank 0 in every step",
+                "band_cuts": job.cuts, "balance": job.balance_log or None,
+                "t_render_ms": round(t_render, 5), "t_gather_ms": round(t_gather, 5), "t_frame_e2e_ms": round(t_frame_host, 5),
+                "queued_tiles_rank0": st["queued_tiles"], "precondition_steps": precondition,
+            },
+            "scene": {
+                "flatten_encode_ms": round(job.scene_t["flatten_encode_ms"], 4), "scene_index_host_ms": round(job.scene_t["scene_index_ms"], 4),
+                "arena_setup_host_ms": round(job.scene_t["arena_setup_ms"], 4), "first_frame_ms": round(job.first_frame_ms, 4),
+                "note": "once per scene, like the reference encodes once per resize (PietRenderer.m:145): flatten_encode = pm_flatten_and_encode's four kernels + "
+                        "their read-backs; scene_index = header/item read-back, validation, pm_index_kernel; arena_setup = per-(scene, viewport) sizing on the host, "
+                        "paid by the first frame; first_frame = all of it fused, resize -> first frame complete (host wall clock)",
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_frame": traffic_frame,
                 "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(dom_ms, 5),
                 "kernels_ms": {k: round(v, 5) for k, v in kernels.items()},
                 "kernels_alone_ms": {k: round(v, 5) for k, v in alone_ms.items()},
-                # what `rocprofv3 --kernel-trace --stats` of this command averages per kernel: the
-                # overlapping launches (warm-up + timed steps + the timed batch) at the in-flight
-                # duration, the serialized ones (alone pass + latency pass) at the alone duration
                 "trace_average_ms": {k: round((n_overlapped * kernels[k] + n_serial * alone_ms[k]) / (n_overlapped + n_serial), 5) for k in kernels},
-                "alone_frac": round(b_alg / (max(alone_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "frame_latency_ms": round(latency_ms, 5), "frame_latency_min_ms": round(lat["min_ms"], 5),
-                "frame_latency_frac": round(b_alg / (latency_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "frac_alone": round(b_alg / (max(alone_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "frame_latency_ms": round(t_render, 5),
+                "frac_frame": round(b_alg_frame / world / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "frame_pipelined_ms": round(pipelined_ms, 5),
-                "frame_pipelined_frac": round(b_alg / (pipelined_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "kernels_ms / kernel_ms: per-launch durations inside the overlapping batch (four frames in flight on four streams, as in the timed region), from events carried by the dispatches -- what rocprofv3 --kernel-trace shows; kernels_alone_ms: the same kernels with frames serialized on one stream; frame_latency_ms: one frame with nothing else in flight, first kernel begin to last kernel end (median of 100; SURVEY 8d's t_frame); the path is latency/VALU bound, not HBM bound (DESIGN.md)",
+                "frac_frame_pipelined": round(b_alg / (pipelined_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "achieved/frac: algorithmic bytes of one launch / the dominant kernel's average launch duration INSIDE the overlapping batch "
+                        "(frames in flight on four streams, as in the timed steps; events carried by the dispatches = what rocprofv3 --kernel-trace shows); "
+                        "frac_alone: the same kernels serialized on one stream (non-overlapped denominator); frac_frame: B_alg(N)/N / the slowest rank's "
+                        "lone-frame time (SURVEY 8d multi-GPU roofline); the path is latency/VALU bound, not HBM bound (DESIGN.md)",
             },
         }
         if issue is not None:
             out["issue_roofline"] = issue
+        if cfg5 is not None:
+            out["config5"] = cfg5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pm, pm.workloads.tiger(3840, 2160))
         print(json.dumps(out), flush=True)
-    if args.dump and rank == 0:
+    if args.dump:
+        # the frame of one more step of the main workload (config 5 may have run in between)
         import numpy as np
 
-        img = full if world > 1 else band[: wl.height]
-        if world > 1 and not do_gather:
-            pass  # `full` holds the frame of the separate gather pass above
-        if world == 1:
-            r.render_to(band, stream)
-            torch.cuda.synchronize()
-        np.save(args.dump, img.cpu().numpy())
+        job2 = job if args.no_config5 else Job(pm, pmd, torch, dist, r, wl, rank, world, local, args)
+        job2.step()
+        job2.fence()
+        if rank == 0:
+            img = job2.full if world > 1 else torch.from_numpy(r.read_pixels())
+            np.save(args.dump, img.cpu().numpy())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     r.close()
     return 0
+
+
+def config5_block(pm, pmd, torch, dist, r, rank, world, local, args):
+    """BASELINE config 5: 8192^2 grid of 25 Tigers, tile rows sharded across the ranks, RCCL
+    framebuffer gather -- the same measurements as the main line, fewer iterations."""
+    wl = pm.workloads.config5_tiger_grid()
+    job = Job(pm, pmd, torch, dist, r, wl, rank, world, local, args)
+    px = wl.width * wl.height
+    steps = 40
+    elapsed = job.sustained(steps, 5, 10)
+    if world > 1:
+        job.r.render_to(job.band, job.stream)
+        job.fence()
+    lat = r.frame_latency(30)
+    t_render = job.max_over_ranks(lat["median_ms"])
+    t_gather = job.gather_alone_ms(10)
+    t_e2e = job.lone_frame_host_ms(20)
+    t_frame = t_render if world == 1 else t_e2e
+    b_alg = world * job.scene_bytes + 4 * px
+    return {
+        "workload": "BASELINE config 5: 5x5 Tigers at scale 8, 8192x8192" + ("" if world == 1 else f", tile rows on {world} GPUs + gather to rank 0"),
+        "items": job.n_items, "scene_bytes": job.scene_bytes, "band_cuts": job.cuts,
+        "value": round(px / (t_frame * 1e-3) / 1e6, 1), "t_frame_ms": round(t_frame, 4),
+        "t_render_ms": round(t_render, 4), "t_gather_ms": round(t_gather, 4), "t_frame_e2e_ms": round(t_e2e, 4),
+        "sustained_mpix_s": round(px / (elapsed / steps) / 1e6, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "frac_frame": round(b_alg / world / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        "gather_GBs_into_root": None if world == 1 or t_gather <= 0 else round(4 * px * (world - 1) / world / (t_gather * 1e-3) / 1e9, 1),
+        "flatten_encode_ms": round(job.scene_t["flatten_encode_ms"], 3), "scene_index_host_ms": round(job.scene_t["scene_index_ms"], 3),
+        "arena_setup_host_ms": round(job.scene_t["arena_setup_ms"], 3), "first_frame_ms": round(job.first_frame_ms, 3),
+    }
+
+
+def _patch_for_host_transport(pmd, torch):
+    """gloo rehearsal on one GPU (tests only): the collectives take CPU tensors, so bands are
+    staged through the host around the very same gather_bands / allgather_bands calls."""
+    g0, a0 = pmd.gather_bands, pmd.allgather_bands
+
+    def gather_bands(band, layout, height, dst=0, full=None):
+        out = g0(band.cpu(), layout, height, dst=dst, full=None if full is None else full.cpu())
+        if out is not None and full is not None:
+            full.copy_(out)
+        return full if out is not None else None
+
+    def allgather_bands(pad, layout, height, full=None, scratch=None):
+        out = a0(pad.cpu(), layout, height)
+        if full is not None:
+            full.copy_(out)
+        return full
+
+    pmd.gather_bands, pmd.allgather_bands = gather_bands, allgather_bands
 
 
 if __name__ == "__main__":

@@ -186,6 +186,38 @@ typedef struct {
 } pm_stats;
 int pm_get_stats(pm_ctx *c, pm_stats *out); /* synchronises */
 
+/* ==== 4. multi-GPU presentation (new: the reference is single-device, PietRenderer.m:27) =====
+ * One process and one pm_ctx per GPU, each rendering a band of tile rows (pm_set_band); the
+ * bands meet once, here: a grouped ncclSend/ncclRecv over RCCL (xGMI inside a node) puts every
+ * rank's band straight into its rows of the root's final image.  RCCL is bound
+ * with dlopen at the first call (PM_RCCL_LIB overrides the library name). */
+#define PM_COMM_ID_BYTES 128 /* = sizeof(ncclUniqueId) */
+typedef struct pm_comm pm_comm;
+/* Rank 0 makes the id; the host carries it to the other ranks (file, env, MPI, a torch store). */
+int pm_comm_unique_id(uint8_t id[PM_COMM_ID_BYTES]);
+/* Collective over all `world` ranks (ncclCommInitRank on the context's device). */
+pm_comm *pm_comm_create(pm_ctx *c, const uint8_t id[PM_COMM_ID_BYTES], int rank, int world, int *err);
+void pm_comm_destroy(pm_comm *m);
+/* Collective.  band_tile_rows = {row0, row1} per rank (2*world entries, what each rank passed to
+ * pm_set_band).  src_band = this rank's band (NULL: the context's last frame), tightly packed
+ * rows of width*4 bytes; dst_image (root only) = the full width*4 x height image.  Asynchronous
+ * on hip_stream (NULL: the context's stream); ordered behind the last frame when src_band is NULL. */
+int pm_gather(pm_ctx *c, pm_comm *m, const void *src_band, size_t src_stride, const uint32_t *band_tile_rows, int root,
+              void *dst_image, size_t dst_stride, void *hip_stream);
+
+/* Host wall-clock cost of the last scene replacement ("flatten+encode timed
+ * separately"): the reference does this work once per resize on the CPU (src/lib.rs:286-328,
+ * PietRenderer.m:145) and never times it.
+ *   flatten_encode_ms  pm_flatten_and_encode: the four flatten kernels incl. their scan
+ *                      read-backs and buffer management (0 after pm_upload_scene)
+ *   scene_index_ms     header/item read-back, validation, chunk index (pm_index_kernel)
+ *   arena_setup_ms     per-(scene, viewport, band) binning-arena sizing on the host, paid by the
+ *                      first pm_render after a scene or viewport change */
+typedef struct {
+    float flatten_encode_ms, scene_index_ms, arena_setup_ms;
+} pm_scene_timings;
+int pm_get_scene_timings(pm_ctx *c, pm_scene_timings *out);
+
 /* Debug/parity hook: re-run the last frame's per-tile kernel with command
  * capture and return every tile's command list in the reference's 24-byte
  * format (TestApp/GenTypes.h:430-495), including the trailing End / the lone

@@ -9,12 +9,12 @@ import fails loudly if that library has not been built.
 from . import _lib
 from ._lib import PietMetalError
 from .encoder import Encoder, PathSet, parse_color, scene_cardioid, scene_path_test
-from .renderer import Renderer, init_test_scene
+from .renderer import Comm, Renderer, init_test_scene
 from . import workloads
 
 _lib.load()  # no library => ImportError here, never a silent fallback
 
 __all__ = [
-    "Encoder", "PathSet", "Renderer", "PietMetalError", "init_test_scene", "parse_color",
+    "Comm", "Encoder", "PathSet", "Renderer", "PietMetalError", "init_test_scene", "parse_color",
     "scene_cardioid", "scene_path_test", "workloads",
 ]

@@ -58,6 +58,10 @@ class Stats(C.Structure):
     ]
 
 
+class SceneTimings(C.Structure):
+    _fields_ = [("flatten_encode_ms", C.c_float), ("scene_index_ms", C.c_float), ("arena_setup_ms", C.c_float)]
+
+
 class Cmd(C.Structure):
     _fields_ = [("tag", C.c_uint32), ("body", C.c_uint32 * 5)]
 
@@ -107,6 +111,11 @@ SIGNATURES = {
     "pm_frame_latency": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_time_frames_pipelined": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "pm_get_scene_timings": (C.c_int, [C.c_void_p, C.POINTER(SceneTimings)]),
+    "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "pm_comm_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "pm_comm_destroy": (None, [C.c_void_p]),
+    "pm_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pm_debug_capture_ptcl": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pm_debug_time_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "pm_debug_time_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -161,7 +162,8 @@ struct FrameSlot {
     hipEvent_t ev_done = nullptr;  // end of the slot's last frame
     bool in_flight = false;        // a frame using this slot was submitted; ev_done marks its end
     pm::FrameParams params{};
-    hipStream_t frame_stream = nullptr;  // stream the slot's last frame ran on
+    hipStream_t frame_stream = nullptr;  // stream the slot's last frame ran on (compared, never dereferenced, if user_stream)
+    bool user_stream = false;            // the frame ran on a caller-owned stream: ev_done was recorded behind it at submit
 };
 
 struct pm_ctx {
@@ -170,6 +172,7 @@ struct pm_ctx {
     std::vector<hipStream_t> streams;  // frame N runs on streams[N % n]; stream == streams[0]
     bool fold_clear = true;  // pm_fine_kernel's launch also writes the resolved tiles (no pm_clear_kernel launch)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
+    uint32_t fine_sparse = 1; // row-sparse Fill evaluation (PM_FINE_SPARSE=0: the straightforward interpreter)
     uint32_t coarse_wg_per_cu = 6, fine_wg_per_cu = 4;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
@@ -209,6 +212,9 @@ struct pm_ctx {
     uint32_t frame = 0;
     int last_slot = -1;  // slot of the most recently submitted frame
 
+    // wall-clock cost of the last scene replacement, host view (pm_get_scene_timings)
+    float t_flatten_ms = 0, t_index_ms = 0, t_arena_ms = 0;
+
     // tables
     uint32_t *d_lut_srgb2lin = nullptr;
     uint32_t *d_lut_unorm2h = nullptr;
@@ -217,13 +223,23 @@ struct pm_ctx {
 
 namespace {
 
+struct WallTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    float ms() const { return std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 uint32_t BandRows(const pm_ctx *c) { return c->row1 - c->row0; }
 size_t BandTiles(const pm_ctx *c) { return std::max<size_t>(static_cast<size_t>(BandRows(c)) * c->tiles_x, 1); }
 
+// Waits for everything this context submitted.  A caller-owned stream (pm_render_to) is never
+// touched after submission -- the caller may have destroyed it: the slot's event, recorded behind
+// the frame at submit time, is waited on instead.
 int SyncAll(pm_ctx *c) {
     for (hipStream_t q : c->streams) PM_TRY(hipStreamSynchronize(q));
-    for (auto &s : c->slot)
-        if (s.in_flight && s.frame_stream) PM_TRY(hipStreamSynchronize(s.frame_stream));  // (a caller's stream)
+    for (auto &s : c->slot) {
+        if (s.in_flight && s.user_stream) PM_TRY(hipEventSynchronize(s.ev_done));
+        s.in_flight = false;
+    }
     return PM_OK;
 }
 
@@ -327,6 +343,7 @@ void StripRowBounds(const pm_ctx *c, std::vector<uint64_t> *need) {
 int EnsureArena(pm_ctx *c) {
     if (!c->arena_dirty && c->slot[0].d_arena) return PM_OK;
     if (c->item_meta.empty() || c->tiles_x == 0) return PM_OK;  // nothing to size against yet
+    const WallTimer timer;
     PM_TRY(SyncAll(c) == PM_OK ? hipSuccess : hipErrorUnknown);
     std::vector<uint64_t> need;
     StripRowBounds(c, &need);
@@ -444,6 +461,7 @@ int EnsureArena(pm_ctx *c) {
         }
     }
     c->arena_dirty = false;
+    c->t_arena_ms = timer.ms();
     return PM_OK;
 }
 
@@ -494,6 +512,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->band_item = c->d_band_item;
     p->n_band_items = c->n_band_items;
     p->split_mode = c->split_mode;
+    p->fine_sparse = c->fine_sparse;
     p->fine_grid = FineGrid(c);
     p->use_row_lists = c->use_row_lists ? 1u : 0u;
     p->row_base = c->d_row_base;
@@ -524,6 +543,7 @@ uint32_t FineGrid(const pm_ctx *c) {
 void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t frame_stream) {
     FrameSlot *s = &c->slot[si];
     s->in_flight = true;
+    s->user_stream = false;
     s->params = p;
     s->frame_stream = frame_stream;
     s->parity ^= 1u;
@@ -550,14 +570,14 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     // (no event is recorded per frame: one recorded on the other stream when the need arises
     //  marks the end of everything submitted there so far, the slot's frame included)
     if (s->in_flight && s->frame_stream != q) {
-        PM_TRY(hipEventRecord(s->ev_done, s->frame_stream));
+        if (!s->user_stream) PM_TRY(hipEventRecord(s->ev_done, s->frame_stream));
         PM_TRY(hipStreamWaitEvent(q, s->ev_done, 0));
     }
     // frames that target the same caller-owned buffer must not overlap each other
     if (c->last_slot >= 0 && c->last_slot != si) {
         FrameSlot &l = c->slot[c->last_slot];
         if (l.in_flight && l.params.fb == fb && l.frame_stream != q) {
-            PM_TRY(hipEventRecord(l.ev_done, l.frame_stream));
+            if (!l.user_stream) PM_TRY(hipEventRecord(l.ev_done, l.frame_stream));
             PM_TRY(hipStreamWaitEvent(q, l.ev_done, 0));
         }
     }
@@ -568,6 +588,8 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     pm::LaunchFine(p, c->fold_clear ? n_striprows : 0u, q, t[6], t[7]);  // (+ the resolved tiles' pixels)
     PM_TRY(hipGetLastError());
     Submitted(c, si, p, q);
+    s->user_stream = user_stream != nullptr && std::find(c->streams.begin(), c->streams.end(), q) == c->streams.end();
+    if (s->user_stream) PM_TRY(hipEventRecord(s->ev_done, q));  // the only handle kept on a caller's stream
     return PM_OK;
 }
 
@@ -618,15 +640,29 @@ int BuildSceneIndex(pm_ctx *c) {
     return PM_OK;
 }
 
+// A scene replacement starts by forgetting the old scene: if the upload, the flatten kernels or
+// the validation fail, no later pm_render can pair the old item count / index / arena bounds
+// with new, unvalidated device bytes (BuildParams refuses to render without a scene).
+void InvalidateScene(pm_ctx *c) {
+    c->scene_bytes = 0;
+    c->n_items = 0;
+    c->n_chunks = 0;
+    c->item_meta.clear();
+    c->last_slot = -1;
+    c->arena_dirty = true;
+}
+
 int SetScene(pm_ctx *c, size_t bytes) {
     // keep a host copy of header + bboxes + items for validation and arena sizing
     if (bytes < 8) return PM_ERR_SCENE;
+    const WallTimer timer;
     uint32_t hdr[2];
     PM_TRY(hipMemcpyAsync(hdr, c->d_scene, 8, hipMemcpyDeviceToHost, c->stream));
     PM_TRY(hipStreamSynchronize(c->stream));
     const uint64_t meta_len = static_cast<uint64_t>(hdr[1]) + 32ull * hdr[0];
     if (meta_len > bytes || hdr[1] < 8ull + 8ull * hdr[0]) {
         SetError("scene header out of range");
+        InvalidateScene(c);
         return PM_ERR_SCENE;
     }
     c->item_meta.resize(meta_len);
@@ -636,18 +672,28 @@ int SetScene(pm_ctx *c, size_t bytes) {
     const int r = ValidateScene(c->item_meta.data(), c->item_meta.size(), bytes, &n);
     if (r != PM_OK) {
         SetError("scene buffer failed validation");
-        c->scene_bytes = 0;
+        InvalidateScene(c);
         return r;
     }
-    c->scene_bytes = bytes;
     c->n_items = n;
     c->arena_dirty = true;
     c->last_slot = -1;
-    return BuildSceneIndex(c);
+    const int ri = BuildSceneIndex(c);
+    if (ri != PM_OK) {
+        InvalidateScene(c);
+        return ri;
+    }
+    c->scene_bytes = bytes;  // only now is there a scene to render
+    c->t_index_ms = timer.ms();
+    return PM_OK;
 }
 
 int ReserveScene(pm_ctx *c, size_t cap) {
     if (cap <= c->scene_cap) return PM_OK;
+    if (cap > 0xffffffffull) {  // offsets in the scene format (and in the kernels' bounds checks) are u32
+        SetError("scene buffers are limited to 4 GiB - 1 (u32 offsets in the scene format)");
+        return PM_ERR_CAPACITY;
+    }
     uint8_t *h = nullptr, *d = nullptr;
     PM_TRY(hipHostMalloc(&h, cap, hipHostMallocDefault));
     hipError_t e = hipMalloc(&d, cap);
@@ -671,6 +717,36 @@ int ReserveScene(pm_ctx *c, size_t cap) {
 }
 
 }  // namespace
+
+// ---- what pm_gather.hip needs to know about a context -------------------------------------
+namespace pm {
+void SetLastError(const std::string &s) { SetError(s); }
+int ContextDevice(const pm_ctx *c) { return c->device; }
+hipStream_t ContextStream(pm_ctx *c) { return c->stream; }
+int ContextViewport(const pm_ctx *c, uint32_t *width, uint32_t *height, uint32_t *row0, uint32_t *row1) {
+    if (!c || c->tiles_x == 0) return PM_ERR_INVALID;
+    *width = c->width;
+    *height = c->height;
+    *row0 = c->row0;
+    *row1 = c->row1;
+    return PM_OK;
+}
+// The last frame's framebuffer; work submitted to gather_stream after this call runs behind the frame.
+int ContextLastFrame(pm_ctx *c, const void **fb, size_t *stride, hipStream_t gather_stream) {
+    if (!c || c->last_slot < 0) {
+        SetError("pm_gather: no frame rendered yet");
+        return PM_ERR_INVALID;
+    }
+    FrameSlot &s = c->slot[c->last_slot];
+    if (s.in_flight && s.frame_stream != gather_stream) {
+        if (!s.user_stream) PM_TRY(hipEventRecord(s.ev_done, s.frame_stream));
+        PM_TRY(hipStreamWaitEvent(gather_stream, s.ev_done, 0));
+    }
+    *fb = s.params.fb;
+    *stride = s.params.fb_stride;
+    return PM_OK;
+}
+}  // namespace pm
 
 extern "C" {
 
@@ -722,6 +798,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->stream = c->streams[0];
     c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 6, 1, 16));
     c->split_mode = static_cast<uint32_t>(EnvInt("PM_FINE_SPLIT", 1, 0, 2));
+    c->fine_sparse = static_cast<uint32_t>(EnvInt("PM_FINE_SPARSE", 1, 0, 1));
     c->fold_clear = EnvInt("PM_FOLD_CLEAR", 1, 0, 1) != 0;
     c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 4, 1, 16));
     for (auto &ev : c->ev)
@@ -829,6 +906,8 @@ int pm_upload_scene(pm_ctx *c, size_t bytes) {
     PM_TRY(hipSetDevice(c->device));
     int r = SyncAll(c);  // frames in flight still read the old scene
     if (r != PM_OK) return r;
+    InvalidateScene(c);
+    c->t_flatten_ms = 0;
     PM_TRY(hipMemcpyAsync(c->d_scene, c->h_scene, bytes, hipMemcpyHostToDevice, c->stream));
     return SetScene(c, bytes);
 }
@@ -844,6 +923,8 @@ int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const
     size_t bytes = 0;
     uint32_t items = 0;
     hipError_t he = hipSuccess;
+    InvalidateScene(c);  // the kernels below overwrite d_scene
+    const WallTimer timer;
     int r = pm::FlattenEncodeOnDevice(c->stream, paths, n_paths, els, n_els, affine, width_scale, c->d_scene, c->scene_cap,
                                       &bytes, &items, &he);
     if (r == PM_ERR_CAPACITY && bytes > c->scene_cap) {
@@ -858,6 +939,7 @@ int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const
         SetError("flatten/encode rejected the paths");
         return r;
     }
+    c->t_flatten_ms = timer.ms();
     r = SetScene(c, bytes);
     if (r != PM_OK) return r;
     if (scene_bytes) *scene_bytes = bytes;
@@ -887,34 +969,66 @@ int pm_render_to(pm_ctx *c, void *dev_framebuffer, size_t stride_bytes, void *hi
     return Enqueue(c, static_cast<uint8_t *>(dev_framebuffer), stride_bytes, hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream);
 }
 
+// pm_sync also repairs frames whose command-list arena ran out: pm_bin_kernel marks their tiles
+// "no list", the tile kernels skip them, and the frame is left with holes.  EVERY slot that
+// carried a frame since the last sync is inspected (up to four frames are in flight, and
+// pm_render_to frames each own a caller buffer): the arena grows and each distinct target whose
+// most recent frame overflowed is rendered again, oldest first, so that after PM_OK every
+// framebuffer handed to this context holds a complete frame.  (A caller that synchronises only
+// its own stream never learns of an overflow: pm_sync is the status channel.)
 int pm_sync(pm_ctx *c) {
     if (!c) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
+    auto own_fb = [&](const uint8_t *fb) {
+        for (auto &t : c->slot)
+            if (fb == t.d_fb) return true;
+        return false;
+    };
     for (int attempt = 0; attempt < 6; ++attempt) {
+        // The frame that defines each target's content: per caller-owned buffer the newest frame
+        // submitted since the last sync; of the context's own slot buffers only the last frame's
+        // (the one pm_read_pixels / pm_framebuffer_device_ptr name).  Oldest first.
+        std::vector<int> latest;
+        for (size_t k = 0; k < c->slot.size(); ++k) {
+            const int si = static_cast<int>((c->frame + k) % c->slot.size());  // slot c->frame % n holds the oldest frame
+            const FrameSlot &s = c->slot[si];
+            if (!s.in_flight) continue;
+            if (own_fb(s.params.fb)) {
+                if (si != c->last_slot) continue;
+            } else {
+                latest.erase(std::remove_if(latest.begin(), latest.end(), [&](int o) { return c->slot[o].params.fb == s.params.fb; }),
+                             latest.end());
+            }
+            latest.push_back(si);
+        }
         int r = SyncAll(c);
         if (r != PM_OK) return r;
-        if (c->last_slot < 0) return PM_OK;
-        FrameSlot *s = &c->slot[c->last_slot];
-        pm::Counters k;
-        PM_TRY(hipMemcpy(&k, s->params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
-        if (!k.overflow) return PM_OK;
-        // the command-list arena was too small for this frame: grow it (all slots) and render
-        // the last frame again
-        const uint64_t want = std::min<uint64_t>(0x7fffffffull, std::max<uint64_t>(4ull * s->ptcl_cap, 2ull * k.ptcl_top));
-        if (want <= s->ptcl_cap) break;
+        std::vector<pm::FrameParams> redo;
+        uint64_t want = 0;
+        for (int si : latest) {
+            const FrameSlot &s = c->slot[si];
+            uint32_t overflow = 0, top = 0;
+            PM_TRY(hipMemcpy(&overflow, &s.params.ctr_cur->overflow, sizeof(overflow), hipMemcpyDeviceToHost));
+            if (!overflow) continue;
+            PM_TRY(hipMemcpy(&top, &s.params.ctr_cur->ptcl_top, sizeof(top), hipMemcpyDeviceToHost));
+            want = std::max<uint64_t>(want, std::max<uint64_t>(4ull * s.ptcl_cap, 2ull * top));
+            redo.push_back(s.params);
+        }
+        if (redo.empty()) return PM_OK;
+        want = std::min<uint64_t>(0x7fffffffull, want);
+        if (want <= c->slot[0].ptcl_cap) break;
         for (auto &t : c->slot) {
             if (t.d_ptcl) (void)hipFree(t.d_ptcl);
             t.d_ptcl = nullptr;
             PM_TRY(hipMalloc(&t.d_ptcl, want * sizeof(pm::Cmd)));
             t.ptcl_cap = static_cast<uint32_t>(want);
         }
-        const pm::FrameParams lp = s->params;
-        hipStream_t ts = s->frame_stream;
-        bool own_fb = false;
-        for (auto &t : c->slot) own_fb = own_fb || (lp.fb == t.d_fb);
-        const bool ours = std::find(c->streams.begin(), c->streams.end(), ts) != c->streams.end();
-        r = Enqueue(c, own_fb ? nullptr : lp.fb, lp.fb_stride, (own_fb || ours) ? nullptr : ts);
-        if (r != PM_OK) return r;
+        // render the damaged targets again on the context's own streams (a caller's stream may be
+        // gone by now; the next pass of this loop waits for them and checks them again)
+        for (const pm::FrameParams &p : redo) {
+            r = Enqueue(c, own_fb(p.fb) ? nullptr : p.fb, p.fb_stride, nullptr);
+            if (r != PM_OK) return r;
+        }
     }
     SetError("command-list arena overflow (frame needs more than 2^31 commands)");
     return PM_ERR_CAPACITY;
@@ -961,7 +1075,7 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             if ((r = Enqueue(c, nullptr, c->fb_stride, nullptr)) != PM_OK) return r;
         for (auto &s : c->slot)  // join: the end event follows the last frame of every stream
             if (s.in_flight && s.frame_stream != c->stream) {
-                PM_TRY(hipEventRecord(s.ev_done, s.frame_stream));
+                if (!s.user_stream) PM_TRY(hipEventRecord(s.ev_done, s.frame_stream));
                 PM_TRY(hipStreamWaitEvent(c->stream, s.ev_done, 0));
             }
         PM_TRY(hipEventRecord(c->ev[1], c->stream));
@@ -1019,7 +1133,7 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
     if (r == PM_OK) {
         for (auto &s : c->slot) {
             if (!s.in_flight || s.frame_stream == c->stream) continue;
-            if (e == hipSuccess) e = hipEventRecord(s.ev_done, s.frame_stream);
+            if (e == hipSuccess && !s.user_stream) e = hipEventRecord(s.ev_done, s.frame_stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, s.ev_done, 0);
         }
         if (e == hipSuccess) e = hipEventRecord(c->ev[1], c->stream);
@@ -1101,6 +1215,14 @@ int pm_get_stats(pm_ctx *c, pm_stats *out) {
         out->ptcl_used_cmds = k.ptcl_top;
         out->overflow = k.overflow;
     }
+    return PM_OK;
+}
+
+int pm_get_scene_timings(pm_ctx *c, pm_scene_timings *out) {
+    if (!c || !out) return PM_ERR_INVALID;
+    out->flatten_encode_ms = c->t_flatten_ms;
+    out->scene_index_ms = c->t_index_ms;
+    out->arena_setup_ms = c->t_arena_ms;
     return PM_OK;
 }
 

@@ -100,6 +100,7 @@ struct FrameParams {
     uint32_t n_band_items;
     uint32_t fine_grid;            // persistent workgroups of pm_fine_kernel (blocks beyond it clear strip rows)
     uint32_t split_mode;           // fine kernel: 0 = one wave per tile always, 1 = at most 4 waves, 2 = 1/4/16 by class
+    uint32_t fine_sparse;          // 1 = pm_fine_sparse_kernel (row-sparse Fill evaluation), 0 = pm_fine_kernel
     // large scenes: per-tile-row item lists written each frame by pm_rowcull_kernel
     uint32_t use_row_lists;
     const uint32_t *row_base;      // [band rows + 1] list offsets (host-computed sizes)

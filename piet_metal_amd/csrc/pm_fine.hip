@@ -312,6 +312,322 @@ __device__ __forceinline__ void Interpret1(const Cmd *cmds, uint32_t n, float px
     }
 }
 
+
+// ---- row-sparse Fill evaluation -----------------------------------------------------------
+// A Fill command only changes the pixels of the rows its segment crosses (wx != wy,
+// PietRender.metal:513-514): at Tiger 4K that is 3.4 of a tile's 16 rows on average, yet the
+// straightforward interpreter above runs the whole area integral -- six IEEE divisions per
+// lane -- for all 16.  Here the (command, row) pairs that are live become FRAGMENTS:
+//   pass 1  lane = (Fill command, row), 4 commands x 16 rows per step: the y-only part (window,
+//           both divides of :515-516), live pairs compacted with a ballot into fragment slots;
+//   pass 2  lane = (fragment, 4 adjacent pixels), 16 fragments per step: the x part (:517-527)
+//           exactly as written, the 16 half contributions of a fragment go to LDS;
+//   pass 3  the command loop in list order; a Fill is one LDS read and one packed half add for
+//           the rows named in the 16-bit row mask pass 1 left in the staged command.
+// Every arithmetic expression is the one of Interpret(); only WHICH (command, row) pairs get
+// evaluated changes, and those are exactly the pairs the reference adds a contribution for.
+// Tiles with long lists are rendered by the 4 waves of a workgroup together: passes 1 and 2
+// are split by command batch, pass 3 by pixel rows (1 pixel per lane).
+constexpr uint32_t kSpChunk = 64;   // commands staged per chunk
+constexpr uint32_t kMaxFrag = 128;  // fragment slots per wave (one step of pass 1 adds <= 64)
+
+struct SparseLds {
+    Cmd cmds[kWaves][kSpChunk];
+    float4 fparam[kWaves * kMaxFrag];     // {tx, ty, wx - wy, bits(command index)}
+    uint2 contrib[kWaves * kMaxFrag][4];  // 16 binary16 contributions per fragment (x = 0..15)
+    uint8_t fill_ix[kWaves][kSpChunk];    // indices of the chunk's Fill commands, in order
+};
+
+__device__ __forceinline__ half2_t Half2FromBits(uint32_t b) { return __builtin_bit_cast(half2_t, b); }
+
+// x part of Fill for one pixel (:517-527), then `half(area * (wx - wy))`
+__device__ __forceinline__ _Float16 FillContribution(float fsx, float fex, float px, float tx, float ty, float wd) {
+    const float sx = fsx - px, ex = fex - px;
+    const float xsx = sx + (ex - sx) * tx;
+    const float xsy = sx + (ex - sx) * ty;
+    const float xmin = fminf(fminf(xsx, xsy), 1.0f) - 1e-6f;
+    const float xmax = fmaxf(xsx, xsy);
+    const float b = fminf(xmax, 1.0f);
+    const float c = fmaxf(b, 0.0f);
+    const float d = fmaxf(xmin, 0.0f);
+    const float area = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
+    return ToHalf(area * wd);
+}
+
+// Passes 1 and 2 for the Fill commands [from, ...) of the staged chunk.  Returns the ordinal
+// of the first Fill NOT covered.  kWG: the four waves of the workgroup share the work (two
+// steps of pass 1 each per call) and the call contains two workgroup barriers.
+template <bool kWG>
+__device__ __forceinline__ uint32_t PrepareFills(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t nfill, uint32_t from,
+                                                  uint32_t x0, uint32_t y0) {
+    const uint32_t lane = LaneId(), wave = threadIdx.x >> 6;
+    const uint32_t rb = wave * kMaxFrag;
+    uint32_t nfrag = 0;
+    auto step = [&](uint32_t pos) {
+        const uint32_t q = lane >> 4, row = lane & 15u;
+        const uint32_t fi = pos + q;
+        const bool valid = fi < nfill;
+        const uint32_t ci = fill_ix[valid ? fi : pos];
+        const float py = static_cast<float>(y0 + row);
+        const float sy = __uint_as_float(cmds[ci].body[2]) - py;
+        const float ey = __uint_as_float(cmds[ci].body[4]) - py;
+        const float wx = Sat(sy), wy = Sat(ey);
+        const bool live = valid && wx != wy;
+        const uint64_t mask = __ballot(live);
+        if (mask == 0) return;  // (the staged body[0] of a Fill is 0: no row, nothing to add)
+        if (live) {
+            const float tx = (wx - sy) / (ey - sy);
+            const float ty = (wy - sy) / (ey - sy);
+            S.fparam[rb + nfrag + RankBelow(mask)] = make_float4(tx, ty, wx - wy, __uint_as_float(ci));
+        }
+        if (row == 0 && valid) {
+            const uint32_t gm = static_cast<uint32_t>(mask >> (16u * q)) & 0xffffu;
+            const uint32_t gb = rb + nfrag + static_cast<uint32_t>(__popcll(mask & ((1ull << (16u * q)) - 1ull)));
+            cmds[ci].body[0] = gm | (gb << 16);
+        }
+        nfrag += static_cast<uint32_t>(__popcll(mask));
+    };
+    uint32_t done;
+    if (kWG) {
+        __syncthreads();  // every wave is through with the contributions of the previous call
+#pragma unroll 1
+        for (uint32_t b = 0; b < 2; ++b) {
+            const uint32_t pos = from + 4u * (wave + kWaves * b);
+            if (pos < nfill) step(pos);
+        }
+        done = min(from + 8u * kWaves, nfill);
+    } else {
+        uint32_t pos = from;
+#pragma unroll 1
+        while (pos < nfill && nfrag + 64u <= kMaxFrag) {
+            step(pos);
+            pos += 4u;
+        }
+        done = min(pos, nfill);
+    }
+    WaveSync();
+#pragma unroll 1
+    for (uint32_t f0 = 0; f0 < nfrag; f0 += 16u) {
+        const uint32_t f = f0 + (lane >> 2), g = lane & 3u;
+        if (f < nfrag) {
+            const float4 p = S.fparam[rb + f];
+            const uint32_t ci = __float_as_uint(p.w);
+            const float fsx = __uint_as_float(cmds[ci].body[1]), fex = __uint_as_float(cmds[ci].body[3]);
+            const float px0 = static_cast<float>(x0 + 4u * g);
+            _Float16 h[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = FillContribution(fsx, fex, px0 + static_cast<float>(k), p.x, p.y, p.z);
+            uint2 v;
+            v.x = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[0])) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[1])) << 16);
+            v.y = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[2])) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[3])) << 16);
+            S.contrib[rb + f][g] = v;
+        }
+    }
+    if (kWG) __syncthreads(); else WaveSync();
+    return done;
+}
+
+// Pixels of one lane, whole-tile layout, signedArea packed (the half adds are per element)
+struct PixelStateS {
+    half2_t r01, r23, g01, g23, b01, b23;
+    float df[4];
+    half2_t sa01, sa23;
+};
+
+__device__ __forceinline__ void Blend4S(PixelStateS &st, uint32_t rg, uint32_t ba, half2_t al01, half2_t al23) {
+    const half2_t fga = Splat(HalfFromBits(ba >> 16));
+    const half2_t a01 = fga * al01, a23 = fga * al23;
+    const half2_t fr = Splat(HalfFromBits(rg)), fg = Splat(HalfFromBits(rg >> 16)), fb = Splat(HalfFromBits(ba));
+    st.r01 = st.r01 + (fr - st.r01) * a01; st.r23 = st.r23 + (fr - st.r23) * a23;
+    st.g01 = st.g01 + (fg - st.g01) * a01; st.g23 = st.g23 + (fg - st.g23) * a23;
+    st.b01 = st.b01 + (fb - st.b01) * a01; st.b23 = st.b23 + (fb - st.b23) * a23;
+}
+
+// renderKernel's command loop (:474-560), whole tile per wave (lane -> row lane/4, 4 pixels)
+__device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t n, uint32_t x0, uint32_t y0,
+                                                PixelStateS &st) {
+    const uint32_t lane = LaneId();
+    const uint32_t row = lane >> 2, g = lane & 3u;
+    const float px0 = static_cast<float>(x0 + 4u * g), py = static_cast<float>(y0 + row);
+    // the chunk's Fill commands, in order
+    const bool isf = lane < n && cmds[lane].tag == kCmdFill;
+    const uint64_t fm = __ballot(isf);
+    if (isf) const_cast<uint8_t *>(fill_ix)[RankBelow(fm)] = static_cast<uint8_t>(lane);
+    const uint32_t nfill = static_cast<uint32_t>(__popcll(fm));
+    WaveSync();
+    uint32_t fo = 0, prepared = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Cmd cmd = cmds[i];
+        switch (cmd.tag) {
+            case kCmdCircle: {
+                const float bx0 = static_cast<float>(cmd.body[1] & 0xffffu), by0 = static_cast<float>(cmd.body[1] >> 16);
+                const float bx1 = static_cast<float>(cmd.body[2] & 0xffffu), by1 = static_cast<float>(cmd.body[2] >> 16);
+                const float cx = bx0 + (bx1 - bx0) * 0.5f, cy = by0 + (by1 - by0) * 0.5f;
+                const float circle_r = fminf(cx - bx0, cy - by0);
+                const float dy = py - cy;
+                _Float16 alpha[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dx = (px0 + static_cast<float>(k)) - cx;
+                    alpha[k] = ToHalf(Sat(circle_r - sqrtf(dx * dx + dy * dy)));
+                }
+                const half2_t zero = Splat(static_cast<_Float16>(0.0f));
+                half2_t a01, a23;
+                a01.x = alpha[0]; a01.y = alpha[1]; a23.x = alpha[2]; a23.y = alpha[3];
+                st.r01 = st.r01 + (zero - st.r01) * a01; st.r23 = st.r23 + (zero - st.r23) * a23;
+                st.g01 = st.g01 + (zero - st.g01) * a01; st.g23 = st.g23 + (zero - st.g23) * a23;
+                st.b01 = st.b01 + (zero - st.b01) * a01; st.b23 = st.b23 + (zero - st.b23) * a23;
+                break;
+            }
+            case kCmdLine: {
+                const float sx = __uint_as_float(cmd.body[1]), sy = __uint_as_float(cmd.body[2]);
+                const float ex = __uint_as_float(cmd.body[3]), ey = __uint_as_float(cmd.body[4]);
+                const float lx = ex - sx, ly = ey - sy;
+                const float den = lx * lx + ly * ly;
+                const float dy = py - sy;
+                const float lydy = ly * dy;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dx = (px0 + static_cast<float>(k)) - sx;
+                    const float t = Sat((lx * dx + lydy) / den);
+                    const float fx = lx * t - dx, fy = ly * t - dy;
+                    st.df[k] = fminf(st.df[k], sqrtf(fx * fx + fy * fy));
+                }
+                break;
+            }
+            case kCmdStroke: {
+                const float half_width = __uint_as_float(cmd.body[0]);
+                _Float16 alpha[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    alpha[k] = ToHalf(Sat(half_width + 0.5f - st.df[k]));
+                    st.df[k] = 1e9f;
+                }
+                half2_t a01, a23;
+                a01.x = alpha[0]; a01.y = alpha[1]; a23.x = alpha[2]; a23.y = alpha[3];
+                Blend4S(st, cmd.body[2], cmd.body[3], a01, a23);
+                break;
+            }
+            case kCmdFill: {
+                if (fo >= prepared) prepared = PrepareFills<false>(S, cmds, fill_ix, nfill, fo, x0, y0);  // uniform
+                ++fo;
+                const uint32_t hdr = cmds[i].body[0];  // row mask | first fragment << 16 (pass 1)
+                if ((hdr >> row) & 1u) {
+                    const uint32_t f = (hdr >> 16) + static_cast<uint32_t>(__popc(hdr & ((1u << row) - 1u)));
+                    const uint2 v = S.contrib[f][g];
+                    st.sa01 = st.sa01 + Half2FromBits(v.x);
+                    st.sa23 = st.sa23 + Half2FromBits(v.y);
+                }
+                break;
+            }
+            case kCmdFillEdge: {
+                const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
+                const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
+                st.sa01.x = ToHalf(static_cast<float>(st.sa01.x) + v);
+                st.sa01.y = ToHalf(static_cast<float>(st.sa01.y) + v);
+                st.sa23.x = ToHalf(static_cast<float>(st.sa23.x) + v);
+                st.sa23.y = ToHalf(static_cast<float>(st.sa23.y) + v);
+                break;
+            }
+            case kCmdDrawFill: {
+                const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
+                const half2_t s01 = st.sa01 + Splat(bd), s23 = st.sa23 + Splat(bd);
+                half2_t a01, a23;
+                a01.x = ToHalf(fminf(fabsf(static_cast<float>(s01.x)), 1.0f));
+                a01.y = ToHalf(fminf(fabsf(static_cast<float>(s01.y)), 1.0f));
+                a23.x = ToHalf(fminf(fabsf(static_cast<float>(s23.x)), 1.0f));
+                a23.y = ToHalf(fminf(fabsf(static_cast<float>(s23.y)), 1.0f));
+                st.sa01 = st.sa23 = Splat(static_cast<_Float16>(0.0f));
+                Blend4S(st, cmd.body[2], cmd.body[3], a01, a23);
+                break;
+            }
+            case kCmdSolid: {
+                const half2_t one = Splat(static_cast<_Float16>(1.0f));
+                Blend4S(st, cmd.body[1], cmd.body[2], one, one);
+                break;
+            }
+            default:
+                break;
+        }
+    }
+}
+
+// The same loop for a quarter of a tile (4 pixel rows, 1 pixel per lane): tiles with long lists,
+// all four waves of the workgroup walk the list together (PrepareFills<true> has barriers).
+__device__ __forceinline__ void InterpretSparseWG(SparseLds &S, Cmd *cmds, uint8_t *fill_ix, uint32_t n, uint32_t x0, uint32_t y0,
+                                                  uint32_t row, uint32_t xi, PixelState1 &st) {
+    const uint32_t lane = LaneId();
+    const float px = static_cast<float>(x0 + xi), py = static_cast<float>(y0 + row);
+    const bool isf = lane < n && cmds[lane].tag == kCmdFill;
+    const uint64_t fm = __ballot(isf);
+    if (isf) fill_ix[RankBelow(fm)] = static_cast<uint8_t>(lane);  // (every wave keeps its own copy)
+    const uint32_t nfill = static_cast<uint32_t>(__popcll(fm));
+    WaveSync();
+    uint32_t fo = 0, prepared = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Cmd cmd = cmds[i];
+        switch (cmd.tag) {
+            case kCmdCircle: {
+                const float bx0 = static_cast<float>(cmd.body[1] & 0xffffu), by0 = static_cast<float>(cmd.body[1] >> 16);
+                const float bx1 = static_cast<float>(cmd.body[2] & 0xffffu), by1 = static_cast<float>(cmd.body[2] >> 16);
+                const float cx = bx0 + (bx1 - bx0) * 0.5f, cy = by0 + (by1 - by0) * 0.5f;
+                const float dx = px - cx, dy = py - cy;
+                const float r = sqrtf(dx * dx + dy * dy);
+                const _Float16 alpha = ToHalf(Sat(fminf(cx - bx0, cy - by0) - r));
+                const _Float16 zero = static_cast<_Float16>(0.0f);
+                st.r = st.r + (zero - st.r) * alpha;
+                st.g = st.g + (zero - st.g) * alpha;
+                st.b = st.b + (zero - st.b) * alpha;
+                break;
+            }
+            case kCmdLine: {
+                const float sx = __uint_as_float(cmd.body[1]), sy = __uint_as_float(cmd.body[2]);
+                const float ex = __uint_as_float(cmd.body[3]), ey = __uint_as_float(cmd.body[4]);
+                const float lx = ex - sx, ly = ey - sy;
+                const float dx = px - sx, dy = py - sy;
+                const float t = Sat((lx * dx + ly * dy) / (lx * lx + ly * ly));
+                const float fx = lx * t - dx, fy = ly * t - dy;
+                st.df = fminf(st.df, sqrtf(fx * fx + fy * fy));
+                break;
+            }
+            case kCmdStroke: {
+                const _Float16 alpha = ToHalf(Sat(__uint_as_float(cmd.body[0]) + 0.5f - st.df));
+                Blend1(st, cmd.body[2], cmd.body[3], alpha);
+                st.df = 1e9f;
+                break;
+            }
+            case kCmdFill: {
+                if (fo >= prepared) prepared = PrepareFills<true>(S, cmds, fill_ix, nfill, fo, x0, y0);  // uniform over the workgroup
+                ++fo;
+                const uint32_t hdr = cmds[i].body[0];
+                if ((hdr >> row) & 1u) {
+                    const uint32_t f = (hdr >> 16) + static_cast<uint32_t>(__popc(hdr & ((1u << row) - 1u)));
+                    st.sa = st.sa + reinterpret_cast<const _Float16 *>(&S.contrib[f][0])[xi];
+                }
+                break;
+            }
+            case kCmdFillEdge: {
+                const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
+                const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
+                st.sa = ToHalf(static_cast<float>(st.sa) + v);
+                break;
+            }
+            case kCmdDrawFill: {
+                _Float16 alpha = st.sa + static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
+                alpha = ToHalf(fminf(fabsf(static_cast<float>(alpha)), 1.0f));
+                Blend1(st, cmd.body[2], cmd.body[3], alpha);
+                st.sa = static_cast<_Float16>(0.0f);
+                break;
+            }
+            case kCmdSolid:
+                Blend1(st, cmd.body[1], cmd.body[2], static_cast<_Float16>(1.0f));
+                break;
+            default:
+                break;
+        }
+    }
+}
+
 }  // namespace
 
 // K3: per-pixel interpreter (renderKernel :457-566) over the per-tile command lists
@@ -469,6 +785,136 @@ __global__ __launch_bounds__(kThreads, PM_FINE_WPS) void pm_fine_kernel(FramePar
         }
     }
 }
+
+// K3 (default): the same interpreter with row-sparse Fill evaluation (see PrepareFills above).
+// Slot scheme as in pm_fine_kernel: the four waves of a workgroup take four consecutive slots
+// of the same pass; a tile with a long list owns four aligned slots, i.e. exactly one workgroup.
+__global__ __launch_bounds__(kThreads, PM_FINE_WPS) void pm_fine_sparse_kernel(FrameParams P) {
+    __shared__ SparseLds S;
+    if (blockIdx.x >= P.fine_grid) {
+        ClearStripRow(P, blockIdx.x - P.fine_grid);
+        return;
+    }
+    const uint32_t lane = LaneId(), wave = threadIdx.x >> 6;
+    const uint32_t n_a = P.ctr_cur->vheavy_count, n_b = P.ctr_cur->heavy_count, n_c = P.ctr_cur->light_count;
+    const uint32_t wave_global = blockIdx.x * kWaves + wave;
+    const uint32_t n_waves = P.fine_grid * kWaves;
+    // more long lists than workgroups: splitting a tile only costs work, every tile gets one wave
+    const bool dense = n_a + n_b >= n_waves || P.split_mode == 0;
+    const uint32_t sh = dense ? 0u : 2u;
+    const uint32_t n_heavy = n_a + n_b;
+    const uint32_t s_h = n_heavy << sh;
+    const uint32_t n_slots = s_h + n_c;
+    const uint8_t *lut = P.lut_lin2srgb;
+    auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {
+        return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, r)]) |
+               (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
+               (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, b)]) << 16) | 0xff000000u;
+    };
+    // slot -> queue entry; queues A and B are one class here (4 waves per tile)
+    auto slot_entry = [&](uint32_t slot) -> uint32_t {
+        if (slot < s_h) {
+            const uint32_t t = slot >> sh;
+            return t < n_a ? t : P.queue_cap + (t - n_a);
+        }
+        return 2u * P.queue_cap + (slot - s_h);
+    };
+    auto pass_slot = [&](uint32_t pass) -> uint32_t {
+        return pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
+    };
+    uint32_t slot = pass_slot(0);
+    uint4 qe = make_uint4(0u, 0u, 0u, 0u);
+    if (slot < n_slots) qe = P.queue[slot_entry(slot)];
+    for (uint32_t pass = 0; pass * n_waves < n_slots; ++pass) {
+        const uint32_t cur_slot = slot;
+        const uint4 cur = qe;
+        slot = pass_slot(pass + 1u);
+        if ((pass + 1u) * n_waves < n_slots && slot < n_slots) qe = P.queue[slot_entry(slot)];
+        if (cur_slot >= n_slots) continue;
+        const bool wg_mode = cur_slot < s_h && sh != 0;  // uniform over the workgroup (slots are aligned)
+        const uint32_t tile = cur.x;
+        unsigned long long t_begin = 0;
+        if (P.dbg_time) t_begin = wall_clock64();
+        const uint32_t n_cmd = cur.w;
+        if (n_cmd != 0) {  // 0: the coarse kernel found one opaque colour and wrote it
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(P.ptcl + cur.y);
+            const uint32_t tx = tile % P.tiles_x;
+            const uint32_t ty_rel = tile / P.tiles_x;
+            const uint32_t x0 = tx * kTileW;
+            const uint32_t y0 = (P.row0 + ty_rel) * kTileH;
+            if (wg_mode) {
+                // lane -> 1 pixel: x = x0 + (lane & 15), row = 4 * (slot & 3) + lane / 16
+                const uint32_t xi = lane & 15u;
+                const uint32_t prow = 4u * (cur_slot & 3u) + (lane >> 4);
+                const uint32_t pxi = x0 + xi, pyi = y0 + prow;
+                PixelState1 s1;
+                s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
+                s1.df = 1e9f;
+                s1.sa = static_cast<_Float16>(0.0f);
+                for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk) {
+                    const uint32_t m = min(kSpChunk, n_cmd - c0);
+                    __syncthreads();  // the previous chunk (or tile) is done with the shared arrays
+                    {
+                        const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
+                        uint2 *l = reinterpret_cast<uint2 *>(S.cmds[0]);
+                        for (uint32_t w = threadIdx.x; w < 3u * m; w += kThreads) l[w] = g[w];
+                    }
+                    __syncthreads();
+                    InterpretSparseWG(S, S.cmds[0], S.fill_ix[wave], m, x0, y0, prow, xi, s1);
+                }
+                __syncthreads();  // the other waves may still read this wave's fragments
+                if (pyi < P.height && pxi < P.width) {
+                    uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
+                    *reinterpret_cast<uint32_t *>(dst) = enc(s1.r, s1.g, s1.b);
+                }
+            } else {
+                // lane -> 4 pixels: x = x0 + 4 * (lane & 3) + k, row = lane / 4
+                const uint32_t pxi = x0 + (lane & 3u) * 4u;
+                const uint32_t prow = lane >> 2;
+                const uint32_t pyi = y0 + prow;
+                Cmd *const cmds = S.cmds[wave];
+                PixelStateS st;
+                st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = Splat(static_cast<_Float16>(1.0f));
+                st.sa01 = st.sa23 = Splat(static_cast<_Float16>(0.0f));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) st.df[k] = 1e9f;
+                for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk) {
+                    const uint32_t m = min(kSpChunk, n_cmd - c0);
+                    WaveSync();
+                    {
+                        const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
+                        uint2 *l = reinterpret_cast<uint2 *>(cmds);
+                        for (uint32_t w = lane; w < 3u * m; w += 64u) l[w] = g[w];
+                    }
+                    WaveSync();
+                    InterpretSparse(S, cmds, S.fill_ix[wave], m, x0, y0, st);
+                }
+                if (pyi < P.height && pxi < P.width) {
+                    uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
+                    uint4 out;
+                    out.x = enc(st.r01.x, st.g01.x, st.b01.x);
+                    out.y = enc(st.r01.y, st.g01.y, st.b01.y);
+                    out.z = enc(st.r23.x, st.g23.x, st.b23.x);
+                    out.w = enc(st.r23.y, st.g23.y, st.b23.y);
+                    if (pxi + 4 <= P.width && P.fb_vec16) {
+                        *reinterpret_cast<uint4 *>(dst) = out;
+                    } else {
+                        const uint32_t o[4] = {out.x, out.y, out.z, out.w};
+                        for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = o[k];
+                    }
+                }
+            }
+        }
+        if (P.dbg_time && lane == 0) {
+            unsigned long long *d = P.dbg_time + 4ull * cur_slot;
+            d[0] = t_begin;
+            d[1] = wall_clock64();
+            d[2] = tile | (wg_mode ? 0x80000000u : 0u);
+            d[3] = (static_cast<unsigned long long>(wave_global) << 32) | n_cmd;
+        }
+    }
+}
+
 // ---- launch wrappers (called from pm_context.hip) -----------------------------------------
 
 void LaunchClear(const FrameParams &p, uint32_t n_striprows, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
@@ -476,7 +922,10 @@ void LaunchClear(const FrameParams &p, uint32_t n_striprows, hipStream_t stream,
 }
 
 void LaunchFine(const FrameParams &p, uint32_t clear_blocks, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
-    PM_LAUNCH(pm_fine_kernel, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
+    if (p.fine_sparse)
+        PM_LAUNCH(pm_fine_sparse_kernel, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
+    else
+        PM_LAUNCH(pm_fine_kernel, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
 }
 
 }  // namespace pm

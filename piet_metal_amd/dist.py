@@ -3,13 +3,16 @@ collective while rendering; ONE framebuffer gather at the end.
 
 The reference has no multi-device code at all (single MTLDevice,
 TestApp/ViewController.m:16).  Tiles are independent given the read-only scene,
-so rank r renders the contiguous band of tile rows workloads.band_rows(...) gives
-it and the bands are gathered to rank 0 over RCCL/xGMI (`nccl` backend) -- 7
-direct links into the root, one band per link.  torch.distributed is used purely
-as the collective transport; on CPU test boxes the same code runs over `gloo`.
+so rank r renders a contiguous band of tile rows and the bands are gathered to
+rank 0 over RCCL/xGMI (`nccl` backend): one grouped send/recv, every band lands
+directly in its rows of the final image (no padded staging, no second copy) and
+the root's 7 links each carry one band.  torch.distributed is used purely as the
+transport; on CPU test boxes the same code runs over `gloo`.  The same exchange
+exists behind the C ABI for non-Python hosts (pm_comm_create / pm_gather).
 """
 from __future__ import annotations
 
+import bisect
 import os
 
 from .workloads import band_rows
@@ -38,42 +41,113 @@ def init_process_group(backend: str | None = None):
     return rank, world, local
 
 
-def band_layout(height: int, world: int) -> list[tuple[int, int, int]]:
-    """[(tile_row0, tile_row1, pixel_rows)] per rank for a viewport of `height` px."""
+def _layout_from_cuts(cuts: list[int], height: int) -> list[tuple[int, int, int]]:
+    return [(a, b, max(0, min(b * 16, height) - a * 16)) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def band_layout(height: int, world: int, cuts: list[int] | None = None) -> list[tuple[int, int, int]]:
+    """[(tile_row0, tile_row1, pixel_rows)] per rank for a viewport of `height` px: the
+    near-equal split, or the split at the given tile-row `cuts` (world + 1 entries)."""
     tiles_y = (height + 15) // 16
-    out = []
+    if cuts is None:
+        cuts = [band_rows(tiles_y, world, r)[0] for r in range(world)] + [tiles_y]
+    assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == tiles_y
+    return _layout_from_cuts(list(cuts), height)
+
+
+def balanced_cuts(cuts: list[int], band_ms: list[float]) -> list[int]:
+    """Cost-balanced tile-row split ("Tiger rows are uneven").
+
+    Input: the current split and the render time every rank measured for its band.  The cost
+    per tile row is taken as constant inside each band; the new cuts are the equal-cost
+    quantiles of that piecewise-constant density.  Every band keeps at least one tile row.
+    Pure host arithmetic -- iterate it (measure, re-cut) two or three times."""
+    world = len(cuts) - 1
+    tiles_y = cuts[-1]
+    if world == 1 or tiles_y <= world:
+        return list(cuts)
+    dens = []
     for r in range(world):
-        r0, r1 = band_rows(tiles_y, world, r)
-        out.append((r0, r1, max(0, min(r1 * 16, height) - r0 * 16)))
+        rows = max(1, cuts[r + 1] - cuts[r])
+        dens += [max(band_ms[r], 1e-9) / rows] * (cuts[r + 1] - cuts[r])
+    cum = [0.0]
+    for d in dens:
+        cum.append(cum[-1] + d)
+    out = [0]
+    for r in range(1, world):
+        target = cum[-1] * r / world
+        c = bisect.bisect_left(cum, target)
+        if c > 0 and target - cum[c - 1] < cum[min(c, tiles_y)] - target:
+            c -= 1
+        out.append(min(max(c, out[-1] + 1), tiles_y - (world - r)))
+    out.append(tiles_y)
     return out
 
 
-def padded_band_rows(height: int, world: int) -> int:
-    return max(p for _, _, p in band_layout(height, world))
+def padded_band_rows(height: int, world: int, cuts: list[int] | None = None) -> int:
+    return max(p for _, _, p in band_layout(height, world, cuts))
 
 
-def gather_framebuffer(band, height: int, dst: int = 0, full=None):
-    """Gather every rank's band ([padded_rows, width, 4] uint8 tensor, same shape on
-    all ranks) into the full [height, width, 4] image on rank `dst`.
+def gather_bands(band, layout, height: int, dst: int = 0, full=None):
+    """ONE grouped send/recv: every rank's band ([>= rows, width, 4] uint8, its first `rows`
+    pixel rows valid) goes straight into rows [row0*16, row0*16 + rows) of `full`
+    ([height, width, 4]) on rank `dst`.  The root's own band is copied locally unless `band`
+    already is that slice of `full` (render straight into the final image).
 
-    Returns the assembled tensor on `dst`, None elsewhere.  With world == 1 the band
-    is the image."""
+    Returns `full` on `dst`, None elsewhere.  With world == 1 the band is the image."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    layout = band_layout(height, world)
     if world == 1:
         return band[:height]
+    r0, _r1, rows = layout[rank]
+    ops = []
     if rank == dst:
-        gathered = torch.empty((world,) + tuple(band.shape), dtype=band.dtype, device=band.device)
-        dist.gather(band, gather_list=list(gathered.unbind(0)), dst=dst)
         if full is None:
             full = torch.empty((height, band.shape[1], 4), dtype=band.dtype, device=band.device)
-        for r, (r0, _r1, rows) in enumerate(layout):
-            if rows:
-                full[r0 * 16 : r0 * 16 + rows] = gathered[r, :rows]
-        return full
-    dist.gather(band, gather_list=None, dst=dst)
-    return None
+        for k, (k0, _k1, krows) in enumerate(layout):
+            if krows == 0:
+                continue
+            view = full[k0 * 16 : k0 * 16 + krows]
+            if k == dst:
+                if view.data_ptr() != band.data_ptr():
+                    view.copy_(band[:krows])
+            else:
+                ops.append(dist.P2POp(dist.irecv, view, k))
+    elif rows:
+        ops.append(dist.P2POp(dist.isend, band[:rows], dst))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()  # (nccl: orders the current stream behind the transfer, does not block the host)
+    return full if rank == dst else None
+
+
+def allgather_bands(band_padded, layout, height: int, full=None, scratch=None):
+    """The all-gather alternative (every rank ends up with the image): bands padded to a common
+    size, ncclAllGather, then one strided copy per band.  Kept to compare schedules on xGMI
+    (a ring all-gather is per-link bound at 7 steps; the grouped gather is not)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        return band_padded[:height]
+    if scratch is None:
+        scratch = torch.empty((world,) + tuple(band_padded.shape), dtype=band_padded.dtype, device=band_padded.device)
+    dist.all_gather(list(scratch.unbind(0)), band_padded)  # one ncclAllGather on the nccl backend
+    if full is None:
+        full = torch.empty((height, band_padded.shape[1], 4), dtype=band_padded.dtype, device=band_padded.device)
+    for k, (k0, _k1, krows) in enumerate(layout):
+        if krows:
+            full[k0 * 16 : k0 * 16 + krows] = scratch[k, :krows]
+    return full
+
+
+def gather_framebuffer(band, height: int, dst: int = 0, full=None):
+    """Equal-split convenience form of gather_bands (kept for callers of the round-1 API)."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    return gather_bands(band, band_layout(height, world), height, dst=dst, full=full)

@@ -147,6 +147,12 @@ class Renderer:
         _lib.check(self._lib.pm_frame_latency(self._h, iters, C.byref(med), C.byref(mn)), "pm_frame_latency")
         return {"median_ms": med.value, "min_ms": mn.value, "iters": iters}
 
+    def scene_timings(self) -> dict:
+        """Host wall-clock cost of the last scene replacement (flatten+encode, index, arena)."""
+        t = _lib.SceneTimings()
+        _lib.check(self._lib.pm_get_scene_timings(self._h, C.byref(t)), "pm_get_scene_timings")
+        return {name: getattr(t, name) for name, _ in t._fields_}
+
     def stats(self) -> dict:
         s = _lib.Stats()
         _lib.check(self._lib.pm_get_stats(self._h, C.byref(s)), "pm_get_stats")
@@ -165,6 +171,52 @@ class Renderer:
             "pm_debug_capture_ptcl",
         )
         return counts, solid, cmds
+
+
+class Comm:
+    """pm_comm_* / pm_gather: the C-ABI form of the band gather (RCCL bound at run time).
+    The 128-byte id comes from rank 0 (Comm.unique_id()) and reaches the other ranks through
+    whatever the host has (here: any picklable channel)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.load().pm_comm_unique_id(buf), "pm_comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, renderer: "Renderer", uid: bytes, rank: int, world: int):
+        self._lib = _lib.load()
+        self._r = renderer
+        self.rank, self.world = rank, world
+        err = C.c_int(0)
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._h = self._lib.pm_comm_create(renderer._h, buf, rank, world, C.byref(err))
+        if not self._h:
+            raise _lib.PietMetalError(err.value, "pm_comm_create")
+
+    def gather(self, layout, root: int = 0, full=None, band=None, stream=None) -> None:
+        """layout = [(tile_row0, tile_row1, ...)] per rank; full = torch uint8 [H, W, 4] on the root;
+        band = this rank's band tensor (None: the renderer's last frame)."""
+        rows = (C.c_uint32 * (2 * self.world))(*[v for b in layout for v in (b[0], b[1])])
+        _lib.check(
+            self._lib.pm_gather(
+                self._r._h, self._h, band.data_ptr() if band is not None else None, band.stride(0) if band is not None else 0, rows, root,
+                full.data_ptr() if full is not None else None, full.stride(0) if full is not None else 0,
+                stream.cuda_stream if stream is not None else None,
+            ),
+            "pm_gather",
+        )
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.pm_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _time_tiles(self, max_slots: int = 1 << 20) -> np.ndarray:

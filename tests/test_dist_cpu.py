@@ -31,17 +31,30 @@ def _worker(rank, world, port, width, height, out_path):
     r, w, _ = pmd.init_process_group("gloo")
     assert (r, w) == (rank, world)
     scene = pmo.scene_cardioid()
-    layout = pmd.band_layout(height, world)
+    # uneven, cost-balanced style cuts: the exchange must not depend on equal band sizes
+    tiles_y = (height + 15) // 16
+    cuts = pmd.balanced_cuts([b[0] for b in pmd.band_layout(height, world)] + [tiles_y], [1.0 + 3.0 * k for k in range(world)])
+    layout = pmd.band_layout(height, world, cuts)
     r0, r1, rows = layout[rank]
-    pad = pmd.padded_band_rows(height, world)
-    band = torch.zeros((pad, width, 4), dtype=torch.uint8)
     P = pmo.Ptcl(scene, width, height)
-    band[:rows] = torch.from_numpy(P.render_rows(r0, r1))
-    full = pmd.gather_framebuffer(band, height, dst=0)
+    mine = torch.from_numpy(P.render_rows(r0, r1))
+    if rank == 0:  # the root renders straight into its rows of the final image
+        full = torch.zeros((height, width, 4), dtype=torch.uint8)
+        band = full[r0 * 16 : r0 * 16 + rows]
+        band.copy_(mine)
+    else:
+        full, band = None, mine
+    got = pmd.gather_bands(band, layout, height, dst=0, full=full)
+    # the all-gather alternative must assemble the same image on every rank
+    pad = torch.zeros((pmd.padded_band_rows(height, world, cuts), width, 4), dtype=torch.uint8)
+    pad[:rows] = mine
+    ag = pmd.allgather_bands(pad, layout, height)
     if rank == 0:
+        assert got is full and torch.equal(ag, full)
         np.save(out_path, full.numpy())
     else:
-        assert full is None
+        assert got is None
+        np.save(out_path + f".{rank}.npy", ag.numpy())
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -56,6 +69,8 @@ def test_band_gather_gloo(tmp_path, pmo, world, height):
     full = np.load(out)
     want = pmo.render(pmo.scene_cardioid(), width, height)
     assert full.shape == want.shape and np.array_equal(full, want)
+    for k in range(1, world):
+        assert np.array_equal(np.load(out + f".{k}.npy"), want)
 
 
 def test_band_layout_covers_viewport():
@@ -68,3 +83,21 @@ def test_band_layout_covers_viewport():
             assert lay[0][0] == 0 and lay[-1][1] == (height + 15) // 16
             assert all(a[1] == b[0] for a, b in zip(lay, lay[1:]))
             assert sum(p for _, _, p in lay) == height
+
+
+def test_balanced_cuts_converge_and_stay_valid():
+    sys.path.insert(0, ROOT)
+    from piet_metal_amd import dist as pmd
+
+    true = np.interp(np.arange(135) + 0.5, [0, 30, 60, 75, 100, 135], [0.2, 1, 5, 6, 2, 0.2])  # Tiger-like: busy in the middle
+    for world in (2, 4, 8):
+        cuts = [b[0] for b in pmd.band_layout(2160, world)] + [135]
+        for _ in range(3):
+            ms = [float(true[a:b].sum()) for a, b in zip(cuts[:-1], cuts[1:])]
+            cuts = pmd.balanced_cuts(cuts, ms)
+            assert cuts[0] == 0 and cuts[-1] == 135 and all(b > a for a, b in zip(cuts, cuts[1:]))
+        ms = [float(true[a:b].sum()) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert max(ms) / (sum(ms) / world) < 1.15
+    # degenerate: more ranks than rows keeps the split untouched; zero times do not divide by zero
+    assert pmd.balanced_cuts([0, 1, 2], [0.0, 0.0]) == [0, 1, 2]
+    assert pmd.balanced_cuts([0, 2, 4, 6], [0.0, 0.0, 0.0])[-1] == 6

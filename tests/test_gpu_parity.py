@@ -308,29 +308,61 @@ def test_pipelined_frames_every_slot_and_scene_switch(pm, pmo, renderer):
 
 
 def test_bench_two_rank_path_rehearsal_on_one_gpu(pm, pmo, tmp_path):
-    """bench.py's N>1 path (bands via pm_set_band + pm_render_to on torch's stream, gather to
-    rank 0) with both ranks on this box's one GPU and gloo as transport: the gathered frame
-    must equal the oracle's render of the stacked scene, and rank 0 prints the JSON line."""
+    """bench.py's N>1 path (cost-balanced bands via pm_set_band, pm_render_to on torch's stream, the
+    grouped gather straight into the final image on rank 0 inside every step) with both ranks on
+    this box's one GPU and gloo as transport: the gathered 3840x2160 frame must equal the
+    oracle's render, and rank 0 prints the JSON line with the strong-scaling fields."""
     import subprocess
     import sys
-
-    sys.path.insert(0, ROOT)
-    import bench
 
     dump = tmp_path / "frame.npy"
     env = dict(os.environ, PM_BENCH_SHARE_DEVICE="1", PM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dump", str(dump)]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-config5",
+           "--dump", str(dump)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     js = json.loads(line)
-    assert js["n_gpus"] == 2 and js["scaling"] == "weak" and js["value"] > 0 and js["config"]["viewport"] == [3840, 4320]
-    wl = bench.stacked_tigers(pm, 2)
+    assert js["n_gpus"] == 2 and js["scaling"] == "strong" and js["value"] > 0 and js["sustained_mpix_s"] > 0
+    cfg = js["config"]
+    assert cfg["viewport"] == [3840, 2160] and cfg["band_cuts"][0] == 0 and cfg["band_cuts"][-1] == 135 and len(cfg["band_cuts"]) == 3
+    assert cfg["t_render_ms"] > 0 and cfg["t_gather_ms"] > 0 and cfg["t_frame_e2e_ms"] > 0
+    wl = pm.workloads.tiger(3840, 2160)
     scene, _ = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
     got = np.load(dump)
-    assert got.shape == (4320, 3840, 4)
-    assert np.array_equal(got, pmo.render(scene, 3840, 4320))
+    assert got.shape == (2160, 3840, 4)
+    assert np.array_equal(got, pmo.render(scene, 3840, 2160))
+
+
+def test_c_abi_gather_single_rank(pm, pmo, renderer):
+    """pm_comm_* / pm_gather (RCCL bound at run time): with one rank the grouped send/recv is a
+    self transfer, which still runs the whole C-ABI path -- id, communicator, band bookkeeping,
+    ncclSend/ncclRecv on the frame's stream -- and must land the frame in the final image."""
+    import torch
+
+    scene = pmo.scene_cardioid()
+    renderer.resize(1000, 600)
+    renderer.set_scene_bytes(scene)
+    comm = pm.Comm(renderer, pm.Comm.unique_id(), 0, 1)
+    try:
+        full = torch.zeros((600, 1000, 4), dtype=torch.uint8, device="cuda:0")
+        renderer.render()
+        comm.gather([(0, 38)], root=0, full=full)  # src = the context's last frame
+        renderer.sync()
+        torch.cuda.synchronize()
+        assert np.array_equal(full.cpu().numpy(), pmo.render(scene, 1000, 600))
+        band = torch.zeros((608, 1000, 4), dtype=torch.uint8, device="cuda:0")
+        full.zero_()
+        s = torch.cuda.current_stream()
+        renderer.render_to(band, s)
+        comm.gather([(0, 38)], root=0, full=full, band=band, stream=s)
+        torch.cuda.synchronize()
+        assert np.array_equal(full.cpu().numpy(), pmo.render(scene, 1000, 600))
+        with pytest.raises(pm.PietMetalError):
+            comm.gather([(0, 37)], root=0, full=full)  # not this context's band
+    finally:
+        comm.close()
 
 
 def test_command_list_arena_overflow_grows_and_rerenders(pm, pmo, monkeypatch):
@@ -352,6 +384,78 @@ def test_command_list_arena_overflow_grows_and_rerenders(pm, pmo, monkeypatch):
         for _ in range(3):
             r.render()
         assert np.array_equal(r.read_pixels(), want)
+    finally:
+        r.close()
+
+
+def test_overflow_in_every_in_flight_frame_is_repaired(pm, pmo, monkeypatch):
+    """Up to four frames are in flight, and pm_render_to frames each own a caller buffer: when the
+    command-list arena runs out, pm_sync must repair EVERY target, not just the last frame's
+    (round-1 advisor finding)."""
+    import torch
+
+    monkeypatch.setenv("PM_PTCL_INITIAL_CMDS", "2048")
+    r = pm.Renderer(0)
+    try:
+        wl = pm.workloads.tiger(960, 540)
+        r.resize(wl.width, wl.height)
+        r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        want = pmo.render(r.download_scene(), 960, 540)
+        bufs = [torch.zeros((544, 960, 4), dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+        side = torch.cuda.Stream()
+        r.render_to(bufs[0], None)
+        r.render_to(bufs[1], side)
+        r.render()
+        r.render_to(bufs[2], None)
+        del side  # the caller's stream may be gone before pm_sync
+        r.sync()
+        for k, b in enumerate(bufs):
+            assert np.array_equal(b[:540].cpu().numpy(), want), k
+        assert r.stats()["overflow"] == 0
+        r.render()
+        assert np.array_equal(r.read_pixels(), want)
+    finally:
+        r.close()
+
+
+def test_failed_scene_replacement_leaves_no_stale_state(pm, pmo, renderer):
+    """A rejected scene must not leave the old item count / index paired with the new bytes
+    (round-1 advisor finding): rendering is refused until a valid scene is resident again."""
+    good = pmo.scene_cardioid()
+    renderer.resize(512, 512)
+    renderer.set_scene_bytes(good)
+    renderer.render()
+    renderer.sync()
+    bad = good.copy()
+    bad[0:4] = np.frombuffer(struct.pack("<I", 0x7fffffff), np.uint8)  # n_items out of range
+    with pytest.raises(pm.PietMetalError):
+        renderer.set_scene_bytes(bad)
+    with pytest.raises(pm.PietMetalError):
+        renderer.render()
+    assert renderer.stats()["n_items"] == 0
+    renderer.set_scene_bytes(good)
+    renderer.render()
+    assert np.array_equal(renderer.read_pixels(), pmo.render(good, 512, 512))
+
+
+@pytest.mark.parametrize("sparse", ["0", "1"])
+def test_both_fine_kernels_agree_with_the_oracle(pm, pmo, monkeypatch, sparse):
+    """PM_FINE_SPARSE=0 keeps the straightforward interpreter (every row of every Fill); the
+    default evaluates only live (command, row) fragments.  Both must be byte-exact, also where
+    tiles with long lists are rendered by four waves and where lists exceed one LDS chunk."""
+    monkeypatch.setenv("PM_FINE_SPARSE", sparse)
+    r = pm.Renderer(0)
+    try:
+        for (w, h, fills) in ((960, 540, False), (1920, 1080, True)):
+            wl = pm.workloads.tiger(w, h, fills_only=fills)
+            r.resize(w, h)
+            r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+            scene = r.download_scene()
+            r.render()
+            assert np.array_equal(r.read_pixels(), pmo.render(scene, w, h)), (w, h)
+        ops = random_ops(77, 700, 256.0, opaque_mask=0)  # translucent: long lists: several chunks, several PrepareFills calls
+        scene = encode_ops(pm, ops)
+        assert np.array_equal(gpu_render(r, scene, 256, 256), pmo.render(scene, 256, 256))
     finally:
         r.close()
 
