@@ -168,9 +168,15 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
                              float *clear_ms);
 
 /* Latency of ONE frame with nothing else in flight: begin of its first kernel to end of its
- * last one, from the dispatches' own timestamps; median and minimum over `iters` frames
- * (SURVEY.md 8d's t_frame; PietRenderer.m has no timing at all). */
+ * last one, two HIP events on the frame's stream around the three launches pm_render makes;
+ * median and minimum over `iters` frames (SURVEY.md 8d's t_frame; PietRenderer.m has no timing
+ * at all). */
 int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms);
+
+/* Developer hook: the lone frame taken apart -- medians over `iters` frames of {pm_bin_kernel,
+ * gap, pm_coarse_kernel, gap, pm_fine_kernel, first begin -> last end}, ms, dispatch timestamps
+ * (needs the default PM_FOLD_CLEAR=1: three launches per frame). */
+int pm_debug_frame_timeline(pm_ctx *c, int iters, float *out6);
 
 typedef struct {
     uint32_t tiles_x, tiles_y;    /* tile grid of the viewport */
@@ -233,7 +239,8 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
 
 /* Developer profiling hook: re-run the last frame's per-tile kernel recording, per queue
  * slot, {start clock, end clock (100 MHz wall clock), tile | quarter << 31,
- * wave << 32 | commands interpreted}.  out receives 4 u64 per slot. */
+ * wave << 32 | commands interpreted, ticks in phase A, ticks in phase B (tiles rendered by a
+ * whole workgroup)}.  out receives 6 u64 per slot. */
 int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_slots); /* pm_fine_kernel */
 /* Same for pm_bin_kernel: renders one frame recording 12 u64 per strip row {start, item scan done,
  * headers done, segment stream done, record finalised, queues done, chunks streamed, end}. */

@@ -110,6 +110,7 @@ SIGNATURES = {
     "pm_time_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_frame_latency": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_time_frames_pipelined": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pm_debug_frame_timeline": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "pm_get_scene_timings": (C.c_int, [C.c_void_p, C.POINTER(SceneTimings)]),
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),

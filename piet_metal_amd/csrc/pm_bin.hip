@@ -170,9 +170,8 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         // here so that no separate memset launch is needed.
         PM_PP(ctr_next)->arena_top = 0;
         PM_PP(ctr_next)->ptcl_top = 0;
-        PM_PP(ctr_next)->vheavy_count = 0;
-        PM_PP(ctr_next)->heavy_count = 0;
-        PM_PP(ctr_next)->light_count = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kClasses; ++k) PM_PP(ctr_next)->cls[k].count = 0;
         PM_PP(ctr_next)->overflow = 0;
     }
     // Developer timeline (kProfile builds only): thread 0 stores the clock straight to memory, so
@@ -658,22 +657,31 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     // {Solid(opaque)} -> Bail: the tile is one opaque colour (TileEncoder::end, :144-151)
     const bool is_solid = est != 0 && s_last_kept[lane & (kStripTiles - 1u)] == s_last_solid[lane & (kStripTiles - 1u)];
     const bool is_queued = est != 0 && !is_solid;
-    const uint32_t vheavy = static_cast<uint32_t>(__ballot(is_queued && est > kVeryHeavyStream));
-    const uint32_t heavy = static_cast<uint32_t>(__ballot(is_queued && est > kHeavyStream && est <= kVeryHeavyStream));
-    const uint32_t light = static_cast<uint32_t>(__ballot(is_queued && est <= kHeavyStream));
-    const uint32_t queued = vheavy | heavy | light;
+    // cost class of the tile's list (0 = longest): the number of thresholds the estimate does not exceed
+    static_assert(kClasses == 8, "seven thresholds spelled out below");
+#define PM_THR(k) ((est <= ParamU32<offsetof(FrameParams, class_thr) + 4 * (k)>(PR)) ? 1u : 0u)
+    const uint32_t cls = PM_THR(0) + PM_THR(1) + PM_THR(2) + PM_THR(3) + PM_THR(4) + PM_THR(5) + PM_THR(6);
+#undef PM_THR
+    uint32_t my_mask = 0;    // queued tiles of this lane's class
+    uint32_t lane_cnt = 0;   // lane c < kClasses: tiles of class c in this strip row
+    uint32_t queued = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kClasses; ++k) {
+        const uint32_t mk = static_cast<uint32_t>(__ballot(is_queued && cls == k));
+        if (cls == k) my_mask = mk;
+        if (lane == k) lane_cnt = static_cast<uint32_t>(__popc(mk));
+        queued |= mk;
+    }
     // command-list slots of a queued tile: an element emits at most 2 commands + its item's
     // closing command, plus End
     const uint32_t slots = is_queued ? 3u * est + 1u : 0u;
     const uint32_t slots_incl = WaveInclusiveScan(slots);
     const uint32_t qtotal = WaveLast(slots_incl);
-    // list space and the three queue positions: four atomics in flight at once
+    // list space and the class queue positions: ONE atomic instruction, a lane per counter
     uint32_t qres = 0;
     if (queued) {  // uniform
-        if (lane == 3) qres = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, qtotal);
-        if (lane == 0 && vheavy) qres = atomicAdd(&PM_PP(ctr_cur)->vheavy_count, static_cast<uint32_t>(__popc(vheavy)));
-        if (lane == 1 && heavy) qres = atomicAdd(&PM_PP(ctr_cur)->heavy_count, static_cast<uint32_t>(__popc(heavy)));
-        if (lane == 2 && light) qres = atomicAdd(&PM_PP(ctr_cur)->light_count, static_cast<uint32_t>(__popc(light)));
+        if (lane < kClasses && lane_cnt) qres = atomicAdd(&PM_PP(ctr_cur)->cls[lane].count, lane_cnt);
+        if (lane == kClasses) qres = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, qtotal);
     }
     // tiles with nothing to draw are background: no item touches them, or every touching
     // item lost all its segments in phase 1 (the reference writes Bail/white for them).  Their
@@ -683,10 +691,8 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     if (tile_lane)  // what this kernel decided per tile: 0 = queued, else the tile's colour
         PM_PP(tile_state)[tile] = is_queued ? 0u : (is_solid ? s_solid_rgba[lane] : 0xffffffffu);
     if (queued) {
-        const uint32_t q_a = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), 0));
-        const uint32_t q_b = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), 1));
-        const uint32_t q_c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), 2));
-        const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), 3));
+        const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), kClasses));
+        const uint32_t q_base = static_cast<uint32_t>(__shfl(static_cast<int>(qres), static_cast<int>(cls)));  // my class's queue position
         const bool fits = base + qtotal <= PM_PU(ptcl_cap) && base + qtotal >= base;
         // (on overflow the tiles are still queued but marked "no list": the tile kernels skip
         //  them, the frame has holes, and pm_sync re-renders it with a larger arena)
@@ -694,14 +700,11 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         if (is_queued) {
             const uint32_t list_slot = fits ? base + (slots_incl - slots) : 0xffffffffu;
             PM_PP(tile_ptcl)[tile] = list_slot;
-            // three queues, by expected list length: the fine kernel starts with the longest.  A
-            // queue entry is everything the tile kernels need to start: {tile, first command
+            // A queue entry is everything the tile kernels need to start: {tile, first command
             // slot, first binning record of the strip row, commands written (pm_coarse_kernel)}
             const uint4 entry = make_uint4(tile, list_slot, head, 0u);
             const uint32_t below = (1u << lane) - 1u;
-            if ((vheavy >> lane) & 1u) PM_PP(queue)[q_a + __popc(vheavy & below)] = entry;
-            if ((heavy >> lane) & 1u) PM_PP(queue)[PM_PU(queue_cap) + q_b + __popc(heavy & below)] = entry;
-            if ((light >> lane) & 1u) PM_PP(queue)[2u * PM_PU(queue_cap) + q_c + __popc(light & below)] = entry;
+            PM_PP(queue)[cls * PM_PU(queue_cap) + q_base + __popc(my_mask & below)] = entry;
         }
     }
     stamp(5);  // queues + list slots done

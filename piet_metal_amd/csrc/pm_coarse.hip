@@ -39,8 +39,16 @@ __global__ __launch_bounds__(kThreads, PM_COARSE_WPS) void pm_coarse_kernel(Fram
 
     const uint32_t lane = LaneId();
     const uint64_t lanes_below = (1ull << lane) - 1ull;
-    const uint32_t n_a = P.ctr_cur->vheavy_count, n_b = P.ctr_cur->heavy_count;
-    const uint32_t n_total = n_a + n_b + P.ctr_cur->light_count;
+    uint32_t cls_end[kClasses];  // running totals of the class queues (longest lists first)
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kClasses; ++k) {
+            run += P.ctr_cur->cls[k].count;
+            cls_end[k] = run;
+        }
+    }
+    const uint32_t n_total = cls_end[kClasses - 1];
 
     // Static snake hand-out over [longest lists..., shortest...]: pass k gives wave g the slot
     // k*G + g (k even) or k*G + (G-1-g) (k odd).  No atomics: one device-scope counter tops out
@@ -51,9 +59,11 @@ __global__ __launch_bounds__(kThreads, PM_COARSE_WPS) void pm_coarse_kernel(Fram
     for (uint32_t pass = 0; pass * n_waves < n_total; ++pass) {
         const uint32_t slot = pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
         if (slot >= n_total) continue;
-        uint4 *const qentry = P.queue + ((slot < n_a) ? slot
-                                         : (slot < n_a + n_b) ? P.queue_cap + (slot - n_a)
-                                                              : 2u * P.queue_cap + (slot - n_a - n_b));
+        uint32_t qix = slot;  // class 0
+#pragma unroll
+        for (uint32_t k = 1; k < kClasses; ++k)
+            if (slot >= cls_end[k - 1]) qix = k * P.queue_cap + (slot - cls_end[k - 1]);
+        uint4 *const qentry = P.queue + qix;
         const uint4 qe = *qentry;
         const uint32_t tile = qe.x;
         if (qe.y == 0xffffffffu) {  // the command-list arena overflowed (pm_sync re-renders the frame)

@@ -172,7 +172,7 @@ struct pm_ctx {
     std::vector<hipStream_t> streams;  // frame N runs on streams[N % n]; stream == streams[0]
     bool fold_clear = true;  // pm_fine_kernel's launch also writes the resolved tiles (no pm_clear_kernel launch)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
-    uint32_t fine_sparse = 1; // row-sparse Fill evaluation (PM_FINE_SPARSE=0: the straightforward interpreter)
+    uint32_t heavy_stream = 32, vheavy_stream = 96;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
     uint32_t coarse_wg_per_cu = 6, fine_wg_per_cu = 4;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
@@ -268,7 +268,7 @@ int AllocViewport(pm_ctx *c) {
     for (auto &s : c->slot) {
         PM_TRY(hipMalloc(&s.d_fb, std::max<size_t>(c->fb_bytes, 16)));
         PM_TRY(hipMalloc(&s.d_striprow, std::max<size_t>(static_cast<size_t>(rows) * c->strips_x, 1) * sizeof(uint32_t)));
-        PM_TRY(hipMalloc(&s.d_queue, 3 * tiles * sizeof(uint4)));  // three class queues
+        PM_TRY(hipMalloc(&s.d_queue, pm::kClasses * tiles * sizeof(uint4)));  // one queue per cost class
         PM_TRY(hipMalloc(&s.d_tile_state, tiles * sizeof(uint32_t)));
         PM_TRY(hipMalloc(&s.d_tile_ptcl, tiles * sizeof(uint32_t)));
         PM_TRY(hipMalloc(&s.d_tile_ncmd, tiles * sizeof(uint32_t)));
@@ -384,6 +384,9 @@ int EnsureArena(pm_ctx *c) {
     std::vector<uint4> desc;
     for (size_t i = 0; i < need.size(); ++i)
         if (((need[i] + 3u) & ~3ull) != c->sr_empty_dwords) desc.push_back(make_uint4(static_cast<uint32_t>(i), base[i], base[i + 1], 0u));
+    // heaviest strip rows first (their arena need is the work estimate): the launch's span is its
+    // longest workgroup, and that one should not start in the second wave of workgroups
+    std::stable_sort(desc.begin(), desc.end(), [](const uint4 &a, const uint4 &b) { return a.z - a.y > b.z - b.y; });
     if (desc.empty()) desc.push_back(make_uint4(0u, base[0], need.empty() ? base[0] : base[1], 0u));
     c->n_sr_active = static_cast<uint32_t>(desc.size());
     if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
@@ -512,7 +515,14 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->band_item = c->d_band_item;
     p->n_band_items = c->n_band_items;
     p->split_mode = c->split_mode;
-    p->fine_sparse = c->fine_sparse;
+    {
+        // class thresholds in stream elements, descending: three classes of long lists (a
+        // workgroup per tile: > vheavy, > midway, > heavy), five of short ones
+        const uint32_t h = c->heavy_stream, v = std::max(c->vheavy_stream, h);
+        const uint32_t thr[pm::kClasses - 1] = {v, (v + h) / 2, h, h * 3 / 4, h / 2, h * 5 / 16, h * 5 / 32};
+        for (uint32_t k = 0; k < pm::kClasses - 1; ++k) p->class_thr[k] = thr[k];
+        p->n_heavy_classes = 3;
+    }
     p->fine_grid = FineGrid(c);
     p->use_row_lists = c->use_row_lists ? 1u : 0u;
     p->row_base = c->d_row_base;
@@ -797,8 +807,9 @@ pm_ctx *pm_create(int device, int *err) {
     }
     c->stream = c->streams[0];
     c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 6, 1, 16));
-    c->split_mode = static_cast<uint32_t>(EnvInt("PM_FINE_SPLIT", 1, 0, 2));
-    c->fine_sparse = static_cast<uint32_t>(EnvInt("PM_FINE_SPARSE", 1, 0, 1));
+    c->split_mode = static_cast<uint32_t>(EnvInt("PM_FINE_SPLIT", 1, 0, 1));
+    c->heavy_stream = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM", 32, 1, 1 << 20));
+    c->vheavy_stream = static_cast<uint32_t>(EnvInt("PM_VHEAVY_STREAM", 96, 1, 1 << 20));
     c->fold_clear = EnvInt("PM_FOLD_CLEAR", 1, 0, 1) != 0;
     c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 4, 1, 16));
     for (auto &ev : c->ev)
@@ -1167,29 +1178,56 @@ int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms) {
     PM_TRY(hipSetDevice(c->device));
     int r;
     if ((r = SyncAll(c)) != PM_OK) return r;
+    std::vector<float> lat;
+    for (int i = 0; i < iters; ++i) {
+        // One frame exactly as pm_render submits it (three plain launches), nothing else in
+        // flight, bracketed by two events on its stream: first kernel begin to last kernel end
+        // (SURVEY 8d's t_frame).  Dispatches that carry their own timestamps
+        // (pm_debug_frame_timeline) show the same kernels but stretch every gap between them
+        // by ~3.5 us, so they are kept for the breakdown only.
+        hipStream_t q = c->streams[c->frame % c->streams.size()];
+        PM_TRY(hipEventRecord(c->ev[0], q));
+        if ((r = Enqueue(c, nullptr, c->fb_stride, nullptr)) != PM_OK) return r;
+        PM_TRY(hipEventRecord(c->ev[1], q));
+        if ((r = SyncAll(c)) != PM_OK) return r;
+        float t = 0;
+        PM_TRY(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
+        lat.push_back(t);
+    }
+    std::sort(lat.begin(), lat.end());
+    if (median_ms) *median_ms = lat[lat.size() / 2];
+    if (min_ms) *min_ms = lat.front();
+    return pm_sync(c);
+}
+
+int pm_debug_frame_timeline(pm_ctx *c, int iters, float *out6) {
+    if (!c || !out6 || iters <= 0 || iters > 4096) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = SyncAll(c)) != PM_OK) return r;
     hipEvent_t tev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipError_t e = hipSuccess;
     for (auto &v : tev)
         if (e == hipSuccess) e = hipEventCreate(&v);
-    std::vector<float> lat;
+    std::vector<float> col[6];
     r = e == hipSuccess ? PM_OK : HipFail(e, "hipEventCreate");
     for (int i = 0; i < iters && r == PM_OK; ++i) {
-        // one frame through the pipeline's streams, nothing else in flight: first kernel's
-        // begin to last kernel's end (SURVEY 8d's t_frame), from the dispatches' own timestamps
         r = Enqueue(c, nullptr, c->fb_stride, nullptr, tev);
         if (r == PM_OK) r = SyncAll(c);
-        float t_fine = 0, t_clear = 0;
-        if (r == PM_OK && hipEventElapsedTime(&t_fine, tev[0], tev[7]) == hipSuccess &&
-            (c->fold_clear || hipEventElapsedTime(&t_clear, tev[0], tev[3]) == hipSuccess))
-            lat.push_back(std::max(t_fine, t_clear));
+        float v[6] = {0, 0, 0, 0, 0, 0};
+        if (r == PM_OK && hipEventElapsedTime(&v[0], tev[0], tev[1]) == hipSuccess && hipEventElapsedTime(&v[1], tev[1], tev[4]) == hipSuccess &&
+            hipEventElapsedTime(&v[2], tev[4], tev[5]) == hipSuccess && hipEventElapsedTime(&v[3], tev[5], tev[6]) == hipSuccess &&
+            hipEventElapsedTime(&v[4], tev[6], tev[7]) == hipSuccess && hipEventElapsedTime(&v[5], tev[0], tev[7]) == hipSuccess)
+            for (int k = 0; k < 6; ++k) col[k].push_back(v[k]);
     }
     for (auto &v : tev)
         if (v) (void)hipEventDestroy(v);
     if (r != PM_OK) return r;
-    if (lat.empty()) return PM_ERR_HIP;
-    std::sort(lat.begin(), lat.end());
-    if (median_ms) *median_ms = lat[lat.size() / 2];
-    if (min_ms) *min_ms = lat.front();
+    if (col[0].empty()) return PM_ERR_HIP;
+    for (int k = 0; k < 6; ++k) {
+        std::sort(col[k].begin(), col[k].end());
+        out6[k] = col[k][col[k].size() / 2];
+    }
     return pm_sync(c);
 }
 
@@ -1209,8 +1247,8 @@ int pm_get_stats(pm_ctx *c, pm_stats *out) {
     if (c->last_slot >= 0) {
         pm::Counters k;
         PM_TRY(hipMemcpy(&k, c->slot[c->last_slot].params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
-        out->queued_tiles = k.vheavy_count + k.heavy_count + k.light_count;
-        out->heavy_tiles = k.vheavy_count + k.heavy_count;
+        for (uint32_t q = 0; q < pm::kClasses; ++q) out->queued_tiles += k.cls[q].count;
+        for (uint32_t q = 0; q < 3; ++q) out->heavy_tiles += k.cls[q].count;  // (n_heavy_classes)
         out->arena_used_dwords = k.arena_top;
         out->ptcl_used_cmds = k.ptcl_top;
         out->overflow = k.overflow;
@@ -1314,18 +1352,22 @@ int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_sl
     pm::Counters k;
     PM_TRY(hipMemcpy(&k, s->params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
     // as pm_fine_kernel decides
-    const bool dense = k.vheavy_count + k.heavy_count >= FineGrid(c) * 4u || c->split_mode == 0;
-    const size_t slots = dense ? static_cast<size_t>(k.vheavy_count) + k.heavy_count + k.light_count
-                               : (c->split_mode == 1 ? 4ull : 16ull) * k.vheavy_count + 4ull * k.heavy_count + k.light_count;
+    size_t heavy = 0, total = 0;
+    for (uint32_t q = 0; q < pm::kClasses; ++q) {
+        total += k.cls[q].count;
+        if (q < 3) heavy += k.cls[q].count;
+    }
+    const bool dense = heavy >= FineGrid(c) * 4u || c->split_mode == 0;
+    const size_t slots = dense ? total : 4 * heavy + (total - heavy);
     if (n_slots) *n_slots = slots;
     if (slots > max_slots) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;
-    PM_TRY(hipMalloc(&d, std::max<size_t>(slots, 1) * 4 * sizeof(unsigned long long)));
+    PM_TRY(hipMalloc(&d, std::max<size_t>(slots, 1) * 6 * sizeof(unsigned long long)));
     pm::FrameParams p = s->params;
     p.dbg_time = d;
     pm::LaunchFine(p, 0u, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(out, d, slots * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out, d, slots * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return HipFail(e, "tile timeline");
     return PM_OK;

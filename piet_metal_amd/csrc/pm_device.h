@@ -9,22 +9,27 @@
 
 namespace pm {
 
+// Tiles with something to draw are queued in kClasses cost classes by the number of stream
+// elements binning counted for them (class 0 = longest lists).  The tile kernels hand the
+// queue slots out statically, longest class first, in snake order over their persistent waves:
+// with fine classes that is a longest-processing-time-first schedule, every wave ends up with
+// one long and one short tile instead of whatever the strip rows' atomics happened to interleave.
+constexpr uint32_t kClasses = 8;
+
 // Per-frame counters; two copies alternate between frames so that frame N's binning
 // kernel can reset frame N+1's copy (no memset launch on the critical path).
 struct Counters {
     // Every strip row of a frame adds to these with returning atomics.  The L2 executes
     // same-cache-line atomics one after the other (~90 per us measured), so each hot counter
     // lives on its own 128-byte line.
-    uint32_t ptcl_top;      // bump pointer into the command-list arena, in commands
+    uint32_t ptcl_top;  // bump pointer into the command-list arena, in commands
     uint32_t pad0[31];
-    uint32_t vheavy_count;  // tiles in queue A (very long lists: 16 waves per tile)
-    uint32_t pad1[31];
-    uint32_t heavy_count;   // tiles in queue B (long lists: 4 waves per tile)
-    uint32_t pad2[31];
-    uint32_t light_count;   // tiles in queue C (one wave per tile)
-    uint32_t pad3[31];
-    uint32_t arena_top;     // dwords of binning records written (statistics)
-    uint32_t overflow;      // set if the command-list arena ran out
+    struct {
+        uint32_t count;  // tiles queued in this class
+        uint32_t pad[31];
+    } cls[kClasses];
+    uint32_t arena_top;  // dwords of binning records written (statistics)
+    uint32_t overflow;   // set if the command-list arena ran out
     uint32_t pad4[30];
 };
 
@@ -49,10 +54,9 @@ struct Counters {
 // the worst case, so the binning kernel allocates with plain arithmetic: no atomics, no
 // counting pass.
 //
-// Tile queues: three class queues (very long / long / short lists, by the number of stream
-// elements binning counted for the tile) of 16-byte entries {tile, first command slot, first
-// binning record of the strip row, commands written}; the tile kernels walk them statically,
-// longest first, so the expensive tiles start first and the cheap ones fill the tail.
+// Tile queues: kClasses class queues of 16-byte entries {tile, first command slot, first binning
+// record of the strip row, commands written}; the tile kernels walk them statically, longest
+// first, so the expensive tiles start first and the cheap ones fill the tail.
 //
 // Scene index (built once per scene upload by pm_index_kernel, like the ShortBbox
 // array the encoder builds at encode time): segments are grouped in chunks of kChunkSegs
@@ -86,7 +90,7 @@ struct FrameParams {
     uint32_t n_sr_active;     // strip rows some item reaches = workgroups of pm_bin_kernel
     uint32_t sr_empty_dwords; // size of a region no item's bbox reaches
     uint32_t *striprow_head;
-    uint4 *queue;             // three class queues of {tile, first command slot, first record, commands}
+    uint4 *queue;             // kClasses class queues of {tile, first command slot, first record, commands}, queue_cap entries each
     uint32_t queue_cap;
     uint32_t *tile_state;     // [tiles of the band] 0 = queued for the tile kernels, else resolved colour
     Cmd *ptcl;                // per-tile command lists (24-byte records, TestApp/GenTypes.h:430-495)
@@ -99,8 +103,9 @@ struct FrameParams {
     const uint32_t *band_item;     // [n_band_items] their scene indices
     uint32_t n_band_items;
     uint32_t fine_grid;            // persistent workgroups of pm_fine_kernel (blocks beyond it clear strip rows)
-    uint32_t split_mode;           // fine kernel: 0 = one wave per tile always, 1 = at most 4 waves, 2 = 1/4/16 by class
-    uint32_t fine_sparse;          // 1 = pm_fine_sparse_kernel (row-sparse Fill evaluation), 0 = pm_fine_kernel
+    uint32_t split_mode;           // fine kernel: 0 = one wave per tile always, 1 = a workgroup per tile with a long list
+    uint32_t class_thr[kClasses - 1];  // descending: a tile with more stream elements than class_thr[c] is in class <= c
+    uint32_t n_heavy_classes;          // classes 0 .. n-1 are rendered by a whole workgroup per tile (long lists)
     // large scenes: per-tile-row item lists written each frame by pm_rowcull_kernel
     uint32_t use_row_lists;
     const uint32_t *row_base;      // [band rows + 1] list offsets (host-computed sizes)

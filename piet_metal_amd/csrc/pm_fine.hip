@@ -42,18 +42,6 @@ namespace {
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
-#ifndef PM_WAVE_CMDS
-#define PM_WAVE_CMDS 256
-#endif
-constexpr uint32_t kFineChunk = PM_WAVE_CMDS;  // commands staged in LDS per wave by the interpreter
-
-// Pixels of one lane: 4 horizontally adjacent pixels (x0 .. x0+3, same y).
-struct PixelState {
-    half2_t r01, r23, g01, g23, b01, b23;  // half3 rgb (PietRender.metal:470), packed
-    float df[4];                           // :471
-    _Float16 sa[4];                        // half signedArea (:472)
-};
-
 // f32 -> binary16 of a value that is the result of f32 arithmetic.  The value is pinned in a
 // register first: otherwise instruction selection folds `half(a * b)` (and friends) into
 // v_fma_mixlo_f16, which rounds the exact result ONCE to binary16 -- not the f32 rounding followed
@@ -72,247 +60,6 @@ __device__ __forceinline__ _Float16 HalfFromBits(uint32_t b) {
 
 __device__ __forceinline__ half2_t Splat(_Float16 v) { half2_t r; r.x = v; r.y = v; return r; }
 
-// rgb = mix(rgb, fg.rgb, fg.a * alpha) per pixel (:505, :543, :549): x + (y - x) * a in half
-__device__ __forceinline__ void Blend4(PixelState &st, uint32_t rg, uint32_t ba, const _Float16 alpha[4]) {
-    const _Float16 fga = HalfFromBits(ba >> 16);
-    half2_t a01, a23;
-    a01.x = fga * alpha[0]; a01.y = fga * alpha[1];
-    a23.x = fga * alpha[2]; a23.y = fga * alpha[3];
-    const half2_t fr = Splat(HalfFromBits(rg)), fg = Splat(HalfFromBits(rg >> 16)), fb = Splat(HalfFromBits(ba));
-    st.r01 = st.r01 + (fr - st.r01) * a01; st.r23 = st.r23 + (fr - st.r23) * a23;
-    st.g01 = st.g01 + (fg - st.g01) * a01; st.g23 = st.g23 + (fg - st.g23) * a23;
-    st.b01 = st.b01 + (fb - st.b01) * a01; st.b23 = st.b23 + (fb - st.b23) * a23;
-}
-
-// renderKernel's command loop (PietRender.metal:474-560) over an LDS-resident list.
-// px0 = x of the lane's first pixel, py = its row.
-__device__ __forceinline__ void Interpret(const Cmd *cmds, uint32_t n, float px0, float py, PixelState &st) {
-    for (uint32_t i = 0; i < n; ++i) {
-        const Cmd cmd = cmds[i];
-        switch (cmd.tag) {
-            case kCmdCircle: {  // :481-494
-                const float x0 = static_cast<float>(cmd.body[1] & 0xffffu), y0 = static_cast<float>(cmd.body[1] >> 16);
-                const float x1 = static_cast<float>(cmd.body[2] & 0xffffu), y1 = static_cast<float>(cmd.body[2] >> 16);
-                const float cx = x0 + (x1 - x0) * 0.5f, cy = y0 + (y1 - y0) * 0.5f;
-                const float circle_r = fminf(cx - x0, cy - y0);
-                const float dy = py - cy;
-                _Float16 alpha[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float dx = (px0 + static_cast<float>(k)) - cx;
-                    const float r = sqrtf(dx * dx + dy * dy);
-                    alpha[k] = ToHalf(Sat(circle_r - r));
-                }
-                const half2_t zero = Splat(static_cast<_Float16>(0.0f));
-                half2_t a01, a23;
-                a01.x = alpha[0]; a01.y = alpha[1]; a23.x = alpha[2]; a23.y = alpha[3];
-                st.r01 = st.r01 + (zero - st.r01) * a01; st.r23 = st.r23 + (zero - st.r23) * a23;
-                st.g01 = st.g01 + (zero - st.g01) * a01; st.g23 = st.g23 + (zero - st.g23) * a23;
-                st.b01 = st.b01 + (zero - st.b01) * a01; st.b23 = st.b23 + (zero - st.b23) * a23;
-                break;
-            }
-            case kCmdLine: {  // stroke(), :49-55
-                const float sx = __uint_as_float(cmd.body[1]), sy = __uint_as_float(cmd.body[2]);
-                const float ex = __uint_as_float(cmd.body[3]), ey = __uint_as_float(cmd.body[4]);
-                const float lx = ex - sx, ly = ey - sy;
-                const float den = lx * lx + ly * ly;
-                const float dy = py - sy;
-                const float lydy = ly * dy;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float dx = (px0 + static_cast<float>(k)) - sx;
-                    const float t = Sat((lx * dx + lydy) / den);
-                    const float fx = lx * t - dx, fy = ly * t - dy;
-                    st.df[k] = fminf(st.df[k], sqrtf(fx * fx + fy * fy));
-                }
-                break;
-            }
-            case kCmdStroke: {  // :500-507, renderDf :58-60
-                const float half_width = __uint_as_float(cmd.body[0]);
-                _Float16 alpha[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    alpha[k] = ToHalf(Sat(half_width + 0.5f - st.df[k]));
-                    st.df[k] = 1e9f;
-                }
-                Blend4(st, cmd.body[2], cmd.body[3], alpha);
-                break;
-            }
-            case kCmdFill: {  // :508-529
-                const float fsx = __uint_as_float(cmd.body[1]), fex = __uint_as_float(cmd.body[3]);
-                const float sy = __uint_as_float(cmd.body[2]) - py;
-                const float ey = __uint_as_float(cmd.body[4]) - py;
-                const float wx = Sat(sy), wy = Sat(ey);
-                if (wx != wy) {  // depends on y only: uniform over the lane's 4 pixels
-                    const float tx = (wx - sy) / (ey - sy);
-                    const float ty = (wy - sy) / (ey - sy);
-                    const float wd = wx - wy;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float px = px0 + static_cast<float>(k);
-                        const float sx = fsx - px, ex = fex - px;
-                        const float xsx = sx + (ex - sx) * tx;
-                        const float xsy = sx + (ex - sx) * ty;
-                        const float xmin = fminf(fminf(xsx, xsy), 1.0f) - 1e-6f;
-                        const float xmax = fmaxf(xsx, xsy);
-                        const float b = fminf(xmax, 1.0f);
-                        const float c = fmaxf(b, 0.0f);
-                        const float d = fmaxf(xmin, 0.0f);
-                        const float area = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-                        st.sa[k] = st.sa[k] + ToHalf(area * wd);
-                    }
-                }
-                break;
-            }
-            case kCmdFillEdge: {  // :530-534 (half + float => f32 add, one rounding)
-                const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
-                const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) st.sa[k] = ToHalf(static_cast<float>(st.sa[k]) + v);
-                break;
-            }
-            case kCmdDrawFill: {  // :535-545
-                const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
-                _Float16 alpha[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const _Float16 a = st.sa[k] + bd;
-                    alpha[k] = ToHalf(fminf(fabsf(static_cast<float>(a)), 1.0f));
-                    st.sa[k] = static_cast<_Float16>(0.0f);
-                }
-                Blend4(st, cmd.body[2], cmd.body[3], alpha);
-                break;
-            }
-            case kCmdSolid: {  // :546-551
-                const _Float16 one = static_cast<_Float16>(1.0f);
-                const _Float16 alpha[4] = {one, one, one, one};
-                Blend4(st, cmd.body[1], cmd.body[2], alpha);
-                break;
-            }
-            default:
-                break;
-        }
-    }
-}
-
-
-// ---- quarter-tile mode: one pixel per lane ---------------------------------------------
-// Tiles with long command lists are rendered by four waves (4 pixel rows each): the list
-// is walked in order by every wave, but a lone pixel per lane leaves the divide/area chains
-// without instruction-level parallelism, so runs of consecutive Fill commands are evaluated
-// four at a time (independent chains) and only ACCUMULATED in list order.
-struct PixelState1 {
-    _Float16 r, g, b;
-    float df;
-    _Float16 sa;
-};
-
-__device__ __forceinline__ void Blend1(PixelState1 &st, uint32_t rg, uint32_t ba, _Float16 alpha) {
-    const _Float16 fa = HalfFromBits(ba >> 16) * alpha;
-    const _Float16 fr = HalfFromBits(rg), fg = HalfFromBits(rg >> 16), fb = HalfFromBits(ba);
-    st.r = st.r + (fr - st.r) * fa;
-    st.g = st.g + (fg - st.g) * fa;
-    st.b = st.b + (fb - st.b) * fa;
-}
-
-__device__ __forceinline__ void Interpret1(const Cmd *cmds, uint32_t n, float px, float py, PixelState1 &st) {
-    for (uint32_t i = 0; i < n; ++i) {
-        const Cmd cmd = cmds[i];
-        switch (cmd.tag) {
-            case kCmdCircle: {
-                const float x0 = static_cast<float>(cmd.body[1] & 0xffffu), y0 = static_cast<float>(cmd.body[1] >> 16);
-                const float x1 = static_cast<float>(cmd.body[2] & 0xffffu), y1 = static_cast<float>(cmd.body[2] >> 16);
-                const float cx = x0 + (x1 - x0) * 0.5f, cy = y0 + (y1 - y0) * 0.5f;
-                const float dx = px - cx, dy = py - cy;
-                const float r = sqrtf(dx * dx + dy * dy);
-                const _Float16 alpha = ToHalf(Sat(fminf(cx - x0, cy - y0) - r));
-                const _Float16 zero = static_cast<_Float16>(0.0f);
-                st.r = st.r + (zero - st.r) * alpha;
-                st.g = st.g + (zero - st.g) * alpha;
-                st.b = st.b + (zero - st.b) * alpha;
-                break;
-            }
-            case kCmdLine: {
-                const float sx = __uint_as_float(cmd.body[1]), sy = __uint_as_float(cmd.body[2]);
-                const float ex = __uint_as_float(cmd.body[3]), ey = __uint_as_float(cmd.body[4]);
-                const float lx = ex - sx, ly = ey - sy;
-                const float dx = px - sx, dy = py - sy;
-                const float t = Sat((lx * dx + ly * dy) / (lx * lx + ly * ly));
-                const float fx = lx * t - dx, fy = ly * t - dy;
-                st.df = fminf(st.df, sqrtf(fx * fx + fy * fy));
-                break;
-            }
-            case kCmdStroke: {
-                const _Float16 alpha = ToHalf(Sat(__uint_as_float(cmd.body[0]) + 0.5f - st.df));
-                Blend1(st, cmd.body[2], cmd.body[3], alpha);
-                st.df = 1e9f;
-                break;
-            }
-            case kCmdFill: {
-                uint32_t run = 1;
-                while (run < 4u && i + run < n && cmds[i + run].tag == kCmdFill) ++run;
-                float sy[4], ey[4], wx[4], wy[4], fsx[4], fex[4];
-                bool live[4];
-                bool any_live = false;
-#pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) {
-                    const Cmd cu = cmds[min(i + u, n - 1u)];
-                    fsx[u] = __uint_as_float(cu.body[1]);
-                    fex[u] = __uint_as_float(cu.body[3]);
-                    sy[u] = __uint_as_float(cu.body[2]) - py;
-                    ey[u] = __uint_as_float(cu.body[4]) - py;
-                    wx[u] = Sat(sy[u]);
-                    wy[u] = Sat(ey[u]);
-                    live[u] = (u < run) && (wx[u] != wy[u]);
-                    any_live = any_live || live[u];
-                }
-                if (any_live) {
-                    float contrib[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) {  // four independent chains
-                        const float tx = (wx[u] - sy[u]) / (ey[u] - sy[u]);
-                        const float ty = (wy[u] - sy[u]) / (ey[u] - sy[u]);
-                        const float sx = fsx[u] - px, ex = fex[u] - px;
-                        const float xsx = sx + (ex - sx) * tx;
-                        const float xsy = sx + (ex - sx) * ty;
-                        const float xmin = fminf(fminf(xsx, xsy), 1.0f) - 1e-6f;
-                        const float xmax = fmaxf(xsx, xsy);
-                        const float b = fminf(xmax, 1.0f);
-                        const float c = fmaxf(b, 0.0f);
-                        const float d = fmaxf(xmin, 0.0f);
-                        const float area = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-                        contrib[u] = area * (wx[u] - wy[u]);
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u)  // accumulate in list order (half adds do not commute)
-                        if (live[u]) st.sa = st.sa + ToHalf(contrib[u]);
-                }
-                i += run - 1u;
-                break;
-            }
-            case kCmdFillEdge: {
-                const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
-                const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
-                st.sa = ToHalf(static_cast<float>(st.sa) + v);
-                break;
-            }
-            case kCmdDrawFill: {
-                _Float16 alpha = st.sa + static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
-                alpha = ToHalf(fminf(fabsf(static_cast<float>(alpha)), 1.0f));
-                Blend1(st, cmd.body[2], cmd.body[3], alpha);
-                st.sa = static_cast<_Float16>(0.0f);
-                break;
-            }
-            case kCmdSolid:
-                Blend1(st, cmd.body[1], cmd.body[2], static_cast<_Float16>(1.0f));
-                break;
-            default:
-                break;
-        }
-    }
-}
-
-
 // ---- row-sparse Fill evaluation -----------------------------------------------------------
 // A Fill command only changes the pixels of the rows its segment crosses (wx != wy,
 // PietRender.metal:513-514): at Tiger 4K that is 3.4 of a tile's 16 rows on average, yet the
@@ -328,15 +75,22 @@ __device__ __forceinline__ void Interpret1(const Cmd *cmds, uint32_t n, float px
 // evaluated changes, and those are exactly the pairs the reference adds a contribution for.
 // Tiles with long lists are rendered by the 4 waves of a workgroup together: passes 1 and 2
 // are split by command batch, pass 3 by pixel rows (1 pixel per lane).
-constexpr uint32_t kSpChunk = 64;   // commands staged per chunk
-constexpr uint32_t kMaxFrag = 128;  // fragment slots per wave (one step of pass 1 adds <= 64)
+constexpr uint32_t kSpChunk = 64;     // commands staged per chunk
+constexpr uint32_t kMaxFrag = 64;     // fragment slots per wave (one step of pass 1 adds <= 64)
+constexpr uint32_t kAlphaSlots = 16;  // workgroup mode: items evaluated ahead per round
 
 struct SparseLds {
     Cmd cmds[kWaves][kSpChunk];
     float4 fparam[kWaves * kMaxFrag];     // {tx, ty, wx - wy, bits(command index)}
     uint2 contrib[kWaves * kMaxFrag][4];  // 16 binary16 contributions per fragment (x = 0..15)
+    // workgroup mode (tiles with long lists):
+    uint2 alpha[kAlphaSlots][64];         // per item: 256 binary16 alphas, pixel-linear (row * 16 + x)
+    uint2 rec[kSpChunk];                  // per item of the chunk: its colour {r | g << 16, b | a << 16} (binary16)
+    uint2 carry_sa[2][64];                // signedArea / distance state of an item cut by the chunk boundary
+    float4 carry_df[2][64];               //   (two copies, alternating per chunk)
     uint8_t fill_ix[kWaves][kSpChunk];    // indices of the chunk's Fill commands, in order
 };
+static_assert(sizeof(SparseLds) <= 40960, "four workgroups per CU");
 
 __device__ __forceinline__ half2_t Half2FromBits(uint32_t b) { return __builtin_bit_cast(half2_t, b); }
 
@@ -354,58 +108,41 @@ __device__ __forceinline__ _Float16 FillContribution(float fsx, float fex, float
     return ToHalf(area * wd);
 }
 
-// Passes 1 and 2 for the Fill commands [from, ...) of the staged chunk.  Returns the ordinal
-// of the first Fill NOT covered.  kWG: the four waves of the workgroup share the work (two
-// steps of pass 1 each per call) and the call contains two workgroup barriers.
-template <bool kWG>
-__device__ __forceinline__ uint32_t PrepareFills(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t nfill, uint32_t from,
-                                                  uint32_t x0, uint32_t y0) {
-    const uint32_t lane = LaneId(), wave = threadIdx.x >> 6;
-    const uint32_t rb = wave * kMaxFrag;
-    uint32_t nfrag = 0;
-    auto step = [&](uint32_t pos) {
-        const uint32_t q = lane >> 4, row = lane & 15u;
-        const uint32_t fi = pos + q;
-        const bool valid = fi < nfill;
-        const uint32_t ci = fill_ix[valid ? fi : pos];
-        const float py = static_cast<float>(y0 + row);
-        const float sy = __uint_as_float(cmds[ci].body[2]) - py;
-        const float ey = __uint_as_float(cmds[ci].body[4]) - py;
-        const float wx = Sat(sy), wy = Sat(ey);
-        const bool live = valid && wx != wy;
-        const uint64_t mask = __ballot(live);
-        if (mask == 0) return;  // (the staged body[0] of a Fill is 0: no row, nothing to add)
-        if (live) {
-            const float tx = (wx - sy) / (ey - sy);
-            const float ty = (wy - sy) / (ey - sy);
-            S.fparam[rb + nfrag + RankBelow(mask)] = make_float4(tx, ty, wx - wy, __uint_as_float(ci));
-        }
-        if (row == 0 && valid) {
-            const uint32_t gm = static_cast<uint32_t>(mask >> (16u * q)) & 0xffffu;
-            const uint32_t gb = rb + nfrag + static_cast<uint32_t>(__popcll(mask & ((1ull << (16u * q)) - 1ull)));
-            cmds[ci].body[0] = gm | (gb << 16);
-        }
-        nfrag += static_cast<uint32_t>(__popcll(mask));
-    };
-    uint32_t done;
-    if (kWG) {
-        __syncthreads();  // every wave is through with the contributions of the previous call
-#pragma unroll 1
-        for (uint32_t b = 0; b < 2; ++b) {
-            const uint32_t pos = from + 4u * (wave + kWaves * b);
-            if (pos < nfill) step(pos);
-        }
-        done = min(from + 8u * kWaves, nfill);
-    } else {
-        uint32_t pos = from;
-#pragma unroll 1
-        while (pos < nfill && nfrag + 64u <= kMaxFrag) {
-            step(pos);
-            pos += 4u;
-        }
-        done = min(pos, nfill);
+// One step of pass 1: the Fill commands [pos, pos + 4) of the chunk's Fill list (those below
+// `limit`) x 16 rows.  Live pairs get the next fragment slots of this wave's region; returns
+// false (and writes nothing) if the region cannot take them.
+__device__ __forceinline__ bool FillStep(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t limit, uint32_t pos, uint32_t rb,
+                                         uint32_t &nfrag, uint32_t y0) {
+    const uint32_t lane = LaneId();
+    const uint32_t q = lane >> 4, row = lane & 15u;
+    const uint32_t fi = pos + q;
+    const bool valid = fi < limit;
+    const uint32_t ci = fill_ix[valid ? fi : pos];
+    const float py = static_cast<float>(y0 + row);
+    const float sy = __uint_as_float(cmds[ci].body[2]) - py;
+    const float ey = __uint_as_float(cmds[ci].body[4]) - py;
+    const float wx = Sat(sy), wy = Sat(ey);
+    const bool live = valid && wx != wy;
+    const uint64_t mask = __ballot(live);
+    if (mask == 0) return true;  // (the staged body[0] of a Fill is 0: no row, nothing to add)
+    if (nfrag + static_cast<uint32_t>(__popcll(mask)) > kMaxFrag) return false;
+    if (live) {
+        const float tx = (wx - sy) / (ey - sy);
+        const float ty = (wy - sy) / (ey - sy);
+        S.fparam[rb + nfrag + RankBelow(mask)] = make_float4(tx, ty, wx - wy, __uint_as_float(ci));
     }
-    WaveSync();
+    if (row == 0 && valid) {
+        const uint32_t gm = static_cast<uint32_t>(mask >> (16u * q)) & 0xffffu;
+        const uint32_t gb = rb + nfrag + static_cast<uint32_t>(__popcll(mask & ((1ull << (16u * q)) - 1ull)));
+        cmds[ci].body[0] = gm | (gb << 16);
+    }
+    nfrag += static_cast<uint32_t>(__popcll(mask));
+    return true;
+}
+
+// Pass 2 over this wave's fragments [rb, rb + nfrag)
+__device__ __forceinline__ void FillPass2(SparseLds &S, const Cmd *cmds, uint32_t rb, uint32_t nfrag, uint32_t x0) {
+    const uint32_t lane = LaneId();
 #pragma unroll 1
     for (uint32_t f0 = 0; f0 < nfrag; f0 += 16u) {
         const uint32_t f = f0 + (lane >> 2), g = lane & 3u;
@@ -423,8 +160,24 @@ __device__ __forceinline__ uint32_t PrepareFills(SparseLds &S, Cmd *cmds, const 
             S.contrib[rb + f][g] = v;
         }
     }
-    if (kWG) __syncthreads(); else WaveSync();
-    return done;
+}
+
+// Single-wave mode: passes 1 and 2 for the Fill commands [from, ...) of the staged chunk, as many
+// as the wave's fragment region takes.  Returns the ordinal of the first Fill NOT covered.
+__device__ __forceinline__ uint32_t PrepareFills(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t nfill, uint32_t from,
+                                                 uint32_t x0, uint32_t y0) {
+    const uint32_t rb = (threadIdx.x >> 6) * kMaxFrag;
+    uint32_t nfrag = 0;
+    uint32_t pos = from;
+#pragma unroll 1
+    while (pos < nfill) {  // (the first step always fits: it adds at most 64)
+        if (!FillStep(S, cmds, fill_ix, nfill, pos, rb, nfrag, y0)) break;
+        pos += 4u;
+    }
+    WaveSync();
+    FillPass2(S, cmds, rb, nfrag, x0);
+    WaveSync();
+    return min(pos, nfill);
 }
 
 // Pixels of one lane, whole-tile layout, signedArea packed (the half adds are per element)
@@ -509,7 +262,7 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 break;
             }
             case kCmdFill: {
-                if (fo >= prepared) prepared = PrepareFills<false>(S, cmds, fill_ix, nfill, fo, x0, y0);  // uniform
+                if (fo >= prepared) prepared = PrepareFills(S, cmds, fill_ix, nfill, fo, x0, y0);  // uniform
                 ++fo;
                 const uint32_t hdr = cmds[i].body[0];  // row mask | first fragment << 16 (pass 1)
                 if ((hdr >> row) & 1u) {
@@ -552,272 +305,251 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
     }
 }
 
-// The same loop for a quarter of a tile (4 pixel rows, 1 pixel per lane): tiles with long lists,
-// all four waves of the workgroup walk the list together (PrepareFills<true> has barriers).
-__device__ __forceinline__ void InterpretSparseWG(SparseLds &S, Cmd *cmds, uint8_t *fill_ix, uint32_t n, uint32_t x0, uint32_t y0,
-                                                  uint32_t row, uint32_t xi, PixelState1 &st) {
+// Tiles with long lists: the four waves of a workgroup render one tile together.
+//
+// A wave alone walks a list at 0.2-0.3 us per command whatever the number of pixels it owns:
+// every command is a dependent chain (LDS fetch + readfirstlane + scalar dispatch 83 ns, an IEEE
+// divide 29 ns, a square root 47 ns -- tools/probes/issue_probe.hip), so the span of the whole
+// kernel used to be its longest list.  But signedArea and the distance field are reset by the
+// command that consumes them (DrawFill :542, Stroke :506): the commands between two blending
+// commands form an ITEM whose alpha does not depend on any other item.  So, per chunk:
+//   phase A  (parallel over ITEMS, one item per wave at a time, 4 pixels per lane): the item's
+//            Fill / FillEdge / Line commands in list order exactly as InterpretSparse() runs
+//            them, then alpha of the closing DrawFill / Stroke / Circle / Solid for all 256
+//            pixels -> a binary16 image in LDS;
+//   phase B  (parallel over PIXELS, 1 pixel per lane): the blends (:505, :543, :549, :491) in
+//            list order, one LDS read and three mixes per item, no dispatch at all.
+// An item cut by the chunk boundary hands its accumulators on through LDS.  (The lists are what
+// pm_coarse_kernel writes: Fill / FillEdge only before their DrawFill, Line only before its Stroke.)
+struct PixelRGB {
+    _Float16 r, g, b;
+};
+
+// Commands [s, e) of one item, whole tile per wave (lane -> row lane / 4, 4 pixels): Fill,
+// FillEdge and Line exactly as in InterpretSparse(); fm = the chunk's Fill commands.
+__device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint64_t fm, uint32_t s, uint32_t e,
+                                                uint32_t x0, uint32_t y0, half2_t &sa01, half2_t &sa23, float (&df)[4]) {
+    if (s >= e) return;
     const uint32_t lane = LaneId();
-    const float px = static_cast<float>(x0 + xi), py = static_cast<float>(y0 + row);
-    const bool isf = lane < n && cmds[lane].tag == kCmdFill;
-    const uint64_t fm = __ballot(isf);
-    if (isf) fill_ix[RankBelow(fm)] = static_cast<uint8_t>(lane);  // (every wave keeps its own copy)
-    const uint32_t nfill = static_cast<uint32_t>(__popcll(fm));
-    WaveSync();
-    uint32_t fo = 0, prepared = 0;
-    for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t row = lane >> 2, g = lane & 3u;
+    const float px0 = static_cast<float>(x0 + 4u * g), py = static_cast<float>(y0 + row);
+    uint32_t fo = static_cast<uint32_t>(__popcll(fm & ((1ull << s) - 1ull)));
+    const uint32_t flimit = static_cast<uint32_t>(__popcll(fm & (e >= 64u ? ~0ull : ((1ull << e) - 1ull))));
+    uint32_t prepared = fo;
+#pragma unroll 1
+    for (uint32_t i = s; i < e; ++i) {
         const Cmd cmd = cmds[i];
-        switch (cmd.tag) {
-            case kCmdCircle: {
+        if (cmd.tag == kCmdFill) {
+            if (fo >= prepared) prepared = PrepareFills(S, cmds, fill_ix, flimit, fo, x0, y0);  // uniform
+            ++fo;
+            const uint32_t hdr = cmds[i].body[0];
+            if ((hdr >> row) & 1u) {
+                const uint32_t f = (hdr >> 16) + static_cast<uint32_t>(__popc(hdr & ((1u << row) - 1u)));
+                const uint2 v = S.contrib[f][g];
+                sa01 = sa01 + Half2FromBits(v.x);
+                sa23 = sa23 + Half2FromBits(v.y);
+            }
+        } else if (cmd.tag == kCmdFillEdge) {
+            const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
+            const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
+            sa01.x = ToHalf(static_cast<float>(sa01.x) + v);
+            sa01.y = ToHalf(static_cast<float>(sa01.y) + v);
+            sa23.x = ToHalf(static_cast<float>(sa23.x) + v);
+            sa23.y = ToHalf(static_cast<float>(sa23.y) + v);
+        } else if (cmd.tag == kCmdLine) {
+            const float sx = __uint_as_float(cmd.body[1]), sy = __uint_as_float(cmd.body[2]);
+            const float ex = __uint_as_float(cmd.body[3]), ey = __uint_as_float(cmd.body[4]);
+            const float lx = ex - sx, ly = ey - sy;
+            const float den = lx * lx + ly * ly;
+            const float dy = py - sy;
+            const float lydy = ly * dy;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dx = (px0 + static_cast<float>(k)) - sx;
+                const float t = Sat((lx * dx + lydy) / den);
+                const float fx = lx * t - dx, fy = ly * t - dy;
+                df[k] = fminf(df[k], sqrtf(fx * fx + fy * fy));
+            }
+        }
+    }
+}
+
+struct PhaseTicks {
+    unsigned long long a = 0, b = 0;
+};
+
+// One staged chunk (n commands, parity = chunk index & 1) of a tile rendered by the workgroup;
+// pix = this lane's pixel in phase B (row * 16 + x).
+template <bool kProf>
+__device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *fill_ix, uint32_t n, uint32_t parity, uint32_t x0,
+                                              uint32_t y0, uint32_t pix, PixelRGB &st, PhaseTicks &prof) {
+    const uint32_t lane = LaneId(), wave = threadIdx.x >> 6;
+    const uint32_t tag = lane < n ? cmds[lane].tag : 0u;
+    const uint64_t fm = __ballot(tag == kCmdFill);
+    const uint64_t bm = __ballot(tag == kCmdDrawFill || tag == kCmdStroke || tag == kCmdSolid || tag == kCmdCircle);
+    if (tag == kCmdFill) fill_ix[RankBelow(fm)] = static_cast<uint8_t>(lane);  // (every wave keeps its own copy)
+    if (wave == 0 && ((bm >> lane) & 1ull)) {
+        // the item's colour, as the blend takes it: Circle is black with alpha exactly `alpha` (:491)
+        uint2 c = make_uint2(0u, 0x3c000000u);
+        if (tag == kCmdSolid) c = make_uint2(cmds[lane].body[1], cmds[lane].body[2]);
+        if (tag == kCmdDrawFill || tag == kCmdStroke) c = make_uint2(cmds[lane].body[2], cmds[lane].body[3]);
+        S.rec[RankBelow(bm)] = c;
+    }
+    WaveSync();
+    const uint32_t nitems = static_cast<uint32_t>(__popcll(bm));
+    const uint32_t r4 = lane >> 2, g = lane & 3u;
+    uint64_t mm = bm;
+    uint32_t unit_begin = 0;  // first command of the next item
+    uint32_t k0 = 0;
+    // items go to the wave with the least work so far (every wave runs the same scalar
+    // bookkeeping): cost = commands of the item, its Fills counted twice
+    uint32_t load[kWaves] = {0u, 0u, 0u, 0u};
+    do {  // rounds of kAlphaSlots items
+        const uint32_t kend = min(k0 + kAlphaSlots, nitems);
+        const bool last_round = kend == nitems;
+        unsigned long long t_a = 0;
+        if (kProf) t_a = wall_clock64();
+        __syncthreads();  // phase B of the previous round (or chunk) is done with the alpha images
+        // ---- phase A -------------------------------------------------------------------------
+#pragma unroll 1
+        for (uint32_t k = k0; k <= kend; ++k) {
+            const bool is_tail = k == kend;
+            if (is_tail && !last_round) break;
+            uint32_t s0 = unit_begin, e0;
+            if (is_tail) {
+                e0 = n;
+            } else {
+                e0 = static_cast<uint32_t>(__builtin_ctzll(mm));
+                mm &= mm - 1ull;
+                unit_begin = e0 + 1u;
+            }
+            uint32_t owner = 0;
+#pragma unroll
+            for (uint32_t w = 1; w < static_cast<uint32_t>(kWaves); ++w)
+                if (load[w] < load[owner]) owner = w;
+            {
+                const uint64_t span = (e0 >= 64u ? ~0ull : ((1ull << e0) - 1ull)) & ~((1ull << s0) - 1ull);  // [s0, e0)
+                load[owner] += 2u + (e0 - s0) + static_cast<uint32_t>(__popcll(fm & span));
+            }
+            if (owner != wave) continue;
+            half2_t sa01 = Splat(static_cast<_Float16>(0.0f)), sa23 = sa01;
+            float df[4] = {1e9f, 1e9f, 1e9f, 1e9f};
+            if (s0 == 0) {  // the chunk opens inside an item: its accumulators so far
+                const uint2 cs = S.carry_sa[parity][lane];
+                const float4 cd = S.carry_df[parity][lane];
+                sa01 = Half2FromBits(cs.x); sa23 = Half2FromBits(cs.y);
+                df[0] = cd.x; df[1] = cd.y; df[2] = cd.z; df[3] = cd.w;
+            }
+            RunItemCommands(S, cmds, fill_ix, fm, s0, e0, x0, y0, sa01, sa23, df);
+            if (is_tail) {  // (also when the tail is empty: the next chunk starts from a clean state)
+                uint2 cs;
+                cs.x = __builtin_bit_cast(uint32_t, sa01); cs.y = __builtin_bit_cast(uint32_t, sa23);
+                S.carry_sa[parity ^ 1u][lane] = cs;
+                S.carry_df[parity ^ 1u][lane] = make_float4(df[0], df[1], df[2], df[3]);
+                continue;
+            }
+            const Cmd cmd = cmds[e0];
+            _Float16 al[4];
+            if (cmd.tag == kCmdDrawFill) {  // :535-542
+                const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
+                const half2_t s01 = sa01 + Splat(bd), s23 = sa23 + Splat(bd);
+                al[0] = ToHalf(fminf(fabsf(static_cast<float>(s01.x)), 1.0f));
+                al[1] = ToHalf(fminf(fabsf(static_cast<float>(s01.y)), 1.0f));
+                al[2] = ToHalf(fminf(fabsf(static_cast<float>(s23.x)), 1.0f));
+                al[3] = ToHalf(fminf(fabsf(static_cast<float>(s23.y)), 1.0f));
+            } else if (cmd.tag == kCmdStroke) {  // :500-504
+                const float half_width = __uint_as_float(cmd.body[0]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) al[u] = ToHalf(Sat(half_width + 0.5f - df[u]));
+            } else if (cmd.tag == kCmdCircle) {  // :481-490
                 const float bx0 = static_cast<float>(cmd.body[1] & 0xffffu), by0 = static_cast<float>(cmd.body[1] >> 16);
                 const float bx1 = static_cast<float>(cmd.body[2] & 0xffffu), by1 = static_cast<float>(cmd.body[2] >> 16);
                 const float cx = bx0 + (bx1 - bx0) * 0.5f, cy = by0 + (by1 - by0) * 0.5f;
-                const float dx = px - cx, dy = py - cy;
-                const float r = sqrtf(dx * dx + dy * dy);
-                const _Float16 alpha = ToHalf(Sat(fminf(cx - bx0, cy - by0) - r));
-                const _Float16 zero = static_cast<_Float16>(0.0f);
-                st.r = st.r + (zero - st.r) * alpha;
-                st.g = st.g + (zero - st.g) * alpha;
-                st.b = st.b + (zero - st.b) * alpha;
-                break;
-            }
-            case kCmdLine: {
-                const float sx = __uint_as_float(cmd.body[1]), sy = __uint_as_float(cmd.body[2]);
-                const float ex = __uint_as_float(cmd.body[3]), ey = __uint_as_float(cmd.body[4]);
-                const float lx = ex - sx, ly = ey - sy;
-                const float dx = px - sx, dy = py - sy;
-                const float t = Sat((lx * dx + ly * dy) / (lx * lx + ly * ly));
-                const float fx = lx * t - dx, fy = ly * t - dy;
-                st.df = fminf(st.df, sqrtf(fx * fx + fy * fy));
-                break;
-            }
-            case kCmdStroke: {
-                const _Float16 alpha = ToHalf(Sat(__uint_as_float(cmd.body[0]) + 0.5f - st.df));
-                Blend1(st, cmd.body[2], cmd.body[3], alpha);
-                st.df = 1e9f;
-                break;
-            }
-            case kCmdFill: {
-                if (fo >= prepared) prepared = PrepareFills<true>(S, cmds, fill_ix, nfill, fo, x0, y0);  // uniform over the workgroup
-                ++fo;
-                const uint32_t hdr = cmds[i].body[0];
-                if ((hdr >> row) & 1u) {
-                    const uint32_t f = (hdr >> 16) + static_cast<uint32_t>(__popc(hdr & ((1u << row) - 1u)));
-                    st.sa = st.sa + reinterpret_cast<const _Float16 *>(&S.contrib[f][0])[xi];
+                const float circle_r = fminf(cx - bx0, cy - by0);
+                const float dy = static_cast<float>(y0 + r4) - cy;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float dx = static_cast<float>(x0 + 4u * g + static_cast<uint32_t>(u)) - cx;
+                    al[u] = ToHalf(Sat(circle_r - sqrtf(dx * dx + dy * dy)));
                 }
-                break;
+            } else {  // Solid (:546-549): alpha 1
+#pragma unroll
+                for (int u = 0; u < 4; ++u) al[u] = static_cast<_Float16>(1.0f);
             }
-            case kCmdFillEdge: {
-                const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
-                const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
-                st.sa = ToHalf(static_cast<float>(st.sa) + v);
-                break;
-            }
-            case kCmdDrawFill: {
-                _Float16 alpha = st.sa + static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
-                alpha = ToHalf(fminf(fabsf(static_cast<float>(alpha)), 1.0f));
-                Blend1(st, cmd.body[2], cmd.body[3], alpha);
-                st.sa = static_cast<_Float16>(0.0f);
-                break;
-            }
-            case kCmdSolid:
-                Blend1(st, cmd.body[1], cmd.body[2], static_cast<_Float16>(1.0f));
-                break;
-            default:
-                break;
+            uint2 v;
+            v.x = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, al[0])) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, al[1])) << 16);
+            v.y = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, al[2])) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, al[3])) << 16);
+            S.alpha[k & (kAlphaSlots - 1u)][lane] = v;
         }
-    }
+        __syncthreads();
+        unsigned long long t_b = 0;
+        if (kProf) {
+            t_b = wall_clock64();
+            prof.a += t_b - t_a;
+        }
+        // ---- phase B: rgb = mix(rgb, fg.rgb, fg.a * alpha), items in list order ---------------------
+#pragma unroll 2
+        for (uint32_t k = k0; k < kend; ++k) {
+            const uint2 c = S.rec[k];
+            const _Float16 a = reinterpret_cast<const _Float16 *>(&S.alpha[k & (kAlphaSlots - 1u)][0])[pix];
+            const _Float16 fa = HalfFromBits(c.y >> 16) * a;
+            st.r = st.r + (HalfFromBits(c.x) - st.r) * fa;
+            st.g = st.g + (HalfFromBits(c.x >> 16) - st.g) * fa;
+            st.b = st.b + (HalfFromBits(c.y) - st.b) * fa;
+        }
+        if (kProf) prof.b += wall_clock64() - t_b;
+        k0 = kend;
+    } while (k0 < nitems);
 }
 
 }  // namespace
 
-// K3: per-pixel interpreter (renderKernel :457-566) over the per-tile command lists
-// =====================================================================================
-// Light tiles: one wave per tile, 4 adjacent pixels per lane.  Tiles with long lists: four
-// waves per tile (4 pixel rows each, 1 pixel per lane, Fill runs evaluated 4 at a time).
-// The list is staged through LDS in chunks with coalesced loads; interpreter state stays
-// in registers across chunks.
-__global__ __launch_bounds__(kThreads, PM_FINE_WPS) void pm_fine_kernel(FrameParams P) {
-    __shared__ Cmd s_cmds[kWaves][kFineChunk];
-    Cmd *const cmds = s_cmds[threadIdx.x >> 6];
-
-    // Workgroups beyond the persistent grid write the pixels of the tiles binning resolved (see
-    // pm_clear_kernel): pure stores that fill the SIMDs this kernel's long tail leaves idle, and
-    // one launch less per frame.
-    if (blockIdx.x >= P.fine_grid) {
-        ClearStripRow(P, blockIdx.x - P.fine_grid);
-        return;
-    }
-    const uint32_t lane = LaneId();
-    const uint32_t n_a = P.ctr_cur->vheavy_count, n_b = P.ctr_cur->heavy_count, n_c = P.ctr_cur->light_count;
-    const uint32_t wave_global = blockIdx.x * kWaves + (threadIdx.x >> 6);
-    const uint32_t n_waves = P.fine_grid * kWaves;
-    // slots: 4 per tile with a long list (16 for the very long ones in split mode 2), 1 per light tile.
-    // Splitting a tile buys latency when few long lists set the span of the launch; with more
-    // long lists than waves it only costs work (the y-only math is no longer shared by 4
-    // pixels), so dense frames render every tile with one wave.
-    const bool dense = n_a + n_b >= n_waves || P.split_mode == 0;
-    const bool split4_only = P.split_mode == 1;  // (default) never 16 waves per tile: measured no faster than 4
-    const uint32_t sh_a = dense ? 0u : (split4_only ? 2u : 4u), sh_b = dense ? 0u : 2u;
-    const uint32_t s_a = n_a << sh_a, s_b = n_b << sh_b;
-    const uint32_t n_slots = s_a + s_b + n_c;
-    const uint8_t *lut = P.lut_lin2srgb;
-    // linear -> sRGB + unorm8 (:563-565): the 65,536-entry table of decision D2.  (A compact
-    // LDS-resident form of the table was measured slower: this kernel is bound by instruction
-    // issue, and twelve byte loads per lane are fewer instructions than twelve decodes.)
-    auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {
-        return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, r)]) |
-               (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
-               (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, b)]) << 16) | 0xff000000u;
-    };
-    // slot -> queue entry index and the rows of the tile this wave renders: [row0, row0 + nrows)
-    auto slot_entry = [&](uint32_t slot, uint32_t &row0, uint32_t &nrows) -> uint32_t {
-        if (slot < s_a) {
-            nrows = 16u >> sh_a;
-            row0 = (slot & ((1u << sh_a) - 1u)) * nrows;
-            return slot >> sh_a;
-        }
-        if (slot < s_a + s_b) {
-            nrows = 16u >> sh_b;
-            row0 = ((slot - s_a) & ((1u << sh_b) - 1u)) * nrows;
-            return P.queue_cap + ((slot - s_a) >> sh_b);
-        }
-        row0 = 0;
-        nrows = 16;
-        return 2u * P.queue_cap + (slot - s_a - s_b);
-    };
-    auto pass_slot = [&](uint32_t pass) -> uint32_t {
-        return pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
-    };
-
-    // The queue entry {tile, first command slot, -, commands} of the NEXT slot is fetched while
-    // the current tile is interpreted: one exposed round trip per tile (the command list) instead
-    // of three dependent ones.
-    uint32_t slot = pass_slot(0);
-    uint4 qe = make_uint4(0u, 0u, 0u, 0u);
-    {
-        uint32_t r0_, nr_;
-        if (slot < n_slots) qe = P.queue[slot_entry(slot, r0_, nr_)];
-    }
-    for (uint32_t pass = 0; pass * n_waves < n_slots; ++pass) {
-        const uint32_t cur_slot = slot;
-        const uint4 cur = qe;
-        slot = pass_slot(pass + 1u);
-        {
-            uint32_t r0_, nr_;
-            if ((pass + 1u) * n_waves < n_slots && slot < n_slots) qe = P.queue[slot_entry(slot, r0_, nr_)];
-        }
-        if (cur_slot >= n_slots) continue;
-        uint32_t row0, nrows;
-        (void)slot_entry(cur_slot, row0, nrows);
-        const uint32_t tile = cur.x;
-        const bool quarter = nrows != 16u;  // one pixel per lane (lanes beyond nrows*16 idle)
-        unsigned long long t_begin = 0;
-        if (P.dbg_time) t_begin = wall_clock64();
-        const uint32_t n_cmd = cur.w;
-        if (n_cmd != 0) {  // 0: the coarse kernel found one opaque colour and wrote it
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(P.ptcl + cur.y);
-            const uint32_t tx = tile % P.tiles_x;
-            const uint32_t ty_rel = tile / P.tiles_x;
-            const uint32_t x0 = tx * kTileW;
-            const uint32_t y0 = (P.row0 + ty_rel) * kTileH;
-            // whole-tile mode: lane -> 4 pixels, x = x0 + 4*(lane&3) + k, y = y0 + lane/4
-            // split mode:      lane -> 1 pixel,  x = x0 + (lane&15),    y = y0 + row0 + lane/16
-            const uint32_t pxi = x0 + (quarter ? (lane & 15u) : (lane & 3u) * 4u);
-            const uint32_t prow = quarter ? (row0 + (lane >> 4)) : (lane >> 2);
-            const uint32_t pyi = y0 + prow;
-            const bool lane_on = !quarter || (lane >> 4) < nrows;
-            const float px0 = static_cast<float>(pxi), py = static_cast<float>(pyi);
-            uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
-            // stage the list through LDS in chunks (24-byte commands, 8-byte aligned: copied as
-            // 64-bit words, coalesced) and interpret; the interpreter state stays in registers
-            auto stage = [&](uint32_t c0, uint32_t m) {
-                WaveSync();
-                const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
-                uint2 *l = reinterpret_cast<uint2 *>(cmds);
-                for (uint32_t w = lane; w < 3u * m; w += 64u) l[w] = g[w];
-                WaveSync();
-            };
-            if (quarter) {  // (the two pixel layouts keep their state in separate live ranges)
-                PixelState1 s1;
-                s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
-                s1.df = 1e9f;
-                s1.sa = static_cast<_Float16>(0.0f);
-                for (uint32_t c0 = 0; c0 < n_cmd; c0 += kFineChunk) {
-                    const uint32_t m = min(kFineChunk, n_cmd - c0);
-                    stage(c0, m);
-                    Interpret1(cmds, m, px0, py, s1);
-                }
-                if (lane_on && pyi < P.height && pxi < P.width) *reinterpret_cast<uint32_t *>(dst) = enc(s1.r, s1.g, s1.b);
-            } else {
-                PixelState st;
-                st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = Splat(static_cast<_Float16>(1.0f));
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    st.df[k] = 1e9f;
-                    st.sa[k] = static_cast<_Float16>(0.0f);
-                }
-                for (uint32_t c0 = 0; c0 < n_cmd; c0 += kFineChunk) {
-                    const uint32_t m = min(kFineChunk, n_cmd - c0);
-                    stage(c0, m);
-                    Interpret(cmds, m, px0, py, st);
-                }
-                if (pyi < P.height && pxi < P.width) {
-                    uint4 out;
-                    out.x = enc(st.r01.x, st.g01.x, st.b01.x);
-                    out.y = enc(st.r01.y, st.g01.y, st.b01.y);
-                    out.z = enc(st.r23.x, st.g23.x, st.b23.x);
-                    out.w = enc(st.r23.y, st.g23.y, st.b23.y);
-                    if (pxi + 4 <= P.width && P.fb_vec16) {
-                        *reinterpret_cast<uint4 *>(dst) = out;
-                    } else {
-                        const uint32_t o[4] = {out.x, out.y, out.z, out.w};
-                        for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = o[k];
-                    }
-                }
-            }
-        }
-        if (P.dbg_time && lane == 0) {
-            unsigned long long *d = P.dbg_time + 4ull * cur_slot;
-            d[0] = t_begin;
-            d[1] = wall_clock64();
-            d[2] = tile | (quarter ? 0x80000000u : 0u);
-            d[3] = (static_cast<unsigned long long>(wave_global) << 32) | n_cmd;
-        }
-    }
-}
-
-// K3 (default): the same interpreter with row-sparse Fill evaluation (see PrepareFills above).
-// Slot scheme as in pm_fine_kernel: the four waves of a workgroup take four consecutive slots
-// of the same pass; a tile with a long list owns four aligned slots, i.e. exactly one workgroup.
-__global__ __launch_bounds__(kThreads, PM_FINE_WPS) void pm_fine_sparse_kernel(FrameParams P) {
+// K3: per-pixel interpreter (renderKernel :457-566) over the per-tile command lists, with row-sparse
+// Fill evaluation (PrepareFills) and item-parallel rendering of the tiles with long lists
+// (RenderChunkWG).  Persistent grid; the four waves of a workgroup take four consecutive slots of
+// the same pass, and a tile with a long list owns four aligned slots, i.e. exactly one workgroup.
+__global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
     __shared__ SparseLds S;
     if (blockIdx.x >= P.fine_grid) {
         ClearStripRow(P, blockIdx.x - P.fine_grid);
         return;
     }
     const uint32_t lane = LaneId(), wave = threadIdx.x >> 6;
-    const uint32_t n_a = P.ctr_cur->vheavy_count, n_b = P.ctr_cur->heavy_count, n_c = P.ctr_cur->light_count;
+    uint32_t cls_end[kClasses];  // running totals of the class queues (longest lists first)
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kClasses; ++k) {
+            run += P.ctr_cur->cls[k].count;
+            cls_end[k] = run;
+        }
+    }
     const uint32_t wave_global = blockIdx.x * kWaves + wave;
     const uint32_t n_waves = P.fine_grid * kWaves;
+    const uint32_t n_tiles = cls_end[kClasses - 1];
+    const uint32_t n_heavy = P.n_heavy_classes ? cls_end[min(P.n_heavy_classes, kClasses) - 1u] : 0u;
     // more long lists than workgroups: splitting a tile only costs work, every tile gets one wave
-    const bool dense = n_a + n_b >= n_waves || P.split_mode == 0;
+    const bool dense = n_heavy >= n_waves || P.split_mode == 0;
     const uint32_t sh = dense ? 0u : 2u;
-    const uint32_t n_heavy = n_a + n_b;
-    const uint32_t s_h = n_heavy << sh;
-    const uint32_t n_slots = s_h + n_c;
+    const uint32_t s_h = n_heavy << sh;  // slots of the tiles with long lists: a workgroup (4 slots) each
+    const uint32_t n_slots = s_h + (n_tiles - n_heavy);
     const uint8_t *lut = P.lut_lin2srgb;
+    // linear -> sRGB + unorm8 (:563-565): the 65,536-entry table of decision D2.  (A compact
+    // LDS-resident form of the table was measured slower: twelve byte loads per lane are fewer
+    // instructions than twelve decodes.)
     auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {
         return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, r)]) |
                (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
                (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, b)]) << 16) | 0xff000000u;
     };
-    // slot -> queue entry; queues A and B are one class here (4 waves per tile)
+    // slot -> queue entry
     auto slot_entry = [&](uint32_t slot) -> uint32_t {
-        if (slot < s_h) {
-            const uint32_t t = slot >> sh;
-            return t < n_a ? t : P.queue_cap + (t - n_a);
-        }
-        return 2u * P.queue_cap + (slot - s_h);
+        const uint32_t t = slot < s_h ? (slot >> sh) : n_heavy + (slot - s_h);  // position in [longest ... shortest]
+        uint32_t qix = t;
+#pragma unroll
+        for (uint32_t k = 1; k < kClasses; ++k)
+            if (t >= cls_end[k - 1]) qix = k * P.queue_cap + (t - cls_end[k - 1]);
+        return qix;
     };
     auto pass_slot = [&](uint32_t pass) -> uint32_t {
         return pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
@@ -834,6 +566,7 @@ __global__ __launch_bounds__(kThreads, PM_FINE_WPS) void pm_fine_sparse_kernel(F
         const bool wg_mode = cur_slot < s_h && sh != 0;  // uniform over the workgroup (slots are aligned)
         const uint32_t tile = cur.x;
         unsigned long long t_begin = 0;
+        PhaseTicks prof;
         if (P.dbg_time) t_begin = wall_clock64();
         const uint32_t n_cmd = cur.w;
         if (n_cmd != 0) {  // 0: the coarse kernel found one opaque colour and wrote it
@@ -843,15 +576,19 @@ __global__ __launch_bounds__(kThreads, PM_FINE_WPS) void pm_fine_sparse_kernel(F
             const uint32_t x0 = tx * kTileW;
             const uint32_t y0 = (P.row0 + ty_rel) * kTileH;
             if (wg_mode) {
-                // lane -> 1 pixel: x = x0 + (lane & 15), row = 4 * (slot & 3) + lane / 16
-                const uint32_t xi = lane & 15u;
-                const uint32_t prow = 4u * (cur_slot & 3u) + (lane >> 4);
-                const uint32_t pxi = x0 + xi, pyi = y0 + prow;
-                PixelState1 s1;
+                // the longest lists set the span of the launch: their waves win the issue arbitration
+                __builtin_amdgcn_s_setprio(2);
+                // phase B: lane -> 1 pixel, pix = 64 * (slot & 3) + lane = row * 16 + x
+                const uint32_t pix = 64u * (cur_slot & 3u) + lane;
+                const uint32_t pxi = x0 + (pix & 15u), pyi = y0 + (pix >> 4);
+                PixelRGB s1;
                 s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
-                s1.df = 1e9f;
-                s1.sa = static_cast<_Float16>(0.0f);
-                for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk) {
+                if (wave == 0) {  // no item is open when a list starts
+                    S.carry_sa[0][lane] = make_uint2(0u, 0u);
+                    S.carry_df[0][lane] = make_float4(1e9f, 1e9f, 1e9f, 1e9f);
+                }
+                uint32_t parity = 0;
+                for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk, parity ^= 1u) {
                     const uint32_t m = min(kSpChunk, n_cmd - c0);
                     __syncthreads();  // the previous chunk (or tile) is done with the shared arrays
                     {
@@ -860,11 +597,15 @@ __global__ __launch_bounds__(kThreads, PM_FINE_WPS) void pm_fine_sparse_kernel(F
                         for (uint32_t w = threadIdx.x; w < 3u * m; w += kThreads) l[w] = g[w];
                     }
                     __syncthreads();
-                    InterpretSparseWG(S, S.cmds[0], S.fill_ix[wave], m, x0, y0, prow, xi, s1);
+                    if (P.dbg_time)
+                        RenderChunkWG<true>(S, S.cmds[0], S.fill_ix[wave], m, parity, x0, y0, pix, s1, prof);
+                    else
+                        RenderChunkWG<false>(S, S.cmds[0], S.fill_ix[wave], m, parity, x0, y0, pix, s1, prof);
                 }
-                __syncthreads();  // the other waves may still read this wave's fragments
+                __syncthreads();  // the other waves may still read this wave's alpha images
+                __builtin_amdgcn_s_setprio(0);
                 if (pyi < P.height && pxi < P.width) {
-                    uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
+                    uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + (pix >> 4)) * P.fb_stride + static_cast<size_t>(pxi) * 4;
                     *reinterpret_cast<uint32_t *>(dst) = enc(s1.r, s1.g, s1.b);
                 }
             } else {
@@ -906,11 +647,13 @@ __global__ __launch_bounds__(kThreads, PM_FINE_WPS) void pm_fine_sparse_kernel(F
             }
         }
         if (P.dbg_time && lane == 0) {
-            unsigned long long *d = P.dbg_time + 4ull * cur_slot;
+            unsigned long long *d = P.dbg_time + 6ull * cur_slot;
             d[0] = t_begin;
             d[1] = wall_clock64();
             d[2] = tile | (wg_mode ? 0x80000000u : 0u);
             d[3] = (static_cast<unsigned long long>(wave_global) << 32) | n_cmd;
+            d[4] = prof.a;  // workgroup mode: ticks in phase A (incl. its barriers) / phase B
+            d[5] = prof.b;
         }
     }
 }
@@ -922,10 +665,7 @@ void LaunchClear(const FrameParams &p, uint32_t n_striprows, hipStream_t stream,
 }
 
 void LaunchFine(const FrameParams &p, uint32_t clear_blocks, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
-    if (p.fine_sparse)
-        PM_LAUNCH(pm_fine_sparse_kernel, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
-    else
-        PM_LAUNCH(pm_fine_kernel, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
+    PM_LAUNCH(pm_fine_kernel, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
 }
 
 }  // namespace pm

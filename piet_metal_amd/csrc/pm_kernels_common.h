@@ -67,8 +67,6 @@ constexpr int kThreads = 256;   // coarse / fine kernel workgroup
 constexpr int kWaves = kThreads / 64;
 constexpr int kBinThreads = 64 * kBinWaves;  // binning workgroup: its waves share one strip row's segment stream
 constexpr uint32_t kBatch = 256;   // candidate items per binning batch
-constexpr uint32_t kHeavyStream = 32;       // stream elements above which a tile is split over 4 waves
-constexpr uint32_t kVeryHeavyStream = 96;   // ... over 16 waves (one pixel row each)
 
 // ---------------------------------------------------------------------------------
 // small helpers

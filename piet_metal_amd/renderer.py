@@ -153,6 +153,12 @@ class Renderer:
         _lib.check(self._lib.pm_get_scene_timings(self._h, C.byref(t)), "pm_get_scene_timings")
         return {name: getattr(t, name) for name, _ in t._fields_}
 
+    def frame_timeline(self, iters: int = 100) -> dict:
+        """The lone frame taken apart (ms, medians): kernels and the gaps between them."""
+        v = (C.c_float * 6)()
+        _lib.check(self._lib.pm_debug_frame_timeline(self._h, iters, v), "pm_debug_frame_timeline")
+        return dict(zip(("bin_ms", "gap1_ms", "coarse_ms", "gap2_ms", "fine_ms", "total_ms"), [float(x) for x in v]))
+
     def stats(self) -> dict:
         s = _lib.Stats()
         _lib.check(self._lib.pm_get_stats(self._h, C.byref(s)), "pm_get_stats")
@@ -221,8 +227,8 @@ class Comm:
 
 def _time_tiles(self, max_slots: int = 1 << 20) -> np.ndarray:
     """Developer profiling: per-slot timeline of pm_fine_kernel, rows =
-    (start, end, tile | quarter << 31, wave << 32 | commands)."""
-    out = np.zeros((max_slots, 4), np.uint64)
+    (start, end, tile | quarter << 31, wave << 32 | commands, phase A ticks, phase B ticks)."""
+    out = np.zeros((max_slots, 6), np.uint64)
     n = C.c_size_t(0)
     _lib.check(self._lib.pm_debug_time_tiles(self._h, out.ctypes.data, max_slots, C.byref(n)), "pm_debug_time_tiles")
     return out[: n.value]

@@ -438,12 +438,14 @@ def test_failed_scene_replacement_leaves_no_stale_state(pm, pmo, renderer):
     assert np.array_equal(renderer.read_pixels(), pmo.render(good, 512, 512))
 
 
-@pytest.mark.parametrize("sparse", ["0", "1"])
-def test_both_fine_kernels_agree_with_the_oracle(pm, pmo, monkeypatch, sparse):
-    """PM_FINE_SPARSE=0 keeps the straightforward interpreter (every row of every Fill); the
-    default evaluates only live (command, row) fragments.  Both must be byte-exact, also where
-    tiles with long lists are rendered by four waves and where lists exceed one LDS chunk."""
-    monkeypatch.setenv("PM_FINE_SPARSE", sparse)
+@pytest.mark.parametrize("split,heavy", [("0", "32"), ("1", "32"), ("1", "4")])
+def test_both_fine_modes_agree_with_the_oracle(pm, pmo, monkeypatch, split, heavy):
+    """pm_fine_kernel renders a tile with one wave (row-sparse Fill fragments, list order) or, for
+    long lists, with a whole workgroup (items evaluated in parallel, blends in list order).
+    PM_FINE_SPLIT=0 forces the first, PM_HEAVY_STREAM=4 pushes almost every tile into the
+    second.  All must be byte-exact, also where lists exceed one LDS chunk."""
+    monkeypatch.setenv("PM_FINE_SPLIT", split)
+    monkeypatch.setenv("PM_HEAVY_STREAM", heavy)
     r = pm.Renderer(0)
     try:
         for (w, h, fills) in ((960, 540, False), (1920, 1080, True)):

@@ -12,16 +12,17 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py"
-timeout 600 $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 1500 $OUT/bench.json
+WL=${PM_PROF_FLAGS:---no-config5}   # the traced / counted runs hold ONE workload: kernel averages are per configuration
+timeout 900 $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 1500 $OUT/bench.json
 # the traced run's own JSON line is kept next to the stats: same process, same launches
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --no-cpu-baseline $WL > $OUT/trace.log 2>&1
 grep '^{"metric"' $OUT/trace.log | tail -1 > $OUT/bench_traced.json
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -8 $OUT/kernel_stats.csv
 find $OUT/trace -name "*kernel_trace.csv" -size +30M -delete
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- $BENCH --steps 20 --warmup 5 --no-cpu-baseline > $OUT/pmc$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- $BENCH --steps 20 --warmup 5 --no-cpu-baseline $WL > $OUT/pmc$i.log 2>&1
   f=$(find $OUT/pmc$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/pmc_pass$i.csv || tail -5 $OUT/pmc$i.log
 done

@@ -7,6 +7,8 @@ wl = pm.workloads.tiger(3840, 2160)
 r = pm.Renderer(0)
 r.resize(wl.width, wl.height)
 r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+if len(sys.argv) > 2:  # only a band of tile rows: the tiles of the band without the rest of the frame around them
+    r.set_band(int(sys.argv[1]), int(sys.argv[2]))
 for _ in range(3):
     r.render()
 r.sync()
@@ -29,4 +31,6 @@ for lo, hi in [(0,0),(1,4),(5,16),(17,48),(49,100),(101,1000)]:
     m = (ncmd >= lo) & (ncmd <= hi)
     if m.any(): print(f"ncmd {lo:3d}-{hi:4d}: {m.sum():6d} slots, mean dur {dur[m].mean():6.2f} us, total {dur[m].sum():8.0f} us, us/cmd {dur[m].sum()/max(1,ncmd[m].sum()):.3f}")
 worst = np.argsort(-dur)[:8]
-for i in worst: print(f"  slot {i} tile {tile[i]} q={quarter[i]} ncmd {ncmd[i]} dur {dur[i]:.1f} us start {(start[i]-t0)*us:.1f}")
+for i in worst: print(f"  slot {i} tile {tile[i]} q={quarter[i]} ncmd {ncmd[i]} dur {dur[i]:.1f} us start {(start[i]-t0)*us:.1f}  phase A {t[i,4]*us:.1f} us  phase B {t[i,5]*us:.1f} us")
+q = quarter & (ncmd > 0)
+if q.any(): print(f"workgroup-mode slots: {q.sum()}, mean dur {dur[q].mean():.2f} us, phase A {t[q,4].mean()*us:.2f} us, phase B {t[q,5].mean()*us:.2f} us, other {(dur[q]-(t[q,4]+t[q,5])*us).mean():.2f} us")
