@@ -62,6 +62,17 @@ int pm_encoder_fill(pm_encoder *e, const double *pts_xy, size_t n_points,
                     uint32_t rgba);                                   /* fill              :195 */
 int pm_encoder_polyline(pm_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba,
                         float width);                                 /* polyline          :209 */
+/* Growth beyond the reference's Encoder, in its own terms:
+ *  - PietFill.flags (src/lib.rs:54 "flags", TestApp/SceneEncoder.h:44 "will be used for winding
+ *    number rule"): bit 0 selects the even-odd rule, the formula the reference leaves in a
+ *    comment (TestApp/PietRender.metal:539-540);
+ *  - nested groups (src/lib.rs:148 "when we have nested groups"): pm_encoder_begin_group inside
+ *    an open group starts a child group that takes one item slot of its parent (item type 5,
+ *    PietGroup {item_type, flags, group_ix}); pm_encoder_end_group closes the innermost group.
+ *    A scene with groups renders exactly like the same items inlined in paint order. */
+#define PM_FILL_EVEN_ODD 1u
+int pm_encoder_fill_rule(pm_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba,
+                         uint32_t fill_flags);
 size_t pm_encoder_bytes_used(const pm_encoder *e);                    /* free_space */
 
 /* The reference's two other test scenes (host only, no flattening involved).
@@ -86,6 +97,7 @@ typedef struct {
 
 #define PM_PATH_FILL 1u
 #define PM_PATH_STROKE 2u
+#define PM_PATH_EVEN_ODD 4u /* fill-rule="evenodd": the fill item gets PM_FILL_EVEN_ODD */
 
 typedef struct {
     uint32_t el_begin, el_end; /* element range of this <path> */

@@ -43,6 +43,12 @@ extern "C" {
 #define PMO_ITEM_LINE 2
 #define PMO_ITEM_FILL 3
 #define PMO_ITEM_POLY 4
+/* Extensions beyond the reference (product and oracle define them together):
+ * a nested group as an item of its parent (src/lib.rs:148 "when we have nested groups"), and the
+ * winding-rule bit of PietFill.flags (src/lib.rs:54, TestApp/SceneEncoder.h:44) selecting the
+ * even-odd formula the reference leaves in a comment (TestApp/PietRender.metal:539-540). */
+#define PMO_ITEM_GROUP 5        /* {item_type, flags, group_ix}: group_ix = offset of a SimpleGroup */
+#define PMO_FILL_EVEN_ODD 1u
 #define PMO_ITEM_SIZE 32  /* sizeof(union PietItem), src/lib.rs:27-31 */
 #define PMO_BBOX_SIZE 8   /* ShortBbox, src/lib.rs:22-24 */
 #define PMO_GROUP_HDR 8   /* SimpleGroup, src/lib.rs:15-20 */
@@ -79,6 +85,7 @@ typedef struct {
 
 #define PMO_PATH_FILL 1u
 #define PMO_PATH_STROKE 2u
+#define PMO_PATH_EVEN_ODD 4u
 
 typedef struct {
     uint32_t el_begin;     /* first element index */
@@ -98,6 +105,9 @@ typedef struct {
     size_t group_ix;
     size_t group_start;
     int error; /* set instead of panicking */
+    int open;  /* a group is being filled (extension: begin_group then nests) */
+    int depth;
+    size_t stack[32][3]; /* enclosing groups: {count, ix, start} */
 } pmo_encoder;
 
 void pmo_encoder_init(pmo_encoder *e, uint8_t *buf, size_t cap);
@@ -108,8 +118,17 @@ void pmo_encoder_circle(pmo_encoder *e, double cx, double cy, double r);
 void pmo_encoder_stroke_line(pmo_encoder *e, double x0, double y0, double x1, double y1,
                              float width, uint32_t rgba);
 void pmo_encoder_fill(pmo_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba);
+void pmo_encoder_fill_rule(pmo_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba,
+                           uint32_t fill_flags);
 void pmo_encoder_polyline(pmo_encoder *e, const double *pts_xy, size_t n_points,
                           uint32_t rgba, float width);
+
+/* A scene with PMO_ITEM_GROUP items means: the same items inlined, depth first, in paint order.
+ * Writes that flat form (the original bytes followed by one flat SimpleGroup) into out (cap
+ * out_cap) and returns its length, *root_out = offset of the flat group; returns the input
+ * unchanged (root 0) if it has no nested group, -1 on malformed input or capacity. */
+int64_t pmo_scene_flatten_groups(const uint8_t *scene, size_t scene_len, uint8_t *out, size_t out_cap,
+                                 size_t *root_out);
 
 /* Scenes of src/lib.rs:257-284.  Return bytes used, or -1 on error. */
 int64_t pmo_scene_cardioid(uint8_t *buf, size_t cap);

@@ -52,6 +52,8 @@ void pmo_encoder_init(pmo_encoder *e, uint8_t *buf, size_t cap) {
     e->group_start = 0;
     e->group_ix = 0;
     e->error = 0;
+    e->open = 0;
+    e->depth = 0;
 }
 
 size_t pmo_encoder_alloc(pmo_encoder *e, size_t size) {
@@ -74,6 +76,18 @@ static void write_bytes(pmo_encoder *e, size_t ix, const void *s, size_t len) {
 
 void pmo_encoder_begin_group(pmo_encoder *e, size_t n_items) {
     /* src/lib.rs:132-144 */
+    if (e->open) { /* extension: a nested group takes the next item slot of the open one */
+        if (!(e->group_ix < e->group_count) || e->depth >= 32) {
+            e->error = 1;
+            return;
+        }
+        e->stack[e->depth][0] = e->group_count;
+        e->stack[e->depth][1] = e->group_ix;
+        e->stack[e->depth][2] = e->group_start;
+        e->depth++;
+        e->group_ix = 0;
+    }
+    e->open = 1;
     size_t item_start = PMO_GROUP_HDR + n_items * PMO_BBOX_SIZE;
     size_t total_size = item_start + n_items * PMO_ITEM_SIZE;
     e->group_start = pmo_encoder_alloc(e, total_size);
@@ -84,9 +98,40 @@ void pmo_encoder_begin_group(pmo_encoder *e, size_t n_items) {
     write_bytes(e, e->group_start, g, 8);
 }
 
+static void add_item(pmo_encoder *e, const void *item, size_t item_len, const uint16_t bbox[4]);
+
 void pmo_encoder_end_group(pmo_encoder *e) {
     /* src/lib.rs:146-149: assert_eq!(group_ix, group_count) */
     if (e->group_ix != e->group_count) e->error = 1;
+    if (e->depth == 0) {
+        e->open = 0;
+        return;
+    }
+    /* extension ("when we have nested groups", :148): the child becomes a group item of its
+     * parent, boxed by the union of its children's boxes */
+    uint16_t u[4] = {0xffff, 0xffff, 0, 0};
+    int any = 0;
+    for (size_t i = 0; i < e->group_count && !e->error; i++) {
+        size_t at = e->group_start + PMO_GROUP_HDR + i * PMO_BBOX_SIZE;
+        uint16_t b[4];
+        if (at + 8 > e->cap) break;
+        memcpy(b, e->buf + at, 8);
+        if (b[0] < u[0]) u[0] = b[0];
+        if (b[1] < u[1]) u[1] = b[1];
+        if (b[2] > u[2]) u[2] = b[2];
+        if (b[3] > u[3]) u[3] = b[3];
+        any = 1;
+    }
+    if (!any) u[0] = u[1] = u[2] = u[3] = 0;
+    uint8_t item[12];
+    put_u32(item + 0, PMO_ITEM_GROUP);
+    put_u32(item + 4, 0);
+    put_u32(item + 8, (uint32_t)e->group_start);
+    e->depth--;
+    e->group_count = e->stack[e->depth][0];
+    e->group_ix = e->stack[e->depth][1];
+    e->group_start = e->stack[e->depth][2];
+    add_item(e, item, 12, u);
 }
 
 /* Encoder::add_item, src/lib.rs:151-163 */
@@ -160,12 +205,16 @@ static size_t encode_points(pmo_encoder *e, const double *pts, size_t n, rect *b
 }
 
 void pmo_encoder_fill(pmo_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba) {
-    /* src/lib.rs:195-207; PietFill layout src/lib.rs:50-58 (20 bytes written) */
+    pmo_encoder_fill_rule(e, pts_xy, n_points, rgba, 0);
+}
+
+void pmo_encoder_fill_rule(pmo_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba, uint32_t fill_flags) {
+    /* src/lib.rs:195-207; PietFill layout src/lib.rs:50-58 (20 bytes written); flags = 0 there */
     rect bb;
     size_t points_ix = encode_points(e, pts_xy, n_points, &bb);
     uint8_t item[20];
     put_u32(item + 0, PMO_ITEM_FILL);
-    put_u32(item + 4, 0);
+    put_u32(item + 4, fill_flags);
     put_u32(item + 8, to_be(rgba));
     put_u32(item + 12, (uint32_t)n_points);
     put_u32(item + 16, (uint32_t)points_ix);
@@ -296,7 +345,8 @@ int64_t pmo_scene_from_paths(uint8_t *buf, size_t cap, const pmo_path *paths, si
             /* encode_path, src/lib.rs:342-347 */
             const double *pp = s.pts;
             for (int64_t k = 0; k < n_sub; k++) {
-                pmo_encoder_fill(&e, pp, s.sub_counts[k], paths[i].fill_rgba);
+                pmo_encoder_fill_rule(&e, pp, s.sub_counts[k], paths[i].fill_rgba,
+                                      (paths[i].flags & PMO_PATH_EVEN_ODD) ? PMO_FILL_EVEN_ODD : 0u);
                 pp += 2 * (size_t)s.sub_counts[k];
             }
         }
@@ -322,5 +372,74 @@ int64_t pmo_scene_from_paths(uint8_t *buf, size_t cap, const pmo_path *paths, si
 done:
     free(s.sub_counts);
     free(s.pts);
+    return result;
+}
+
+/* ---- nested groups -> flat paint order (extension, see pmo.h) ----------------- */
+
+typedef struct {
+    const uint8_t *sc;
+    size_t len;
+    uint8_t *bb, *it; /* growing arrays of 8-byte boxes and 32-byte items */
+    size_t n, cap;
+    int bad;
+} flat_t;
+
+static uint32_t fl_u32(flat_t *f, size_t off) {
+    uint32_t v = 0;
+    if (off + 4 > f->len) { f->bad = 1; return 0; }
+    memcpy(&v, f->sc + off, 4);
+    return v;
+}
+
+static void flatten_group(flat_t *f, size_t group, int depth) {
+    if (depth > 32) { f->bad = 1; return; }
+    uint32_t n = fl_u32(f, group), items = fl_u32(f, group + 4);
+    if (f->bad) return;
+    if (group + 8 + 8ull * n > f->len || (size_t)items + 32ull * n > f->len) { f->bad = 1; return; }
+    for (uint32_t i = 0; i < n && !f->bad; i++) {
+        size_t it = (size_t)items + 32ull * i;
+        if ((fl_u32(f, it) & 0xffffu) == PMO_ITEM_GROUP) {
+            flatten_group(f, fl_u32(f, it + 8), depth + 1);
+            continue;
+        }
+        if (f->n == f->cap) {
+            f->cap = f->cap ? 2 * f->cap : 256;
+            f->bb = (uint8_t *)realloc(f->bb, f->cap * 8);
+            f->it = (uint8_t *)realloc(f->it, f->cap * 32);
+        }
+        if (f->n >= (1u << 24)) { f->bad = 1; return; } /* (also stops cyclic scenes) */
+        memcpy(f->bb + 8 * f->n, f->sc + group + 8 + 8ull * i, 8);
+        memcpy(f->it + 32 * f->n, f->sc + it, 32);
+        f->n++;
+    }
+}
+
+int64_t pmo_scene_flatten_groups(const uint8_t *scene, size_t scene_len, uint8_t *out, size_t out_cap, size_t *root_out) {
+    if (scene_len < 8 || out_cap < scene_len) return -1;
+    flat_t f = {scene, scene_len, NULL, NULL, 0, 0, 0};
+    uint32_t n = fl_u32(&f, 0), items = fl_u32(&f, 4);
+    int nested = 0;
+    if ((size_t)items + 32ull * n > scene_len) return -1;
+    for (uint32_t i = 0; i < n; i++)
+        if ((fl_u32(&f, (size_t)items + 32ull * i) & 0xffffu) == PMO_ITEM_GROUP) nested = 1;
+    memcpy(out, scene, scene_len);
+    if (root_out) *root_out = 0;
+    if (!nested) return (int64_t)scene_len;
+    flatten_group(&f, 0, 0);
+    int64_t result = -1;
+    size_t root = (scene_len + 7u) & ~(size_t)7u;
+    size_t total = root + 8 + 40 * f.n;
+    if (!f.bad && total <= out_cap) {
+        memset(out + scene_len, 0, root - scene_len);
+        put_u32(out + root, (uint32_t)f.n);
+        put_u32(out + root + 4, (uint32_t)(root + 8 + 8 * f.n));
+        memcpy(out + root + 8, f.bb, 8 * f.n);
+        memcpy(out + root + 8 + 8 * f.n, f.it, 32 * f.n);
+        if (root_out) *root_out = root;
+        result = (int64_t)total;
+    }
+    free(f.bb);
+    free(f.it);
     return result;
 }

@@ -191,8 +191,18 @@ static int render_pixel_half(const pmo_cmd *cmds, uint32_t x, uint32_t y, uint8_
                 int32_t backdrop = (int32_t)cmd->body[0];
                 uint32_t rgba = cmd->body[1];
                 pmo_half alpha = pmo_hadd(signed_area, pmo_f2h((float)backdrop));
-                float fa_abs = fabsf(pmo_h2f(alpha));
-                alpha = pmo_f2h(fminf(fa_abs, 1.0f)); /* min(abs(alpha), 1.0h) */
+                if (cmd->body[4] & PMO_FILL_EVEN_ODD) {
+                    /* the reference's comment (:539): alpha = abs(alpha - 2.0 * round(0.5 * alpha)), in
+                     * half.  Decision D9: round = nearest integer, ties to even -- a tie means alpha is an
+                     * odd integer, where either neighbour gives |+-1| = 1, so the tie rule cannot show. */
+                    pmo_half t = pmo_hmul(pmo_f2h(0.5f), alpha);
+                    pmo_half r = pmo_f2h(rintf(pmo_h2f(t)));
+                    pmo_half v = pmo_hsub(alpha, pmo_hmul(pmo_f2h(2.0f), r));
+                    alpha = pmo_f2h(fabsf(pmo_h2f(v)));
+                } else {
+                    float fa_abs = fabsf(pmo_h2f(alpha));
+                    alpha = pmo_f2h(fminf(fa_abs, 1.0f)); /* min(abs(alpha), 1.0h) */
+                }
                 pmo_half fa = pmo_hmul(g_unorm2h[rgba >> 24], alpha);
                 for (int k = 0; k < 3; k++)
                     rgb[k] = pmo_hmix(rgb[k], g_srgb2lin[(rgba >> (8 * k)) & 0xffu], fa);
@@ -268,7 +278,9 @@ static int render_pixel_f32(const pmo_cmd *cmds, uint32_t x, uint32_t y, uint8_t
                 break;
             case PMO_CMD_DRAW_FILL: {
                 uint32_t rgba = cmd->body[1];
-                float alpha = fminf(fabsf(signed_area + (float)(int32_t)cmd->body[0]), 1.0f);
+                float alpha = signed_area + (float)(int32_t)cmd->body[0];
+                if (cmd->body[4] & PMO_FILL_EVEN_ODD) alpha = fabsf(alpha - 2.0f * rintf(0.5f * alpha));
+                else alpha = fminf(fabsf(alpha), 1.0f);
                 float fa = ((float)(rgba >> 24) / 255.0f) * alpha;
                 for (int k = 0; k < 3; k++)
                     rgb[k] = mixf(rgb[k], srgb_to_linear_f32((rgba >> (8 * k)) & 0xffu), fa);
@@ -395,7 +407,9 @@ int pmo_fill_coverage(const uint8_t *scene, size_t scene_len, uint32_t item_ix, 
                 } else if (cmd->tag == PMO_CMD_FILL_EDGE) {
                     sa += (float)(int32_t)cmd->body[0] * saturatef((float)y - u2f(cmd->body[1]) + 1.0f);
                 } else if (cmd->tag == PMO_CMD_DRAW_FILL) {
-                    cov = fminf(fabsf(sa + (float)(int32_t)cmd->body[0]), 1.0f);
+                    cov = sa + (float)(int32_t)cmd->body[0];
+                    if (cmd->body[4] & PMO_FILL_EVEN_ODD) cov = fabsf(cov - 2.0f * rintf(0.5f * cov));
+                    else cov = fminf(fabsf(cov), 1.0f);
                     sa = 0.0f;
                 } else if (cmd->tag == PMO_CMD_SOLID) {
                     cov = 1.0f;

@@ -33,6 +33,7 @@ typedef struct {
     const uint8_t *p;
     size_t len;
     int oob;
+    size_t root; /* offset of the SimpleGroup the tile pass walks (0, or the flat form of nested groups) */
 } scene_t;
 
 static uint32_t rd_u32(scene_t *s, size_t off) {
@@ -106,11 +107,12 @@ static void enc_fill_edge(tile_enc *e, float sign, float y) { /* :110-117 */
     c->body[0] = (uint32_t)(int32_t)sign; /* cmd.sign is int */
     c->body[1] = f2u(y);
 }
-static void enc_draw_fill(tile_enc *e, uint32_t rgba, int backdrop) { /* :118-126 */
+static void enc_draw_fill(tile_enc *e, uint32_t rgba, int backdrop, uint32_t even_odd) { /* :118-126 */
     pmo_cmd *c = enc_push(e);
     c->tag = PMO_CMD_DRAW_FILL;
     c->body[0] = (uint32_t)backdrop;
     c->body[1] = rgba;
+    c->body[4] = even_odd; /* extension: the rule travels in the command's unused last word */
     e->solid_color = 0;
 }
 static void enc_solid(tile_enc *e, uint32_t rgba) { /* :127-142 */
@@ -152,9 +154,9 @@ static void run_group(scene_t *sc, uint32_t gx, uint32_t gy, tile_enc enc[LANES]
         enc[t].n = 0;
         enc[t].solid_color = 0xffffffffu; /* :74 */
     }
-    const uint32_t n = rd_u32(sc, 0);        /* SimpleGroup_n_items(scene, 0) :187 */
-    const uint32_t items_ref = rd_u32(sc, 4); /* :188 */
-    const size_t bboxes = 8;                  /* &group->bbox :186 */
+    const uint32_t n = rd_u32(sc, sc->root);         /* SimpleGroup_n_items(scene, 0) :187 */
+    const uint32_t items_ref = rd_u32(sc, sc->root + 4); /* :188 */
+    const size_t bboxes = sc->root + 8;               /* &group->bbox :186 */
 
     for (uint32_t i = 0; i < n; i += LANES) { /* :189, tgs = 32 */
         uint32_t rd = 0;
@@ -210,6 +212,7 @@ static void run_group(scene_t *sc, uint32_t gx, uint32_t gy, tile_enc enc[LANES]
                 }
                 case PMO_ITEM_FILL: { /* :248-365 */
                     uint32_t rgba = rd_u32(sc, item_ref + 8);
+                    uint32_t even_odd = rd_u32(sc, item_ref + 4) & PMO_FILL_EVEN_ODD; /* PietFill.flags (extension) */
                     uint32_t n_points = rd_u32(sc, item_ref + 12);
                     size_t pts = rd_u32(sc, item_ref + 16);
                     float backdrop[LANES];
@@ -299,8 +302,9 @@ static void run_group(scene_t *sc, uint32_t gx, uint32_t gy, tile_enc enc[LANES]
                         }
                     }
                     for (int t = 0; t < LANES; t++) { /* :359-363 (state only changes under hit) */
-                        if (any_fill[t]) enc_draw_fill(&enc[t], rgba, (int)backdrop[t]);
-                        else if (backdrop[t] != 0.0f) enc_solid(&enc[t], rgba);
+                        if (any_fill[t]) enc_draw_fill(&enc[t], rgba, (int)backdrop[t], even_odd);
+                        /* a tile wholly inside: covered if the winding is non-zero / odd */
+                        else if (even_odd ? (((int)backdrop[t]) & 1) != 0 : backdrop[t] != 0.0f) enc_solid(&enc[t], rgba);
                     }
                     break;
                 }
@@ -397,7 +401,38 @@ pmo_ptcl *pmo_ptcl_build(const uint8_t *scene, size_t scene_len, uint32_t width,
     p->solid = (uint32_t *)calloc(nt ? nt : 1, sizeof(uint32_t));
     uint32_t groups_x = (p->tiles_x + PMO_TILER_GROUP_W - 1) / PMO_TILER_GROUP_W;
     uint32_t groups_y = (p->tiles_y + PMO_TILER_GROUP_H - 1) / PMO_TILER_GROUP_H;
-    scene_t sc = {scene, scene_len, 0};
+    /* nested groups (extension): the tile pass walks the flat form */
+    uint8_t *flat = NULL;
+    size_t root = 0;
+    {
+        uint32_t n0 = 0, it0 = 0;
+        memcpy(&n0, scene, 4);
+        memcpy(&it0, scene + 4, 4);
+        int nested = 0;
+        if ((size_t)it0 + 32ull * n0 <= scene_len)
+            for (uint32_t i = 0; i < n0; i++) {
+                uint32_t tg;
+                memcpy(&tg, scene + it0 + 32ull * i, 4);
+                if ((tg & 0xffffu) == PMO_ITEM_GROUP) nested = 1;
+            }
+        if (nested) {
+            size_t cap = scene_len * 8 + 4096; /* a flat group is at most 40 B per item reached */
+            int64_t fl = -1;
+            for (int tries = 0; tries < 6 && fl < 0; tries++, cap *= 4) {
+                free(flat);
+                flat = (uint8_t *)malloc(cap);
+                fl = pmo_scene_flatten_groups(scene, scene_len, flat, cap, &root);
+            }
+            if (fl < 0) {
+                free(flat);
+                pmo_ptcl_free(p);
+                return NULL;
+            }
+            scene = flat;
+            scene_len = (size_t)fl;
+        }
+    }
+    scene_t sc = {scene, scene_len, 0, root};
     tile_enc enc[LANES];
     memset(enc, 0, sizeof(enc));
     for (uint32_t gy = 0; gy < groups_y; gy++) {
@@ -417,6 +452,7 @@ pmo_ptcl *pmo_ptcl_build(const uint8_t *scene, size_t scene_len, uint32_t width,
         }
     }
     for (int t = 0; t < LANES; t++) free(enc[t].cmds);
+    free(flat);
     if (sc.oob) {
         pmo_ptcl_free(p);
         return NULL;

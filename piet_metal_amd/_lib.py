@@ -21,7 +21,8 @@ PM_ERR_SCENE = -5
 PM_ERR_PARSE = -6
 
 PM_EL_MOVE, PM_EL_LINE, PM_EL_QUAD, PM_EL_CURVE, PM_EL_CLOSE = range(5)
-PM_PATH_FILL, PM_PATH_STROKE = 1, 2
+PM_PATH_FILL, PM_PATH_STROKE, PM_PATH_EVEN_ODD = 1, 2, 4
+PM_FILL_EVEN_ODD = 1
 PM_SVG_REJECT_ARC_PATHS = 1
 PM_FMT_RGBA8, PM_FMT_BGRA8 = 0, 1
 
@@ -79,6 +80,7 @@ SIGNATURES = {
     "pm_encoder_circle": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "pm_encoder_stroke_line": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_float, C.c_uint32]),
     "pm_encoder_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]),
+    "pm_encoder_fill_rule": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]),
     "pm_encoder_polyline": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_float]),
     "pm_encoder_bytes_used": (C.c_size_t, [C.c_void_p]),
     "pm_scene_cardioid": (C.c_int64, [C.c_void_p, C.c_size_t]),

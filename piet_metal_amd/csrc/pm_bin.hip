@@ -8,12 +8,11 @@ namespace pm {
 // K0: scene index, once per scene
 // =====================================================================================
 
-__global__ void pm_index_kernel(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks,
-                                float4 *chunk_bbox) {
+__global__ void pm_index_kernel(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, const uint32_t *chunk_base,
+                                uint32_t n_chunks, float4 *chunk_bbox) {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= n_chunks) return;
     const uint32_t item = FindOwner(chunk_base, n_items, ch);
-    const uint32_t items_ix = LoadU32(scene + 4);
     const uint8_t *it = scene + items_ix + static_cast<size_t>(item) * kItemSize;
     const uint32_t tag = LoadU32(it) & 0xffffu;
     const uint32_t npt = LoadU32(it + 12);
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             const uint2 w01 = *reinterpret_cast<const uint2 *>(item);
             const uint2 w23 = *reinterpret_cast<const uint2 *>(item + 8);
             const uint32_t w4 = LoadU32(item + 16);
-            const uint2 ibb = *reinterpret_cast<const uint2 *>(scene + 8 + static_cast<size_t>(idx) * 8);
+            const uint2 ibb = *reinterpret_cast<const uint2 *>(scene + PM_PU(bbox_ix) + static_cast<size_t>(idx) * 8);
             uint32_t cbase = PM_PP(chunk_base)[idx];
             {   // keep the compiler from sinking any of these loads into the tag branches below
                 uint32_t a0 = w01.x, a1 = w01.y, a2 = w23.x, a3 = w23.y, a4 = w4, a5 = ibb.x, a6 = ibb.y;
@@ -318,6 +317,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                 nch = 1;  // never culled at strip level (PietRender.metal:223-247)
             } else if (tag == kItemFill) {
                 rgba = w23v.x;
+                aux0 = w01v.y & kFillEvenOdd;  // PietFill.flags: the winding rule
                 npt = w23v.y;
                 pts = w4v;
                 nseg = FillSegs(npt);
@@ -566,6 +566,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                 const uint32_t cm = s_cmask[tid];
                 const uint32_t tag = s_ctag[tid], rgba = s_crgba[tid];
                 const bool opaque = (rgba & 0xff000000u) == 0xff000000u;
+                const bool even_odd = tag == kItemFill && (s_caux0[tid] & kFillEvenOdd) != 0;
                 uint4 *ctw = reinterpret_cast<uint4 *>(ct_tab + kCtDwords * tid);
 #pragma unroll 1
                 for (uint32_t q = 0; q < 4; ++q) {
@@ -577,7 +578,8 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                         const uint32_t cnt = raw & kCtCountMask;
                         run += static_cast<int>(raw) >> kCtShift;
                         ct[k] = (static_cast<uint32_t>(run) << kCtShift) | cnt;
-                        const bool pseudo = tag == kItemCircle || (tag == kItemFill && run != 0);
+                        // a tile wholly inside a fill is covered if its winding is non-zero / odd
+                        const bool pseudo = tag == kItemCircle || (tag == kItemFill && (even_odd ? (run & 1) != 0 : run != 0));
                         uint32_t n_el = cnt ? cnt : (pseudo ? 1u : 0u);
                         if (!((cm >> t) & 1u) || tag == 0) n_el = 0;
                         if (n_el) hm |= 1u << t;
@@ -715,11 +717,11 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
 // =====================================================================================
 // ---- launch wrappers (called from pm_context.hip) -----------------------------------------
 
-void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks, float4 *chunk_bbox,
-                 hipStream_t stream) {
+void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, const uint32_t *chunk_base, uint32_t n_chunks,
+                 float4 *chunk_bbox, hipStream_t stream) {
     if (n_chunks == 0) return;
-    hipLaunchKernelGGL(pm_index_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, scene, n_items, chunk_base, n_chunks,
-                       chunk_bbox);
+    hipLaunchKernelGGL(pm_index_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, scene, n_items, items_ix, chunk_base,
+                       n_chunks, chunk_bbox);
 }
 
 void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {

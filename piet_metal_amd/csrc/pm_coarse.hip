@@ -332,13 +332,14 @@ __global__ __launch_bounds__(kThreads, PM_COARSE_WPS) void pm_coarse_kernel(Fram
                         const uint32_t rg = L.hrg[c], ba = L.hba[c];
                         if (ctag == kItemFill) {  // :359-363
                             const int backdrop = L.backdrop[c];
+                            const uint32_t even_odd = L.haux0[c] & kFillEvenOdd;  // PietFill.flags (extension)
                             if (L.any[c]) {
                                 has_fin = true;
                                 fin.tag = kCmdDrawFill;
                                 fin.body[0] = static_cast<uint32_t>(backdrop);
-                                fin.body[1] = frgba; fin.body[2] = rg; fin.body[3] = ba; fin.body[4] = 0;
+                                fin.body[1] = frgba; fin.body[2] = rg; fin.body[3] = ba; fin.body[4] = even_odd;
                                 draws = true;
-                            } else if (backdrop != 0) {
+                            } else if (even_odd ? (backdrop & 1) != 0 : backdrop != 0) {  // wholly inside: non-zero / odd winding
                                 has_fin = true;
                                 fin.tag = kCmdSolid;
                                 fin.body[0] = frgba; fin.body[1] = rg; fin.body[2] = ba; fin.body[3] = 0; fin.body[4] = 0;

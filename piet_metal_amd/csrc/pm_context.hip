@@ -181,7 +181,9 @@ struct pm_ctx {
     uint8_t *h_scene = nullptr;  // pinned staging
     size_t scene_cap = 0;
     uint8_t *d_scene = nullptr;
-    size_t scene_bytes = 0;
+    size_t scene_bytes = 0;       // resident bytes (with the flat form of nested groups appended)
+    size_t user_scene_bytes = 0;  // what the caller uploaded / the flatten kernels wrote
+    uint32_t dev_bbox_ix = 8, dev_items_ix = 0;  // the drawn group's ShortBbox / item arrays in d_scene
     uint32_t n_items = 0;
     std::vector<uint8_t> item_meta;  // copy of header + bboxes + items (arena sizing)
     uint32_t *d_chunk_base = nullptr;  // scene index: first chunk of every item (+ total)
@@ -485,7 +487,8 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->scene = c->d_scene;
     p->scene_bytes = static_cast<uint32_t>(c->scene_bytes);
     p->n_items = c->n_items;
-    std::memcpy(&p->items_ix, c->item_meta.data() + 4, 4);
+    p->items_ix = c->dev_items_ix;
+    p->bbox_ix = c->dev_bbox_ix;
     p->width = c->width;
     p->height = c->height;
     p->tiles_x = c->tiles_x;
@@ -644,7 +647,7 @@ int BuildSceneIndex(pm_ctx *c) {
     }
     c->n_chunks = static_cast<uint32_t>(total);
     PM_TRY(hipMemcpyAsync(c->d_chunk_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    pm::LaunchIndex(c->d_scene, n, c->d_chunk_base, c->n_chunks, c->d_chunk_bbox, c->stream);
+    pm::LaunchIndex(c->d_scene, n, c->dev_items_ix, c->d_chunk_base, c->n_chunks, c->d_chunk_bbox, c->stream);
     PM_TRY(hipGetLastError());
     PM_TRY(hipStreamSynchronize(c->stream));  // `base` is a stack-owned source buffer
     return PM_OK;
@@ -655,6 +658,7 @@ int BuildSceneIndex(pm_ctx *c) {
 // with new, unvalidated device bytes (BuildParams refuses to render without a scene).
 void InvalidateScene(pm_ctx *c) {
     c->scene_bytes = 0;
+    c->user_scene_bytes = 0;
     c->n_items = 0;
     c->n_chunks = 0;
     c->item_meta.clear();
@@ -662,30 +666,117 @@ void InvalidateScene(pm_ctx *c) {
     c->arena_dirty = true;
 }
 
-int SetScene(pm_ctx *c, size_t bytes) {
-    // keep a host copy of header + bboxes + items for validation and arena sizing
+int ReserveScene(pm_ctx *c, size_t cap, size_t keep_bytes);
+
+// Nested groups (extension, src/lib.rs:148): a scene with PietGroup items renders like the same
+// items inlined depth first, in paint order.  The kernels only ever see a flat group, so the
+// host appends that flat form -- {n, items_ix}, boxes, 32-byte items, the items' point arrays
+// stay where they are -- behind the scene bytes.  Every offset is checked here.
+struct FlatGroup {
+    std::vector<uint8_t> boxes, items;
+    uint32_t n = 0;
+};
+
+bool FlattenGroup(const uint8_t *sc, size_t len, uint64_t group, int depth, FlatGroup *out) {
+    if (depth > 32 || group + 8 > len || (group & 3u)) return false;
+    uint32_t n, items_ix;
+    std::memcpy(&n, sc + group, 4);
+    std::memcpy(&items_ix, sc + group + 4, 4);
+    if (group + 8ull + 8ull * n > len || static_cast<uint64_t>(items_ix) + 32ull * n > len || (items_ix & 3u)) return false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint8_t *it = sc + items_ix + 32ull * i;
+        uint32_t tag, child;
+        std::memcpy(&tag, it, 4);
+        if ((tag & 0xffffu) == pm::kItemGroup) {
+            std::memcpy(&child, it + 8, 4);
+            if (!FlattenGroup(sc, len, child, depth + 1, out)) return false;
+            continue;
+        }
+        if (out->n >= (1u << 24)) return false;  // (also ends cyclic scenes)
+        out->boxes.insert(out->boxes.end(), sc + group + 8 + 8ull * i, sc + group + 16 + 8ull * i);
+        out->items.insert(out->items.end(), it, it + 32);
+        out->n += 1;
+    }
+    return true;
+}
+
+// The scene bytes are resident in d_scene (`host` = the same bytes in host memory, or nullptr for
+// a scene the flatten kernels wrote).  Builds the host copy of the drawn group in normal form
+// {n, 8 + 8n}{boxes}{items} (validation, arena sizing) and the scene index.
+int SetScene(pm_ctx *c, size_t bytes, const uint8_t *host) {
     if (bytes < 8) return PM_ERR_SCENE;
     const WallTimer timer;
-    uint32_t hdr[2];
-    PM_TRY(hipMemcpyAsync(hdr, c->d_scene, 8, hipMemcpyDeviceToHost, c->stream));
-    PM_TRY(hipStreamSynchronize(c->stream));
-    const uint64_t meta_len = static_cast<uint64_t>(hdr[1]) + 32ull * hdr[0];
-    if (meta_len > bytes || hdr[1] < 8ull + 8ull * hdr[0]) {
-        SetError("scene header out of range");
+    auto fail = [&](const char *what) {
+        SetError(what);
         InvalidateScene(c);
         return PM_ERR_SCENE;
+    };
+    uint32_t hdr[2];
+    if (host) {
+        std::memcpy(hdr, host, 8);
+    } else {
+        PM_TRY(hipMemcpyAsync(hdr, c->d_scene, 8, hipMemcpyDeviceToHost, c->stream));
+        PM_TRY(hipStreamSynchronize(c->stream));
     }
-    c->item_meta.resize(meta_len);
-    PM_TRY(hipMemcpyAsync(c->item_meta.data(), c->d_scene, meta_len, hipMemcpyDeviceToHost, c->stream));
-    PM_TRY(hipStreamSynchronize(c->stream));
-    uint32_t n = 0;
-    const int r = ValidateScene(c->item_meta.data(), c->item_meta.size(), bytes, &n);
+    const uint64_t n0 = hdr[0], items0 = hdr[1];
+    if (items0 + 32ull * n0 > bytes || items0 < 8ull + 8ull * n0 || (items0 & 7u)) return fail("scene header out of range");
+    std::vector<uint8_t> meta(8 + 40 * n0);
+    uint32_t dev_bbox_ix = 8, dev_items_ix = hdr[1];
+    size_t total = bytes;
+    bool nested = false;
+    if (host)
+        for (uint64_t i = 0; i < n0 && !nested; ++i) {
+            uint32_t tag;
+            std::memcpy(&tag, host + items0 + 32 * i, 4);
+            nested = (tag & 0xffffu) == pm::kItemGroup;
+        }
+    uint32_t n = hdr[0];
+    if (nested) {
+        FlatGroup flat;
+        if (!FlattenGroup(host, bytes, 0, 0, &flat)) return fail("nested groups: offset out of range, too deep, or cyclic");
+        n = flat.n;
+        const size_t root = (bytes + 7u) & ~static_cast<size_t>(7u);
+        total = root + 8 + 40ull * n;
+        std::vector<uint8_t> blk(total - bytes, 0);
+        const uint32_t ghdr[2] = {n, static_cast<uint32_t>(root + 8 + 8ull * n)};
+        std::memcpy(blk.data() + (root - bytes), ghdr, 8);
+        std::memcpy(blk.data() + (root - bytes) + 8, flat.boxes.data(), flat.boxes.size());
+        std::memcpy(blk.data() + (root - bytes) + 8 + 8ull * n, flat.items.data(), flat.items.size());
+        if (total > c->scene_cap) {
+            PM_TRY(hipStreamSynchronize(c->stream));  // the upload of the scene bytes is still in flight
+            const int rr = ReserveScene(c, total + (total >> 3), bytes);
+            if (rr != PM_OK) {
+                InvalidateScene(c);
+                return rr;
+            }
+        }
+        PM_TRY(hipMemcpyAsync(c->d_scene + bytes, blk.data(), blk.size(), hipMemcpyHostToDevice, c->stream));
+        PM_TRY(hipStreamSynchronize(c->stream));  // blk is a stack-owned source
+        dev_bbox_ix = static_cast<uint32_t>(root + 8);
+        dev_items_ix = ghdr[1];
+        meta.resize(8 + 40ull * n);
+        std::memcpy(meta.data() + 8, flat.boxes.data(), flat.boxes.size());
+        std::memcpy(meta.data() + 8 + 8ull * n, flat.items.data(), flat.items.size());
+    } else if (host) {
+        std::memcpy(meta.data() + 8, host + 8, 8 * n0);
+        std::memcpy(meta.data() + 8 + 8 * n0, host + items0, 32 * n0);
+    } else if (n0) {
+        PM_TRY(hipMemcpyAsync(meta.data() + 8, c->d_scene + 8, 8 * n0, hipMemcpyDeviceToHost, c->stream));
+        PM_TRY(hipMemcpyAsync(meta.data() + 8 + 8 * n0, c->d_scene + items0, 32 * n0, hipMemcpyDeviceToHost, c->stream));
+        PM_TRY(hipStreamSynchronize(c->stream));
+    }
+    const uint32_t mhdr[2] = {n, 8u + 8u * n};
+    std::memcpy(meta.data(), mhdr, 8);
+    uint32_t n_checked = 0;
+    const int r = ValidateScene(meta.data(), meta.size(), total, &n_checked);
     if (r != PM_OK) {
-        SetError("scene buffer failed validation");
-        InvalidateScene(c);
+        (void)fail("scene buffer failed validation");
         return r;
     }
+    c->item_meta.swap(meta);
     c->n_items = n;
+    c->dev_bbox_ix = dev_bbox_ix;
+    c->dev_items_ix = dev_items_ix;
     c->arena_dirty = true;
     c->last_slot = -1;
     const int ri = BuildSceneIndex(c);
@@ -693,13 +784,15 @@ int SetScene(pm_ctx *c, size_t bytes) {
         InvalidateScene(c);
         return ri;
     }
-    c->scene_bytes = bytes;  // only now is there a scene to render
+    c->user_scene_bytes = bytes;
+    c->scene_bytes = total;  // only now is there a scene to render
     c->t_index_ms = timer.ms();
     return PM_OK;
 }
 
-int ReserveScene(pm_ctx *c, size_t cap) {
+int ReserveScene(pm_ctx *c, size_t cap, size_t keep_bytes = 0) {
     if (cap <= c->scene_cap) return PM_OK;
+    keep_bytes = std::max(keep_bytes, c->scene_bytes);
     if (cap > 0xffffffffull) {  // offsets in the scene format (and in the kernels' bounds checks) are u32
         SetError("scene buffers are limited to 4 GiB - 1 (u32 offsets in the scene format)");
         return PM_ERR_CAPACITY;
@@ -717,7 +810,7 @@ int ReserveScene(pm_ctx *c, size_t cap) {
         (void)hipHostFree(c->h_scene);
     }
     if (c->d_scene) {
-        if (c->scene_bytes) (void)hipMemcpy(d, c->d_scene, c->scene_bytes, hipMemcpyDeviceToDevice);
+        if (keep_bytes) (void)hipMemcpy(d, c->d_scene, std::min(keep_bytes, c->scene_cap), hipMemcpyDeviceToDevice);
         (void)hipFree(c->d_scene);
     }
     c->h_scene = h;
@@ -920,7 +1013,7 @@ int pm_upload_scene(pm_ctx *c, size_t bytes) {
     InvalidateScene(c);
     c->t_flatten_ms = 0;
     PM_TRY(hipMemcpyAsync(c->d_scene, c->h_scene, bytes, hipMemcpyHostToDevice, c->stream));
-    return SetScene(c, bytes);
+    return SetScene(c, bytes, c->h_scene);  // (stream order: the appended flat group follows the upload)
 }
 
 int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const pm_path_el *els, size_t n_els,
@@ -951,7 +1044,7 @@ int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const
         return r;
     }
     c->t_flatten_ms = timer.ms();
-    r = SetScene(c, bytes);
+    r = SetScene(c, bytes, nullptr);
     if (r != PM_OK) return r;
     if (scene_bytes) *scene_bytes = bytes;
     if (n_items) *n_items = items;
@@ -960,10 +1053,10 @@ int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const
 
 int pm_download_scene(pm_ctx *c, uint8_t *dst, size_t cap, size_t *bytes) {
     if (!c || !dst) return PM_ERR_INVALID;
-    if (bytes) *bytes = c->scene_bytes;
-    if (cap < c->scene_bytes) return PM_ERR_CAPACITY;
+    if (bytes) *bytes = c->user_scene_bytes;
+    if (cap < c->user_scene_bytes) return PM_ERR_CAPACITY;
     PM_TRY(hipSetDevice(c->device));
-    PM_TRY(hipMemcpyAsync(dst, c->d_scene, c->scene_bytes, hipMemcpyDeviceToHost, c->stream));
+    PM_TRY(hipMemcpyAsync(dst, c->d_scene, c->user_scene_bytes, hipMemcpyDeviceToHost, c->stream));
     PM_TRY(hipStreamSynchronize(c->stream));
     return PM_OK;
 }
@@ -1070,7 +1163,7 @@ void *pm_framebuffer_device_ptr(pm_ctx *c, size_t *stride_bytes, uint32_t *rows)
 
 void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes) {
     if (!c) return nullptr;
-    if (bytes) *bytes = c->scene_bytes;
+    if (bytes) *bytes = c->user_scene_bytes;
     return c->d_scene;
 }
 
@@ -1243,7 +1336,7 @@ int pm_get_stats(pm_ctx *c, pm_stats *out) {
     out->band_row1 = c->row1;
     out->n_items = c->n_items;
     out->arena_cap_dwords = c->arena_cap;
-    out->scene_bytes = static_cast<uint32_t>(c->scene_bytes);
+    out->scene_bytes = static_cast<uint32_t>(c->user_scene_bytes);
     if (c->last_slot >= 0) {
         pm::Counters k;
         PM_TRY(hipMemcpy(&k, c->slot[c->last_slot].params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));

@@ -40,7 +40,7 @@ struct Counters {
 //       (one 16-byte load per lane of the coarse kernel covers 256 candidates); a hit
 //       bit survives only where the candidate can emit a command
 //   ncand x 8 dwords: { tag | hitmask16 << 16, rgba, aux0, aux1, item index, 0, rg, ba }
-//       aux0/aux1 = bbox words (circle) or width bits (line, polyline)
+//       aux0/aux1 = bbox words (circle), width bits (line, polyline) or PietFill.flags (fill)
 //       rg/ba = the colour already through unpack_unorm4x8_srgb_to_half (4 x binary16)
 //   ncand x 16 dwords: per tile of the strip { backdrop << 20 | relevant segments }
 //       backdrop = the reference's per-tile left-ray winding sum (PietRender.metal
@@ -76,7 +76,8 @@ constexpr uint32_t kCtCountMask = (1u << kCtShift) - 1u;
 struct FrameParams {
     const uint8_t *scene;
     uint32_t scene_bytes;
-    uint32_t n_items, items_ix;  // the scene header (SimpleGroup), validated on the host
+    uint32_t n_items, items_ix;  // the group the frame draws (the scene header, or the flat form of nested groups), validated on the host
+    uint32_t bbox_ix;            // its ShortBbox array (8 for the scene header)
     uint32_t width, height;
     uint32_t tiles_x, tiles_y;
     uint32_t row0, row1;  // band of tile rows rendered by this context
@@ -127,8 +128,8 @@ struct FrameParams {
     unsigned long long *dbg_bin;  // per strip row of pm_bin_kernel: 8 x u64 phase clocks (developer profiling)
 };
 
-void LaunchIndex(const uint8_t *scene, uint32_t n_items, const uint32_t *chunk_base, uint32_t n_chunks, float4 *chunk_bbox,
-                 hipStream_t stream);
+void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, const uint32_t *chunk_base, uint32_t n_chunks,
+                 float4 *chunk_bbox, hipStream_t stream);
 // (t0, t1): optional timing events carried by the dispatch itself
 void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 void LaunchClear(const FrameParams &p, uint32_t n_striprows, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);

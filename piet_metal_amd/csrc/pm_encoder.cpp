@@ -57,6 +57,16 @@ void Encoder::Put(size_t at, const void *src, size_t len) {
 }
 
 void Encoder::BeginGroup(size_t n_items) {
+    if (group_open_) {
+        // nested: the new group takes the next item slot of the open one
+        if (group_ix_ >= group_count_ || depth_ >= kMaxDepth) {
+            if (status_ == kOk) status_ = kMisuse;
+            return;
+        }
+        stack_[depth_++] = Frame{group_count_, group_ix_, group_start_};
+        group_ix_ = 0;
+    }
+    group_open_ = true;
     const size_t item_start = sizeof(SimpleGroup) + n_items * sizeof(ShortBbox);
     group_start_ = Alloc(item_start + n_items * kItemSize);
     group_count_ = n_items;
@@ -66,6 +76,32 @@ void Encoder::BeginGroup(size_t n_items) {
 
 void Encoder::EndGroup() {
     if (group_ix_ != group_count_ && status_ == kOk) status_ = kMisuse;  // assert_eq!, :147
+    if (depth_ == 0) {
+        group_open_ = false;  // (the reference keeps no such flag: one group per scene)
+        return;
+    }
+    // "This will get more interesting when we have nested groups" (:148): the closed group becomes
+    // a PietGroup item of its parent, boxed by the union of its children's boxes
+    ShortBbox u{0xffff, 0xffff, 0, 0};
+    bool any = false;
+    for (size_t i = 0; i < group_count_ && status_ == kOk; ++i) {
+        ShortBbox b;
+        const size_t at = group_start_ + sizeof(SimpleGroup) + i * sizeof(ShortBbox);
+        if (at + sizeof(b) > cap_) break;
+        std::memcpy(&b, buf_ + at, sizeof(b));
+        u.x0 = std::min(u.x0, b.x0);
+        u.y0 = std::min(u.y0, b.y0);
+        u.x1 = std::max(u.x1, b.x1);
+        u.y1 = std::max(u.y1, b.y1);
+        any = true;
+    }
+    if (!any) u = ShortBbox{0, 0, 0, 0};
+    const PietGroup item{kItemGroup, 0, static_cast<uint32_t>(group_start_)};
+    const Frame f = stack_[--depth_];
+    group_count_ = f.count;
+    group_ix_ = f.ix;
+    group_start_ = f.start;
+    AddItem(item, u);
 }
 
 template <typename Item>
@@ -122,10 +158,10 @@ size_t Encoder::EncodePoints(const double *pts_xy, size_t n, double bbox_out[4])
     return points_ix;
 }
 
-void Encoder::Fill(const double *pts_xy, size_t n, uint32_t rgba) {
+void Encoder::Fill(const double *pts_xy, size_t n, uint32_t rgba, uint32_t flags) {
     double bb[4] = {0, 0, 0, 0};
     const size_t points_ix = EncodePoints(pts_xy, n, bb);
-    PietFill item{kItemFill, 0, ByteSwap(rgba), static_cast<uint32_t>(n),
+    PietFill item{kItemFill, flags, ByteSwap(rgba), static_cast<uint32_t>(n),
                   static_cast<uint32_t>(points_ix)};
     AddItem(item, ToShortBbox(Rect{bb[0], bb[1], bb[2], bb[3]}));
 }
@@ -209,6 +245,11 @@ int pm_encoder_stroke_line(pm_encoder *e, double x0, double y0, double x1, doubl
 int pm_encoder_fill(pm_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba) {
     if (!e || (!pts_xy && n_points)) return PM_ERR_INVALID;
     e->enc.Fill(pts_xy, n_points, rgba);
+    return e->enc.c_status();
+}
+int pm_encoder_fill_rule(pm_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba, uint32_t fill_flags) {
+    if (!e || (!pts_xy && n_points) || (fill_flags & ~PM_FILL_EVEN_ODD)) return PM_ERR_INVALID;
+    e->enc.Fill(pts_xy, n_points, rgba, fill_flags);
     return e->enc.c_status();
 }
 int pm_encoder_polyline(pm_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba,

@@ -4,6 +4,10 @@
 #include <cstddef>
 #include <cstdint>
 
+// Beyond the reference: BeginGroup inside an open group starts a NESTED group (it takes one item
+// slot of its parent; EndGroup closes it and writes its bounding box), and Fill takes the
+// winding-rule flag the reference reserves.
+
 #include "../../include/piet_metal_amd.h"
 #include "pm_layout.h"
 
@@ -20,7 +24,7 @@ public:
     void EndGroup();                                 // :146
     void Circle(double cx, double cy, double r);     // :167
     void StrokeLine(double x0, double y0, double x1, double y1, float width, uint32_t rgba);  // :177
-    void Fill(const double *pts_xy, size_t n, uint32_t rgba);                                 // :195
+    void Fill(const double *pts_xy, size_t n, uint32_t rgba, uint32_t flags = 0);             // :195 (+ PietFill.flags)
     void Polyline(const double *pts_xy, size_t n, uint32_t rgba, float width);                // :209
     // :224 -- returns points_ix, bbox_out = {x0,y0,x1,y1}
     size_t EncodePoints(const double *pts_xy, size_t n, double bbox_out[4]);
@@ -42,6 +46,13 @@ private:
     size_t group_count_ = 0;
     size_t group_ix_ = 0;
     size_t group_start_ = 0;
+    bool group_open_ = false;
+    struct Frame {
+        size_t count, ix, start;
+    };
+    static constexpr int kMaxDepth = 32;
+    Frame stack_[kMaxDepth];  // enclosing groups of the one being filled
+    int depth_ = 0;
     Status status_ = kOk;
 };
 

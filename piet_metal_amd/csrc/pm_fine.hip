@@ -58,6 +58,23 @@ __device__ __forceinline__ _Float16 HalfFromBits(uint32_t b) {
     return __builtin_bit_cast(_Float16, u);
 }
 
+// alpha of DrawFill from signedArea + backdrop (binary16): the non-zero rule (:538), or -- with
+// the rule bit the command carries in its last word -- the even-odd formula the reference leaves
+// in a comment (:539): abs(alpha - 2 * round(0.5 * alpha)), every step in binary16.  (round =
+// nearest-even here and in the oracle: a tie means alpha is an odd integer, and either
+// neighbour then gives |+-1| = 1.)
+__device__ __forceinline__ _Float16 FillAlpha(_Float16 a, bool even_odd) {
+    if (even_odd) {
+        const _Float16 t = static_cast<_Float16>(0.5f) * a;
+        const _Float16 r = __builtin_rintf16(t);
+        const _Float16 v = a - static_cast<_Float16>(2.0f) * r;
+        return __builtin_fabsf16(v);
+    }
+    float f = fminf(fabsf(static_cast<float>(a)), 1.0f);
+    asm volatile("" : "+v"(f));
+    return static_cast<_Float16>(f);
+}
+
 __device__ __forceinline__ half2_t Splat(_Float16 v) { half2_t r; r.x = v; r.y = v; return r; }
 
 // ---- row-sparse Fill evaluation -----------------------------------------------------------
@@ -285,11 +302,12 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
             case kCmdDrawFill: {
                 const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
                 const half2_t s01 = st.sa01 + Splat(bd), s23 = st.sa23 + Splat(bd);
+                const bool eo = (cmd.body[4] & kFillEvenOdd) != 0;
                 half2_t a01, a23;
-                a01.x = ToHalf(fminf(fabsf(static_cast<float>(s01.x)), 1.0f));
-                a01.y = ToHalf(fminf(fabsf(static_cast<float>(s01.y)), 1.0f));
-                a23.x = ToHalf(fminf(fabsf(static_cast<float>(s23.x)), 1.0f));
-                a23.y = ToHalf(fminf(fabsf(static_cast<float>(s23.y)), 1.0f));
+                a01.x = FillAlpha(s01.x, eo);
+                a01.y = FillAlpha(s01.y, eo);
+                a23.x = FillAlpha(s23.x, eo);
+                a23.y = FillAlpha(s23.y, eo);
                 st.sa01 = st.sa23 = Splat(static_cast<_Float16>(0.0f));
                 Blend4S(st, cmd.body[2], cmd.body[3], a01, a23);
                 break;
@@ -453,10 +471,11 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
             if (cmd.tag == kCmdDrawFill) {  // :535-542
                 const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
                 const half2_t s01 = sa01 + Splat(bd), s23 = sa23 + Splat(bd);
-                al[0] = ToHalf(fminf(fabsf(static_cast<float>(s01.x)), 1.0f));
-                al[1] = ToHalf(fminf(fabsf(static_cast<float>(s01.y)), 1.0f));
-                al[2] = ToHalf(fminf(fabsf(static_cast<float>(s23.x)), 1.0f));
-                al[3] = ToHalf(fminf(fabsf(static_cast<float>(s23.y)), 1.0f));
+                const bool eo = (cmd.body[4] & kFillEvenOdd) != 0;
+                al[0] = FillAlpha(s01.x, eo);
+                al[1] = FillAlpha(s01.y, eo);
+                al[2] = FillAlpha(s23.x, eo);
+                al[3] = FillAlpha(s23.y, eo);
             } else if (cmd.tag == kCmdStroke) {  // :500-504
                 const float half_width = __uint_as_float(cmd.body[0]);
 #pragma unroll

@@ -301,7 +301,7 @@ __global__ void KItems(const pm_path *paths, uint32_t n_paths, const pm_path_el 
             *reinterpret_cast<ShortBbox *>(scene + bbox_start + static_cast<size_t>(item) * sizeof(ShortBbox)) = sb;
             uint32_t *it = reinterpret_cast<uint32_t *>(scene + items_start + static_cast<size_t>(item) * kItemSize);
             it[0] = kItemFill;
-            it[1] = 0;
+            it[1] = (path.flags & PM_PATH_EVEN_ODD) ? kFillEvenOdd : 0u;  // PietFill.flags (0 in the reference)
             it[2] = __builtin_bswap32(path.fill_rgba);
             it[3] = n_points;
             it[4] = static_cast<uint32_t>(pts_ix);

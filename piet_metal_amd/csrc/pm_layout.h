@@ -28,7 +28,13 @@ enum ItemTag : uint32_t {  // src/lib.rs:70-77
     kItemLine = 2,
     kItemFill = 3,
     kItemPoly = 4,
+    // Extension (not in the reference, which stops at "This will get more interesting when we
+    // have nested groups", src/lib.rs:148): an item that stands for a nested SimpleGroup.
+    kItemGroup = 5,
 };
+
+// PietFill.flags (src/lib.rs:54, "will be used for winding number rule", TestApp/SceneEncoder.h:44)
+constexpr uint32_t kFillEvenOdd = 1u;  // even-odd instead of non-zero (PietRender.metal:539-540)
 
 struct SimpleGroup {  // src/lib.rs:15-20
     uint32_t n_items;
@@ -81,6 +87,13 @@ static_assert(sizeof(PietStrokePolyLine) == 20 && offsetof(PietStrokePolyLine, r
                   offsetof(PietStrokePolyLine, n_points) == 12 &&
                   offsetof(PietStrokePolyLine, points_ix) == 16,
               "PietStrokePolyLine offsets (GenTypes.h:257-273)");
+
+struct PietGroup {  // extension: a nested group in its parent's item list
+    uint32_t item_type;  // kItemGroup
+    uint32_t flags;      // reserved, 0
+    uint32_t group_ix;   // byte offset of the nested SimpleGroup (+ its ShortBbox array, like the root's)
+};
+static_assert(sizeof(PietGroup) == 12 && offsetof(PietGroup, group_ix) == 8, "PietGroup offsets");
 
 constexpr size_t kItemSize = 32;  // sizeof(union PietItem), src/lib.rs:27-31
 

@@ -39,6 +39,7 @@ class Encoder:
         return int(self._lib.pm_encoder_alloc(self._h, size))
 
     def begin_group(self, n_items: int) -> None:
+        """`Encoder::begin_group`; inside an open group it starts a nested group (extension)."""
         _lib.check(self._lib.pm_encoder_begin_group(self._h, n_items), "begin_group")
 
     def end_group(self) -> None:
@@ -60,9 +61,14 @@ class Encoder:
             raise ValueError("points must be (n, 2)")
         return a
 
-    def fill(self, points, rgba: int) -> None:
+    def fill(self, points, rgba: int, even_odd: bool = False) -> None:
+        """`Encoder::fill`; even_odd sets the winding-rule bit of PietFill.flags (an extension
+        the reference reserves the field for, src/lib.rs:54)."""
         a = self._pts(points)
-        _lib.check(self._lib.pm_encoder_fill(self._h, a.ctypes.data, a.shape[0], rgba & 0xFFFFFFFF), "fill")
+        if even_odd:
+            _lib.check(self._lib.pm_encoder_fill_rule(self._h, a.ctypes.data, a.shape[0], rgba & 0xFFFFFFFF, _lib.PM_FILL_EVEN_ODD), "fill")
+        else:
+            _lib.check(self._lib.pm_encoder_fill(self._h, a.ctypes.data, a.shape[0], rgba & 0xFFFFFFFF), "fill")
 
     def polyline(self, points, rgba: int, width: float) -> None:
         a = self._pts(points)

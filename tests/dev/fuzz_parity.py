@@ -1,7 +1,7 @@
 """Randomised parity sweep (GPU box): random scenes x random viewports x random bands,
 GPU pixels (and, for a subset, per-tile command lists) against the oracle.
 
-    python tests/dev/fuzz_parity.py [first_seed] [count]
+    python tests/dev/fuzz_parity.py [first_seed] [count] [--ext]   (--ext: even-odd fills, nested groups)
 """
 import os, sys, time
 import numpy as np
@@ -9,11 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import piet_metal_amd as pm
 from oracle import pmo
-from test_host_cpu import random_ops, encode_ops
+from test_host_cpu import random_ops, encode_ops, extend_ops
 
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    ext = "--ext" in sys.argv
     r = pm.Renderer(0)
     bad = 0
     t0 = time.time()
@@ -22,7 +23,10 @@ def main():
         n = int(rng.integers(1, 500))
         extent = float(rng.choice([120.0, 400.0, 900.0, 2000.0]))
         w, h = int(rng.integers(16, 1800)), int(rng.integers(16, 1400))
-        scene = encode_ops(pm, random_ops(seed, n, extent=extent), cap=4 << 20)
+        ops = random_ops(seed, n, extent=extent)
+        if ext:  # even-odd fills + nested groups
+            ops = extend_ops(seed, ops)
+        scene = encode_ops(pm, ops, cap=8 << 20)
         r.resize(w, h)
         r.set_scene_bytes(scene)
         for _ in range(int(rng.integers(1, 4))):

@@ -40,7 +40,7 @@ def ptcl_sha(P) -> str:
     return hsh.hexdigest()
 
 
-def scene_entry(scene, w, h, with_image=True):
+def scene_entry(scene, w, h, with_image=True, with_f32=True):
     P = pmo.Ptcl(scene, w, h)
     tot, mx = P.total_cmds()
     e = {"scene_bytes": int(scene.size), "scene_sha256": sha(scene), "viewport": [w, h], "total_cmds": tot, "max_cmds_per_tile": mx}
@@ -48,8 +48,9 @@ def scene_entry(scene, w, h, with_image=True):
         img = P.render()
         e["rgba_sha256"] = sha(img)
         e["rgba_sum"] = int(img.astype(np.uint64).sum())
-        f32 = P.render(pmo.MODE_F32)
-        e["half_vs_f32_max_lsb"] = int(np.abs(img.astype(int) - f32.astype(int)).max())
+        if with_f32:
+            f32 = P.render(pmo.MODE_F32)
+            e["half_vs_f32_max_lsb"] = int(np.abs(img.astype(int) - f32.astype(int)).max())
     solid = np.array([[P.solid(tx, ty) for tx in range(P.tiles_x)] for ty in range(P.tiles_y)], np.uint32)
     e["solid_sha256"] = sha(solid)
     e["ptcl_sha256"] = ptcl_sha(P)
@@ -57,7 +58,27 @@ def scene_entry(scene, w, h, with_image=True):
     return e
 
 
+def big_main():
+    """python tests/golden/make_golden.py --big : full-size pins of BASELINE configs 4 and 5
+    (minutes of CPU each; merged into golden.json, everything else untouched)."""
+    import time
+
+    path = os.path.join(os.path.dirname(__file__), "golden.json")
+    out = json.load(open(path))
+    for wl in [pm.workloads.config4_blobs(), pm.workloads.config5_tiger_grid()]:
+        t0 = time.time()
+        scene, n_items = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
+        e = scene_entry(scene, wl.width, wl.height, with_f32=False)
+        e["n_items"] = n_items
+        out[wl.name] = e
+        print(wl.name, e, f"{time.time() - t0:.0f} s", flush=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+
+
 def main():
+    if "--big" in sys.argv:
+        return big_main()
     out = {}
     out["path_test_512x832"] = scene_entry(pmo.scene_path_test(), 512, 832)
     out["cardioid_2048x1536"] = scene_entry(pmo.scene_cardioid(), 2048, 1536)
@@ -78,7 +99,11 @@ def main():
     np.save(os.path.join(os.path.dirname(__file__), "tiger_x8_crop_704_496_64x64.npy"), img[496:560, 704:768].copy())
     a, b, c = pmo.luts()
     out["luts"] = {"srgb2lin_sha256": sha(a), "unorm2h_sha256": sha(b), "lin2srgb_sha256": sha(c)}
-    with open(os.path.join(os.path.dirname(__file__), "golden.json"), "w") as f:
+    path = os.path.join(os.path.dirname(__file__), "golden.json")
+    if os.path.exists(path):  # keep the full-size pins of `--big` runs
+        for k, v in json.load(open(path)).items():
+            out.setdefault(k, v)
+    with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print(json.dumps(out, indent=1, sort_keys=True))
 

@@ -117,7 +117,11 @@ def render_tile(cmds, tx, ty, tables):
             elif tag == 7:  # DrawFill :535-545
                 bd = f16(f32(np.uint32(b[0]).view(np.int32)))
                 alpha = (sa + bd).astype(f16)
-                alpha = np.fmin(np.abs(alpha.astype(f32)), f32(1)).astype(f16)
+                if b[4] & 1:  # extension: even-odd, the formula in the reference's comment (:539), all in half
+                    r = np.rint((f16(0.5) * alpha).astype(f16)).astype(f16)
+                    alpha = np.abs((alpha - (f16(2) * r).astype(f16)).astype(f16))
+                else:
+                    alpha = np.fmin(np.abs(alpha.astype(f32)), f32(1)).astype(f16)
                 blend(b[1], alpha)
                 sa = np.zeros((16, 16), f16)
             elif tag == 8:  # Solid :546-551

@@ -60,8 +60,23 @@ def tile_lists(scene: bytes, width: int, height: int):
     u32 = lambda o: struct.unpack_from("<I", scene, o)[0]
     flt = lambda o: f32(struct.unpack_from("<f", scene, o)[0])
     pt = lambda base, i: (flt(base + 8 * i), flt(base + 8 * i + 4))
-    n, items_ix = u32(0), u32(4)
-    bbox = [struct.unpack_from("<4H", scene, 8 + 8 * i) for i in range(n)]
+    # Extension (nested groups): an item of type 5 {tag, flags, group_ix} stands for the items of the
+    # SimpleGroup at group_ix, in place and in order -- walked here by explicit recursion into
+    # (bbox, item offset) pairs, nothing is copied or appended.
+    def walk(group, depth=0):
+        assert depth <= 32
+        gn, gitems = u32(group), u32(group + 4)
+        for i in range(gn):
+            it = gitems + 32 * i
+            if (u32(it) & 0xFFFF) == 5:
+                yield from walk(u32(it + 8), depth + 1)
+            else:
+                yield struct.unpack_from("<4H", scene, group + 8 + 8 * i), it
+
+    flat = list(walk(0))
+    n = len(flat)
+    bbox = [b for b, _ in flat]
+    item_at = [it for _, it in flat]
     tiles_x, tiles_y = (width + 15) // 16, (height + 15) // 16
     out = {}
     for gy in range((tiles_y + GROUP_H - 1) // GROUP_H):
@@ -76,7 +91,7 @@ def tile_lists(scene: bytes, width: int, height: int):
                 bx, by, bz, bw = bbox[ix]
                 if not (bz >= sx0 and bx < sx0 + stw and bw >= sy0 and by < sy0 + sth):
                     continue
-                item = items_ix + 32 * ix
+                item = item_at[ix]
                 tag = u32(item) & 0xFFFF
                 hits = [bz >= L["x0"] and bx < L["x0"] + TILE_W and bw >= L["y0"] and by < L["y0"] + TILE_H for L in lanes]
                 if tag == 1:  # Circle :218-222
@@ -102,6 +117,7 @@ def tile_lists(scene: bytes, width: int, height: int):
                             L["enc"].push(STROKE, bits(f32(f32(0.5) * width_)), rgba)
                 elif tag == 3:  # Fill :248-362
                     rgba, npts, pix = u32(item + 8), u32(item + 12), u32(item + 16)
+                    even_odd = u32(item + 4) & 1  # extension: PietFill.flags bit 0 (src/lib.rs:54)
                     P = lambda k: pt(pix, k)
                     backdrop = [f32(0.0)] * 32
                     any_fill = [False] * 32
@@ -169,8 +185,8 @@ def tile_lists(scene: bytes, width: int, height: int):
                                     any_fill[tix] = True
                     for tix, L in enumerate(lanes):
                         if any_fill[tix]:
-                            L["enc"].push(DRAW_FILL, int(backdrop[tix]) & 0xFFFFFFFF, rgba)
-                        elif backdrop[tix] != 0:
+                            L["enc"].push(DRAW_FILL, int(backdrop[tix]) & 0xFFFFFFFF, rgba, 0, 0, even_odd)
+                        elif (int(backdrop[tix]) % 2 != 0) if even_odd else (backdrop[tix] != 0):  # wholly inside
                             L["enc"].solid_cmd(rgba)
                 elif tag == 4:  # Poly :363-446
                     rgba, width_, npts, pix = u32(item + 4), flt(item + 8), u32(item + 12), u32(item + 16)

@@ -11,7 +11,7 @@ import struct
 import numpy as np
 import pytest
 
-from test_host_cpu import encode_ops, random_ops
+from test_host_cpu import encode_ops, extend_ops, inline_ops, random_ops
 
 pytestmark = pytest.mark.gpu
 
@@ -221,6 +221,43 @@ def test_config4_blobs_reduced_vs_oracle_and_full_properties(pm, pmo, renderer):
     P = pmo.Ptcl(scene, wl.width, wl.height)
     assert np.array_equal(band[:32], P.render_rows(100, 102))
     P.close()
+
+
+@pytest.mark.parametrize("cfg", ["config4", "config5"])
+def test_baseline_configs_4_and_5_full_size_goldens(pm, pmo, renderer, golden, cfg):
+    """BASELINE configs 4 (10 k blobs, 4096^2) and 5 (25 Tigers, 8192^2) at FULL size against the
+    committed pins the oracle produced in the build container (tests/golden/make_golden.py --big):
+    device-flattened scene bytes, every pixel, every tile's command list and solid colour."""
+    wl = pm.workloads.config4_blobs() if cfg == "config4" else pm.workloads.config5_tiger_grid()
+    g = golden[wl.name]
+    renderer.resize(wl.width, wl.height)
+    nbytes, nitems = renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    assert (nbytes, nitems) == (g["scene_bytes"], g["n_items"])
+    assert sha(renderer.download_scene()) == g["scene_sha256"]
+    renderer.render()
+    img = renderer.read_pixels()
+    assert int(img.astype(np.uint64).sum()) == g["rgba_sum"]
+    assert sha(img) == g["rgba_sha256"]
+    del img
+    # command lists band by band (the capture buffer of the whole frame would be > 1 GB)
+    tiles_y = (wl.height + 15) // 16
+    hsh, solid_all, total, mx = hashlib.sha256(), [], 0, 0
+    for r0 in range(0, tiles_y, 32):
+        renderer.set_band(r0, min(r0 + 32, tiles_y))
+        renderer.render()
+        counts, solid, cmds = renderer.capture_ptcl(g["max_cmds_per_tile"])
+        solid_all.append(solid)
+        total += int(counts.sum())
+        mx = max(mx, int(counts.max()))
+        flat_counts = counts.reshape(-1)
+        flat_cmds = cmds.reshape(-1, cmds.shape[2], 6)
+        for t in range(flat_counts.size):
+            n = int(flat_counts[t])
+            hsh.update(np.uint32(n).tobytes())
+            hsh.update(flat_cmds[t, :n].tobytes())
+    assert (total, mx) == (g["total_cmds"], g["max_cmds_per_tile"])
+    assert sha(np.concatenate(solid_all, axis=0)) == g["solid_sha256"]
+    assert hsh.hexdigest() == g["ptcl_sha256"]
 
 
 def test_bands_reassemble_to_full_frame(pm, pmo, renderer):
@@ -460,6 +497,56 @@ def test_both_fine_modes_agree_with_the_oracle(pm, pmo, monkeypatch, split, heav
         assert np.array_equal(gpu_render(r, scene, 256, 256), pmo.render(scene, 256, 256))
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("seed,n,extent,w,h", [(31, 200, 500.0, 520, 500), (32, 400, 300.0, 330, 310), (33, 60, 1500.0, 1400, 900)])
+def test_even_odd_fills_and_nested_groups(pm, pmo, renderer, seed, n, extent, w, h):
+    """The encoder extensions end to end on the GPU: scenes with even-odd fills (PietFill.flags)
+    inside nested groups -- pixels and per-tile command lists against the oracle, and the nested
+    scene against its own inlined form."""
+    tree = extend_ops(seed, random_ops(seed, n, extent=extent, opaque_mask=0xFF if seed != 32 else 0))
+    nested, flat = encode_ops(pm, tree, cap=4 << 20), encode_ops(pm, inline_ops(tree), cap=4 << 20)
+    got = gpu_render(renderer, nested, w, h)
+    assert np.array_equal(got, pmo.render(nested, w, h))
+    assert_ptcl_equal(renderer, pmo, nested, w, h, maxc=2048)
+    assert np.array_equal(renderer.download_scene(), nested)  # the flat form stays the renderer's business
+    assert np.array_equal(gpu_render(renderer, flat, w, h), got)
+    st = renderer.stats()
+    assert st["n_items"] == len(inline_ops(tree))
+
+
+def test_even_odd_through_the_device_flatten(pm, pmo, renderer):
+    """PM_PATH_EVEN_ODD on a path reaches PietFill.flags through the flatten kernels: scene bytes
+    equal the oracle's encoder, pixels equal its render (Tiger, every fill under even-odd)."""
+    wl = pm.workloads.tiger(960, 540)
+    ps = pm.PathSet(wl.paths.paths.copy(), wl.paths.els)
+    ps.paths["flags"] |= np.where(ps.paths["flags"] & pm._lib.PM_PATH_FILL, pm._lib.PM_PATH_EVEN_ODD, 0).astype(np.uint32)
+    renderer.resize(wl.width, wl.height)
+    renderer.flatten_and_encode(ps, wl.affine, wl.width_scale)
+    scene = renderer.download_scene()
+    want_scene, _ = pmo.scene_from_paths(pmo.scaled_paths(ps.paths, wl.width_scale), ps.els, wl.affine)
+    assert np.array_equal(scene, want_scene)
+    renderer.render()
+    got = renderer.read_pixels()
+    assert np.array_equal(got, pmo.render(scene, wl.width, wl.height))
+    plain, _ = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
+    assert (got != pmo.render(plain, wl.width, wl.height)).any()  # the Tiger has self-overlapping outlines
+
+
+def test_malformed_nested_groups_are_rejected(pm, renderer):
+    good = encode_ops(pm, [("group", [("circle", 50.0, 50.0, 9.0)]), ("circle", 20.0, 20.0, 5.0)])
+    renderer.resize(128, 128)
+    renderer.set_scene_bytes(good)
+    renderer.render()
+    renderer.sync()
+    items = struct.unpack("<I", good[4:8].tobytes())[0]
+    for group_ix in (0, 4, 0xFFFFFFF0):  # itself (a cycle), misaligned into the header, out of range
+        bad = good.copy()
+        bad[items + 8 : items + 12] = np.frombuffer(struct.pack("<I", group_ix), np.uint8)
+        with pytest.raises(pm.PietMetalError):
+            renderer.set_scene_bytes(bad)
+        with pytest.raises(pm.PietMetalError):
+            renderer.render()
 
 
 def test_cli_renders_svg_to_png(pm, pmo, tmp_path):

@@ -70,24 +70,34 @@ def _oracle_encode(pmo, ops, cap=1 << 20):
 
     class Enc(C.Structure):
         _fields_ = [("buf", C.c_void_p), ("cap", C.c_size_t), ("free_space", C.c_size_t), ("group_count", C.c_size_t),
-                    ("group_ix", C.c_size_t), ("group_start", C.c_size_t), ("error", C.c_int)]
+                    ("group_ix", C.c_size_t), ("group_start", C.c_size_t), ("error", C.c_int), ("open", C.c_int),
+                    ("depth", C.c_int), ("stack", C.c_size_t * 3 * 32)]
 
     buf = np.zeros(cap, np.uint8)
     e = Enc()
     lib.pmo_encoder_init(C.byref(e), C.c_void_p(buf.ctypes.data), C.c_size_t(cap))
-    lib.pmo_encoder_begin_group(C.byref(e), C.c_size_t(len(ops)))
-    for op in ops:
-        if op[0] == "circle":
-            lib.pmo_encoder_circle(C.byref(e), C.c_double(op[1]), C.c_double(op[2]), C.c_double(op[3]))
-        elif op[0] == "line":
-            lib.pmo_encoder_stroke_line(C.byref(e), *[C.c_double(v) for v in op[1:5]], C.c_float(op[5]), C.c_uint32(op[6]))
-        elif op[0] == "fill":
-            a = np.ascontiguousarray(op[1], np.float64)
-            lib.pmo_encoder_fill(C.byref(e), C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), C.c_uint32(op[2]))
-        else:
-            a = np.ascontiguousarray(op[1], np.float64)
-            lib.pmo_encoder_polyline(C.byref(e), C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), C.c_uint32(op[2]), C.c_float(op[3]))
-    lib.pmo_encoder_end_group(C.byref(e))
+
+    def emit(group):
+        lib.pmo_encoder_begin_group(C.byref(e), C.c_size_t(len(group)))
+        for op in group:
+            if op[0] == "circle":
+                lib.pmo_encoder_circle(C.byref(e), C.c_double(op[1]), C.c_double(op[2]), C.c_double(op[3]))
+            elif op[0] == "line":
+                lib.pmo_encoder_stroke_line(C.byref(e), *[C.c_double(v) for v in op[1:5]], C.c_float(op[5]), C.c_uint32(op[6]))
+            elif op[0] == "fill":
+                a = np.ascontiguousarray(op[1], np.float64)
+                lib.pmo_encoder_fill(C.byref(e), C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), C.c_uint32(op[2]))
+            elif op[0] == "fill_eo":  # extension: PietFill.flags bit 0
+                a = np.ascontiguousarray(op[1], np.float64)
+                lib.pmo_encoder_fill_rule(C.byref(e), C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), C.c_uint32(op[2]), C.c_uint32(1))
+            elif op[0] == "group":  # extension: nested group
+                emit(op[1])
+            else:
+                a = np.ascontiguousarray(op[1], np.float64)
+                lib.pmo_encoder_polyline(C.byref(e), C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), C.c_uint32(op[2]), C.c_float(op[3]))
+        lib.pmo_encoder_end_group(C.byref(e))
+
+    emit(ops)
     assert e.error == 0
     return buf[: e.free_space].copy()
 
@@ -125,26 +135,103 @@ def random_ops(seed, n, extent=700.0, opaque_mask=0xFF):
 def encode_ops(pm, ops, cap=1 << 20):
     buf = np.zeros(cap, np.uint8)
     e = pm.Encoder(buf)
-    e.begin_group(len(ops))
-    for op in ops:
-        if op[0] == "circle":
-            e.circle((op[1], op[2]), op[3])
-        elif op[0] == "line":
-            e.stroke_line((op[1], op[2]), (op[3], op[4]), op[5], op[6])
-        elif op[0] == "fill":
-            e.fill(op[1], op[2])
-        else:
-            e.polyline(op[1], op[2], op[3])
-    e.end_group()
+
+    def emit(group):
+        e.begin_group(len(group))
+        for op in group:
+            if op[0] == "circle":
+                e.circle((op[1], op[2]), op[3])
+            elif op[0] == "line":
+                e.stroke_line((op[1], op[2]), (op[3], op[4]), op[5], op[6])
+            elif op[0] == "fill":
+                e.fill(op[1], op[2])
+            elif op[0] == "fill_eo":
+                e.fill(op[1], op[2], even_odd=True)
+            elif op[0] == "group":
+                emit(op[1])
+            else:
+                e.polyline(op[1], op[2], op[3])
+        e.end_group()
+
+    emit(ops)
     n = e.bytes_used
     e.close()
     return buf[:n].copy()
+
+
+def extend_ops(seed, ops):
+    """The extensions on top of a random op list: about a third of the fills take the even-odd
+    rule (and self-overlap, so that the rule shows), and runs of items move into nested groups
+    (up to three levels).  inline_ops() gives the flat list a nested one must render like."""
+    rng = np.random.default_rng(seed ^ 0xE0)
+    out = []
+    for op in ops:
+        if op[0] == "fill" and rng.random() < 0.35:
+            pts = np.asarray(op[1], np.float64)
+            if len(pts) >= 3 and rng.random() < 0.7:  # walk the outline twice, the second time shrunk: winding 2 inside
+                c = pts.mean(axis=0)
+                pts = np.concatenate([pts, pts[:1], c + (pts - c) * 0.55, c + (pts[:1] - c) * 0.55])
+            op = ("fill_eo", pts, op[2])
+        out.append(op)
+
+    def nest(lst, depth):
+        res, i = [], 0
+        while i < len(lst):
+            if depth < 3 and rng.random() < 0.15:
+                k = int(rng.integers(0, 7))  # (empty groups too)
+                res.append(("group", nest(lst[i : i + k], depth + 1)))
+                i += k
+            else:
+                res.append(lst[i])
+                i += 1
+        return res
+
+    return nest(out, 0)
+
+
+def inline_ops(ops):
+    flat = []
+    for op in ops:
+        flat.extend(inline_ops(op[1]) if op[0] == "group" else [op])
+    return flat
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_encoder_random_scenes_match_oracle(pm, pmo, seed):
     ops = random_ops(seed, 60)
     assert np.array_equal(encode_ops(pm, ops), _oracle_encode(pmo, ops))
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_encoder_nested_groups_and_fill_rule_match_oracle(pm, pmo, seed):
+    """The two encoder extensions (nested groups, PietFill.flags) byte for byte against the
+    oracle's encoder, and the layout itself: a group is an item {5, 0, group_ix} of its parent
+    whose box is the union of its children's boxes."""
+    ops = extend_ops(seed, random_ops(seed, 80))
+    got = encode_ops(pm, ops)
+    assert np.array_equal(got, _oracle_encode(pmo, ops))
+    u32 = lambda o: int(np.frombuffer(got[o : o + 4].tobytes(), "<u4")[0])
+    def check(group, ops_):
+        assert u32(group) == len(ops_)
+        items = u32(group + 4)
+        assert items == group + 8 + 8 * len(ops_)
+        for i, op in enumerate(ops_):
+            it = items + 32 * i
+            if op[0] == "group":
+                assert u32(it) == 5 and u32(it + 4) == 0
+                child = u32(it + 8)
+                check(child, op[1])
+                bb = np.frombuffer(got[group + 8 + 8 * i : group + 16 + 8 * i].tobytes(), "<u2")
+                cb = np.frombuffer(got[child + 8 : child + 8 + 8 * len(op[1])].tobytes(), "<u2").reshape(-1, 4)
+                if len(cb):
+                    assert list(bb) == [cb[:, 0].min(), cb[:, 1].min(), cb[:, 2].max(), cb[:, 3].max()]
+                else:
+                    assert list(bb) == [0, 0, 0, 0]
+            elif op[0] == "fill_eo":
+                assert u32(it) == 3 and u32(it + 4) == 1
+            elif op[0] == "fill":
+                assert u32(it) == 3 and u32(it + 4) == 0
+    check(0, ops)
 
 
 def test_encoder_misuse_is_an_error_not_a_crash(pm):

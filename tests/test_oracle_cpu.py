@@ -194,6 +194,81 @@ def test_kat_rotated_rect_area(pm, pmo):
     assert abs(float(cov.astype(np.float64).sum()) - 65536.0) < 2.0
 
 
+def _slit_double_square(angle_deg=17.0, centre=(150.3, 140.7), outer=90.0, inner=40.0):
+    """One closed polyline that walks a square and then, through a slit, a smaller concentric one
+    in the SAME direction: winding 1 in the ring, 2 in the core (general position: rotated)."""
+    th = np.deg2rad(angle_deg)
+    rot = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    sq = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], np.float64)
+    o, i = sq * outer, sq * inner
+    pts = np.concatenate([o, o[:1], i, i[:1]])  # the closing edge walks the slit back: it cancels
+    return pts @ rot.T + np.asarray(centre)
+
+
+def test_kat_even_odd_rule(pm, pmo):
+    """Extension: PietFill.flags bit 0 = even-odd (the formula in the reference's comment,
+    PietRender.metal:539-540).  Known answers on a doubly wound core: non-zero fills it, even-odd
+    leaves a hole; ring pixels are covered either way; total coverage = ring area resp. full
+    square; and tiles wholly inside the core (backdrop 2) become nothing instead of Solid."""
+    from test_host_cpu import encode_ops
+
+    pts = _slit_double_square()
+    nz = encode_ops(pm, [("fill", pts, 0x203040FF)])
+    eo = encode_ops(pm, [("fill_eo", pts, 0x203040FF)])
+    cov_nz, cov_eo = pmo.fill_coverage(nz, 0, 304, 288), pmo.fill_coverage(eo, 0, 304, 288)
+    cy, cx = 141, 150
+    assert cov_nz[cy, cx] == 1.0 and cov_eo[cy, cx] == 0.0            # the core
+    assert cov_nz[cy, cx + 65] == 1.0 and cov_eo[cy, cx + 65] == 1.0  # the ring
+    assert cov_nz[5, 5] == 0.0 and cov_eo[5, 5] == 0.0
+    assert abs(float(cov_nz.astype(np.float64).sum()) - 180.0 ** 2) < 3.0
+    assert abs(float(cov_eo.astype(np.float64).sum()) - (180.0 ** 2 - 80.0 ** 2)) < 6.0
+    assert float(cov_eo.max()) <= 1.0 and float(cov_eo.min()) >= 0.0
+    P_nz, P_eo = pmo.Ptcl(nz, 304, 288), pmo.Ptcl(eo, 304, 288)
+    tx, ty = cx // 16, cy // 16  # a tile wholly inside the core: backdrop 2
+    assert P_nz.solid(tx, ty) == 0xFF403020 and P_nz.cmds(tx, ty)[0, 0] == 9       # Solid(opaque) -> Bail
+    assert P_eo.solid(tx, ty) == 0xFFFFFFFF and P_eo.cmds(tx, ty)[0, 0] == 9       # nothing drawn: background
+    # the rule travels in the last word of DrawFill; everything else of the lists is identical
+    seen = 0
+    for yy in range(P_nz.tiles_y):
+        for xx in range(P_nz.tiles_x):
+            a, b = P_nz.cmds(xx, yy), P_eo.cmds(xx, yy)
+            if len(a) == len(b) and len(a) > 1:
+                d = a != b
+                assert not d[:, :5].any() and set(b[d[:, 5], 5]) <= {1}
+                assert all(b[k, 0] == 7 for k in np.nonzero(d[:, 5])[0])
+                seen += int(d.any())
+    assert seen > 10
+    # in the rendered bytes: the hole shows the background, edge tiles of the ring the blended colour
+    # (tiles wholly inside the ring hit the reference's translucent-Solid quirk and stay white)
+    img = pmo.render(encode_ops(pm, [("fill_eo", pts, 0x20304080)]), 304, 288)
+    assert tuple(img[cy, cx]) == (255, 255, 255, 255) and (img[:, :, :3] != 255).any()
+    img_nz = pmo.render(encode_ops(pm, [("fill", pts, 0x20304080)]), 304, 288)
+    assert (img_nz != img).any()
+
+
+def test_nested_groups_render_like_the_inlined_items(pm, pmo):
+    """Extension: a PietGroup item stands for its children, in place and in order.  Lists, solid
+    colours and pixels of nested scenes equal those of the same items in one flat group, and
+    the flat form the oracle builds keeps the original bytes in front."""
+    from test_host_cpu import encode_ops, extend_ops, inline_ops, random_ops
+
+    for seed in (21, 22, 23):
+        tree = extend_ops(seed, random_ops(seed, 120, extent=400.0))
+        assert any(op[0] == "group" for op in tree)
+        nested, flat = encode_ops(pm, tree), encode_ops(pm, inline_ops(tree))
+        assert np.array_equal(pmo.render(nested, 416, 400), pmo.render(flat, 416, 400))
+        Pn, Pf = pmo.Ptcl(nested, 416, 400), pmo.Ptcl(flat, 416, 400)
+        for ty in range(Pn.tiles_y):
+            for tx in range(Pn.tiles_x):
+                assert Pn.solid(tx, ty) == Pf.solid(tx, ty) and np.array_equal(Pn.cmds(tx, ty), Pf.cmds(tx, ty)), (seed, tx, ty)
+    # malformed nesting is rejected, not followed: a group that contains itself
+    bad = encode_ops(pm, [("group", [("circle", 50.0, 50.0, 9.0)])]).copy()
+    items = int(np.frombuffer(bad[4:8].tobytes(), "<u4")[0])
+    bad[items + 8 : items + 12] = np.frombuffer(np.uint32(0).tobytes(), np.uint8)  # group_ix -> the root
+    with pytest.raises(RuntimeError):
+        pmo.render(bad, 128, 128)
+
+
 def test_quirk_q1_axis_aligned_rect_is_reproduced(pm, pmo):
     # BASELINE config 1 (a): horizontal edges crossing a tile's left boundary lose their
     # winding (SURVEY.md Q1).  The oracle reproduces the source; only self-consistency
@@ -274,7 +349,7 @@ def test_render_half_matches_independent_numpy_restatement(pm, pmo):
     of the colour tables written from the Metal source with numpy float32 / float16 arrays:
     the three tables and every non-Bail tile of four scenes (incl. the Tiger), byte for byte."""
     import np_render
-    from test_host_cpu import encode_ops, random_ops
+    from test_host_cpu import encode_ops, extend_ops, random_ops
 
     a, b, c = pmo.luts()
     tables = (np_render.lut_srgb_to_linear_half(), np_render.lut_unorm_to_half(), np_render.lut_linear_half_to_srgb8())
@@ -285,6 +360,7 @@ def test_render_half_matches_independent_numpy_restatement(pm, pmo):
         (pmo.scene_path_test(), 256, 320),
         (pmo.scene_cardioid(), 480, 352),
         (encode_ops(pm, random_ops(77, 150, extent=300.0)), 320, 304),
+        (encode_ops(pm, extend_ops(81, random_ops(81, 150, extent=300.0))), 320, 304),  # even-odd fills, nested groups
     ]
     wl = pm.workloads.tiger(640, 360)
     scenes.append((pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)[0], 640, 360))
@@ -311,7 +387,7 @@ def test_tile_lists_match_independent_python_restatement(pm, pmo):
     tests/np_render.py -- the pixels of the whole independent pipeline, byte for byte."""
     import np_render
     import np_tile
-    from test_host_cpu import encode_ops, random_ops
+    from test_host_cpu import encode_ops, extend_ops, random_ops
 
     tables = (np_render.lut_srgb_to_linear_half(), np_render.lut_unorm_to_half(), np_render.lut_linear_half_to_srgb8())
     wl = pm.workloads.tiger(256, 144)
@@ -322,6 +398,7 @@ def test_tile_lists_match_independent_python_restatement(pm, pmo):
         ("random77", encode_ops(pm, random_ops(77, 150, extent=300.0)), 320, 304, True),
         ("random78", encode_ops(pm, random_ops(78, 200, extent=700.0)), 700, 500, False),
         ("random79", encode_ops(pm, random_ops(79, 120, extent=120.0)), 130, 100, True),
+        ("extended82", encode_ops(pm, extend_ops(82, random_ops(82, 160, extent=300.0))), 320, 304, True),  # even-odd, nested groups
         ("tiger", tiger, 256, 144, True),
     ]
     for name, scene, w, h, pixels in scenes:
