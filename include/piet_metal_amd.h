@@ -249,6 +249,13 @@ typedef struct {
 int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *counts,
                           uint32_t *solid, pm_cmd *cmds);
 
+/* Developer / test hook for the generated layout code (piet_metal_amd/csrc/pm_layout_gen.h, printed by
+ * pm_layoutgen from piet_metal_amd/layout/piet_layout.pgpu -- the HIP / C++ target of the reference's
+ * piet-gpu-derive generator, piet-gpu-derive/src/lib.rs): every item of `scene`'s root group and
+ * every command of `cmds` goes through the generated readers, loaders and writers and must come
+ * back byte for byte.  0 = agreement. */
+int pm_layout_selfcheck(const uint8_t *scene, size_t scene_len, const pm_cmd *cmds, size_t n_cmds);
+
 /* Developer profiling hook: re-run the last frame's per-tile kernel recording, per queue
  * slot, {start clock, end clock (100 MHz wall clock), tile | quarter << 31,
  * wave << 32 | commands interpreted, ticks in phase A, ticks in phase B (tiles rendered by a

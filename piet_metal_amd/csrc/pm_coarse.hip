@@ -333,24 +333,20 @@ __global__ __launch_bounds__(kThreads, PM_COARSE_WPS) void pm_coarse_kernel(Fram
                         if (ctag == kItemFill) {  // :359-363
                             const int backdrop = L.backdrop[c];
                             const uint32_t even_odd = L.haux0[c] & kFillEvenOdd;  // PietFill.flags (extension)
+                            // (closing commands are built by the writers pm_layoutgen emits from the layout description)
                             if (L.any[c]) {
                                 has_fin = true;
-                                fin.tag = kCmdDrawFill;
-                                fin.body[0] = static_cast<uint32_t>(backdrop);
-                                fin.body[1] = frgba; fin.body[2] = rg; fin.body[3] = ba; fin.body[4] = even_odd;
+                                fin = gen::ptcl::Cmd_DrawFill_pack(backdrop, frgba, rg, ba, even_odd);
                                 draws = true;
                             } else if (even_odd ? (backdrop & 1) != 0 : backdrop != 0) {  // wholly inside: non-zero / odd winding
                                 has_fin = true;
-                                fin.tag = kCmdSolid;
-                                fin.body[0] = frgba; fin.body[1] = rg; fin.body[2] = ba; fin.body[3] = 0; fin.body[4] = 0;
+                                fin = gen::ptcl::Cmd_Solid_pack(frgba, rg, ba);
                                 opaque_solid = (frgba & 0xff000000u) == 0xff000000u;  // :132
                             }
                         } else if (ctag == kItemPoly || ctag == kItemLine) {  // :441-443, :243
                             if (L.any[c]) {
                                 has_fin = true;
-                                fin.tag = kCmdStroke;
-                                fin.body[0] = __float_as_uint(0.5f * __uint_as_float(L.haux0[c]));
-                                fin.body[1] = frgba; fin.body[2] = rg; fin.body[3] = ba; fin.body[4] = 0;
+                                fin = gen::ptcl::Cmd_Stroke_pack(0.5f * __uint_as_float(L.haux0[c]), frgba, rg, ba);
                                 draws = true;
                             }
                         }

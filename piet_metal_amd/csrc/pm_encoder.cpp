@@ -260,6 +260,101 @@ int pm_encoder_polyline(pm_encoder *e, const double *pts_xy, size_t n_points, ui
 }
 size_t pm_encoder_bytes_used(const pm_encoder *e) { return e ? e->enc.bytes_used() : 0; }
 
+// Developer / test hook for the generated layout code (pm_layout_gen.h): reads `scene` through
+// the generated accessors and through the hand-written structs, takes every command apart with
+// the generated loaders and rebuilds it with the generated packers.  0 = everything agrees,
+// else the (negative) number of the first check that failed.
+int pm_layout_selfcheck(const uint8_t *scene, size_t scene_len, const pm_cmd *cmds, size_t n_cmds) {
+    namespace gs = pm::gen::scene;
+    namespace gp = pm::gen::ptcl;
+    if (scene && scene_len >= 8) {
+        pm::SimpleGroup g;
+        std::memcpy(&g, scene, sizeof(g));
+        if (gs::SimpleGroup_n_items(scene, 0) != g.n_items || gs::SimpleGroup_items_ix(scene, 0) != g.items_ix) return -1;
+        if (static_cast<uint64_t>(g.items_ix) + 32ull * g.n_items > scene_len) return -2;
+        for (uint32_t i = 0; i < g.n_items; ++i) {
+            const uint32_t ref = g.items_ix + i * gs::PIET_ITEM_SIZE;
+            const gs::PietItem rec = gs::PietItem_read(scene, ref);
+            uint32_t tag;
+            std::memcpy(&tag, scene + ref, 4);
+            if (gs::PietItem_tag(scene, ref) != tag || rec.tag != tag) return -3;
+            pm::ShortBbox bb;
+            std::memcpy(&bb, scene + 8 + 8ull * i, 8);
+            const pm::gen::pm_u16x4 gb = gs::SimpleGroup_bbox(scene, 8 * i);  // element i of the box array that starts at `bbox`
+            if (gb.v[0] != bb.x0 || gb.v[1] != bb.y0 || gb.v[2] != bb.x1 || gb.v[3] != bb.y1) return -4;
+            gs::PietItem again;
+            switch (tag & 0xffffu) {
+                case gs::PietItem_Circle:
+                    again = gs::PietItem_Circle_pack();
+                    break;
+                case gs::PietItem_Line: {
+                    pm::PietStrokeLine h;
+                    std::memcpy(&h, scene + ref, sizeof(h));
+                    const gs::PietStrokeLinePacked q = gs::PietStrokeLine_load(rec);
+                    if (q.flags != h.flags || q.rgba_color != h.rgba || q.width != h.width || q.start.v[0] != h.start[0] || q.start.v[1] != h.start[1] ||
+                        q.end.v[0] != h.end[0] || q.end.v[1] != h.end[1] || gs::PietStrokeLine_width(scene, ref) != h.width)
+                        return -5;
+                    again = gs::PietItem_Line_pack(q.flags, q.rgba_color, q.width, q.start, q.end);
+                    break;
+                }
+                case gs::PietItem_Fill: {
+                    pm::PietFill h;
+                    std::memcpy(&h, scene + ref, sizeof(h));
+                    const gs::PietFillPacked q = gs::PietFill_load(rec);
+                    if (q.flags != h.flags || q.rgba_color != h.rgba || q.n_points != h.n_points || q.points_ix != h.points_ix ||
+                        gs::PietFill_points_ix(scene, ref) != h.points_ix)
+                        return -6;
+                    again = gs::PietItem_Fill_pack(q.flags, q.rgba_color, q.n_points, q.points_ix);
+                    break;
+                }
+                case gs::PietItem_Poly: {
+                    pm::PietStrokePolyLine h;
+                    std::memcpy(&h, scene + ref, sizeof(h));
+                    const gs::PietStrokePolyLinePacked q = gs::PietStrokePolyLine_load(rec);
+                    if (q.rgba_color != h.rgba || q.width != h.width || q.n_points != h.n_points || q.points_ix != h.points_ix) return -7;
+                    again = gs::PietItem_Poly_pack(q.rgba_color, q.width, q.n_points, q.points_ix);
+                    break;
+                }
+                case gs::PietItem_Group: {
+                    pm::PietGroup h;
+                    std::memcpy(&h, scene + ref, sizeof(h));
+                    const gs::PietGroupPacked q = gs::PietGroup_load(rec);
+                    if (q.flags != h.flags || q.group_ix != h.group_ix) return -8;
+                    again = gs::PietItem_Group_pack(q.flags, q.group_ix);
+                    break;
+                }
+                default:
+                    return -9;
+            }
+            // the encoder writes sizeof(T) bytes of a variant into a zeroed 32-byte slot (src/lib.rs:122-130)
+            if (std::memcmp(&again, scene + ref, sizeof(again)) != 0) return -10;
+        }
+    }
+    for (size_t k = 0; k < n_cmds; ++k) {
+        gp::Cmd c;
+        std::memcpy(&c, &cmds[k], sizeof(c));
+        gp::Cmd again;
+        switch (c.tag) {
+            case gp::Cmd_End:
+            case gp::Cmd_Bail:
+                std::memset(&again, 0, sizeof(again));
+                again.tag = c.tag;
+                break;
+            case gp::Cmd_Circle: again = gp::Cmd_Circle_pack(gp::CmdCircle_load(c).bbox); break;
+            case gp::Cmd_Line: { const gp::CmdLinePacked q = gp::CmdLine_load(c); again = gp::Cmd_Line_pack(q.start, q.end); break; }
+            case gp::Cmd_Fill: { const gp::CmdFillPacked q = gp::CmdFill_load(c); again = gp::Cmd_Fill_pack(q.start, q.end); break; }
+            case gp::Cmd_Stroke: { const gp::CmdStrokePacked q = gp::CmdStroke_load(c); again = gp::Cmd_Stroke_pack(q.halfWidth, q.rgba_color, q.rg, q.ba); break; }
+            case gp::Cmd_FillEdge: { const gp::CmdFillEdgePacked q = gp::CmdFillEdge_load(c); again = gp::Cmd_FillEdge_pack(q.sign, q.y); break; }
+            case gp::Cmd_DrawFill: { const gp::CmdDrawFillPacked q = gp::CmdDrawFill_load(c); again = gp::Cmd_DrawFill_pack(q.backdrop, q.rgba_color, q.rg, q.ba, q.flags); break; }
+            case gp::Cmd_Solid: { const gp::CmdSolidPacked q = gp::CmdSolid_load(c); again = gp::Cmd_Solid_pack(q.rgba_color, q.rg, q.ba); break; }
+            default:
+                return -20;
+        }
+        if (std::memcmp(&again, &c, sizeof(c)) != 0) return -21 - static_cast<int>(c.tag);
+    }
+    return 0;
+}
+
 int64_t pm_scene_cardioid(uint8_t *buf, size_t cap) {
     return buf ? pm::SceneCardioid(buf, cap) : PM_ERR_INVALID;
 }

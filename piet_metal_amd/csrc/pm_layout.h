@@ -11,6 +11,8 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "pm_layout_gen.h"  // generated from piet_metal_amd/layout/piet_layout.pgpu by pm_layoutgen
+
 namespace pm {
 
 constexpr uint32_t kTileW = 16;
@@ -109,10 +111,41 @@ enum CmdTag : uint32_t {  // TestApp/GenTypes.h:440-495
     kCmdBail = 9,
 };
 
-struct Cmd {  // TestApp/GenTypes.h:430-433
-    uint32_t tag;
-    uint32_t body[5];
-};
+using Cmd = gen::ptcl::Cmd;  // {tag, body[5]}, TestApp/GenTypes.h:430-433 -- the generated record
 static_assert(sizeof(Cmd) == 24, "Cmd is 24 bytes");
+
+// The hand-written structs above are what the host encoder writes; the generated header is what
+// the layout description says.  They must agree, field by field.
+namespace layout_check {
+using namespace gen::scene;
+using namespace gen::ptcl;
+static_assert(PIET_ITEM_SIZE == kItemSize && CMD_SIZE == sizeof(Cmd), "record sizes");
+static_assert(PietItem_Circle == kItemCircle && PietItem_Line == kItemLine && PietItem_Fill == kItemFill &&
+                  PietItem_Poly == kItemPoly && PietItem_Group == kItemGroup, "item tags");
+static_assert(Cmd_End == kCmdEnd && Cmd_Circle == kCmdCircle && Cmd_Line == kCmdLine && Cmd_Fill == kCmdFill &&
+                  Cmd_Stroke == kCmdStroke && Cmd_FillEdge == kCmdFillEdge && Cmd_DrawFill == kCmdDrawFill &&
+                  Cmd_Solid == kCmdSolid && Cmd_Bail == kCmdBail, "command tags");
+static_assert(SimpleGroup_items_ix_OFFSET == offsetof(SimpleGroup, items_ix) && SimpleGroup_bbox_OFFSET == sizeof(SimpleGroup), "SimpleGroup");
+static_assert(PietStrokeLine_rgba_color_OFFSET == offsetof(PietStrokeLine, rgba) && PietStrokeLine_width_OFFSET == offsetof(PietStrokeLine, width) &&
+                  PietStrokeLine_start_OFFSET == offsetof(PietStrokeLine, start) && PietStrokeLine_end_OFFSET == offsetof(PietStrokeLine, end) &&
+                  PIET_STROKE_LINE_SIZE == sizeof(PietStrokeLine), "PietStrokeLine");
+static_assert(PietFill_flags_OFFSET == offsetof(PietFill, flags) && PietFill_rgba_color_OFFSET == offsetof(PietFill, rgba) &&
+                  PietFill_n_points_OFFSET == offsetof(PietFill, n_points) && PietFill_points_ix_OFFSET == offsetof(PietFill, points_ix) &&
+                  PIET_FILL_SIZE == sizeof(PietFill), "PietFill");
+static_assert(PietStrokePolyLine_rgba_color_OFFSET == offsetof(PietStrokePolyLine, rgba) && PietStrokePolyLine_width_OFFSET == offsetof(PietStrokePolyLine, width) &&
+                  PietStrokePolyLine_n_points_OFFSET == offsetof(PietStrokePolyLine, n_points) &&
+                  PietStrokePolyLine_points_ix_OFFSET == offsetof(PietStrokePolyLine, points_ix) && PIET_STROKE_POLY_LINE_SIZE == sizeof(PietStrokePolyLine),
+              "PietStrokePolyLine");
+static_assert(PietGroup_flags_OFFSET == offsetof(PietGroup, flags) && PietGroup_group_ix_OFFSET == offsetof(PietGroup, group_ix) &&
+                  PIET_GROUP_SIZE == sizeof(PietGroup), "PietGroup");
+// command words as the kernels index them (body[k] sits at byte 4 + 4k)
+static_assert(CmdCircle_bbox_OFFSET == 8 && CmdLine_start_OFFSET == 8 && CmdLine_end_OFFSET == 16 && CmdFill_start_OFFSET == 8 &&
+                  CmdFill_end_OFFSET == 16, "geometry words: body[1..4]");
+static_assert(CmdStroke_halfWidth_OFFSET == 4 && CmdStroke_rgba_color_OFFSET == 8 && CmdStroke_rg_OFFSET == 12 && CmdStroke_ba_OFFSET == 16, "CmdStroke");
+static_assert(CmdFillEdge_sign_OFFSET == 4 && CmdFillEdge_y_OFFSET == 8, "CmdFillEdge");
+static_assert(CmdDrawFill_backdrop_OFFSET == 4 && CmdDrawFill_rgba_color_OFFSET == 8 && CmdDrawFill_rg_OFFSET == 12 && CmdDrawFill_ba_OFFSET == 16 &&
+                  CmdDrawFill_flags_OFFSET == 20, "CmdDrawFill");
+static_assert(CmdSolid_rgba_color_OFFSET == 4 && CmdSolid_rg_OFFSET == 8 && CmdSolid_ba_OFFSET == 12, "CmdSolid");
+}  // namespace layout_check
 
 }  // namespace pm
