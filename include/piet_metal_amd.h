@@ -249,6 +249,14 @@ typedef struct {
 int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *counts,
                           uint32_t *solid, pm_cmd *cmds);
 
+/* Winding coverage (alpha before colour) of ONE Fill item of the resident scene over the viewport
+ * band, accumulated in f32 instead of the frame path's binary16 (the reference declares
+ * signedArea `half`, TestApp/PietRender.metal:472; north star: "coverage within 1 ULP of the f32
+ * reference").  The item is binned and encoded alone, exactly as a frame would, then its commands
+ * are evaluated per pixel in binary32.  dst = rows of `width` floats, row stride in floats.
+ * A validation call: it synchronises and rebuilds the scene index twice. */
+int pm_fill_coverage(pm_ctx *c, uint32_t item_ix, float *dst, size_t dst_stride_floats);
+
 /* Developer / test hook for the generated layout code (piet_metal_amd/csrc/pm_layout_gen.h, printed by
  * pm_layoutgen from piet_metal_amd/layout/piet_layout.pgpu -- the HIP / C++ target of the reference's
  * piet-gpu-derive generator, piet-gpu-derive/src/lib.rs): every item of `scene`'s root group and

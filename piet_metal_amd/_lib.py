@@ -114,6 +114,7 @@ SIGNATURES = {
     "pm_time_frames_pipelined": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_debug_frame_timeline": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "pm_fill_coverage": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
     "pm_layout_selfcheck": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "pm_get_scene_timings": (C.c_int, [C.c_void_p, C.POINTER(SceneTimings)]),
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),

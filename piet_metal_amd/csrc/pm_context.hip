@@ -388,7 +388,8 @@ int EnsureArena(pm_ctx *c) {
         if (((need[i] + 3u) & ~3ull) != c->sr_empty_dwords) desc.push_back(make_uint4(static_cast<uint32_t>(i), base[i], base[i + 1], 0u));
     // heaviest strip rows first (their arena need is the work estimate): the launch's span is its
     // longest workgroup, and that one should not start in the second wave of workgroups
-    std::stable_sort(desc.begin(), desc.end(), [](const uint4 &a, const uint4 &b) { return a.z - a.y > b.z - b.y; });
+    if (EnvInt("PM_BIN_SORT", 1, 0, 1))
+        std::stable_sort(desc.begin(), desc.end(), [](const uint4 &a, const uint4 &b) { return a.z - a.y > b.z - b.y; });
     if (desc.empty()) desc.push_back(make_uint4(0u, base[0], need.empty() ? base[0] : base[1], 0u));
     c->n_sr_active = static_cast<uint32_t>(desc.size());
     if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
@@ -1355,6 +1356,102 @@ int pm_get_scene_timings(pm_ctx *c, pm_scene_timings *out) {
     out->scene_index_ms = c->t_index_ms;
     out->arena_setup_ms = c->t_arena_ms;
     return PM_OK;
+}
+
+int pm_fill_coverage(pm_ctx *c, uint32_t item_ix, float *dst, size_t dst_stride_floats) {
+    if (!c || !dst || dst_stride_floats < c->width) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    int r = pm_sync(c);
+    if (r != PM_OK) return r;
+    if (c->scene_bytes < 8 || item_ix >= c->n_items || c->tiles_x == 0) {
+        SetError("pm_fill_coverage: no such item (or no scene / viewport)");
+        return PM_ERR_INVALID;
+    }
+    const uint8_t *meta = c->item_meta.data();  // normal form: {n, 8 + 8n}{boxes}{items}
+    const uint8_t *item = meta + 8 + 8ull * c->n_items + 32ull * item_ix;
+    uint32_t tag;
+    std::memcpy(&tag, item, 4);
+    if ((tag & 0xffffu) != pm::kItemFill) {
+        SetError("pm_fill_coverage: the item is not a Fill");
+        return PM_ERR_INVALID;
+    }
+    // the item alone as a one-item group behind the resident bytes (its points stay where they are)
+    const size_t root = (c->scene_bytes + 7u) & ~static_cast<size_t>(7u);
+    uint8_t mini[8 + 8 + 32];
+    const uint32_t hdr[2] = {1u, static_cast<uint32_t>(root + 16)};
+    std::memcpy(mini, hdr, 8);
+    std::memcpy(mini + 8, meta + 8 + 8ull * item_ix, 8);
+    std::memcpy(mini + 16, item, 32);
+    if (root + sizeof(mini) > c->scene_cap) {
+        r = ReserveScene(c, root + sizeof(mini) + 4096, c->scene_bytes);
+        if (r != PM_OK) return r;
+    }
+    PM_TRY(hipMemcpy(c->d_scene + root, mini, sizeof(mini), hipMemcpyHostToDevice));
+    // swap the drawn group for the mini group, render bin + coarse (+ recorded solid colours),
+    // run the coverage kernel, put everything back
+    std::vector<uint8_t> saved_meta;
+    saved_meta.swap(c->item_meta);
+    const uint32_t saved_n = c->n_items, saved_bbox = c->dev_bbox_ix, saved_items = c->dev_items_ix;
+    c->item_meta.assign(8 + 40, 0);
+    const uint32_t mhdr[2] = {1u, 16u};
+    std::memcpy(c->item_meta.data(), mhdr, 8);
+    std::memcpy(c->item_meta.data() + 8, mini + 8, 40);
+    c->n_items = 1;
+    c->dev_bbox_ix = static_cast<uint32_t>(root + 8);
+    c->dev_items_ix = static_cast<uint32_t>(root + 16);
+    c->arena_dirty = true;
+    const size_t tiles = static_cast<size_t>(BandRows(c)) * c->tiles_x;
+    const size_t rows_px = std::min<size_t>(static_cast<size_t>(BandRows(c)) * pm::kTileH, c->height - c->row0 * pm::kTileH);
+    uint32_t *d_counts = nullptr, *d_solid = nullptr;
+    float *d_out = nullptr;
+    int status = BuildSceneIndex(c);
+    hipError_t e = hipSuccess;
+    if (status == PM_OK) {
+        e = hipMalloc(&d_counts, std::max<size_t>(tiles, 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&d_solid, std::max<size_t>(tiles, 1) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&d_out, static_cast<size_t>(BandRows(c)) * pm::kTileH * c->width * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(d_solid, 0, std::max<size_t>(tiles, 1) * sizeof(uint32_t));
+    }
+    if (status == PM_OK && e == hipSuccess) {
+        const int si = static_cast<int>(c->frame % c->slot.size());
+        FrameSlot *s = &c->slot[si];
+        pm::FrameParams p;
+        status = BuildParams(c, s, s->d_fb, c->fb_stride, &p);
+        if (status == PM_OK) {
+            p.dbg_counts = d_counts;
+            p.dbg_solid = d_solid;
+            p.dbg_cmds = nullptr;
+            p.dbg_max = 0;
+            pm::LaunchBin(p, c->stream);
+            pm::LaunchCoarse(p, CoarseGrid(c), true, c->stream);
+            pm::LaunchCoverage(p, static_cast<uint32_t>(tiles), d_solid, d_out, c->width, c->stream);
+            p.dbg_counts = p.dbg_solid = nullptr;
+            Submitted(c, si, p, c->stream);
+            e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess)
+                e = hipMemcpy2D(dst, dst_stride_floats * sizeof(float), d_out, static_cast<size_t>(c->width) * sizeof(float),
+                                static_cast<size_t>(c->width) * sizeof(float), rows_px, hipMemcpyDeviceToHost);
+            pm::Counters k;
+            if (e == hipSuccess) e = hipMemcpy(&k, p.ctr_cur, sizeof(k), hipMemcpyDeviceToHost);
+            if (e == hipSuccess && k.overflow) {
+                SetError("pm_fill_coverage: command-list arena overflow");
+                status = PM_ERR_CAPACITY;
+            }
+        }
+    }
+    if (d_counts) (void)hipFree(d_counts);
+    if (d_solid) (void)hipFree(d_solid);
+    if (d_out) (void)hipFree(d_out);
+    // restore the scene
+    c->item_meta.swap(saved_meta);
+    c->n_items = saved_n;
+    c->dev_bbox_ix = saved_bbox;
+    c->dev_items_ix = saved_items;
+    c->arena_dirty = true;
+    c->last_slot = -1;
+    const int rb = BuildSceneIndex(c);
+    if (e != hipSuccess) return HipFail(e, "pm_fill_coverage");
+    return status != PM_OK ? status : rb;
 }
 
 int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *counts, uint32_t *solid, pm_cmd *cmds) {

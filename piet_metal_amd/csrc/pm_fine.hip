@@ -677,10 +677,73 @@ __global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
     }
 }
 
+// Validation kernel behind pm_fill_coverage: the winding coverage (alpha before colour) of the
+// frame's Fill commands with an f32 accumulator -- signedArea as `float` instead of `half`
+// (SURVEY.md D7's second mode, north star: "coverage within 1 ULP of the f32 reference").  One
+// workgroup per tile, one pixel per thread, the command list read straight from HBM; every
+// operation is the one of renderKernel :508-545 in binary32, in list order.  Not on the frame path.
+__global__ __launch_bounds__(kThreads) void pm_coverage_kernel(FrameParams P, const uint32_t *tile_solid, float *out, uint32_t out_stride) {
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tx = tile % P.tiles_x, ty_rel = tile / P.tiles_x;
+    const uint32_t xi = threadIdx.x & 15u, yi = threadIdx.x >> 4;
+    const uint32_t pxi = tx * kTileW + xi, pyi = (P.row0 + ty_rel) * kTileH + yi;
+    if (pxi >= P.width || pyi >= P.height) return;
+    const float px = static_cast<float>(pxi), py = static_cast<float>(pyi);
+    float cov = 0.0f;
+    const uint32_t state = P.tile_state[tile];
+    if (state != 0) {  // resolved by binning: background, or one opaque colour
+        cov = state != 0xffffffffu ? 1.0f : 0.0f;
+    } else {
+        const uint32_t solid = tile_solid[tile];  // TileEncoder::end() as pm_coarse_kernel<true> recorded it
+        if (solid != 0) {
+            cov = solid != 0xffffffffu ? 1.0f : 0.0f;
+        } else {
+            const Cmd *cmds = P.ptcl + P.tile_ptcl[tile];
+            const uint32_t n = P.tile_ncmd[tile];
+            float sa = 0.0f;
+            for (uint32_t i = 0; i < n; ++i) {
+                const Cmd cmd = cmds[i];
+                if (cmd.tag == kCmdFill) {
+                    const float sx = __uint_as_float(cmd.body[1]) - px, sy = __uint_as_float(cmd.body[2]) - py;
+                    const float ex = __uint_as_float(cmd.body[3]) - px, ey = __uint_as_float(cmd.body[4]) - py;
+                    const float wx = Sat(sy), wy = Sat(ey);
+                    if (wx != wy) {
+                        const float tx_ = (wx - sy) / (ey - sy);
+                        const float ty_ = (wy - sy) / (ey - sy);
+                        const float xsx = sx + (ex - sx) * tx_;
+                        const float xsy = sx + (ex - sx) * ty_;
+                        const float xmin = fminf(fminf(xsx, xsy), 1.0f) - 1e-6f;
+                        const float xmax = fmaxf(xsx, xsy);
+                        const float b = fminf(xmax, 1.0f);
+                        const float c = fmaxf(b, 0.0f);
+                        const float d = fmaxf(xmin, 0.0f);
+                        const float area = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
+                        sa += area * (wx - wy);
+                    }
+                } else if (cmd.tag == kCmdFillEdge) {
+                    sa += static_cast<float>(static_cast<int>(cmd.body[0])) * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
+                } else if (cmd.tag == kCmdDrawFill) {
+                    cov = sa + static_cast<float>(static_cast<int>(cmd.body[0]));
+                    if (cmd.body[4] & kFillEvenOdd) cov = fabsf(cov - 2.0f * rintf(0.5f * cov));
+                    else cov = fminf(fabsf(cov), 1.0f);
+                    sa = 0.0f;
+                } else if (cmd.tag == kCmdSolid) {
+                    cov = 1.0f;
+                }
+            }
+        }
+    }
+    out[static_cast<size_t>(ty_rel * kTileH + yi) * out_stride + pxi] = cov;
+}
+
 // ---- launch wrappers (called from pm_context.hip) -----------------------------------------
 
 void LaunchClear(const FrameParams &p, uint32_t n_striprows, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
     PM_LAUNCH(pm_clear_kernel, dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
+}
+
+void LaunchCoverage(const FrameParams &p, uint32_t n_tiles, const uint32_t *tile_solid, float *out, uint32_t out_stride, hipStream_t stream) {
+    hipLaunchKernelGGL(pm_coverage_kernel, dim3(n_tiles), dim3(kThreads), 0, stream, p, tile_solid, out, out_stride);
 }
 
 void LaunchFine(const FrameParams &p, uint32_t clear_blocks, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {

@@ -147,6 +147,12 @@ class Renderer:
         _lib.check(self._lib.pm_frame_latency(self._h, iters, C.byref(med), C.byref(mn)), "pm_frame_latency")
         return {"median_ms": med.value, "min_ms": mn.value, "iters": iters}
 
+    def fill_coverage(self, item_ix: int) -> np.ndarray:
+        """f32-accumulated winding coverage of one Fill item over the viewport band (validation)."""
+        out = np.zeros((self.band_pixel_rows, self.width), np.float32)
+        _lib.check(self._lib.pm_fill_coverage(self._h, item_ix, out.ctypes.data, self.width), "pm_fill_coverage")
+        return out
+
     def scene_timings(self) -> dict:
         """Host wall-clock cost of the last scene replacement (flatten+encode, index, arena)."""
         t = _lib.SceneTimings()

@@ -549,6 +549,48 @@ def test_malformed_nested_groups_are_rejected(pm, renderer):
             renderer.render()
 
 
+def test_f32_coverage_matches_the_f32_reference(pm, pmo, renderer):
+    """North star: "coverage within 1 ULP of the f32 reference".  pm_fill_coverage evaluates one
+    Fill item's commands with an f32 signedArea (the frame path keeps the reference's `half`); the
+    oracle's pmo_fill_coverage is the same arithmetic on the CPU.  Every operation is one IEEE
+    rounding on both sides, so the bar here is tighter than the north star's: 0 ULP."""
+    def ulps(a, b):
+        ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+        return int(np.abs(ia - ib).max())
+
+    from test_oracle_cpu import _slit_double_square
+
+    cases = []
+    quad = np.array([(20.25, 20.5), (100.75, 23.5), (97.75, 100.25), (17.25, 96.5)])
+    cases.append((encode_ops(pm, [("fill", quad, 0x102030FF)]), 0, 128, 128))
+    cases.append((encode_ops(pm, [("fill_eo", _slit_double_square(), 0x20304080)]), 0, 304, 288))
+    ops = [op for op in random_ops(91, 200, extent=500.0) if op[0] in ("fill", "circle")]
+    scene = encode_ops(pm, ops)
+    fills = [i for i, op in enumerate(ops) if op[0] == "fill"]
+    cases += [(scene, i, 520, 500) for i in fills[:6]]
+    wl = pm.workloads.tiger(960, 540)
+    renderer.resize(wl.width, wl.height)
+    renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    tiger = renderer.download_scene()
+    t_items = struct.unpack("<I", tiger[4:8].tobytes())[0]
+    t_fills = [i for i in range(struct.unpack("<I", tiger[0:4].tobytes())[0]) if tiger[t_items + 32 * i] == 3]
+    cases += [(tiger, i, 960, 540) for i in (t_fills[0], t_fills[7], t_fills[40], t_fills[-1])]
+    worst = 0
+    for scene, item, w, h in cases:
+        renderer.resize(w, h)
+        renderer.set_scene_bytes(scene)
+        got = renderer.fill_coverage(item)
+        want = pmo.fill_coverage(scene, item, w, h)
+        worst = max(worst, ulps(got, want))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (item, w, h, ulps(got, want))
+        # the scene is intact afterwards: a frame still renders as before
+        renderer.render()
+        assert np.array_equal(renderer.read_pixels(), pmo.render(scene, w, h))
+    assert worst == 0
+    with pytest.raises(pm.PietMetalError):
+        renderer.fill_coverage(10 ** 6)
+
+
 def test_cli_renders_svg_to_png(pm, pmo, tmp_path):
     from piet_metal_amd import cli
 
