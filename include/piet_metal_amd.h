@@ -108,6 +108,16 @@ typedef struct {
 } pm_path;                     /* 24 bytes */
 
 #define PM_SVG_REJECT_ARC_PATHS 1 /* drop any path whose data holds A/a */
+#define PM_SVG_SPEC_DEFAULTS 2    /* SVG's initial `fill: black`; default: make_tiger's rule -- only a fill
+                                     property (own or inherited) fills (src/lib.rs:299) */
+
+/* Beyond what make_tiger reads (d / fill / stroke / stroke-width of every <path>), pm_svg_parse
+ * understands: <g>/<svg> nesting with inherited presentation properties, `transform`
+ * (matrix translate scale rotate skewX skewY), `style="..."`, opacity / fill-opacity /
+ * stroke-opacity (folded into the items' alpha: no group compositing), fill-rule (evenodd ->
+ * PM_PATH_EVEN_ODD), #rgb / #rrggbb / rgb() / basic colour names / none, and rect (rounded too),
+ * circle, ellipse, line, polyline, polygon as paths; <defs> and friends are skipped.  Coordinates
+ * come out in the root user space; stroke widths are scaled by sqrt|det| of the matrix. */
 
 typedef struct pm_svg pm_svg;
 pm_svg *pm_svg_parse(const char *text, size_t len, int flags, int *err);
@@ -148,6 +158,11 @@ int pm_upload_scene(pm_ctx *c, size_t bytes);
 int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths,
                           const pm_path_el *els, size_t n_els, const double affine[6],
                           float width_scale, size_t *scene_bytes, uint32_t *n_items);
+/* Animation: flatten + encode the paths of the last pm_flatten_and_encode AGAIN under another
+ * affine (they stay resident on the device; nothing is uploaded or allocated).  The reference
+ * re-encodes on the CPU when the view changes (PietRenderer.m:90-101, :145); here a view change
+ * is four small kernels plus the scene index. */
+int pm_reflatten(pm_ctx *c, const double affine[6], float width_scale, size_t *scene_bytes, uint32_t *n_items);
 /* Copy the resident scene back (parity checks, init_test_scene). */
 int pm_download_scene(pm_ctx *c, uint8_t *dst, size_t cap, size_t *bytes);
 

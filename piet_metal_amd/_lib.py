@@ -24,6 +24,7 @@ PM_EL_MOVE, PM_EL_LINE, PM_EL_QUAD, PM_EL_CURVE, PM_EL_CLOSE = range(5)
 PM_PATH_FILL, PM_PATH_STROKE, PM_PATH_EVEN_ODD = 1, 2, 4
 PM_FILL_EVEN_ODD = 1
 PM_SVG_REJECT_ARC_PATHS = 1
+PM_SVG_SPEC_DEFAULTS = 2
 PM_FMT_RGBA8, PM_FMT_BGRA8 = 0, 1
 
 
@@ -102,6 +103,7 @@ SIGNATURES = {
     "pm_scene_reserve": (C.c_int, [C.c_void_p, C.c_size_t]),
     "pm_upload_scene": (C.c_int, [C.c_void_p, C.c_size_t]),
     "pm_flatten_and_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.c_float, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
+    "pm_reflatten": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_float, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "pm_download_scene": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "pm_render": (C.c_int, [C.c_void_p]),
     "pm_render_to": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -198,6 +198,7 @@ struct pm_ctx {
     size_t fb_bytes = 0;
 
     // binning state shared by the slots
+    size_t sr_desc_cap = 0, band_cap = 0;
     uint4 *d_sr_desc = nullptr;     // strip rows some item reaches: {strip row, arena region begin, end, 0}
     uint32_t n_sr_active = 0;
     uint32_t sr_empty_dwords = 0;   // size of a region no item reaches
@@ -213,6 +214,8 @@ struct pm_ctx {
     std::vector<FrameSlot> slot;
     uint32_t frame = 0;
     int last_slot = -1;  // slot of the most recently submitted frame
+
+    pm::FlattenCache flatten_cache;  // resident paths + scratch of the flatten stage
 
     // wall-clock cost of the last scene replacement, host view (pm_get_scene_timings)
     float t_flatten_ms = 0, t_index_ms = 0, t_arena_ms = 0;
@@ -361,12 +364,15 @@ int EnsureArena(pm_ctx *c) {
     }
     base[need.size()] = static_cast<uint32_t>(total);
     // what StripRowBounds gives a strip row before any item adds to it
+    // (a quarter of headroom: an animation's demand creeps from frame to frame, and re-allocating
+    //  four 100 MB arenas costs milliseconds)
+    const uint64_t alloc_dwords = total > c->arena_cap ? std::min<uint64_t>(0xfffffff0ull, total + total / 4) : c->arena_cap;
     c->sr_empty_dwords = static_cast<uint32_t>((static_cast<uint64_t>(pm::kRecHdrDwords + 3u) * ((c->n_items + 255u) / 256u) + 3u) & ~3ull);
     for (auto &s : c->slot) {
         if (!s.d_arena || total > c->arena_cap) {
             if (s.d_arena) (void)hipFree(s.d_arena);
             s.d_arena = nullptr;
-            PM_TRY(hipMalloc(&s.d_arena, total * sizeof(uint32_t)));
+            PM_TRY(hipMalloc(&s.d_arena, alloc_dwords * sizeof(uint32_t)));
         }
         if (!s.d_ptcl) {
             // Command-list arena: lists are sized from what binning actually found, so there is no
@@ -379,7 +385,7 @@ int EnsureArena(pm_ctx *c) {
             s.ptcl_cap = static_cast<uint32_t>(cmds);
         }
     }
-    c->arena_cap = std::max<uint32_t>(c->arena_cap, static_cast<uint32_t>(total));
+    c->arena_cap = std::max<uint32_t>(c->arena_cap, static_cast<uint32_t>(alloc_dwords));
     // The strip rows some item's bbox reaches get a workgroup of pm_bin_kernel each; the others are
     // background for as long as this scene and viewport last: their tile_state is set to white
     // once, here.  (An empty list still launches one workgroup: it resets the frame counters.)
@@ -388,13 +394,17 @@ int EnsureArena(pm_ctx *c) {
         if (((need[i] + 3u) & ~3ull) != c->sr_empty_dwords) desc.push_back(make_uint4(static_cast<uint32_t>(i), base[i], base[i + 1], 0u));
     // heaviest strip rows first (their arena need is the work estimate): the launch's span is its
     // longest workgroup, and that one should not start in the second wave of workgroups
-    if (EnvInt("PM_BIN_SORT", 1, 0, 1))
+    if (EnvInt("PM_BIN_SORT", 0, 0, 1))  // (measured: +2.5 us when the heavy rows share CUs -- off)
         std::stable_sort(desc.begin(), desc.end(), [](const uint4 &a, const uint4 &b) { return a.z - a.y > b.z - b.y; });
     if (desc.empty()) desc.push_back(make_uint4(0u, base[0], need.empty() ? base[0] : base[1], 0u));
     c->n_sr_active = static_cast<uint32_t>(desc.size());
-    if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
-    c->d_sr_desc = nullptr;
-    PM_TRY(hipMalloc(&c->d_sr_desc, desc.size() * sizeof(uint4)));
+    if (desc.size() > c->sr_desc_cap) {  // (grow only: an animation re-sizes every frame)
+        if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
+        c->d_sr_desc = nullptr;
+        c->sr_desc_cap = 0;
+        PM_TRY(hipMalloc(&c->d_sr_desc, (desc.size() + desc.size() / 4 + 16) * sizeof(uint4)));
+        c->sr_desc_cap = desc.size() + desc.size() / 4 + 16;
+    }
     PM_TRY(hipMemcpy(c->d_sr_desc, desc.data(), desc.size() * sizeof(uint4), hipMemcpyHostToDevice));
     for (auto &s : c->slot) {
         PM_TRY(hipMemset(s.d_tile_state, 0xff, BandTiles(c) * sizeof(uint32_t)));
@@ -415,13 +425,18 @@ int EnsureArena(pm_ctx *c) {
                 ids.push_back(i);
             }
         }
-        if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
-        if (c->d_band_item) (void)hipFree(c->d_band_item);
-        c->d_band_bbox = nullptr;
-        c->d_band_item = nullptr;
         c->n_band_items = static_cast<uint32_t>(ids.size());
-        PM_TRY(hipMalloc(&c->d_band_bbox, std::max<size_t>(ids.size(), 1) * sizeof(uint2)));
-        PM_TRY(hipMalloc(&c->d_band_item, std::max<size_t>(ids.size(), 1) * sizeof(uint32_t)));
+        if (ids.size() > c->band_cap || !c->d_band_bbox) {
+            if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
+            if (c->d_band_item) (void)hipFree(c->d_band_item);
+            c->d_band_bbox = nullptr;
+            c->d_band_item = nullptr;
+            c->band_cap = 0;
+            const size_t want = ids.size() + ids.size() / 4 + 16;
+            PM_TRY(hipMalloc(&c->d_band_bbox, want * sizeof(uint2)));
+            PM_TRY(hipMalloc(&c->d_band_item, want * sizeof(uint32_t)));
+            c->band_cap = want;
+        }
         if (!ids.empty()) {
             PM_TRY(hipMemcpy(c->d_band_bbox, bbs.data(), ids.size() * sizeof(uint2), hipMemcpyHostToDevice));
             PM_TRY(hipMemcpy(c->d_band_item, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -954,6 +969,7 @@ void pm_destroy(pm_ctx *c) {
     if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
     if (c->d_band_item) (void)hipFree(c->d_band_item);
     if (c->d_row_base) (void)hipFree(c->d_row_base);
+    c->flatten_cache.Free();
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->h_scene) (void)hipHostFree(c->h_scene);
     if (c->d_chunk_base) (void)hipFree(c->d_chunk_base);
@@ -1017,9 +1033,20 @@ int pm_upload_scene(pm_ctx *c, size_t bytes) {
     return SetScene(c, bytes, c->h_scene);  // (stream order: the appended flat group follows the upload)
 }
 
+namespace {
+int FlattenAndEncode(pm_ctx *c, bool resident, const pm_path *paths, size_t n_paths, const pm_path_el *els, size_t n_els,
+                     const double affine[6], float width_scale, size_t *scene_bytes, uint32_t *n_items);
+}
+
 int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const pm_path_el *els, size_t n_els,
                           const double affine[6], float width_scale, size_t *scene_bytes, uint32_t *n_items) {
     if (!c || !affine || (n_paths && !paths) || (n_els && !els)) return PM_ERR_INVALID;
+    return FlattenAndEncode(c, false, paths, n_paths, els, n_els, affine, width_scale, scene_bytes, n_items);
+}
+
+namespace {
+int FlattenAndEncode(pm_ctx *c, bool resident, const pm_path *paths, size_t n_paths, const pm_path_el *els, size_t n_els,
+                     const double affine[6], float width_scale, size_t *scene_bytes, uint32_t *n_items) {
     PM_TRY(hipSetDevice(c->device));
     {
         const int rs = SyncAll(c);  // frames in flight still read the old scene
@@ -1030,14 +1057,14 @@ int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const
     hipError_t he = hipSuccess;
     InvalidateScene(c);  // the kernels below overwrite d_scene
     const WallTimer timer;
-    int r = pm::FlattenEncodeOnDevice(c->stream, paths, n_paths, els, n_els, affine, width_scale, c->d_scene, c->scene_cap,
-                                      &bytes, &items, &he);
+    int r = pm::FlattenEncodeOnDevice(c->stream, &c->flatten_cache, resident, paths, n_paths, els, n_els, affine, width_scale, c->d_scene,
+                                      c->scene_cap, &bytes, &items, &he);
     if (r == PM_ERR_CAPACITY && bytes > c->scene_cap) {
         // grow the scene buffers and retry once
         const int rr = ReserveScene(c, bytes + (bytes >> 3));
         if (rr != PM_OK) return rr;
-        r = pm::FlattenEncodeOnDevice(c->stream, paths, n_paths, els, n_els, affine, width_scale, c->d_scene, c->scene_cap,
-                                      &bytes, &items, &he);
+        r = pm::FlattenEncodeOnDevice(c->stream, &c->flatten_cache, resident, paths, n_paths, els, n_els, affine, width_scale, c->d_scene,
+                                      c->scene_cap, &bytes, &items, &he);
     }
     if (r == PM_ERR_HIP) return HipFail(he, "flatten kernels");
     if (r != PM_OK) {
@@ -1050,6 +1077,16 @@ int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const
     if (scene_bytes) *scene_bytes = bytes;
     if (n_items) *n_items = items;
     return PM_OK;
+}
+}  // namespace
+
+int pm_reflatten(pm_ctx *c, const double affine[6], float width_scale, size_t *scene_bytes, uint32_t *n_items) {
+    if (!c || !affine) return PM_ERR_INVALID;
+    if (!c->flatten_cache.resident) {
+        SetError("pm_reflatten: no paths resident (pm_flatten_and_encode first)");
+        return PM_ERR_INVALID;
+    }
+    return FlattenAndEncode(c, true, nullptr, 0, nullptr, 0, affine, width_scale, scene_bytes, n_items);
 }
 
 int pm_download_scene(pm_ctx *c, uint8_t *dst, size_t cap, size_t *bytes) {

@@ -9,9 +9,25 @@
 
 namespace pm {
 
+// Device buffers of the flatten stage, kept between calls (grow only): the parsed paths and the
+// scratch arrays.  With `resident` set the paths of the last upload are flattened again -- the
+// per-frame re-encode of an animation (PietRenderer.m:90-101 does it on the CPU) then costs four
+// kernels and two small read-backs, no allocation and no path upload.
+struct FlattenCache {
+    pm_path *d_paths = nullptr;
+    pm_path_el *d_els = nullptr;
+    uint32_t *d_u32 = nullptr;
+    double *d_bbox = nullptr;
+    size_t cap_paths = 0, cap_els = 0, cap_u32 = 0, cap_bbox = 0;
+    size_t n_paths = 0, n_els = 0;  // what is resident in d_paths / d_els
+    bool resident = false;
+    void Free();
+};
+
 // Flatten + encode on the device (see pm_flatten.hip).  Synchronises `stream`.
+// use_resident: ignore h_paths / h_els and flatten the paths resident in `cache` again.
 // On PM_ERR_CAPACITY *scene_bytes holds the size that would have been needed.
-int FlattenEncodeOnDevice(hipStream_t stream, const pm_path *h_paths, size_t n_paths, const pm_path_el *h_els,
+int FlattenEncodeOnDevice(hipStream_t stream, FlattenCache *cache, bool use_resident, const pm_path *h_paths, size_t n_paths, const pm_path_el *h_els,
                           size_t n_els, const double affine[6], float width_scale, uint8_t *d_scene, size_t scene_cap,
                           size_t *scene_bytes, uint32_t *n_items_out, hipError_t *hip_error);
 

@@ -351,11 +351,38 @@ __global__ void KHeader(uint8_t *scene, uint32_t n_items) {
         if (e_ != hipSuccess) { hip_err = e_; goto fail; } \
     } while (0)
 
-int FlattenEncodeOnDevice(hipStream_t stream, const pm_path *h_paths, size_t n_paths, const pm_path_el *h_els,
+void FlattenCache::Free() {
+    if (d_paths) (void)hipFree(d_paths);
+    if (d_els) (void)hipFree(d_els);
+    if (d_u32) (void)hipFree(d_u32);
+    if (d_bbox) (void)hipFree(d_bbox);
+    *this = FlattenCache();
+}
+
+namespace {
+template <typename T>
+hipError_t Grow(T **p, size_t *cap, size_t need) {
+    if (need <= *cap && *p) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = need + (need >> 2) + 16;
+    const hipError_t e = hipMalloc(p, want * sizeof(T));
+    if (e == hipSuccess) *cap = want;
+    return e;
+}
+}  // namespace
+
+int FlattenEncodeOnDevice(hipStream_t stream, FlattenCache *cache, bool use_resident, const pm_path *h_paths, size_t n_paths, const pm_path_el *h_els,
                           size_t n_els, const double affine[6], float width_scale, uint8_t *d_scene, size_t scene_cap,
                           size_t *scene_bytes, uint32_t *n_items_out, hipError_t *hip_error) {
     hipError_t hip_err = hipSuccess;
     int status = PM_OK;
+    if (use_resident) {
+        if (!cache->resident) return PM_ERR_INVALID;
+        n_paths = cache->n_paths;
+        n_els = cache->n_els;
+    }
     pm_path *d_paths = nullptr;
     pm_path_el *d_els = nullptr;
     uint32_t *d_u32 = nullptr;  // el_npts, el_move, el_ptoff(+1), el_mvoff(+1), path_item_base, path_pt_base, sub_first, totals(4), err
@@ -367,13 +394,14 @@ int FlattenEncodeOnDevice(hipStream_t stream, const pm_path *h_paths, size_t n_p
     const size_t n_u32 = static_cast<size_t>(ne) * 2 + (static_cast<size_t>(ne) + 1) * 2 + static_cast<size_t>(np) * 2 + ne + 8;
 
     // host-side structural check: paths must tile the element array in order
-    {
+    if (!use_resident) {
         uint32_t expect = 0;
         for (size_t p = 0; p < n_paths; ++p) {
             if (h_paths[p].el_begin != expect || h_paths[p].el_end < h_paths[p].el_begin || h_paths[p].el_end > ne) return PM_ERR_INVALID;
             expect = h_paths[p].el_end;
         }
         if (expect != ne) return PM_ERR_INVALID;
+        cache->resident = false;
     }
     if (n_paths == 0 || n_els == 0) {
         // empty group
@@ -385,12 +413,18 @@ int FlattenEncodeOnDevice(hipStream_t stream, const pm_path *h_paths, size_t n_p
         return PM_OK;
     }
 
-    PM_HIP_TRY(hipMalloc(&d_paths, n_paths * sizeof(pm_path)));
-    PM_HIP_TRY(hipMalloc(&d_els, n_els * sizeof(pm_path_el)));
-    PM_HIP_TRY(hipMalloc(&d_u32, n_u32 * sizeof(uint32_t)));
-    PM_HIP_TRY(hipMalloc(&d_bbox, n_els * 4 * sizeof(double)));
-    PM_HIP_TRY(hipMemcpyAsync(d_paths, h_paths, n_paths * sizeof(pm_path), hipMemcpyHostToDevice, stream));
-    PM_HIP_TRY(hipMemcpyAsync(d_els, h_els, n_els * sizeof(pm_path_el), hipMemcpyHostToDevice, stream));
+    PM_HIP_TRY(Grow(&cache->d_paths, &cache->cap_paths, n_paths));
+    PM_HIP_TRY(Grow(&cache->d_els, &cache->cap_els, n_els));
+    PM_HIP_TRY(Grow(&cache->d_u32, &cache->cap_u32, n_u32));
+    PM_HIP_TRY(Grow(&cache->d_bbox, &cache->cap_bbox, n_els * 4));
+    d_paths = cache->d_paths;
+    d_els = cache->d_els;
+    d_u32 = cache->d_u32;
+    d_bbox = cache->d_bbox;
+    if (!use_resident) {
+        PM_HIP_TRY(hipMemcpyAsync(d_paths, h_paths, n_paths * sizeof(pm_path), hipMemcpyHostToDevice, stream));
+        PM_HIP_TRY(hipMemcpyAsync(d_els, h_els, n_els * sizeof(pm_path_el), hipMemcpyHostToDevice, stream));
+    }
     {
         uint32_t *el_npts = d_u32;
         uint32_t *el_move = el_npts + ne;
@@ -433,12 +467,11 @@ int FlattenEncodeOnDevice(hipStream_t stream, const pm_path *h_paths, size_t n_p
         PM_HIP_TRY(hipStreamSynchronize(stream));
         *scene_bytes = need;
         *n_items_out = n_items;
+        cache->resident = true;
+        cache->n_paths = n_paths;
+        cache->n_els = n_els;
     }
 fail:
-    if (d_paths) (void)hipFree(d_paths);
-    if (d_els) (void)hipFree(d_els);
-    if (d_u32) (void)hipFree(d_u32);
-    if (d_bbox) (void)hipFree(d_bbox);
     if (hip_err != hipSuccess) {
         if (hip_error) *hip_error = hip_err;
         return PM_ERR_HIP;

@@ -389,10 +389,327 @@ uint32_t ParseColor(const char *s, size_t len) {  // parse_color, src/lib.rs:375
     return 0xff00ff80u;
 }
 
+// ---- the document: element tree, inherited presentation state -------------------------------
+// make_tiger reads d / fill / stroke / stroke-width of every <path> and nothing else
+// (src/lib.rs:291-326).  That is this front-end on the Tiger, byte for byte; on other documents
+// it goes on where the reference stops: <g> nesting with inherited properties, `transform`,
+// `style="..."`, opacity / fill-opacity / stroke-opacity, fill-rule, rgb() and the basic colour
+// names, and the basic shapes (rect, circle, ellipse, line, polyline, polygon) as paths.
+// Not understood (ignored): gradients and patterns (painted as if `none`), clipping, masks,
+// text, <use>, CSS style sheets, units other than user units / px, stroke joins / caps / dashes.
+
+struct Affine {  // x' = a x + c y + e, y' = b x + d y + f (the SVG matrix(a b c d e f))
+    double a = 1, b = 0, c = 0, d = 1, e = 0, f = 0;
+    Affine Then(const Affine &m) const {  // this * m: m is applied first
+        return {a * m.a + c * m.b, b * m.a + d * m.b, a * m.c + c * m.d, b * m.c + d * m.d, a * m.e + c * m.f + e, b * m.e + d * m.f + f};
+    }
+    void Apply(double *x, double *y) const {
+        const double nx = a * *x + c * *y + e, ny = b * *x + d * *y + f;
+        *x = nx;
+        *y = ny;
+    }
+    bool IsIdentity() const { return a == 1 && b == 0 && c == 0 && d == 1 && e == 0 && f == 0; }
+};
+
+struct Paint {
+    bool none = true;
+    uint32_t rgb = 0;  // 0xRRGGBB
+};
+
+struct Style {
+    Paint fill, stroke;
+    float stroke_width = 1.0f;
+    double opacity = 1.0, fill_opacity = 1.0, stroke_opacity = 1.0;  // opacity: product of the ancestors'
+    bool even_odd = false;
+    Affine ctm;
+};
+
+std::string Trim(const char *s, size_t n) {
+    while (n && std::isspace(static_cast<unsigned char>(*s))) ++s, --n;
+    while (n && std::isspace(static_cast<unsigned char>(s[n - 1]))) --n;
+    return std::string(s, n);
+}
+
+bool ParsePaint(const std::string &v, Paint *out) {
+    static const struct { const char *name; uint32_t rgb; } kNames[] = {
+        {"black", 0x000000}, {"white", 0xffffff}, {"red", 0xff0000}, {"green", 0x008000}, {"lime", 0x00ff00}, {"blue", 0x0000ff},
+        {"yellow", 0xffff00}, {"cyan", 0x00ffff}, {"aqua", 0x00ffff}, {"magenta", 0xff00ff}, {"fuchsia", 0xff00ff}, {"gray", 0x808080},
+        {"grey", 0x808080}, {"silver", 0xc0c0c0}, {"maroon", 0x800000}, {"olive", 0x808000}, {"navy", 0x000080}, {"purple", 0x800080},
+        {"teal", 0x008080}, {"orange", 0xffa500},
+    };
+    if (v.empty() || v == "inherit" || v == "currentColor") return false;  // leave the inherited value
+    if (v == "none" || v == "transparent" || v.compare(0, 4, "url(") == 0) {
+        out->none = true;
+        return true;
+    }
+    if (v[0] == '#') {
+        if (v.size() != 4 && v.size() != 7) return false;
+        const uint32_t c = ParseColor(v.c_str(), v.size());
+        if (c == 0xff00ff80u) return false;
+        out->none = false;
+        out->rgb = c >> 8;
+        return true;
+    }
+    if (v.compare(0, 4, "rgb(") == 0) {
+        double ch[3] = {0, 0, 0};
+        const char *p = v.c_str() + 4;
+        for (int i = 0; i < 3; ++i) {
+            char *q = nullptr;
+            ch[i] = std::strtod(p, &q);
+            if (q == p) return false;
+            p = q;
+            while (std::isspace(static_cast<unsigned char>(*p))) ++p;
+            if (*p == '%') {
+                ch[i] = ch[i] * 255.0 / 100.0;
+                ++p;
+            }
+            while (*p == ',' || std::isspace(static_cast<unsigned char>(*p))) ++p;
+        }
+        uint32_t rgb = 0;
+        for (int i = 0; i < 3; ++i) rgb = (rgb << 8) | static_cast<uint32_t>(std::lround(std::fmin(255.0, std::fmax(0.0, ch[i]))));
+        out->none = false;
+        out->rgb = rgb;
+        return true;
+    }
+    for (const auto &n : kNames)
+        if (v == n.name) {
+            out->none = false;
+            out->rgb = n.rgb;
+            return true;
+        }
+    return false;
+}
+
+// transform="matrix(..) translate(..) scale(..) rotate(..) skewX(..) skewY(..)", left to right
+bool ParseTransform(const std::string &v, Affine *out) {
+    Affine m;
+    const char *p = v.c_str();
+    while (*p) {
+        while (std::isspace(static_cast<unsigned char>(*p)) || *p == ',') ++p;
+        if (!*p) break;
+        const char *n0 = p;
+        while (std::isalpha(static_cast<unsigned char>(*p))) ++p;
+        const std::string name(n0, p);
+        while (std::isspace(static_cast<unsigned char>(*p))) ++p;
+        if (*p != '(') return false;
+        ++p;
+        double arg[6];
+        int n = 0;
+        while (*p && *p != ')') {
+            char *q = nullptr;
+            const double x = std::strtod(p, &q);
+            if (q == p || n >= 6) return false;
+            arg[n++] = x;
+            p = q;
+            while (std::isspace(static_cast<unsigned char>(*p)) || *p == ',') ++p;
+        }
+        if (*p != ')') return false;
+        ++p;
+        Affine t;
+        if (name == "matrix" && n == 6) {
+            t = {arg[0], arg[1], arg[2], arg[3], arg[4], arg[5]};
+        } else if (name == "translate" && (n == 1 || n == 2)) {
+            t.e = arg[0];
+            t.f = n == 2 ? arg[1] : 0.0;
+        } else if (name == "scale" && (n == 1 || n == 2)) {
+            t.a = arg[0];
+            t.d = n == 2 ? arg[1] : arg[0];
+        } else if (name == "rotate" && (n == 1 || n == 3)) {
+            const double th = arg[0] * M_PI / 180.0, cs = std::cos(th), sn = std::sin(th);
+            Affine r{cs, sn, -sn, cs, 0, 0};
+            if (n == 3) {
+                Affine to{1, 0, 0, 1, arg[1], arg[2]}, back{1, 0, 0, 1, -arg[1], -arg[2]};
+                r = to.Then(r).Then(back);
+            }
+            t = r;
+        } else if (name == "skewX" && n == 1) {
+            t.c = std::tan(arg[0] * M_PI / 180.0);
+        } else if (name == "skewY" && n == 1) {
+            t.b = std::tan(arg[0] * M_PI / 180.0);
+        } else {
+            return false;
+        }
+        m = m.Then(t);
+    }
+    *out = m;
+    return true;
+}
+
+double ParseOpacity(const std::string &v, double dflt) {
+    char *q = nullptr;
+    double x = std::strtod(v.c_str(), &q);
+    if (q == v.c_str()) return dflt;
+    if (*q == '%') x /= 100.0;
+    return std::fmin(1.0, std::fmax(0.0, x));
+}
+
+double ParseLength(const Attr *a, double dflt = 0.0) {
+    if (!a) return dflt;
+    const std::string v(a->val, a->val_len);
+    char *q = nullptr;
+    const double x = std::strtod(v.c_str(), &q);
+    return q == v.c_str() ? dflt : x;  // a trailing "px" is user units; other units are not converted
+}
+
+// One presentation property, from an attribute or a `style` declaration (which wins, CSS cascade).
+void ApplyProperty(const std::string &name, const std::string &value, Style *st) {
+    if (name == "fill") {
+        (void)ParsePaint(value, &st->fill);
+    } else if (name == "stroke") {
+        (void)ParsePaint(value, &st->stroke);
+    } else if (name == "stroke-width") {
+        st->stroke_width = std::strtof(value.c_str(), nullptr);  // f32::from_str, src/lib.rs:320
+    } else if (name == "fill-rule") {
+        if (value == "evenodd") st->even_odd = true;
+        else if (value == "nonzero") st->even_odd = false;
+    } else if (name == "fill-opacity") {
+        st->fill_opacity = ParseOpacity(value, st->fill_opacity);
+    } else if (name == "stroke-opacity") {
+        st->stroke_opacity = ParseOpacity(value, st->stroke_opacity);
+    }
+}
+
+bool ApplyElementStyle(const std::vector<Attr> &attrs, Style *st) {
+    static const char *kProps[] = {"fill", "stroke", "stroke-width", "fill-rule", "fill-opacity", "stroke-opacity"};
+    for (const char *pn : kProps)
+        if (const Attr *a = Find(attrs, pn)) ApplyProperty(pn, Trim(a->val, a->val_len), st);
+    if (const Attr *a = Find(attrs, "opacity")) st->opacity *= ParseOpacity(Trim(a->val, a->val_len), 1.0);  // not inherited: it multiplies
+    if (const Attr *a = Find(attrs, "style")) {
+        const char *p = a->val, *end = a->val + a->val_len;
+        while (p < end) {
+            const char *semi = static_cast<const char *>(std::memchr(p, ';', end - p));
+            const char *de = semi ? semi : end;
+            const char *colon = static_cast<const char *>(std::memchr(p, ':', de - p));
+            if (colon) {
+                const std::string name = Trim(p, colon - p), value = Trim(colon + 1, de - colon - 1);
+                if (name == "opacity") st->opacity *= ParseOpacity(value, 1.0);
+                else ApplyProperty(name, value, st);
+            }
+            p = de + 1;
+        }
+    }
+    if (const Attr *a = Find(attrs, "transform")) {
+        Affine t;
+        if (!ParseTransform(std::string(a->val, a->val_len), &t)) return false;
+        st->ctm = st->ctm.Then(t);
+    }
+    return true;
+}
+
+uint32_t PaintRgba(const Paint &p, double opacity) {
+    const uint32_t a = static_cast<uint32_t>(std::lround(255.0 * std::fmin(1.0, std::fmax(0.0, opacity))));
+    return (p.rgb << 8) | a;
+}
+
+// elements [el0, end) through the current transformation matrix (an affine map of a Bezier's
+// control points is the map of the curve)
+void TransformEls(std::vector<pm_path_el> *els, size_t el0, const Affine &m) {
+    if (m.IsIdentity()) return;
+    for (size_t i = el0; i < els->size(); ++i) {
+        pm_path_el &e = (*els)[i];
+        const int npt = e.tag == PM_EL_CURVE ? 3 : (e.tag == PM_EL_QUAD ? 2 : (e.tag == PM_EL_CLOSE ? 0 : 1));
+        for (int k = 0; k < npt; ++k) m.Apply(&e.p[2 * k], &e.p[2 * k + 1]);
+    }
+}
+
+// basic shapes as path elements (SVG 1.1 section 9); false = the shape renders nothing
+bool ShapeToEls(const char *name, size_t name_len, const std::vector<Attr> &attrs, std::vector<pm_path_el> *els, bool *closed) {
+    PathBuilder out{els};
+    const std::string n(name, name_len);
+    *closed = true;
+    auto ellipse = [&](double cx, double cy, double rx, double ry) {
+        if (!(rx > 0.0) || !(ry > 0.0)) return false;
+        out.Push(PM_EL_MOVE, cx + rx, cy);  // four quarter arcs, as 9.3 / 9.4 prescribe
+        ArcToCubics(out, cx + rx, cy, rx, ry, 0.0, false, true, cx, cy + ry);
+        ArcToCubics(out, cx, cy + ry, rx, ry, 0.0, false, true, cx - rx, cy);
+        ArcToCubics(out, cx - rx, cy, rx, ry, 0.0, false, true, cx, cy - ry);
+        ArcToCubics(out, cx, cy - ry, rx, ry, 0.0, false, true, cx + rx, cy);
+        out.Push(PM_EL_CLOSE);
+        return true;
+    };
+    if (n == "rect") {
+        const double x = ParseLength(Find(attrs, "x")), y = ParseLength(Find(attrs, "y"));
+        const double w = ParseLength(Find(attrs, "width")), h = ParseLength(Find(attrs, "height"));
+        if (!(w > 0.0) || !(h > 0.0)) return false;
+        const Attr *arx = Find(attrs, "rx"), *ary = Find(attrs, "ry");
+        double rx = ParseLength(arx, -1.0), ry = ParseLength(ary, -1.0);
+        if (rx < 0.0 && ry < 0.0) rx = ry = 0.0;
+        else if (rx < 0.0) rx = ry;
+        else if (ry < 0.0) ry = rx;
+        rx = std::fmin(rx, w / 2.0);
+        ry = std::fmin(ry, h / 2.0);
+        if (rx == 0.0 || ry == 0.0) {
+            out.Push(PM_EL_MOVE, x, y);
+            out.Push(PM_EL_LINE, x + w, y);
+            out.Push(PM_EL_LINE, x + w, y + h);
+            out.Push(PM_EL_LINE, x, y + h);
+            out.Push(PM_EL_CLOSE);
+        } else {  // 9.2: the rounded outline
+            out.Push(PM_EL_MOVE, x + rx, y);
+            out.Push(PM_EL_LINE, x + w - rx, y);
+            ArcToCubics(out, x + w - rx, y, rx, ry, 0.0, false, true, x + w, y + ry);
+            out.Push(PM_EL_LINE, x + w, y + h - ry);
+            ArcToCubics(out, x + w, y + h - ry, rx, ry, 0.0, false, true, x + w - rx, y + h);
+            out.Push(PM_EL_LINE, x + rx, y + h);
+            ArcToCubics(out, x + rx, y + h, rx, ry, 0.0, false, true, x, y + h - ry);
+            out.Push(PM_EL_LINE, x, y + ry);
+            ArcToCubics(out, x, y + ry, rx, ry, 0.0, false, true, x + rx, y);
+            out.Push(PM_EL_CLOSE);
+        }
+        return true;
+    }
+    if (n == "circle") {
+        const double r = ParseLength(Find(attrs, "r"));
+        return ellipse(ParseLength(Find(attrs, "cx")), ParseLength(Find(attrs, "cy")), r, r);
+    }
+    if (n == "ellipse")
+        return ellipse(ParseLength(Find(attrs, "cx")), ParseLength(Find(attrs, "cy")), ParseLength(Find(attrs, "rx")), ParseLength(Find(attrs, "ry")));
+    if (n == "line") {
+        *closed = false;
+        out.Push(PM_EL_MOVE, ParseLength(Find(attrs, "x1")), ParseLength(Find(attrs, "y1")));
+        out.Push(PM_EL_LINE, ParseLength(Find(attrs, "x2")), ParseLength(Find(attrs, "y2")));
+        return true;
+    }
+    if (n == "polyline" || n == "polygon") {
+        const Attr *pts = Find(attrs, "points");
+        if (!pts) return false;
+        PathLexer lx(pts->val, pts->val + pts->val_len);
+        double x, y;
+        size_t count = 0;
+        while (lx.Number(&x)) {
+            if (!lx.Number(&y)) break;  // an odd coordinate count ends the list (error handling of 9.7)
+            out.Push(count ? PM_EL_LINE : PM_EL_MOVE, x, y);
+            ++count;
+        }
+        if (count < 2) {
+            els->resize(els->size() - count);
+            return false;
+        }
+        *closed = n == "polygon";
+        if (*closed) out.Push(PM_EL_CLOSE);
+        return true;
+    }
+    return false;
+}
+
+bool IsShape(const char *n, size_t len) {
+    static const char *k[] = {"rect", "circle", "ellipse", "line", "polyline", "polygon"};
+    for (const char *s : k)
+        if (std::strlen(s) == len && std::memcmp(s, n, len) == 0) return true;
+    return false;
+}
+
 int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
     const char *p = text;
     const char *end = text + len;
     std::vector<Attr> attrs;
+    std::vector<Style> stack(1);  // [0] = the initial values
+    // SVG's initial fill is black; make_tiger only fills a path that HAS a fill attribute
+    // (src/lib.rs:299).  The Tiger wraps everything in <g fill="none">, where both readings
+    // agree; elsewhere the reference's reading is the default and PM_SVG_SPEC_DEFAULTS the SVG one.
+    stack[0].fill.none = (flags & PM_SVG_SPEC_DEFAULTS) == 0;
+    stack[0].fill.rgb = 0;
+    std::vector<bool> container;  // open elements: does this one own a stack entry
     while (p < end) {
         const char *lt = static_cast<const char *>(std::memchr(p, '<', end - p));
         if (!lt) break;
@@ -404,9 +721,18 @@ int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
             p = (q + 3 <= end) ? q + 3 : end;
             continue;
         }
-        if (*p == '?' || *p == '!' || *p == '/') {  // PI, doctype, end tag
+        if (*p == '?' || *p == '!') {  // PI, doctype
             const char *gt = static_cast<const char *>(std::memchr(p, '>', end - p));
             p = gt ? gt + 1 : end;
+            continue;
+        }
+        if (*p == '/') {  // end tag: leave the element
+            const char *gt = static_cast<const char *>(std::memchr(p, '>', end - p));
+            p = gt ? gt + 1 : end;
+            if (!container.empty()) {
+                if (container.back() && stack.size() > 1) stack.pop_back();
+                container.pop_back();
+            }
             continue;
         }
         const char *n0 = p;
@@ -424,34 +750,78 @@ int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
             ++q;
         }
         if (q >= end) return PM_ERR_PARSE;
-        if (name_len == 4 && std::memcmp(n0, "path", 4) == 0) {
-            if (!ScanAttrs(p, q, &attrs)) return PM_ERR_PARSE;
-            const Attr *d = Find(attrs, "d");
-            if (!d) return PM_ERR_PARSE;  // .attribute("d").unwrap(), src/lib.rs:295
-            const size_t el0 = out->els.size();
-            bool has_arc = false;
-            const bool ok = ParsePathData(d->val, d->val_len, &out->els, &has_arc);
-            if (!ok || (has_arc && (flags & PM_SVG_REJECT_ARC_PATHS))) {
-                out->els.resize(el0);  // `if let Ok(ref bp) = ...` skips the path, src/lib.rs:296
-            } else {
-                pm_path path{};
-                path.el_begin = static_cast<uint32_t>(el0);
-                path.el_end = static_cast<uint32_t>(out->els.size());
-                if (const Attr *f = Find(attrs, "fill")) {
-                    path.flags |= PM_PATH_FILL;
-                    path.fill_rgba = ParseColor(f->val, f->val_len);
-                }
-                if (const Attr *s = Find(attrs, "stroke")) {
-                    path.flags |= PM_PATH_STROKE;
-                    path.stroke_rgba = ParseColor(s->val, s->val_len);
-                    path.stroke_width = 1.0f;
-                    if (const Attr *w = Find(attrs, "stroke-width")) {
-                        std::string tok(w->val, w->val_len);
-                        path.stroke_width = std::strtof(tok.c_str(), nullptr);  // f32::from_str
-                    }
-                }
-                out->paths.push_back(path);
+        const bool self_closing = q > p && q[-1] == '/';
+        const bool is_path = name_len == 4 && std::memcmp(n0, "path", 4) == 0;
+        const bool is_shape = !is_path && IsShape(n0, name_len);
+        const bool is_group = (name_len == 1 && n0[0] == 'g') || (name_len == 3 && std::memcmp(n0, "svg", 3) == 0) ||
+                              (name_len == 1 && n0[0] == 'a') || (name_len == 6 && std::memcmp(n0, "switch", 6) == 0);
+        const bool skipped = (name_len == 4 && std::memcmp(n0, "defs", 4) == 0) || (name_len == 8 && std::memcmp(n0, "clipPath", 8) == 0) ||
+                             (name_len == 4 && std::memcmp(n0, "mask", 4) == 0) || (name_len == 6 && std::memcmp(n0, "symbol", 6) == 0) ||
+                             (name_len == 7 && std::memcmp(n0, "pattern", 7) == 0) || (name_len == 6 && std::memcmp(n0, "marker", 6) == 0);
+        if (skipped && !self_closing) {
+            // definitions are not rendered directly: skip to the matching end tag
+            const std::string close = "</" + std::string(n0, name_len);
+            int depth = 1;
+            const char *r = q + 1;
+            const std::string open = "<" + std::string(n0, name_len);
+            while (r < end && depth > 0) {
+                const char *nx = static_cast<const char *>(std::memchr(r, '<', end - r));
+                if (!nx) { r = end; break; }
+                if (static_cast<size_t>(end - nx) >= close.size() && std::memcmp(nx, close.c_str(), close.size()) == 0) --depth;
+                else if (static_cast<size_t>(end - nx) >= open.size() && std::memcmp(nx, open.c_str(), open.size()) == 0 &&
+                         (nx[open.size()] == '>' || std::isspace(static_cast<unsigned char>(nx[open.size()])))) ++depth;
+                r = nx + 1;
             }
+            const char *gt = r < end ? static_cast<const char *>(std::memchr(r, '>', end - r)) : nullptr;
+            p = gt ? gt + 1 : end;
+            continue;
+        }
+        if (is_path || is_shape || is_group) {
+            if (!ScanAttrs(p, q, &attrs)) return PM_ERR_PARSE;
+            Style st = stack.back();
+            if (!ApplyElementStyle(attrs, &st)) return PM_ERR_PARSE;
+            if (is_group) {
+                if (!self_closing) {
+                    stack.push_back(st);
+                    container.push_back(true);
+                }
+            } else {
+                const size_t el0 = out->els.size();
+                bool ok = true, has_arc = false, closed = true;
+                if (is_path) {
+                    const Attr *d = Find(attrs, "d");
+                    if (!d) return PM_ERR_PARSE;  // .attribute("d").unwrap(), src/lib.rs:295
+                    ok = ParsePathData(d->val, d->val_len, &out->els, &has_arc);
+                    if (has_arc && (flags & PM_SVG_REJECT_ARC_PATHS)) ok = false;
+                } else {
+                    ok = ShapeToEls(n0, name_len, attrs, &out->els, &closed);
+                }
+                if (!ok) {
+                    out->els.resize(el0);  // `if let Ok(ref bp) = ...` skips the path, src/lib.rs:296
+                } else {
+                    TransformEls(&out->els, el0, st.ctm);
+                    pm_path path{};
+                    path.el_begin = static_cast<uint32_t>(el0);
+                    path.el_end = static_cast<uint32_t>(out->els.size());
+                    if (!st.fill.none && (closed || is_path || name_len == 8 /* polyline fills its implicit closure */)) {
+                        path.flags |= PM_PATH_FILL;
+                        if (st.even_odd) path.flags |= PM_PATH_EVEN_ODD;
+                        path.fill_rgba = PaintRgba(st.fill, st.opacity * st.fill_opacity);
+                    }
+                    if (!st.stroke.none) {
+                        path.flags |= PM_PATH_STROKE;
+                        path.stroke_rgba = PaintRgba(st.stroke, st.opacity * st.stroke_opacity);
+                        // widths scale with the geometric mean of the matrix's stretch (exact for similarities)
+                        const double det = std::fabs(st.ctm.a * st.ctm.d - st.ctm.b * st.ctm.c);
+                        path.stroke_width = st.ctm.IsIdentity() ? st.stroke_width : static_cast<float>(st.stroke_width * std::sqrt(det));
+                    }
+                    if (path.flags & (PM_PATH_FILL | PM_PATH_STROKE)) out->paths.push_back(path);
+                    else out->els.resize(el0);
+                }
+                if (!self_closing) container.push_back(false);
+            }
+        } else if (!self_closing) {
+            container.push_back(false);  // an element this front-end does not draw (its children may still be drawn)
         }
         p = q + 1;
     }

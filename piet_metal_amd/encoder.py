@@ -131,11 +131,14 @@ class PathSet:
         return cls(paths, els)
 
     @classmethod
-    def from_svg(cls, text: bytes | str, reject_arc_paths: bool = False) -> "PathSet":
+    def from_svg(cls, text: bytes | str, reject_arc_paths: bool = False, spec_defaults: bool = False) -> "PathSet":
+        """Parse an SVG document.  spec_defaults: SVG's initial `fill: black` instead of the
+        reference's rule that only a fill property fills (src/lib.rs:299)."""
         lib = _lib.load()
         data = text.encode() if isinstance(text, str) else bytes(text)
         err = C.c_int(0)
-        h = lib.pm_svg_parse(data, len(data), _lib.PM_SVG_REJECT_ARC_PATHS if reject_arc_paths else 0, C.byref(err))
+        flags = (_lib.PM_SVG_REJECT_ARC_PATHS if reject_arc_paths else 0) | (_lib.PM_SVG_SPEC_DEFAULTS if spec_defaults else 0)
+        h = lib.pm_svg_parse(data, len(data), flags, C.byref(err))
         if not h:
             raise _lib.PietMetalError(err.value, "pm_svg_parse")
         return cls._from_handle(lib, h)

@@ -96,6 +96,14 @@ class Renderer:
         )
         return nbytes.value, nitems.value
 
+    def reflatten(self, affine, width_scale: float) -> tuple[int, int]:
+        """Re-flatten the resident paths of the last flatten_and_encode under a new affine
+        (animation: no upload, no allocation); returns (scene_bytes, n_items)."""
+        aff = (C.c_double * 6)(*[float(v) for v in affine])
+        nbytes, nitems = C.c_size_t(0), C.c_uint32(0)
+        _lib.check(self._lib.pm_reflatten(self._h, aff, float(width_scale), C.byref(nbytes), C.byref(nitems)), "pm_reflatten")
+        return nbytes.value, nitems.value
+
     def download_scene(self) -> np.ndarray:
         nbytes = C.c_size_t(0)
         self._lib.pm_scene_device_ptr(self._h, C.byref(nbytes))

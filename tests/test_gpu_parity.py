@@ -601,6 +601,58 @@ def test_cli_renders_svg_to_png(pm, pmo, tmp_path):
     assert np.array_equal(cli.read_png_rgba(out), pmo.render(scene, 640, 400))
 
 
+def test_second_svg_document_end_to_end(pm, pmo, tmp_path):
+    """tests/data/shapes.svg -- nested groups with transforms, style declarations, opacity, both
+    fill rules, every basic shape -- through the CLI (SVG document layer, on-device flatten, the
+    three frame kernels, PNG) against the oracle on the same parsed paths."""
+    from piet_metal_amd import cli
+
+    src = os.path.join(ROOT, "tests", "data", "shapes.svg")
+    out = str(tmp_path / "shapes.png")
+    assert cli.main([src, out, "--width", "1200", "--height", "900", "--scale", "3"]) == 0
+    ps = pm.PathSet.from_svg(open(src).read(), spec_defaults=True)
+    assert len(ps.paths) == 10 and (ps.paths["flags"] & pm._lib.PM_PATH_EVEN_ODD).any()
+    scene, n_items = pmo.scene_from_paths(pmo.scaled_paths(ps.paths, 3.0), ps.els, (3.0, 0.0, 0.0, 3.0, 0.0, 0.0))
+    want = pmo.render(scene, 1200, 900)
+    got = cli.read_png_rgba(out)
+    assert np.array_equal(got, want)
+    # sanity of the picture itself: the even-odd outline has a hole where the non-zero twin is filled
+    page = tuple(got[3 * 295, 3 * 395][:3])
+    assert page == (0xEE, 0xF4, 0xFA)
+    assert tuple(got[3 * 212, 3 * 103][:3]) == page        # even-odd: the doubly wound core is a hole
+    assert tuple(got[3 * 212, 3 * 50][:3]) == (0xC9, 0x2A, 0x2A)   # its ring is painted
+    assert tuple(got[3 * 212, 3 * 273][:3]) == (0, 0x80, 0x80)   # the non-zero twin's core is painted (teal)
+
+
+def test_animation_reflatten_resident_paths(pm, pmo, renderer, tmp_path):
+    """Per-frame re-encode (PietRenderer.m:90-101, :145) on the device: pm_reflatten flattens the
+    resident paths again under a new affine -- scene bytes and pixels of every frame equal the
+    oracle's for that affine, and equal a fresh pm_flatten_and_encode."""
+    from piet_metal_amd import cli
+
+    wl = pm.workloads.tiger(640, 400)
+    renderer.resize(wl.width, wl.height)
+    with pytest.raises(pm.PietMetalError):
+        pm.Renderer(0).reflatten(wl.affine, wl.width_scale)  # nothing resident yet in a fresh context
+    renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    for k in range(4):
+        aff = cli.spin_affine(wl.affine, np.deg2rad(25.0 * k), 320.0, 200.0)
+        nbytes, nitems = renderer.reflatten(aff, wl.width_scale)
+        scene = renderer.download_scene()
+        want_scene, want_items = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, aff)
+        assert nitems == want_items and np.array_equal(scene, want_scene), k
+        renderer.render()
+        assert np.array_equal(renderer.read_pixels(), pmo.render(scene, wl.width, wl.height)), k
+    t = renderer.scene_timings()
+    assert t["flatten_encode_ms"] > 0
+    out = str(tmp_path / "spin.png")
+    assert cli.main(["tiger", out, "--width", "320", "--height", "200", "--frames", "3", "--spin", "90"]) == 0
+    assert all(os.path.exists(str(tmp_path / f"spin-{k:03d}.png")) for k in range(3))
+    a = cli.read_png_rgba(str(tmp_path / "spin-001.png"))
+    scene1, _ = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, 1.0), wl.paths.els, cli.spin_affine((1.0, 0.0, 0.0, 1.0, 60.0, 0.0), np.deg2rad(30.0), 160.0, 100.0))
+    assert np.array_equal(a, pmo.render(scene1, 320, 200))
+
+
 def test_per_row_item_lists_large_scene_path(pm, pmo, monkeypatch):
     """Scenes with thousands of items bin through per-tile-row item lists
     (pm_rowcull_kernel); forced on here for small scenes, full frame and bands."""

@@ -2,6 +2,7 @@
 oracle's restatement of src/lib.rs, the SVG front-end against an independent
 parser, the C-ABI surface, and the absence of any CPU rendering fallback."""
 import ctypes as C
+import math
 import os
 import re
 import struct
@@ -340,9 +341,22 @@ def py_parse_path(d):
             p1 = (2.0 * cur[0] - ctrl[0], 2.0 * cur[1] - ctrl[1])
             p2, p3 = pt(), pt()
             out.append(("C", [*p1, *p2, *p3])); ctrl, cur = p2, p3
+        elif C_ == "Q":
+            p1, p2 = pt(), pt()
+            out.append(("Q", [*p1, *p2])); ctrl, cur = p1, p2
+        elif C_ == "T":
+            prev_quad = bool(out) and out[-1][0] == "Q"
+            p1 = (2.0 * cur[0] - ctrl[0], 2.0 * cur[1] - ctrl[1]) if prev_quad else cur
+            p2 = pt()
+            out.append(("Q", [*p1, *p2])); ctrl, cur = p1, p2
         else:
             raise NotImplementedError(cmd)
     return out
+
+
+def _svg_path_elements(d):
+    tags = {"M": 0, "L": 1, "Q": 2, "C": 3, "Z": 4}
+    return [(tags[t], coords) for t, coords in py_parse_path(d)]
 
 
 def test_svg_front_end_matches_independent_parser(pm):
@@ -404,6 +418,227 @@ def test_svg_syntax_edge_cases(pm):
     assert len(bad.paths) == 1  # a path kurbo would reject is skipped (src/lib.rs:296), not fatal
     with pytest.raises(pm.PietMetalError):
         pm.PathSet.from_svg("<svg><path fill='#000'/></svg>")  # .attribute("d").unwrap(), src/lib.rs:295
+
+
+# ---- independent SVG document walker (pure Python, from the SVG 1.1 spec) -----------------------
+# Second witness for the document layer of the C++ front-end: element nesting, property inheritance,
+# `style`, opacity, transforms, fill-rule, basic shapes.  It produces (flags, fill, stroke, width) per
+# drawn element and the element's geometry as absolute path elements in root user space; arcs are
+# compared through sample points (the conversion to cubics is product-defined).
+
+def _svg_walk(svg_text, spec_defaults=False):
+    import xml.etree.ElementTree as ET
+
+    NAMES = {"black": 0x000000, "white": 0xFFFFFF, "red": 0xFF0000, "green": 0x008000, "blue": 0x0000FF, "teal": 0x008080,
+             "purple": 0x800080, "yellow": 0xFFFF00, "orange": 0xFFA500, "gray": 0x808080}
+
+    def paint(v, cur):
+        v = v.strip()
+        if v in ("none", "transparent") or v.startswith("url("):
+            return None
+        if v.startswith("#"):
+            h = v[1:]
+            if len(h) == 3:
+                h = "".join(c * 2 for c in h)
+            return int(h, 16)
+        if v.startswith("rgb("):
+            parts = [t.strip() for t in v[4:-1].split(",")]
+            ch = [float(t[:-1]) * 255 / 100 if t.endswith("%") else float(t) for t in parts]
+            return (int(round(min(255, max(0, ch[0])))) << 16) | (int(round(min(255, max(0, ch[1])))) << 8) | int(round(min(255, max(0, ch[2]))))
+        return NAMES.get(v, cur)
+
+    def mat_mul(A, B):  # A * B, B applied first; [a b c d e f]
+        a, b, c, d, e, f = A
+        g, h, i, j, k, l = B
+        return [a * g + c * h, b * g + d * h, a * i + c * j, b * i + d * j, a * k + c * l + e, b * k + d * l + f]
+
+    def transform(v):
+        M = [1, 0, 0, 1, 0, 0]
+        for name, args in re.findall(r"([a-zA-Z]+)\s*\(([^)]*)\)", v):
+            x = [float(t) for t in re.split(r"[\s,]+", args.strip()) if t]
+            if name == "matrix":
+                T = x
+            elif name == "translate":
+                T = [1, 0, 0, 1, x[0], x[1] if len(x) > 1 else 0]
+            elif name == "scale":
+                T = [x[0], 0, 0, x[1] if len(x) > 1 else x[0], 0, 0]
+            elif name == "rotate":
+                c, s_ = math.cos(math.radians(x[0])), math.sin(math.radians(x[0]))
+                T = [c, s_, -s_, c, 0, 0]
+                if len(x) == 3:
+                    T = mat_mul(mat_mul([1, 0, 0, 1, x[1], x[2]], T), [1, 0, 0, 1, -x[1], -x[2]])
+            elif name == "skewX":
+                T = [1, 0, math.tan(math.radians(x[0])), 1, 0, 0]
+            elif name == "skewY":
+                T = [1, math.tan(math.radians(x[0])), 0, 1, 0, 0]
+            M = mat_mul(M, T)
+        return M
+
+    def opac(v):
+        v = v.strip()
+        return min(1.0, max(0.0, float(v[:-1]) / 100 if v.endswith("%") else float(v)))
+
+    out = []
+
+    def visit(el, st):
+        tag = el.tag.split("}")[-1]
+        if tag in ("defs", "clipPath", "mask", "symbol", "pattern", "marker"):
+            return
+        st = dict(st)
+        props = {k: v for k, v in el.attrib.items()}
+        decl = {}
+        for d in props.get("style", "").split(";"):
+            if ":" in d:
+                k, v = d.split(":", 1)
+                decl[k.strip()] = v.strip()
+        for k in ("fill", "stroke"):
+            for src in (props, decl):
+                if k in src:
+                    st[k] = paint(src[k], st[k])
+        for src in (props, decl):
+            if "stroke-width" in src:
+                st["width"] = float(np.float32(float(src["stroke-width"])))
+            if "fill-rule" in src:
+                st["evenodd"] = src["fill-rule"].strip() == "evenodd"
+            if "fill-opacity" in src:
+                st["fo"] = opac(src["fill-opacity"])
+            if "stroke-opacity" in src:
+                st["so"] = opac(src["stroke-opacity"])
+            if "opacity" in src:
+                st["op"] = st["op"] * opac(src["opacity"])
+        if "transform" in props:
+            st["ctm"] = mat_mul(st["ctm"], transform(props["transform"]))
+        if tag in ("g", "svg", "a", "switch"):
+            for ch in el:
+                visit(ch, st)
+            return
+        f = lambda k, dflt=0.0: float(re.match(r"\s*([-+0-9.eE]+)", props[k]).group(1)) if k in props else dflt
+        geom, closed = None, True
+        if tag == "path":
+            geom = ("path", props["d"])
+        elif tag == "rect":
+            w, h = f("width"), f("height")
+            if w > 0 and h > 0:
+                rx, ry = f("rx", -1.0), f("ry", -1.0)
+                if rx < 0 and ry < 0: rx = ry = 0.0
+                elif rx < 0: rx = ry
+                elif ry < 0: ry = rx
+                geom = ("rect", f("x"), f("y"), w, h, min(rx, w / 2), min(ry, h / 2))
+        elif tag in ("circle", "ellipse"):
+            rx, ry = (f("r"), f("r")) if tag == "circle" else (f("rx"), f("ry"))
+            if rx > 0 and ry > 0:
+                geom = ("ellipse", f("cx"), f("cy"), rx, ry)
+        elif tag == "line":
+            geom, closed = ("poly", [(f("x1"), f("y1")), (f("x2"), f("y2"))], False), False
+        elif tag in ("polyline", "polygon"):
+            nums = [float(t) for t in re.findall(r"[-+]?(?:\d+\.?\d*|\.\d+)(?:[eE][-+]?\d+)?", props.get("points", ""))]
+            pts = list(zip(nums[0::2], nums[1::2]))
+            if len(pts) >= 2:
+                geom, closed = ("poly", pts, tag == "polygon"), tag == "polygon"
+        if geom is None:
+            return
+        flags, fill_rgba, stroke_rgba, width = 0, 0, 0, 0.0
+        if st["fill"] is not None and (closed or tag in ("path", "polyline")):
+            flags |= 1 | (4 if st["evenodd"] else 0)
+            fill_rgba = (st["fill"] << 8) | int(round(255 * min(1.0, max(0.0, st["op"] * st["fo"]))))
+        if st["stroke"] is not None:
+            flags |= 2
+            stroke_rgba = (st["stroke"] << 8) | int(round(255 * min(1.0, max(0.0, st["op"] * st["so"]))))
+            a, b, c, d, _, _ = st["ctm"]
+            ident = st["ctm"] == [1, 0, 0, 1, 0, 0]
+            width = st["width"] if ident else float(np.float32(st["width"] * math.sqrt(abs(a * d - b * c))))
+        if flags & 3:
+            out.append({"flags": flags, "fill": fill_rgba, "stroke": stroke_rgba, "width": width, "geom": geom, "ctm": st["ctm"]})
+
+    root = ET.fromstring(svg_text)
+    visit(root, {"fill": 0 if spec_defaults else None, "stroke": None, "width": 1.0, "evenodd": False, "fo": 1.0, "so": 1.0, "op": 1.0,
+                 "ctm": [1, 0, 0, 1, 0, 0]})
+    return out
+
+
+def _apply(M, p):
+    return (M[0] * p[0] + M[2] * p[1] + M[4], M[1] * p[0] + M[3] * p[1] + M[5])
+
+
+def _bez(p0, els_row, t):
+    tag = int(els_row["tag"])
+    P = els_row["p"]
+    if tag == 1:
+        return (p0[0] + (P[0] - p0[0]) * t, p0[1] + (P[1] - p0[1]) * t)
+    if tag == 2:
+        mt = 1 - t
+        return (mt * mt * p0[0] + 2 * mt * t * P[0] + t * t * P[2], mt * mt * p0[1] + 2 * mt * t * P[1] + t * t * P[3])
+    mt = 1 - t
+    return (mt ** 3 * p0[0] + 3 * mt * mt * t * P[0] + 3 * mt * t * t * P[2] + t ** 3 * P[4],
+            mt ** 3 * p0[1] + 3 * mt * mt * t * P[1] + 3 * mt * t * t * P[3] + t ** 3 * P[5])
+
+
+@pytest.mark.parametrize("spec_defaults", [False, True])
+def test_svg_document_layer_matches_independent_walker(pm, spec_defaults):
+    """tests/data/shapes.svg (nested groups, transforms, style, opacity, both fill rules, every basic
+    shape) through the C++ front-end and through the independent Python walker: the same drawn
+    elements in the same order with the same paints, rule bits and widths; straight geometry
+    bit for bit after the transform, curved geometry (arcs -> cubics are product-defined) on the
+    transformed outline it has to follow."""
+    svg = open(os.path.join(ROOT, "tests", "data", "shapes.svg")).read()
+    ps = pm.PathSet.from_svg(svg, spec_defaults=spec_defaults)
+    want = _svg_walk(svg, spec_defaults)
+    assert len(ps.paths) == len(want) == 10
+    for p, w in zip(ps.paths, want):
+        assert int(p["flags"]) == w["flags"], w
+        if w["flags"] & 1:
+            assert int(p["fill_rgba"]) == w["fill"], (hex(int(p["fill_rgba"])), hex(w["fill"]))
+        if w["flags"] & 2:
+            assert int(p["stroke_rgba"]) == w["stroke"] and float(p["stroke_width"]) == pytest.approx(w["width"], rel=1e-6)
+        els = ps.els[int(p["el_begin"]) : int(p["el_end"])]
+        M, g = w["ctm"], w["geom"]
+        if g[0] == "poly":
+            pts = [_apply(M, q) for q in g[1]]
+            assert els["tag"].tolist() == [0] + [1] * (len(pts) - 1) + ([4] if g[2] else [])
+            assert [tuple(r) for r in els["p"][: len(pts), :2].tolist()] == pts
+        elif g[0] == "rect" and g[5] == 0:
+            x, y, ww, hh = g[1:5]
+            pts = [_apply(M, q) for q in ((x, y), (x + ww, y), (x + ww, y + hh), (x, y + hh))]
+            assert els["tag"].tolist() == [0, 1, 1, 1, 4] and [tuple(r) for r in els["p"][:4, :2].tolist()] == pts
+        elif g[0] == "path":
+            ref = _svg_path_elements(g[1])
+            assert [int(t) for t in els["tag"]] == [e[0] for e in ref]
+            for row, e in zip(els, ref):
+                for k in range(len(e[1]) // 2):
+                    q = _apply(M, (e[1][2 * k], e[1][2 * k + 1]))
+                    assert row["p"][2 * k] == pytest.approx(q[0], abs=1e-9) and row["p"][2 * k + 1] == pytest.approx(q[1], abs=1e-9)
+        else:  # ellipse / rounded rect: sample the emitted curves; every sample lies on the transformed outline
+            a, b, c, d, e_, f_ = M
+            det = a * d - b * c
+            inv = [d / det, -b / det, -c / det, a / det, (c * f_ - d * e_) / det, (b * e_ - a * f_) / det]
+            cur = None
+            n_curves = 0
+            for row in els:
+                tag = int(row["tag"])
+                if tag == 0:
+                    cur = (row["p"][0], row["p"][1])
+                    continue
+                if tag == 4:
+                    continue
+                for t in (0.0, 0.25, 0.5, 0.75, 1.0):
+                    q = _apply(inv, _bez(cur, row, t))  # back in the shape's own user space
+                    if g[0] == "ellipse":
+                        r = math.hypot((q[0] - g[1]) / g[3], (q[1] - g[2]) / g[4])
+                        assert abs(r - 1.0) < 3e-4
+                    else:
+                        x, y, ww, hh, rx, ry = g[1:]
+                        dx = max(x + rx - q[0], 0.0, q[0] - (x + ww - rx)) / rx
+                        dy = max(y + ry - q[1], 0.0, q[1] - (y + hh - ry)) / ry
+                        inside_core = dx == 0.0 or dy == 0.0
+                        if inside_core:
+                            assert min(abs(q[0] - x), abs(q[0] - x - ww), abs(q[1] - y), abs(q[1] - y - hh)) < 1e-9
+                        else:
+                            assert abs(math.hypot(dx, dy) - 1.0) < 3e-4
+                n_curves += tag == 3
+                k = {1: 0, 2: 2, 3: 4}[tag]
+                cur = (row["p"][k], row["p"][k + 1])
+            assert n_curves == 4
+    # the reference's reading is unchanged on the Tiger by all of this: see test_tiger_paths_are_pinned
 
 
 def test_tiger_paths_are_pinned(pm):
