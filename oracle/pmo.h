@@ -142,6 +142,9 @@ int64_t pmo_scene_from_paths(uint8_t *buf, size_t cap, const pmo_path *paths, si
                              const pmo_path_el *els, size_t n_els, const double affine[6],
                              uint32_t *n_items_out);
 
+/* Segments a cubic is cut into (kurbo to_quads' n, libm-free: smallest n >= 1 with n^6 >= x). */
+size_t pmo_subdivision_count(double x);
+
 /* src/flatten.rs:10-47 on elements [el_begin, el_end) after `affine`.
  * Writes subpath point counts into sub_counts (cap sub_cap) and points (x,y
  * doubles) into pts (cap pts_cap points).  Returns number of subpaths or -1 if

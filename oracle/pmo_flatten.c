@@ -32,6 +32,23 @@ static double cubic_eval(double p0, double p1, double p2, double p3, double t) {
     return p0 * (mt * mt * mt) + (p1 * (mt * mt * 3.0) + (p2 * (mt * 3.0) + p3 * t) * t) * t;
 }
 
+/* kurbo to_quads: n = ceil((err / max_hypot2)^(1/6)), at least 1.  The 6th root through pow() makes
+ * the count depend on the last ulp of somebody's libm (glibc here, the device's OCML there, Rust's
+ * powf in the reference); the count is an integer property of x, so it is DEFINED without libm:
+ * the smallest n >= 1 with n^6 >= x, n^6 = ((n*n)*(n*n))*(n*n) in binary64 (exact below 2^53,
+ * monotone beyond).  pow() only supplies the starting guess.  Non-finite x: as the cast does. */
+size_t pmo_subdivision_count(double x) {
+    if (!(x > 1.0)) return 1;           /* also NaN */
+    if (x > 1e96) return (size_t)1e16;  /* (inf as usize saturates in Rust; never reached by real paths) */
+    double g = ceil(pow(x, 1.0 / 6.0));
+    uint64_t n = g >= 1.0 ? (uint64_t)g : 1;
+#define P6(v) ((((double)(v)) * ((double)(v))) * (((double)(v)) * ((double)(v))) * (((double)(v)) * ((double)(v))))
+    while (n > 1 && P6(n - 1) >= x) n--;
+    while (P6(n) < x) n++;
+#undef P6
+    return (size_t)n;
+}
+
 int64_t pmo_flatten_path(const pmo_path_el *els, uint32_t el_begin, uint32_t el_end,
                          const double affine[6], double tolerance, uint32_t *sub_counts,
                          size_t sub_cap, double *pts, size_t pts_cap, size_t *n_points_out) {
@@ -92,8 +109,7 @@ int64_t pmo_flatten_path(const pmo_path_el *els, uint32_t el_begin, uint32_t el_
                 double bx = p2x * 3.0 - p3x, by = p2y * 3.0 - p3y;     /* p2x2 */
                 double dx = bx - ax, dy = by - ay;
                 double err = dx * dx + dy * dy;
-                double nf = ceil(pow(err / max_hypot2, 1.0 / 6.0));
-                size_t n = (nf >= 1.0) ? (size_t)nf : 1; /* (… as usize).max(1) */
+                size_t n = pmo_subdivision_count(err / max_hypot2); /* (ceil(x^(1/6)) as usize).max(1) */
                 for (size_t k = 0; k < n; k++) {
                     double t1 = (double)(k + 1) / (double)n;
                     double x = cubic_eval(lx, p1x, p2x, p3x, t1);

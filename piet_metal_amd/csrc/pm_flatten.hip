@@ -74,6 +74,23 @@ __device__ __forceinline__ double CubicEval(double p0, double p1, double p2, dou
     return p0 * (mt * mt * mt) + (p1 * (mt * mt * 3.0) + (p2 * (mt * 3.0) + p3 * t) * t) * t;
 }
 
+// kurbo to_quads: n = ceil(x^(1/6)), at least 1 -- defined without libm so that host, device and
+// reference cannot disagree in the last ulp of pow(): the smallest n >= 1 with n^6 >= x,
+// n^6 = ((n*n)*(n*n))*(n*n) in binary64.  pow() only supplies the starting guess.
+__device__ __forceinline__ uint32_t SubdivisionCount(double x) {
+    if (!(x > 1.0)) return 1u;
+    if (x > 1e54) return 1u << 30;  // (no viewport-sized path gets here; keeps the arithmetic below in range)
+    const double g = ceil(pow(x, 1.0 / 6.0));
+    unsigned long long n = g >= 1.0 ? static_cast<unsigned long long>(g) : 1ull;
+    auto p6 = [](unsigned long long v) {
+        const double d = static_cast<double>(v);
+        return ((d * d) * (d * d)) * (d * d);
+    };
+    while (n > 1 && p6(n - 1) >= x) --n;
+    while (p6(n) < x) ++n;
+    return static_cast<uint32_t>(n);
+}
+
 __global__ void KCount(const pm_path *paths, uint32_t n_paths, const pm_path_el *els, uint32_t n_els, Affine aff,
                        uint32_t *el_npts, uint32_t *el_move, uint32_t *err) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,8 +126,7 @@ __global__ void KCount(const pm_path *paths, uint32_t n_paths, const pm_path_el 
                 const double bx = p2x * 3.0 - p3x, by = p2y * 3.0 - p3y;
                 const double dx = bx - ax, dy = by - ay;
                 const double e = dx * dx + dy * dy;
-                const double nf = ceil(pow(e / max_hypot2, 1.0 / 6.0));
-                n = (nf >= 1.0) ? static_cast<uint32_t>(nf) : 1u;
+                n = SubdivisionCount(e / max_hypot2);
             }
         }
     }

@@ -5,6 +5,22 @@ parity unpinned), the thin-line rule and the Encoder's byte layou
 Cross-checks oracle/pmo_flatten.c + pmo_encoder.c.  Test infrastructure.
 """
 import math
+
+
+def subdivision_count(x):
+    """kurbo to_quads' n = max(1, ceil(x^(1/6))) as an exact integer property of x: the smallest
+    n >= 1 with n^6 >= x (Python integers against the exact rational value of the double x)."""
+    from fractions import Fraction
+
+    if not x > 1.0:
+        return 1
+    fx = Fraction(x)
+    n = max(1, int(round(x ** (1.0 / 6.0))))
+    while n > 1 and (n - 1) ** 6 >= fx:
+        n -= 1
+    while n ** 6 < fx:
+        n += 1
+    return n
 import struct
 
 import numpy as np
@@ -37,7 +53,7 @@ def flatten(els, affine):
             bx, by = p2[0] * 3.0 - p3[0], p2[1] * 3.0 - p3[1]
             dx, dy = bx - ax, by - ay
             err = dx * dx + dy * dy
-            nf = math.ceil(math.pow(err / max_hypot2, 1.0 / 6.0))
+            nf = subdivision_count(err / max_hypot2)
             n = int(nf) if nf >= 1.0 else 1
             for k in range(n):
                 t = (k + 1) / n

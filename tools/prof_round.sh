@@ -13,7 +13,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py"
 WL=${PM_PROF_FLAGS:---no-config5}   # the traced / counted runs hold ONE workload: kernel averages are per configuration
-timeout 900 $BENCH > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 1500 $OUT/bench.json
+timeout 900 $BENCH ${PM_PROF_MAIN:-} > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 1500 $OUT/bench.json
 # the traced run's own JSON line is kept next to the stats: same process, same launches
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --no-cpu-baseline $WL > $OUT/trace.log 2>&1
 grep '^{"metric"' $OUT/trace.log | tail -1 > $OUT/bench_traced.json
