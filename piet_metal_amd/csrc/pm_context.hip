@@ -173,7 +173,7 @@ struct pm_ctx {
     bool fold_clear = true;  // pm_fine_kernel's launch also writes the resolved tiles (no pm_clear_kernel launch)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
     uint32_t heavy_stream = 32, vheavy_stream = 96;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
-    uint32_t coarse_wg_per_cu = 6, fine_wg_per_cu = 4;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
+    uint32_t coarse_wg_per_cu = 5, fine_wg_per_cu = 4;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
 
@@ -915,7 +915,7 @@ pm_ctx *pm_create(int device, int *err) {
         c->streams.push_back(q);
     }
     c->stream = c->streams[0];
-    c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 6, 1, 16));
+    c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 5, 1, 16));
     c->split_mode = static_cast<uint32_t>(EnvInt("PM_FINE_SPLIT", 1, 0, 1));
     c->heavy_stream = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM", 32, 1, 1 << 20));
     c->vheavy_stream = static_cast<uint32_t>(EnvInt("PM_VHEAVY_STREAM", 96, 1, 1 << 20));
