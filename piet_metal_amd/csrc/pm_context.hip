@@ -364,9 +364,9 @@ int EnsureArena(pm_ctx *c) {
     }
     base[need.size()] = static_cast<uint32_t>(total);
     // what StripRowBounds gives a strip row before any item adds to it
-    // (a quarter of headroom: an animation's demand creeps from frame to frame, and re-allocating
-    //  four 100 MB arenas costs milliseconds)
-    const uint64_t alloc_dwords = total > c->arena_cap ? std::min<uint64_t>(0xfffffff0ull, total + total / 4) : c->arena_cap;
+    // (exact for a context's first scene; a quarter of headroom when it has to GROW: an animation's
+    //  demand creeps from frame to frame, and re-allocating four 100 MB arenas costs milliseconds)
+    const uint64_t alloc_dwords = total <= c->arena_cap ? c->arena_cap : (c->arena_cap == 0 ? total : std::min<uint64_t>(0xfffffff0ull, total + total / 4));
     c->sr_empty_dwords = static_cast<uint32_t>((static_cast<uint64_t>(pm::kRecHdrDwords + 3u) * ((c->n_items + 255u) / 256u) + 3u) & ~3ull);
     for (auto &s : c->slot) {
         if (!s.d_arena || total > c->arena_cap) {
