@@ -1,0 +1,434 @@
+// CoarseTile: the tile-level half of tileKernel + TileEncoder for ONE queued tile, run by one wave.
+// Shared by pm_coarse_kernel (stand-alone pass, capture variant) and pm_tile_kernel (coarse + fine
+// fused per tile, pm_fine.hip).  See pm_kernels_common.h for the decomposition.
+#pragma once
+#include "pm_kernels_common.h"
+
+namespace pm {
+namespace {
+
+constexpr uint32_t kWaveCands = 64;  // candidates handled per pass
+constexpr uint32_t kRing = 256;      // >= 64 (one round) + 127 (scan overshoot), power of two
+
+struct CoarseLds {
+    uint32_t ring[kRing];     // indices of the record's segments relevant to this tile
+    uint8_t hidx[kThreads];   // candidates of the record that hit this tile (indices)
+    uint32_t htag[kWaveCands];
+    uint32_t hrgba[kWaveCands];
+    uint32_t haux0[kWaveCands];
+    uint32_t haux1[kWaveCands];
+    uint32_t hrel[kWaveCands];   // relevant segments of the candidate in this tile
+    uint32_t hwoff[kWaveCands];  // index of its first relevant segment (ring position)
+    uint32_t hcnt[kWaveCands];   // stream elements (relevant segments, or 1 pseudo element)
+    uint32_t hrg[kWaveCands];
+    uint32_t hba[kWaveCands];
+    uint32_t hoff[kWaveCands + 1];
+    uint32_t own[64];            // stream position of a round -> candidate that starts there
+    int backdrop[kWaveCands];
+    uint32_t any[kWaveCands];
+};
+
+
+// Returns the number of commands left in the tile's list for the fine stage (0: nothing to
+// interpret -- empty, Bail tile already painted here, or arena overflow).
+template <bool kCapture>
+__device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &L, uint4 *const qentry, const uint4 qe,
+                                               const uint32_t lane, const uint64_t lanes_below) {
+    const uint32_t tile = qe.x;
+    if (qe.y == 0xffffffffu) {  // the command-list arena overflowed (pm_sync re-renders the frame)
+        if (lane == 0) qentry->w = 0;
+        return 0;
+    }
+    Cmd *const out_cmds = P.ptcl + qe.y;  // this tile's private command slots
+    const uint32_t tx = tile % P.tiles_x;
+    const uint32_t ty_rel = tile / P.tiles_x;
+    const uint32_t ty = P.row0 + ty_rel;
+    const int x0 = static_cast<int>(tx * kTileW);
+    const int y0 = static_cast<int>(ty * kTileH);
+    const float fx0 = static_cast<float>(x0), fy0 = static_cast<float>(y0);
+    const float fx1 = static_cast<float>(x0 + static_cast<int>(kTileW));
+    const float fy1 = static_cast<float>(y0 + static_cast<int>(kTileH));
+    const uint32_t tbit = tx & (kStripTiles - 1);
+
+    uint32_t solid_color = 0xffffffffu;  // TileEncoder::solidColor (:74)
+    uint32_t n_pending = 0;              // commands written to the tile's list so far
+    uint32_t list_len = 0;               // logical list length since tileBegin (capture)
+
+    uint32_t rec = qe.z;  // (= striprow_head[sr])
+    while (rec != 0) {
+        // header and mask table sit next to each other: all loads are in flight together
+        const uint4 hdr = *reinterpret_cast<const uint4 *>(P.arena + rec);
+        const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * lane);
+        const uint32_t next = hdr.x;
+        const uint32_t ncand = hdr.y;
+        const uint32_t mask_dwords = (ncand + 3u) & ~3u;
+        const uint32_t *cand_rec = P.arena + rec + kRecHdrDwords + mask_dwords;
+        const uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
+        const float4 *segs = reinterpret_cast<const float4 *>(ct_tab + kCtDwords * ncand);
+        const uint32_t *meta = reinterpret_cast<const uint32_t *>(segs + kChunkSegs * hdr.z);
+        // Worklist of the segments that matter to THIS tile: the record's segment slots are
+        // scanned linearly (2 meta words per lane per step, independent loads) and the slots
+        // carrying this tile's bit are kept, in paint order, in a small LDS ring.
+        const uint32_t n_slots = hdr.w;
+        uint32_t scan_pos = 0;  // next segment to scan
+        uint32_t ring_cnt = 0;  // relevant segments found so far (ring write position)
+        uint32_t rel_done = 0;  // relevant segments owned by earlier candidate passes
+
+        // ---- candidates that hit this tile, in paint order (lane owns 4 consecutive) ------
+        const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+        uint32_t hbits = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (4u * lane + k < ncand && ((mw[k] >> (16 + tbit)) & 1u)) hbits |= 1u << k;
+        const uint32_t hcount = __popc(hbits);
+        const uint32_t hincl = WaveInclusiveScan(hcount);
+        const uint32_t nhit = WaveLast(hincl);
+        if (nhit == 0) {
+            rec = next;
+            continue;
+        }
+        WaveSync();
+        {
+            uint32_t hp = hincl - hcount;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if ((hbits >> k) & 1u) L.hidx[hp++] = static_cast<uint8_t>(4u * lane + k);
+        }
+        WaveSync();
+
+        for (uint32_t cb = 0; cb < nhit; cb += kWaveCands) {
+            const uint32_t nh = min(kWaveCands, nhit - cb);
+            if (lane < nh) {
+                const uint4 *cr = reinterpret_cast<const uint4 *>(cand_rec + kCandDwords * L.hidx[cb + lane]);
+                const uint4 a = cr[0];
+                const uint4 b = cr[1];
+                L.htag[lane] = a.x & 0xffffu;
+                L.hrgba[lane] = a.y;
+                L.haux0[lane] = a.z;
+                L.haux1[lane] = a.w;
+                const uint32_t ct = ct_tab[kCtDwords * L.hidx[cb + lane] + tbit];
+                const uint32_t rel = ct & kCtCountMask;
+                L.hrel[lane] = rel;
+                L.hcnt[lane] = rel ? rel : 1u;  // circle / backdrop-only fill: one pseudo element
+                L.hrg[lane] = b.z;
+                L.hba[lane] = b.w;
+                L.backdrop[lane] = static_cast<int>(ct) >> kCtShift;
+                L.any[lane] = 0;
+            }
+            WaveSync();
+            uint32_t stream_len, pass_rel;
+            {
+                const uint32_t v = (lane < nh) ? L.hcnt[lane] : 0u;
+                const uint32_t r = (lane < nh) ? L.hrel[lane] : 0u;
+                const uint32_t incl = WaveInclusiveScan(v);
+                const uint32_t rincl = WaveInclusiveScan(r);
+                if (lane < nh) {
+                    L.hoff[lane] = incl - v;
+                    L.hwoff[lane] = rel_done + rincl - r;  // first relevant segment of the candidate
+                }
+                stream_len = WaveLast(incl);
+                pass_rel = WaveLast(rincl);
+                if (lane == 0) L.hoff[nh] = stream_len;
+            }
+            WaveSync();
+
+            // ---- stream rounds: phase-2 tests -> ordered commands --------------------------
+            uint32_t own_carry = 0;  // owner of the last element of the previous round
+            for (uint32_t e0 = 0; e0 < stream_len; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                // Owner of every element without a search: each candidate marks the stream
+                // position where it starts, a prefix maximum spreads the marks (owners only
+                // grow along the stream).
+                L.own[lane] = 0;
+                WaveSync();
+                if (lane < nh) {
+                    const uint32_t p = L.hoff[lane] - e0;
+                    if (p < 64u) L.own[p] = lane;
+                }
+                WaveSync();
+                const uint32_t owner = max(WaveInclusiveMax(L.own[lane]), own_carry);
+                own_carry = WaveLast(owner);
+                uint32_t n_em = 0;   // commands of this stream element (0..2)
+                Cmd c0, c1;
+                c0.tag = 0; c1.tag = 0;
+                bool is_last = false;
+                bool draws = false;  // any of this lane's commands clears solidColor
+                uint32_t c = 0, ctag = 0;
+                if (e < stream_len) {
+                    c = owner;
+                    const uint32_t k = e - L.hoff[c];
+                    is_last = (k + 1 == L.hcnt[c]);
+                    ctag = L.htag[c];
+                    if (ctag == kItemCircle) {  // :218-222
+                        n_em = 1;
+                        c0.tag = kCmdCircle;
+                        c0.body[0] = 0;
+                        c0.body[1] = L.haux0[c];
+                        c0.body[2] = L.haux1[c];
+                        c0.body[3] = 0;
+                        c0.body[4] = 0;
+                        draws = true;
+                    }
+                }
+                // make sure the ring holds every relevant segment this round needs
+                {
+                    const bool wants = (e < stream_len) && ctag != kItemCircle && L.hrel[c] != 0;
+                    const uint64_t wm = __ballot(wants);
+                    if (wm) {
+                        const uint32_t my_need = wants ? (L.hwoff[c] + (e - L.hoff[c]) + 1u) : 0u;
+                        const uint32_t need = WaveAtHighest(my_need, wm);
+                        while (ring_cnt < need && scan_pos < n_slots) {
+                            const uint32_t cnt_x = n_slots;
+                            const uint32_t st_x = 0;
+                            const uint32_t i0 = scan_pos + 2u * lane;
+                            uint2 mv = make_uint2(0u, 0u);
+                            if (i0 < cnt_x) mv = *reinterpret_cast<const uint2 *>(meta + st_x + i0);
+                            const uint32_t ma[2] = {mv.x, mv.y};
+                            uint32_t rb = 0;
+#pragma unroll
+                            for (uint32_t q = 0; q < 2; ++q)
+                                if (i0 + q < cnt_x && ((ma[q] >> tbit) & 1u)) rb |= 1u << q;
+                            const uint32_t rc = __popc(rb);
+                            const uint32_t rincl = WaveInclusiveScan(rc);
+                            uint32_t wp = ring_cnt + rincl - rc;
+#pragma unroll
+                            for (uint32_t q = 0; q < 2; ++q)
+                                if ((rb >> q) & 1u) L.ring[(wp++) & (kRing - 1u)] = st_x + i0 + q;
+                            ring_cnt += WaveLast(rincl);
+                            scan_pos += 128u;
+                        }
+                        WaveSync();
+                    }
+                }
+                if (e < stream_len) {
+                    if (ctag == kItemFill && L.hrel[c] == 0) {
+                        // backdrop-only fill: nothing to test, the closing command decides
+                    } else if (ctag != kItemCircle) {
+                        const uint32_t k = e - L.hoff[c];
+                        const float4 s = segs[L.ring[(L.hwoff[c] + k) & (kRing - 1u)]];
+                        const float a = s.w - s.y;
+                        const float b = s.x - s.z;
+                        const float cc = -(a * s.x + b * s.y);
+                        if (ctag == kItemFill) {  // :302-357
+                            const float xmin = fminf(s.x, s.z), ymin = fminf(s.y, s.w);
+                            const float xmax = fmaxf(s.x, s.z), ymax = fmaxf(s.y, s.w);
+                            const float left = a * fx0;
+                            const float right = a * fx1;
+                            const float ytop = fmaxf(fy0, ymin);
+                            const float ybot = fminf(fy1, ymax);
+                            const float top = b * ytop;
+                            const float bot = b * ybot;
+                            const float s00 = Sgn(top + left + cc);
+                            const float s01 = Sgn(top + right + cc);
+                            const float s10 = Sgn(bot + left + cc);
+                            const float s11 = Sgn(bot + right + cc);
+                            // (the backdrop term of :326-333 was summed by the binning kernel)
+                            const bool straddle = Straddles(s00, s01, s10, s11);
+                            if (xmin < fx0 && xmax > fx0) {
+                                const float tt = (s.x - fx0) / b;
+                                const float y_edge = s.y + (s.w - s.y) * tt;  // mix(start.y, end.y, tt)
+                                if (y_edge >= fy0 && y_edge < fy1) {
+                                    n_em = 2;
+                                    c0.tag = kCmdFillEdge;
+                                    c0.body[0] = static_cast<uint32_t>(static_cast<int>(s00));
+                                    c0.body[1] = __float_as_uint(y_edge);
+                                    c0.body[2] = 0; c0.body[3] = 0; c0.body[4] = 0;
+                                    c1.tag = kCmdFill;
+                                    c1.body[0] = 0;
+                                    if (b > 0.0f) {
+                                        c1.body[1] = __float_as_uint(s.x); c1.body[2] = __float_as_uint(s.y);
+                                        c1.body[3] = __float_as_uint(fx0); c1.body[4] = __float_as_uint(y_edge);
+                                    } else {
+                                        c1.body[1] = __float_as_uint(fx0); c1.body[2] = __float_as_uint(y_edge);
+                                        c1.body[3] = __float_as_uint(s.z); c1.body[4] = __float_as_uint(s.w);
+                                    }
+                                } else if (straddle) {
+                                    n_em = 1;
+                                }
+                            } else if (straddle && xmin < fx1 && xmax > fx0) {
+                                n_em = 1;
+                            }
+                            if (n_em == 1) {
+                                c0.tag = kCmdFill;
+                                c0.body[0] = 0;
+                                c0.body[1] = __float_as_uint(s.x); c0.body[2] = __float_as_uint(s.y);
+                                c0.body[3] = __float_as_uint(s.z); c0.body[4] = __float_as_uint(s.w);
+                            }
+                            if (n_em) atomicOr(&L.any[c], 1u);
+                        } else {
+                            // Line (:223-247) and Poly phase 2 (:406-440) share the inflated-box test
+                            const float width = __uint_as_float(L.haux0[c]);
+                            const float hw = 0.5f * width + 0.5f;
+                            bool pass = true;
+                            if (ctag == kItemPoly) {
+                                const float xmin = fminf(s.x, s.z), ymin = fminf(s.y, s.w);
+                                const float xmax = fmaxf(s.x, s.z), ymax = fmaxf(s.y, s.w);
+                                pass = ymax > fy0 - hw && ymin < fy1 + hw && xmax > fx0 - hw && xmin < fx1 + hw;
+                            }
+                            if (pass) {
+                                const float left = a * (fx0 - hw);
+                                const float right = a * (fx1 + hw);
+                                const float top = b * (fy0 - hw);
+                                const float bot = b * (fy1 + hw);
+                                const float s00 = Sgn(top + left + cc);
+                                const float s01 = Sgn(top + right + cc);
+                                const float s10 = Sgn(bot + left + cc);
+                                const float s11 = Sgn(bot + right + cc);
+                                pass = Straddles(s00, s01, s10, s11);
+                            }
+                            if (pass) {
+                                n_em = 1;
+                                c0.tag = kCmdLine;
+                                c0.body[0] = 0;
+                                c0.body[1] = __float_as_uint(s.x); c0.body[2] = __float_as_uint(s.y);
+                                c0.body[3] = __float_as_uint(s.z); c0.body[4] = __float_as_uint(s.w);
+                                draws = true;
+                                atomicOr(&L.any[c], 1u);
+                            }
+                        }
+                    }
+                }
+                WaveSync();  // per-candidate accumulators complete for elements <= this round
+
+                // ---- per-item closing command (DrawFill / Solid / Stroke) --------------------
+                bool has_fin = false;
+                bool opaque_solid = false;
+                Cmd fin;
+                fin.tag = 0;
+                fin.body[0] = fin.body[1] = fin.body[2] = fin.body[3] = fin.body[4] = 0;
+                if (is_last) {
+                    const uint32_t frgba = L.hrgba[c];
+                    const uint32_t rg = L.hrg[c], ba = L.hba[c];
+                    if (ctag == kItemFill) {  // :359-363
+                        const int backdrop = L.backdrop[c];
+                        const uint32_t even_odd = L.haux0[c] & kFillEvenOdd;  // PietFill.flags (extension)
+                        // (closing commands are built by the writers pm_layoutgen emits from the layout description)
+                        if (L.any[c]) {
+                            has_fin = true;
+                            fin = gen::ptcl::Cmd_DrawFill_pack(backdrop, frgba, rg, ba, even_odd);
+                            draws = true;
+                        } else if (even_odd ? (backdrop & 1) != 0 : backdrop != 0) {  // wholly inside: non-zero / odd winding
+                            has_fin = true;
+                            fin = gen::ptcl::Cmd_Solid_pack(frgba, rg, ba);
+                            opaque_solid = (frgba & 0xff000000u) == 0xff000000u;  // :132
+                        }
+                    } else if (ctag == kItemPoly || ctag == kItemLine) {  // :441-443, :243
+                        if (L.any[c]) {
+                            has_fin = true;
+                            fin = gen::ptcl::Cmd_Stroke_pack(0.5f * __uint_as_float(L.haux0[c]), frgba, rg, ba);
+                            draws = true;
+                        }
+                    }
+                }
+                const uint32_t lane_total = n_em + (has_fin ? 1u : 0u);  // 0..3
+
+                // ---- wave-wide slots (ballots + popcounts, no scan network) ---------------------
+                const uint64_t m0 = __ballot((lane_total & 1u) != 0);
+                const uint64_t m1 = __ballot((lane_total & 2u) != 0);
+                const uint32_t pos = static_cast<uint32_t>(__popcll(m0 & lanes_below)) + 2u * static_cast<uint32_t>(__popcll(m1 & lanes_below));
+                const uint32_t round_total = static_cast<uint32_t>(__popcll(m0)) + 2u * static_cast<uint32_t>(__popcll(m1));
+                if (round_total == 0) continue;  // uniform
+                const uint64_t ms = __ballot(opaque_solid);
+                const uint64_t md = __ballot(draws);
+                int last_solid = -1, last_draw = -1;
+                if (ms) last_solid = static_cast<int>(WaveAtHighest(pos + n_em, ms));
+                if (md) last_draw = static_cast<int>(WaveAtHighest(pos + lane_total, md)) - 1;
+
+                uint32_t base;        // list slot of round position 0 (may be "negative")
+                uint32_t first_kept;  // round positions below this are dropped
+                if (last_solid >= 0) {
+                    // TileEncoder::encodeSolid with an opaque colour (:132-135): dst = tileBegin
+                    first_kept = static_cast<uint32_t>(last_solid);
+                    n_pending = 0;
+                    list_len = 0;
+                    base = 0u - first_kept;
+                } else {
+                    first_kept = 0;
+                    base = n_pending;
+                }
+                {
+                    uint32_t p = pos;
+                    if (n_em >= 1) {
+                        if (p >= first_kept) {
+                            out_cmds[base + p] = c0;
+                            if (kCapture) {
+                                const uint32_t li = list_len + p - first_kept;
+                                if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = c0;
+                            }
+                        }
+                        ++p;
+                    }
+                    if (n_em == 2) {
+                        if (p >= first_kept) {
+                            out_cmds[base + p] = c1;
+                            if (kCapture) {
+                                const uint32_t li = list_len + p - first_kept;
+                                if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = c1;
+                            }
+                        }
+                        ++p;
+                    }
+                    if (has_fin && p >= first_kept) {
+                        out_cmds[base + p] = fin;
+                        if (kCapture) {
+                            const uint32_t li = list_len + p - first_kept;
+                            if (li < P.dbg_max) {
+                                // capture in the reference's layout: no pre-converted colour words
+                                Cmd ref = fin;
+                                if (fin.tag == kCmdSolid) { ref.body[1] = 0; ref.body[2] = 0; }
+                                else { ref.body[2] = 0; ref.body[3] = 0; }
+                                P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = ref;
+                            }
+                        }
+                    }
+                }
+                n_pending = base + round_total;
+                list_len += round_total - first_kept;
+                if (last_solid >= 0) solid_color = WaveAtHighest(fin.body[0], ms);
+                if (last_draw > last_solid) solid_color = 0;  // encodeCircle/Line/Stroke/DrawFill (:81,:90,:99,:124)
+                WaveSync();
+            }
+            rel_done += pass_rel;
+        }
+        rec = next;
+    }
+
+    // ---- TileEncoder::end() (:144-151): Bail tiles are finished here (composite :34-44) ----
+    if (lane == 0) {
+        P.tile_ncmd[tile] = solid_color ? 0u : n_pending;
+        qentry->w = solid_color ? 0u : n_pending;  // what pm_fine_kernel reads
+    }
+    if (solid_color != 0) {
+        // the tile is one opaque colour, bytes as stored: 64 lanes x 16 B = the whole tile
+        const uint32_t pxi = static_cast<uint32_t>(x0) + (lane & 3u) * 4u;
+        const uint32_t prow = lane >> 2;
+        const uint32_t pyi = static_cast<uint32_t>(y0) + prow;
+        if (pyi < P.height && pxi < P.width) {
+            uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
+            if (pxi + 4 <= P.width && P.fb_vec16) {
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(solid_color, solid_color, solid_color, solid_color);
+            } else {
+                for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = solid_color;
+            }
+        }
+    }
+    if (kCapture && lane == 0) {
+        // list as the reference leaves it: {Bail} or cmds + End
+        P.dbg_solid[tile] = solid_color;
+        Cmd tail;
+        tail.body[0] = tail.body[1] = tail.body[2] = tail.body[3] = tail.body[4] = 0;
+        if (solid_color != 0) {
+            P.dbg_counts[tile] = 1;
+            tail.tag = kCmdBail;
+            if (P.dbg_max > 0) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max] = tail;
+        } else {
+            P.dbg_counts[tile] = list_len + 1;
+            tail.tag = kCmdEnd;
+            if (list_len < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + list_len] = tail;
+        }
+    }
+    return solid_color ? 0u : n_pending;
+}
+
+}  // namespace
+}  // namespace pm

@@ -171,6 +171,7 @@ struct pm_ctx {
     hipStream_t stream = nullptr;      // == streams[0]: scene upload, flatten, index, debug replays
     std::vector<hipStream_t> streams;  // frame N runs on streams[N % n]; stream == streams[0]
     bool fold_clear = true;  // pm_fine_kernel's launch also writes the resolved tiles (no pm_clear_kernel launch)
+    bool fused = true;       // pm_fine_kernel<true>: each tile's list is built and interpreted by the same wave(s)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
     uint32_t heavy_stream = 32, vheavy_stream = 96;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
     uint32_t coarse_wg_per_cu = 5, fine_wg_per_cu = 4;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
@@ -613,8 +614,8 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     const uint32_t n_striprows = BandRows(c) * c->strips_x;
     pm::LaunchBin(p, q, t[0], t[1]);
     if (!c->fold_clear) pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // the resolved tiles' pixels (needs tile_state)
-    pm::LaunchCoarse(p, CoarseGrid(c), false, q, t[4], t[5]);
-    pm::LaunchFine(p, c->fold_clear ? n_striprows : 0u, q, t[6], t[7]);  // (+ the resolved tiles' pixels)
+    if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, q, t[4], t[5]);
+    pm::LaunchFine(p, c->fold_clear ? n_striprows : 0u, c->fused, q, t[6], t[7]);  // (+ the resolved tiles' pixels)
     PM_TRY(hipGetLastError());
     Submitted(c, si, p, q);
     s->user_stream = user_stream != nullptr && std::find(c->streams.begin(), c->streams.end(), q) == c->streams.end();
@@ -920,6 +921,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->heavy_stream = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM", 32, 1, 1 << 20));
     c->vheavy_stream = static_cast<uint32_t>(EnvInt("PM_VHEAVY_STREAM", 96, 1, 1 << 20));
     c->fold_clear = EnvInt("PM_FOLD_CLEAR", 1, 0, 1) != 0;
+    c->fused = EnvInt("PM_FUSED", 1, 0, 1) != 0;
     c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 4, 1, 16));
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -1235,14 +1237,14 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             if ((r = BuildParams(c, s, s->d_fb, c->fb_stride, &p)) != PM_OK) return r;
             // each dispatch carries its own begin / end events: pure kernel durations
             pm::LaunchBin(p, c->stream, c->ev[0], c->ev[1]);
-            pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream, c->ev[2], c->ev[3]);
-            pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->stream, c->ev[4], c->ev[5]);
+            if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream, c->ev[2], c->ev[3]);
+            pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->fused, c->stream, c->ev[4], c->ev[5]);
             if (!c->fold_clear) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream, c->ev[6], c->ev[7]);
             PM_TRY(hipStreamSynchronize(c->stream));
             Submitted(c, si, p, c->stream);
             float t1 = 0, t2 = 0, t3 = 0, t4 = 0;
             PM_TRY(hipEventElapsedTime(&t1, c->ev[0], c->ev[1]));
-            PM_TRY(hipEventElapsedTime(&t2, c->ev[2], c->ev[3]));
+            if (!c->fused) PM_TRY(hipEventElapsedTime(&t2, c->ev[2], c->ev[3]));
             PM_TRY(hipEventElapsedTime(&t3, c->ev[4], c->ev[5]));
             if (!c->fold_clear) PM_TRY(hipEventElapsedTime(&t4, c->ev[6], c->ev[7]));
             a1 += t1;
@@ -1285,6 +1287,7 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
         for (int i = 0; i < iters && e == hipSuccess && r == PM_OK; ++i)
             for (int k = 0; k < 4 && e == hipSuccess; ++k) {
                 if (k == 1 && c->fold_clear) continue;  // no separate clear launch
+                if (k == 2 && c->fused) continue;       // no separate coarse launch
                 float t = 0;
                 e = hipEventElapsedTime(&t, tev[static_cast<size_t>(i) * 8 + 2 * k], tev[static_cast<size_t>(i) * 8 + 2 * k + 1]);
                 acc[k] += t;
@@ -1346,9 +1349,14 @@ int pm_debug_frame_timeline(pm_ctx *c, int iters, float *out6) {
         r = Enqueue(c, nullptr, c->fb_stride, nullptr, tev);
         if (r == PM_OK) r = SyncAll(c);
         float v[6] = {0, 0, 0, 0, 0, 0};
-        if (r == PM_OK && hipEventElapsedTime(&v[0], tev[0], tev[1]) == hipSuccess && hipEventElapsedTime(&v[1], tev[1], tev[4]) == hipSuccess &&
-            hipEventElapsedTime(&v[2], tev[4], tev[5]) == hipSuccess && hipEventElapsedTime(&v[3], tev[5], tev[6]) == hipSuccess &&
-            hipEventElapsedTime(&v[4], tev[6], tev[7]) == hipSuccess && hipEventElapsedTime(&v[5], tev[0], tev[7]) == hipSuccess)
+        bool ok = r == PM_OK && hipEventElapsedTime(&v[0], tev[0], tev[1]) == hipSuccess &&
+                  hipEventElapsedTime(&v[4], tev[6], tev[7]) == hipSuccess && hipEventElapsedTime(&v[5], tev[0], tev[7]) == hipSuccess;
+        if (ok && c->fused)  // bin, gap, (no coarse launch), fine
+            ok = hipEventElapsedTime(&v[1], tev[1], tev[6]) == hipSuccess;
+        else if (ok)
+            ok = hipEventElapsedTime(&v[1], tev[1], tev[4]) == hipSuccess && hipEventElapsedTime(&v[2], tev[4], tev[5]) == hipSuccess &&
+                 hipEventElapsedTime(&v[3], tev[5], tev[6]) == hipSuccess;
+        if (ok)
             for (int k = 0; k < 6; ++k) col[k].push_back(v[k]);
     }
     for (auto &v : tev)
@@ -1558,8 +1566,8 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
         hipError_t e = hipSuccess;
         pm::LaunchBin(p, c->stream);
         if (!c->fold_clear) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
-        pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
-        pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->stream);
+        if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
+        pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->fused, c->stream);
         p.dbg_bin = nullptr;
         Submitted(c, si, p, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1589,12 +1597,12 @@ int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_sl
     if (n_slots) *n_slots = slots;
     if (slots > max_slots) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;
-    PM_TRY(hipMalloc(&d, std::max<size_t>(slots, 1) * 6 * sizeof(unsigned long long)));
+    PM_TRY(hipMalloc(&d, std::max<size_t>(slots, 1) * 8 * sizeof(unsigned long long)));
     pm::FrameParams p = s->params;
     p.dbg_time = d;
-    pm::LaunchFine(p, 0u, c->stream);
+    pm::LaunchFine(p, 0u, c->fused, c->stream);  // (the fused kernel rebuilds the same lists: idempotent)
     hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(out, d, slots * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out, d, slots * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return HipFail(e, "tile timeline");
     return PM_OK;

@@ -137,6 +137,6 @@ void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t
                   hipEvent_t t1 = nullptr);
 void LaunchCoverage(const FrameParams &p, uint32_t n_tiles, const uint32_t *tile_solid, float *out, uint32_t out_stride, hipStream_t stream);
 // clear_blocks: strip rows whose resolved tiles the launch also writes (0: pm_clear_kernel did)
-void LaunchFine(const FrameParams &p, uint32_t clear_blocks, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+void LaunchFine(const FrameParams &p, uint32_t clear_blocks, bool fused, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 }  // namespace pm

@@ -1,6 +1,7 @@
 // pm_fine_kernel (+ pm_clear_kernel): renderKernel and the composite
 // (see pm_kernels_common.h for the decomposition and the rules shared by the three files)
 #include "pm_kernels_common.h"
+#include "pm_coarse_tile.h"
 
 namespace pm {
 
@@ -9,7 +10,7 @@ namespace pm {
 // runs next to pm_coarse_kernel / pm_fine_kernel, which write the other tiles.
 // =====================================================================================
 __device__ __forceinline__ void ClearStripRow(const FrameParams &P, uint32_t striprow) {
-    const uint32_t lane = LaneId(), wave = threadIdx.x >> 6;
+    const uint32_t lane = LaneId(), wave = WaveId();
     const uint32_t strip = striprow % P.strips_x;
     const uint32_t row_rel = striprow / P.strips_x;
     const uint32_t t = lane >> 2;  // tile of this lane's 4 pixels
@@ -96,16 +97,27 @@ constexpr uint32_t kSpChunk = 64;     // commands staged per chunk
 constexpr uint32_t kMaxFrag = 64;     // fragment slots per wave (one step of pass 1 adds <= 64)
 constexpr uint32_t kAlphaSlots = 16;  // workgroup mode: items evaluated ahead per round
 
+// Per wave: the staged chunk and the fragment region of its Fills.  The fused kernel builds the
+// tile's list first (CoarseTile) in the same bytes.
+struct WaveFineLds {
+    Cmd cmds[kSpChunk];
+    float4 fparam[kMaxFrag];        // {tx, ty, wx - wy, bits(command index)}
+    uint2 contrib[kMaxFrag][4];     // 16 binary16 contributions per fragment (x = 0..15)
+    uint8_t fill_ix[kSpChunk];      // indices of the chunk's Fill commands, in order
+};
+union WaveLds {
+    WaveFineLds f;
+    CoarseLds c;
+};
+
 struct SparseLds {
-    Cmd cmds[kWaves][kSpChunk];
-    float4 fparam[kWaves * kMaxFrag];     // {tx, ty, wx - wy, bits(command index)}
-    uint2 contrib[kWaves * kMaxFrag][4];  // 16 binary16 contributions per fragment (x = 0..15)
+    WaveLds w[kWaves];
     // workgroup mode (tiles with long lists):
     uint2 alpha[kAlphaSlots][64];         // per item: 256 binary16 alphas, pixel-linear (row * 16 + x)
     uint2 rec[kSpChunk];                  // per item of the chunk: its colour {r | g << 16, b | a << 16} (binary16)
     uint2 carry_sa[2][64];                // signedArea / distance state of an item cut by the chunk boundary
     float4 carry_df[2][64];               //   (two copies, alternating per chunk)
-    uint8_t fill_ix[kWaves][kSpChunk];    // indices of the chunk's Fill commands, in order
+    uint32_t wg_ncmd[2];                  // fused kernel: list length found by wave 0 (alternating per pass)
 };
 static_assert(sizeof(SparseLds) <= 40960, "four workgroups per CU");
 
@@ -128,7 +140,7 @@ __device__ __forceinline__ _Float16 FillContribution(float fsx, float fex, float
 // One step of pass 1: the Fill commands [pos, pos + 4) of the chunk's Fill list (those below
 // `limit`) x 16 rows.  Live pairs get the next fragment slots of this wave's region; returns
 // false (and writes nothing) if the region cannot take them.
-__device__ __forceinline__ bool FillStep(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t limit, uint32_t pos, uint32_t rb,
+__device__ __forceinline__ bool FillStep(WaveFineLds &W, Cmd *cmds, const uint8_t *fill_ix, uint32_t limit, uint32_t pos,
                                          uint32_t &nfrag, uint32_t y0) {
     const uint32_t lane = LaneId();
     const uint32_t q = lane >> 4, row = lane & 15u;
@@ -146,25 +158,25 @@ __device__ __forceinline__ bool FillStep(SparseLds &S, Cmd *cmds, const uint8_t 
     if (live) {
         const float tx = (wx - sy) / (ey - sy);
         const float ty = (wy - sy) / (ey - sy);
-        S.fparam[rb + nfrag + RankBelow(mask)] = make_float4(tx, ty, wx - wy, __uint_as_float(ci));
+        W.fparam[nfrag + RankBelow(mask)] = make_float4(tx, ty, wx - wy, __uint_as_float(ci));
     }
     if (row == 0 && valid) {
         const uint32_t gm = static_cast<uint32_t>(mask >> (16u * q)) & 0xffffu;
-        const uint32_t gb = rb + nfrag + static_cast<uint32_t>(__popcll(mask & ((1ull << (16u * q)) - 1ull)));
+        const uint32_t gb = nfrag + static_cast<uint32_t>(__popcll(mask & ((1ull << (16u * q)) - 1ull)));
         cmds[ci].body[0] = gm | (gb << 16);
     }
     nfrag += static_cast<uint32_t>(__popcll(mask));
     return true;
 }
 
-// Pass 2 over this wave's fragments [rb, rb + nfrag)
-__device__ __forceinline__ void FillPass2(SparseLds &S, const Cmd *cmds, uint32_t rb, uint32_t nfrag, uint32_t x0) {
+// Pass 2 over this wave's fragments [0, nfrag)
+__device__ __forceinline__ void FillPass2(WaveFineLds &W, const Cmd *cmds, uint32_t nfrag, uint32_t x0) {
     const uint32_t lane = LaneId();
 #pragma unroll 1
     for (uint32_t f0 = 0; f0 < nfrag; f0 += 16u) {
         const uint32_t f = f0 + (lane >> 2), g = lane & 3u;
         if (f < nfrag) {
-            const float4 p = S.fparam[rb + f];
+            const float4 p = W.fparam[f];
             const uint32_t ci = __float_as_uint(p.w);
             const float fsx = __uint_as_float(cmds[ci].body[1]), fex = __uint_as_float(cmds[ci].body[3]);
             const float px0 = static_cast<float>(x0 + 4u * g);
@@ -174,7 +186,7 @@ __device__ __forceinline__ void FillPass2(SparseLds &S, const Cmd *cmds, uint32_
             uint2 v;
             v.x = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[0])) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[1])) << 16);
             v.y = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[2])) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[3])) << 16);
-            S.contrib[rb + f][g] = v;
+            W.contrib[f][g] = v;
         }
     }
 }
@@ -183,16 +195,16 @@ __device__ __forceinline__ void FillPass2(SparseLds &S, const Cmd *cmds, uint32_
 // as the wave's fragment region takes.  Returns the ordinal of the first Fill NOT covered.
 __device__ __forceinline__ uint32_t PrepareFills(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t nfill, uint32_t from,
                                                  uint32_t x0, uint32_t y0) {
-    const uint32_t rb = (threadIdx.x >> 6) * kMaxFrag;
+    WaveFineLds &W = S.w[WaveId()].f;
     uint32_t nfrag = 0;
     uint32_t pos = from;
 #pragma unroll 1
     while (pos < nfill) {  // (the first step always fits: it adds at most 64)
-        if (!FillStep(S, cmds, fill_ix, nfill, pos, rb, nfrag, y0)) break;
+        if (!FillStep(W, cmds, fill_ix, nfill, pos, nfrag, y0)) break;
         pos += 4u;
     }
     WaveSync();
-    FillPass2(S, cmds, rb, nfrag, x0);
+    FillPass2(W, cmds, nfrag, x0);
     WaveSync();
     return min(pos, nfill);
 }
@@ -284,7 +296,7 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 const uint32_t hdr = cmds[i].body[0];  // row mask | first fragment << 16 (pass 1)
                 if ((hdr >> row) & 1u) {
                     const uint32_t f = (hdr >> 16) + static_cast<uint32_t>(__popc(hdr & ((1u << row) - 1u)));
-                    const uint2 v = S.contrib[f][g];
+                    const uint2 v = S.w[WaveId()].f.contrib[f][g];
                     st.sa01 = st.sa01 + Half2FromBits(v.x);
                     st.sa23 = st.sa23 + Half2FromBits(v.y);
                 }
@@ -363,7 +375,7 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const u
             const uint32_t hdr = cmds[i].body[0];
             if ((hdr >> row) & 1u) {
                 const uint32_t f = (hdr >> 16) + static_cast<uint32_t>(__popc(hdr & ((1u << row) - 1u)));
-                const uint2 v = S.contrib[f][g];
+                const uint2 v = S.w[WaveId()].f.contrib[f][g];
                 sa01 = sa01 + Half2FromBits(v.x);
                 sa23 = sa23 + Half2FromBits(v.y);
             }
@@ -393,7 +405,7 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const u
 }
 
 struct PhaseTicks {
-    unsigned long long a = 0, b = 0;
+    unsigned long long a = 0, b = 0, c = 0;
 };
 
 // One staged chunk (n commands, parity = chunk index & 1) of a tile rendered by the workgroup;
@@ -401,7 +413,7 @@ struct PhaseTicks {
 template <bool kProf>
 __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *fill_ix, uint32_t n, uint32_t parity, uint32_t x0,
                                               uint32_t y0, uint32_t pix, PixelRGB &st, PhaseTicks &prof) {
-    const uint32_t lane = LaneId(), wave = threadIdx.x >> 6;
+    const uint32_t lane = LaneId(), wave = WaveId();
     const uint32_t tag = lane < n ? cmds[lane].tag : 0u;
     const uint64_t fm = __ballot(tag == kCmdFill);
     const uint64_t bm = __ballot(tag == kCmdDrawFill || tag == kCmdStroke || tag == kCmdSolid || tag == kCmdCircle);
@@ -527,13 +539,18 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
 // Fill evaluation (PrepareFills) and item-parallel rendering of the tiles with long lists
 // (RenderChunkWG).  Persistent grid; the four waves of a workgroup take four consecutive slots of
 // the same pass, and a tile with a long list owns four aligned slots, i.e. exactly one workgroup.
+//
+// kFused: the wave (or, for a long list, wave 0 of the workgroup) first builds the tile's list with
+// CoarseTile -- pm_coarse_kernel's body -- and interprets it straight away: no launch boundary
+// between the two stages, and the list is read back while it is still in L2.
+template <bool kFused>
 __global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
     __shared__ SparseLds S;
     if (blockIdx.x >= P.fine_grid) {
         ClearStripRow(P, blockIdx.x - P.fine_grid);
         return;
     }
-    const uint32_t lane = LaneId(), wave = threadIdx.x >> 6;
+    const uint32_t lane = LaneId(), wave = WaveId();
     uint32_t cls_end[kClasses];  // running totals of the class queues (longest lists first)
     {
         uint32_t run = 0;
@@ -573,21 +590,43 @@ __global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
     auto pass_slot = [&](uint32_t pass) -> uint32_t {
         return pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
     };
+    const uint64_t lanes_below = (1ull << lane) - 1ull;
     uint32_t slot = pass_slot(0);
     uint4 qe = make_uint4(0u, 0u, 0u, 0u);
-    if (slot < n_slots) qe = P.queue[slot_entry(slot)];
+    uint32_t qix = 0;
+    if (slot < n_slots) {
+        qix = slot_entry(slot);
+        qe = P.queue[qix];
+    }
     for (uint32_t pass = 0; pass * n_waves < n_slots; ++pass) {
         const uint32_t cur_slot = slot;
         const uint4 cur = qe;
+        uint4 *const qentry = P.queue + qix;
         slot = pass_slot(pass + 1u);
-        if ((pass + 1u) * n_waves < n_slots && slot < n_slots) qe = P.queue[slot_entry(slot)];
+        if ((pass + 1u) * n_waves < n_slots && slot < n_slots) {
+            qix = slot_entry(slot);
+            qe = P.queue[qix];
+        }
         if (cur_slot >= n_slots) continue;
         const bool wg_mode = cur_slot < s_h && sh != 0;  // uniform over the workgroup (slots are aligned)
         const uint32_t tile = cur.x;
         unsigned long long t_begin = 0;
         PhaseTicks prof;
         if (P.dbg_time) t_begin = wall_clock64();
-        const uint32_t n_cmd = cur.w;
+        uint32_t n_cmd = cur.w;
+        if (kFused) {
+            // (wave 0 of a workgroup-mode tile has wave == 0: its region is S.w[0] either way)
+            if (!wg_mode || wave == 0) n_cmd = CoarseTile<false>(P, S.w[wave].c, qentry, cur, lane, lanes_below);
+            if (wg_mode) {
+                if (wave == 0 && lane == 0) S.wg_ncmd[pass & 1u] = n_cmd;
+                __syncthreads();  // (workgroup-scope release/acquire: the list wave 0 wrote is visible)
+                n_cmd = S.wg_ncmd[pass & 1u];
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's list stores before its loads
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            if (P.dbg_time) prof.c = wall_clock64();
+        }
         if (n_cmd != 0) {  // 0: the coarse kernel found one opaque colour and wrote it
             const uint32_t *src = reinterpret_cast<const uint32_t *>(P.ptcl + cur.y);
             const uint32_t tx = tile % P.tiles_x;
@@ -612,14 +651,14 @@ __global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
                     __syncthreads();  // the previous chunk (or tile) is done with the shared arrays
                     {
                         const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
-                        uint2 *l = reinterpret_cast<uint2 *>(S.cmds[0]);
+                        uint2 *l = reinterpret_cast<uint2 *>(S.w[0].f.cmds);
                         for (uint32_t w = threadIdx.x; w < 3u * m; w += kThreads) l[w] = g[w];
                     }
                     __syncthreads();
                     if (P.dbg_time)
-                        RenderChunkWG<true>(S, S.cmds[0], S.fill_ix[wave], m, parity, x0, y0, pix, s1, prof);
+                        RenderChunkWG<true>(S, S.w[0].f.cmds, S.w[wave].f.fill_ix, m, parity, x0, y0, pix, s1, prof);
                     else
-                        RenderChunkWG<false>(S, S.cmds[0], S.fill_ix[wave], m, parity, x0, y0, pix, s1, prof);
+                        RenderChunkWG<false>(S, S.w[0].f.cmds, S.w[wave].f.fill_ix, m, parity, x0, y0, pix, s1, prof);
                 }
                 __syncthreads();  // the other waves may still read this wave's alpha images
                 __builtin_amdgcn_s_setprio(0);
@@ -632,7 +671,7 @@ __global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
                 const uint32_t pxi = x0 + (lane & 3u) * 4u;
                 const uint32_t prow = lane >> 2;
                 const uint32_t pyi = y0 + prow;
-                Cmd *const cmds = S.cmds[wave];
+                Cmd *const cmds = S.w[wave].f.cmds;
                 PixelStateS st;
                 st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = Splat(static_cast<_Float16>(1.0f));
                 st.sa01 = st.sa23 = Splat(static_cast<_Float16>(0.0f));
@@ -647,7 +686,7 @@ __global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
                         for (uint32_t w = lane; w < 3u * m; w += 64u) l[w] = g[w];
                     }
                     WaveSync();
-                    InterpretSparse(S, cmds, S.fill_ix[wave], m, x0, y0, st);
+                    InterpretSparse(S, cmds, S.w[wave].f.fill_ix, m, x0, y0, st);
                 }
                 if (pyi < P.height && pxi < P.width) {
                     uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
@@ -666,13 +705,15 @@ __global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
             }
         }
         if (P.dbg_time && lane == 0) {
-            unsigned long long *d = P.dbg_time + 6ull * cur_slot;
+            unsigned long long *d = P.dbg_time + 8ull * cur_slot;
             d[0] = t_begin;
             d[1] = wall_clock64();
             d[2] = tile | (wg_mode ? 0x80000000u : 0u);
             d[3] = (static_cast<unsigned long long>(wave_global) << 32) | n_cmd;
             d[4] = prof.a;  // workgroup mode: ticks in phase A (incl. its barriers) / phase B
             d[5] = prof.b;
+            d[6] = prof.c;  // fused kernel: when the tile's list was complete (0: separate coarse pass)
+            d[7] = 0;
         }
     }
 }
@@ -746,8 +787,11 @@ void LaunchCoverage(const FrameParams &p, uint32_t n_tiles, const uint32_t *tile
     hipLaunchKernelGGL(pm_coverage_kernel, dim3(n_tiles), dim3(kThreads), 0, stream, p, tile_solid, out, out_stride);
 }
 
-void LaunchFine(const FrameParams &p, uint32_t clear_blocks, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
-    PM_LAUNCH(pm_fine_kernel, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
+void LaunchFine(const FrameParams &p, uint32_t clear_blocks, bool fused, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
+    if (fused)
+        PM_LAUNCH(pm_fine_kernel<true>, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
+    else
+        PM_LAUNCH(pm_fine_kernel<false>, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
 }
 
 }  // namespace pm

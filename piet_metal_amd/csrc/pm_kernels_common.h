@@ -72,6 +72,9 @@ constexpr uint32_t kBatch = 256;   // candidate items per binning batch
 // small helpers
 // ---------------------------------------------------------------------------------
 
+// wave index in the workgroup, as a scalar (the compiler cannot prove threadIdx.x >> 6 uniform)
+__device__ __forceinline__ uint32_t WaveId() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
 __device__ __forceinline__ uint32_t LaneId() { return __lane_id(); }
 
 __device__ __forceinline__ uint32_t RankBelow(uint64_t mask) {

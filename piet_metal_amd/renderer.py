@@ -241,8 +241,9 @@ class Comm:
 
 def _time_tiles(self, max_slots: int = 1 << 20) -> np.ndarray:
     """Developer profiling: per-slot timeline of pm_fine_kernel, rows =
-    (start, end, tile | quarter << 31, wave << 32 | commands, phase A ticks, phase B ticks)."""
-    out = np.zeros((max_slots, 6), np.uint64)
+    (start, end, tile | quarter << 31, wave << 32 | commands, phase A ticks, phase B ticks,
+    list complete (fused kernel), 0)."""
+    out = np.zeros((max_slots, 8), np.uint64)
     n = C.c_size_t(0)
     _lib.check(self._lib.pm_debug_time_tiles(self._h, out.ctypes.data, max_slots, C.byref(n)), "pm_debug_time_tiles")
     return out[: n.value]
