@@ -57,7 +57,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
     uint32_t rec = qe.z;  // (= striprow_head[sr])
     while (rec != 0) {
         // header and mask table sit next to each other: all loads are in flight together
-        const uint4 hdr = *reinterpret_cast<const uint4 *>(P.arena + rec);
+        const uint4 hdr = Scalar4(*reinterpret_cast<const uint4 *>(P.arena + rec));
         const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * lane);
         const uint32_t next = hdr.x;
         const uint32_t ncand = hdr.y;

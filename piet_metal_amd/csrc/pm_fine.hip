@@ -118,6 +118,8 @@ struct SparseLds {
     uint2 carry_sa[2][64];                // signedArea / distance state of an item cut by the chunk boundary
     float4 carry_df[2][64];               //   (two copies, alternating per chunk)
     uint32_t wg_ncmd[2];                  // fused kernel: list length found by wave 0 (alternating per pass)
+    uint32_t next_item;                   // next item of the round nobody has taken yet
+    uint16_t item_se[kSpChunk + 1];       // per item: first command | blend command << 8 (last entry: the open tail)
 };
 static_assert(sizeof(SparseLds) <= 40960, "four workgroups per CU");
 
@@ -405,7 +407,7 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const u
 }
 
 struct PhaseTicks {
-    unsigned long long a = 0, b = 0, c = 0;
+    unsigned long long a = 0, b = 0, c = 0, busy = 0;
 };
 
 // One staged chunk (n commands, parity = chunk index & 1) of a tile rendered by the workgroup;
@@ -418,50 +420,46 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
     const uint64_t fm = __ballot(tag == kCmdFill);
     const uint64_t bm = __ballot(tag == kCmdDrawFill || tag == kCmdStroke || tag == kCmdSolid || tag == kCmdCircle);
     if (tag == kCmdFill) fill_ix[RankBelow(fm)] = static_cast<uint8_t>(lane);  // (every wave keeps its own copy)
-    if (wave == 0 && ((bm >> lane) & 1ull)) {
-        // the item's colour, as the blend takes it: Circle is black with alpha exactly `alpha` (:491)
-        uint2 c = make_uint2(0u, 0x3c000000u);
-        if (tag == kCmdSolid) c = make_uint2(cmds[lane].body[1], cmds[lane].body[2]);
-        if (tag == kCmdDrawFill || tag == kCmdStroke) c = make_uint2(cmds[lane].body[2], cmds[lane].body[3]);
-        S.rec[RankBelow(bm)] = c;
+    const uint32_t nitems = static_cast<uint32_t>(__popcll(bm));
+    if (wave == 0) {
+        const uint64_t below = bm & ((1ull << lane) - 1ull);
+        const uint32_t begin = below ? 64u - static_cast<uint32_t>(__builtin_clzll(below)) : 0u;  // after the previous blend
+        if ((bm >> lane) & 1ull) {
+            // the item's colour, as the blend takes it: Circle is black with alpha exactly `alpha` (:491)
+            uint2 c = make_uint2(0u, 0x3c000000u);
+            if (tag == kCmdSolid) c = make_uint2(cmds[lane].body[1], cmds[lane].body[2]);
+            if (tag == kCmdDrawFill || tag == kCmdStroke) c = make_uint2(cmds[lane].body[2], cmds[lane].body[3]);
+            S.rec[RankBelow(bm)] = c;
+            S.item_se[RankBelow(bm)] = static_cast<uint16_t>(begin | (lane << 8));
+        }
+        if (lane == 0) {
+            const uint32_t tail = bm ? 64u - static_cast<uint32_t>(__builtin_clzll(bm)) : 0u;
+            S.item_se[nitems] = static_cast<uint16_t>(tail | (n << 8));
+            S.next_item = 0;
+        }
     }
     WaveSync();
-    const uint32_t nitems = static_cast<uint32_t>(__popcll(bm));
     const uint32_t r4 = lane >> 2, g = lane & 3u;
-    uint64_t mm = bm;
-    uint32_t unit_begin = 0;  // first command of the next item
     uint32_t k0 = 0;
-    // items go to the wave with the least work so far (every wave runs the same scalar
-    // bookkeeping): cost = commands of the item, its Fills counted twice
-    uint32_t load[kWaves] = {0u, 0u, 0u, 0u};
     do {  // rounds of kAlphaSlots items
         const uint32_t kend = min(k0 + kAlphaSlots, nitems);
         const bool last_round = kend == nitems;
+        const uint32_t limit = last_round ? nitems + 1u : kend;  // (the open tail goes with the last round)
         unsigned long long t_a = 0;
         if (kProf) t_a = wall_clock64();
         __syncthreads();  // phase B of the previous round (or chunk) is done with the alpha images
-        // ---- phase A -------------------------------------------------------------------------
+        // ---- phase A: every wave takes the next item nobody has taken --------------------------
 #pragma unroll 1
-        for (uint32_t k = k0; k <= kend; ++k) {
-            const bool is_tail = k == kend;
-            if (is_tail && !last_round) break;
-            uint32_t s0 = unit_begin, e0;
-            if (is_tail) {
-                e0 = n;
-            } else {
-                e0 = static_cast<uint32_t>(__builtin_ctzll(mm));
-                mm &= mm - 1ull;
-                unit_begin = e0 + 1u;
-            }
-            uint32_t owner = 0;
-#pragma unroll
-            for (uint32_t w = 1; w < static_cast<uint32_t>(kWaves); ++w)
-                if (load[w] < load[owner]) owner = w;
-            {
-                const uint64_t span = (e0 >= 64u ? ~0ull : ((1ull << e0) - 1ull)) & ~((1ull << s0) - 1ull);  // [s0, e0)
-                load[owner] += 2u + (e0 - s0) + static_cast<uint32_t>(__popcll(fm & span));
-            }
-            if (owner != wave) continue;
+        for (;;) {
+            uint32_t k = 0;
+            if (lane == 0) k = atomicAdd(&S.next_item, 1u);
+            k = __builtin_amdgcn_readfirstlane(k);
+            if (k >= limit) break;
+            const bool is_tail = k == nitems;
+            const uint32_t se = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(S.item_se[k]));
+            const uint32_t s0 = se & 0xffu, e0 = se >> 8;
+            unsigned long long t_i = 0;
+            if (kProf) t_i = wall_clock64();
             half2_t sa01 = Splat(static_cast<_Float16>(0.0f)), sa23 = sa01;
             float df[4] = {1e9f, 1e9f, 1e9f, 1e9f};
             if (s0 == 0) {  // the chunk opens inside an item: its accumulators so far
@@ -511,8 +509,10 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
             v.x = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, al[0])) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, al[1])) << 16);
             v.y = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, al[2])) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, al[3])) << 16);
             S.alpha[k & (kAlphaSlots - 1u)][lane] = v;
+            if (kProf) prof.busy += wall_clock64() - t_i;
         }
         __syncthreads();
+        if (wave == 0 && lane == 0) S.next_item = kend;  // (nobody takes an item before the next round's barrier)
         unsigned long long t_b = 0;
         if (kProf) {
             t_b = wall_clock64();
@@ -544,7 +544,7 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
 // CoarseTile -- pm_coarse_kernel's body -- and interprets it straight away: no launch boundary
 // between the two stages, and the list is read back while it is still in L2.
 template <bool kFused>
-__global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
+__global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     __shared__ SparseLds S;
     if (blockIdx.x >= P.fine_grid) {
         ClearStripRow(P, blockIdx.x - P.fine_grid);
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
     }
     for (uint32_t pass = 0; pass * n_waves < n_slots; ++pass) {
         const uint32_t cur_slot = slot;
-        const uint4 cur = qe;
+        const uint4 cur = Scalar4(qe);
         uint4 *const qentry = P.queue + qix;
         slot = pass_slot(pass + 1u);
         if ((pass + 1u) * n_waves < n_slots && slot < n_slots) {
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(kThreads, 4) void pm_fine_kernel(FrameParams P) {
             d[4] = prof.a;  // workgroup mode: ticks in phase A (incl. its barriers) / phase B
             d[5] = prof.b;
             d[6] = prof.c;  // fused kernel: when the tile's list was complete (0: separate coarse pass)
-            d[7] = 0;
+            d[7] = prof.busy;  // workgroup mode: ticks this wave spent on its own items in phase A
         }
     }
 }

@@ -75,6 +75,12 @@ constexpr uint32_t kBatch = 256;   // candidate items per binning batch
 // wave index in the workgroup, as a scalar (the compiler cannot prove threadIdx.x >> 6 uniform)
 __device__ __forceinline__ uint32_t WaveId() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 
+// a 16-byte value every lane loaded from the same address, moved to scalar registers
+__device__ __forceinline__ uint4 Scalar4(uint4 v) {
+    return make_uint4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
+                      __builtin_amdgcn_readfirstlane(v.w));
+}
+
 __device__ __forceinline__ uint32_t LaneId() { return __lane_id(); }
 
 __device__ __forceinline__ uint32_t RankBelow(uint64_t mask) {
