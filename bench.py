@@ -5,7 +5,7 @@ fraction of the dominant kernel and the CPU oracle timed beside it.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame of the hot path -- pm_bin_kernel, pm_coarse_kernel, pm_fine_kernel
+A "step" is one frame of the hot path -- pm_bin_kernel, then pm_fine_kernel (list building fused in)
 (tileKernel + renderKernel + composite of the reference) -- over the scene already
 resident in HBM (flatten/encode happens once per scene, like the reference encodes once
 per resize, PietRenderer.m:145; its cost is reported as scene.*).
@@ -317,6 +317,9 @@ def main() -> int:
         if kernels["pm_clear_kernel"] == 0:  # folded into pm_fine_kernel's launch
             kernels.pop("pm_clear_kernel")
             alone_ms.pop("pm_clear_kernel")
+        if kernels["pm_coarse_kernel"] == 0:  # fused: pm_fine_kernel<true> builds each tile's list itself
+            kernels.pop("pm_coarse_kernel")
+            alone_ms.pop("pm_coarse_kernel")
         dom = max(kernels, key=kernels.get)
         dom_ms = kernels[dom]
         achieved = b_alg / (dom_ms * 1e-3) / 1e9

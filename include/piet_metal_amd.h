@@ -282,8 +282,10 @@ int pm_layout_selfcheck(const uint8_t *scene, size_t scene_len, const pm_cmd *cm
 /* Developer profiling hook: re-run the last frame's per-tile kernel recording, per queue
  * slot, {start clock, end clock (100 MHz wall clock), tile | quarter << 31,
  * wave << 32 | commands interpreted, ticks in phase A, ticks in phase B (tiles rendered by a
- * whole workgroup), clock when the tile's list was complete (fused kernel; else 0), 0}.
- * out receives 8 u64 per slot. */
+ * whole workgroup), clock when the tile's list was complete (fused kernel; else 0), ticks on
+ * the wave's own items, then four words of list-building stages (fused kernel, packed pairs:
+ * header | candidates, owners | scan, segments | emission, rounds | records)}.
+ * out receives 12 u64 per slot. */
 int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_slots); /* pm_fine_kernel */
 /* Same for pm_bin_kernel: renders one frame recording 12 u64 per strip row {start, item scan done,
  * headers done, segment stream done, record finalised, queues done, chunks streamed, end}. */

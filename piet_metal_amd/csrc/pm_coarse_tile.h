@@ -31,9 +31,23 @@ struct CoarseLds {
 
 // Returns the number of commands left in the tile's list for the fine stage (0: nothing to
 // interpret -- empty, Bail tile already painted here, or arena overflow).
-template <bool kCapture>
+// Developer timeline (kProf instantiations only): 10 ns ticks per stage of the list building
+struct CoarseTicks {
+    unsigned long long hdr = 0;    // record header + mask table + candidates that hit the tile
+    unsigned long long cand = 0;   // candidate records + their scans
+    unsigned long long owner = 0;  // round: owners of the stream elements
+    unsigned long long scan = 0;   // round: worklist of relevant segments (meta scan)
+    unsigned long long seg = 0;    // round: segment load + phase-2 tests
+    unsigned long long emit = 0;   // round: closing commands, slots, stores
+    unsigned long long rounds = 0, records = 0;
+};
+#define PM_CT_TICK(v) \
+    if (kProf) v = wall_clock64()
+
+template <bool kCapture, bool kProf = false>
 __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &L, uint4 *const qentry, const uint4 qe,
-                                               const uint32_t lane, const uint64_t lanes_below) {
+                                               const uint32_t lane, const uint64_t lanes_below, CoarseTicks *ticks = nullptr) {
+    unsigned long long tk0 = 0, tk1 = 0;
     const uint32_t tile = qe.x;
     if (qe.y == 0xffffffffu) {  // the command-list arena overflowed (pm_sync re-renders the frame)
         if (lane == 0) qentry->w = 0;
@@ -56,6 +70,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
 
     uint32_t rec = qe.z;  // (= striprow_head[sr])
     while (rec != 0) {
+        PM_CT_TICK(tk0);
         // header and mask table sit next to each other: all loads are in flight together.
         // (Requesting the NEXT record's pair here as well saves 0.4 us per tile at 128 VGPRs and
         //  costs more than that in spills at the 96 the fused kernel is built for.)
@@ -89,6 +104,11 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
         const uint32_t hcount = __popc(hbits);
         const uint32_t hincl = WaveInclusiveScan(hcount);
         const uint32_t nhit = WaveLast(hincl);
+        if (kProf) {
+            tk1 = wall_clock64();
+            ticks->hdr += tk1 - tk0;
+            ticks->records += 1;
+        }
         if (nhit == 0) {
             rec = next;
             continue;
@@ -103,6 +123,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
         WaveSync();
 
         for (uint32_t cb = 0; cb < nhit; cb += kWaveCands) {
+            PM_CT_TICK(tk0);
             const uint32_t nh = min(kWaveCands, nhit - cb);
             if (lane < nh) {
                 const uint4 *cr = reinterpret_cast<const uint4 *>(cand_rec + kCandDwords * L.hidx[cb + lane]);
@@ -138,9 +159,14 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
             }
             WaveSync();
 
+            if (kProf) {
+                tk1 = wall_clock64();
+                ticks->cand += tk1 - tk0;
+            }
             // ---- stream rounds: phase-2 tests -> ordered commands --------------------------
             uint32_t own_carry = 0;  // owner of the last element of the previous round
             for (uint32_t e0 = 0; e0 < stream_len; e0 += 64) {
+                PM_CT_TICK(tk0);
                 const uint32_t e = e0 + lane;
                 // Owner of every element without a search: each candidate marks the stream
                 // position where it starts, a prefix maximum spreads the marks (owners only
@@ -176,6 +202,11 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                         draws = true;
                     }
                 }
+                if (kProf) {
+                    tk1 = wall_clock64();
+                    ticks->owner += tk1 - tk0;
+                    ticks->rounds += 1;
+                }
                 // make sure the ring holds every relevant segment this round needs
                 {
                     const bool wants = (e < stream_len) && ctag != kItemCircle && L.hrel[c] != 0;
@@ -208,6 +239,10 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                         }
                         WaveSync();
                     }
+                }
+                if (kProf) {
+                    tk0 = wall_clock64();
+                    ticks->scan += tk0 - tk1;
                 }
                 if (e < stream_len) {
                     if (ctag == kItemFill && L.hrel[c] == 0) {
@@ -298,6 +333,10 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                     }
                 }
                 WaveSync();  // per-candidate accumulators complete for elements <= this round
+                if (kProf) {
+                    tk1 = wall_clock64();
+                    ticks->seg += tk1 - tk0;
+                }
 
                 // ---- per-item closing command (DrawFill / Solid / Stroke) --------------------
                 bool has_fin = false;
@@ -396,6 +435,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                 if (last_solid >= 0) solid_color = WaveAtHighest(fin.body[0], ms);
                 if (last_draw > last_solid) solid_color = 0;  // encodeCircle/Line/Stroke/DrawFill (:81,:90,:99,:124)
                 WaveSync();
+                if (kProf) ticks->emit += wall_clock64() - tk1;
             }
             rel_done += pass_rel;
         }

@@ -1597,12 +1597,12 @@ int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_sl
     if (n_slots) *n_slots = slots;
     if (slots > max_slots) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;
-    PM_TRY(hipMalloc(&d, std::max<size_t>(slots, 1) * 8 * sizeof(unsigned long long)));
+    PM_TRY(hipMalloc(&d, std::max<size_t>(slots, 1) * 12 * sizeof(unsigned long long)));
     pm::FrameParams p = s->params;
     p.dbg_time = d;
     pm::LaunchFine(p, 0u, c->fused, c->stream);  // (the fused kernel rebuilds the same lists: idempotent)
     hipError_t e = hipStreamSynchronize(c->stream);
-    if (e == hipSuccess) e = hipMemcpy(out, d, slots * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out, d, slots * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return HipFail(e, "tile timeline");
     return PM_OK;

@@ -543,7 +543,8 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
 // kFused: the wave (or, for a long list, wave 0 of the workgroup) first builds the tile's list with
 // CoarseTile -- pm_coarse_kernel's body -- and interprets it straight away: no launch boundary
 // between the two stages, and the list is read back while it is still in L2.
-template <bool kFused>
+// kProf: the developer timeline build (pm_debug_time_tiles); P.dbg_time is only read there.
+template <bool kFused, bool kProf>
 __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     __shared__ SparseLds S;
     if (blockIdx.x >= P.fine_grid) {
@@ -612,11 +613,12 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
         const uint32_t tile = cur.x;
         unsigned long long t_begin = 0;
         PhaseTicks prof;
-        if (P.dbg_time) t_begin = wall_clock64();
+        CoarseTicks ct;
+        if (kProf) t_begin = wall_clock64();
         uint32_t n_cmd = cur.w;
         if (kFused) {
             // (wave 0 of a workgroup-mode tile has wave == 0: its region is S.w[0] either way)
-            if (!wg_mode || wave == 0) n_cmd = CoarseTile<false>(P, S.w[wave].c, qentry, cur, lane, lanes_below);
+            if (!wg_mode || wave == 0) n_cmd = CoarseTile<false, kProf>(P, S.w[wave].c, qentry, cur, lane, lanes_below, &ct);
             if (wg_mode) {
                 if (wave == 0 && lane == 0) S.wg_ncmd[pass & 1u] = n_cmd;
                 __syncthreads();  // (workgroup-scope release/acquire: the list wave 0 wrote is visible)
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's list stores before its loads
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            if (P.dbg_time) prof.c = wall_clock64();
+            if (kProf) prof.c = wall_clock64();
         }
         if (n_cmd != 0) {  // 0: the coarse kernel found one opaque colour and wrote it
             const uint32_t *src = reinterpret_cast<const uint32_t *>(P.ptcl + cur.y);
@@ -655,10 +657,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                         for (uint32_t w = threadIdx.x; w < 3u * m; w += kThreads) l[w] = g[w];
                     }
                     __syncthreads();
-                    if (P.dbg_time)
-                        RenderChunkWG<true>(S, S.w[0].f.cmds, S.w[wave].f.fill_ix, m, parity, x0, y0, pix, s1, prof);
-                    else
-                        RenderChunkWG<false>(S, S.w[0].f.cmds, S.w[wave].f.fill_ix, m, parity, x0, y0, pix, s1, prof);
+                    RenderChunkWG<kProf>(S, S.w[0].f.cmds, S.w[wave].f.fill_ix, m, parity, x0, y0, pix, s1, prof);
                 }
                 __syncthreads();  // the other waves may still read this wave's alpha images
                 __builtin_amdgcn_s_setprio(0);
@@ -704,8 +703,8 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                 }
             }
         }
-        if (P.dbg_time && lane == 0) {
-            unsigned long long *d = P.dbg_time + 8ull * cur_slot;
+        if (kProf && lane == 0) {
+            unsigned long long *d = P.dbg_time + 12ull * cur_slot;
             d[0] = t_begin;
             d[1] = wall_clock64();
             d[2] = tile | (wg_mode ? 0x80000000u : 0u);
@@ -714,6 +713,11 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
             d[5] = prof.b;
             d[6] = prof.c;  // fused kernel: when the tile's list was complete (0: separate coarse pass)
             d[7] = prof.busy;  // workgroup mode: ticks this wave spent on its own items in phase A
+            // list building by stage (fused kernel; workgroup mode: wave 0's row)
+            d[8] = ct.hdr | (ct.cand << 32);
+            d[9] = ct.owner | (ct.scan << 32);
+            d[10] = ct.seg | (ct.emit << 32);
+            d[11] = ct.rounds | (ct.records << 32);
         }
     }
 }
@@ -788,10 +792,17 @@ void LaunchCoverage(const FrameParams &p, uint32_t n_tiles, const uint32_t *tile
 }
 
 void LaunchFine(const FrameParams &p, uint32_t clear_blocks, bool fused, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
-    if (fused)
-        PM_LAUNCH(pm_fine_kernel<true>, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
-    else
-        PM_LAUNCH(pm_fine_kernel<false>, dim3(p.fine_grid + clear_blocks), dim3(kThreads), stream, t0, t1, p);
+    const dim3 grid(p.fine_grid + clear_blocks), block(kThreads);
+    if (p.dbg_time) {
+        if (fused)
+            PM_LAUNCH((pm_fine_kernel<true, true>), grid, block, stream, t0, t1, p);
+        else
+            PM_LAUNCH((pm_fine_kernel<false, true>), grid, block, stream, t0, t1, p);
+    } else if (fused) {
+        PM_LAUNCH((pm_fine_kernel<true, false>), grid, block, stream, t0, t1, p);
+    } else {
+        PM_LAUNCH((pm_fine_kernel<false, false>), grid, block, stream, t0, t1, p);
+    }
 }
 
 }  // namespace pm

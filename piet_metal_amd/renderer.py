@@ -242,8 +242,8 @@ class Comm:
 def _time_tiles(self, max_slots: int = 1 << 20) -> np.ndarray:
     """Developer profiling: per-slot timeline of pm_fine_kernel, rows =
     (start, end, tile | quarter << 31, wave << 32 | commands, phase A ticks, phase B ticks,
-    list complete (fused kernel), 0)."""
-    out = np.zeros((max_slots, 8), np.uint64)
+    list complete (fused kernel), own-item ticks, 4 x packed list-building stages)."""
+    out = np.zeros((max_slots, 12), np.uint64)
     n = C.c_size_t(0)
     _lib.check(self._lib.pm_debug_time_tiles(self._h, out.ctypes.data, max_slots, C.byref(n)), "pm_debug_time_tiles")
     return out[: n.value]

@@ -37,3 +37,18 @@ worst = np.argsort(-dur)[:8]
 for i in worst: print(f"  slot {i} tile {tile[i]} q={quarter[i]} ncmd {ncmd[i]} dur {dur[i]:.1f} us start {(start[i]-t0)*us:.1f}  phase A {t[i,4]*us:.1f} us  phase B {t[i,5]*us:.1f} us  list {coarse[i]:.1f} us  own items {t[i,7]*us:.1f} us")
 q = quarter & (ncmd > 0)
 if q.any(): print(f"workgroup-mode slots: {q.sum()}, mean dur {dur[q].mean():.2f} us, phase A {t[q,4].mean()*us:.2f} us, phase B {t[q,5].mean()*us:.2f} us, other {(dur[q]-(t[q,4]+t[q,5])*us).mean():.2f} us")
+
+if t.shape[1] >= 12 and (t[:, 11] > 0).any():
+    lo = lambda c: (t[:, c] & 0xffffffff).astype(np.float64) * us
+    hi = lambda c: (t[:, c] >> 32).astype(np.float64) * us
+    stages = {"header+hits": lo(8), "candidates": hi(8), "owners": lo(9), "scan": hi(9), "segments": lo(10), "emission": hi(10)}
+    rounds = (t[:, 11] & 0xffffffff).astype(np.int64); records = (t[:, 11] >> 32).astype(np.int64)
+    built = records > 0
+    print(f"list building by stage (tiles whose wave built a list: {built.sum()}; records/tile {records[built].mean():.2f}, rounds/tile {rounds[built].mean():.2f}):")
+    for name, v in stages.items():
+        print(f"   {name:12s} mean {v[built].mean():5.2f} us   p90 {np.percentile(v[built], 90):5.2f}   max {v[built].max():5.2f}")
+    tot = sum(stages.values())
+    print(f"   sum of stages mean {tot[built].mean():.2f} us (list building total mean {coarse[built].mean():.2f})")
+    w = np.argsort(-coarse)[:3]
+    for i in w:
+        print(f"   slot {i} ncmd {ncmd[i]} list {coarse[i]:.1f} us: " + ", ".join(f"{k} {v[i]:.1f}" for k, v in stages.items()) + f", rounds {rounds[i]}, records {records[i]}")
