@@ -71,6 +71,10 @@ int pm_encoder_polyline(pm_encoder *e, const double *pts_xy, size_t n_points, ui
  *    PietGroup {item_type, flags, group_ix}); pm_encoder_end_group closes the innermost group.
  *    A scene with groups renders exactly like the same items inlined in paint order. */
 #define PM_FILL_EVEN_ODD 1u
+/* Beyond the reference (PietRender.metal:488-489, "I should make this shade an ellipse properly"):
+ * the ellipse inscribed in the bbox of (cx +- rx, cy +- ry), black like the circle.  Encoded as a
+ * Circle item with bit 16 of its item_type word set (the reference reads the tag as a ushort). */
+int pm_encoder_ellipse(pm_encoder *e, double cx, double cy, double rx, double ry);
 int pm_encoder_fill_rule(pm_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba,
                          uint32_t fill_flags);
 size_t pm_encoder_bytes_used(const pm_encoder *e);                    /* free_space */

@@ -40,6 +40,10 @@ extern "C" {
 
 /* ---- scene item tags: src/lib.rs:70-77, TestApp/GenTypes.h:325-328 ----- */
 #define PMO_ITEM_CIRCLE 1
+/* Extension (decision D10): bit 16 of a Circle's item_type word (the reference reads the tag as a
+ * ushort, PietRender.metal:216) asks for the ellipse inscribed in the item's bbox -- the shading
+ * PietRender.metal:488-489 leaves as a TODO.  Carried to the tile's list in CmdCircle's padding word. */
+#define PMO_CIRCLE_ELLIPSE 0x10000u
 #define PMO_ITEM_LINE 2
 #define PMO_ITEM_FILL 3
 #define PMO_ITEM_POLY 4
@@ -115,6 +119,7 @@ size_t pmo_encoder_alloc(pmo_encoder *e, size_t size);
 void pmo_encoder_begin_group(pmo_encoder *e, size_t n_items);
 void pmo_encoder_end_group(pmo_encoder *e);
 void pmo_encoder_circle(pmo_encoder *e, double cx, double cy, double r);
+void pmo_encoder_ellipse(pmo_encoder *e, double cx, double cy, double rx, double ry); /* extension D10 */
 void pmo_encoder_stroke_line(pmo_encoder *e, double x0, double y0, double x1, double y1,
                              float width, uint32_t rgba);
 void pmo_encoder_fill(pmo_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba);

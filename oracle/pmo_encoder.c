@@ -159,6 +159,17 @@ void pmo_encoder_circle(pmo_encoder *e, double cx, double cy, double r) {
     add_item(e, item, 4, sb);
 }
 
+void pmo_encoder_ellipse(pmo_encoder *e, double cx, double cy, double rx, double ry) {
+    /* Extension D10: a Circle item with the ellipse bit; the shape is the ellipse inscribed in the
+     * item's (integer) bbox, as the circle is the one inscribed in its bbox (PietRender.metal:484-490). */
+    uint8_t item[4];
+    put_u32(item, PMO_ITEM_CIRCLE | PMO_CIRCLE_ELLIPSE);
+    rect bb = {cx - rx, cy - ry, cx + rx, cy + ry};
+    uint16_t sb[4];
+    short_bbox(bb, sb);
+    add_item(e, item, 4, sb);
+}
+
 void pmo_encoder_stroke_line(pmo_encoder *e, double x0, double y0, double x1, double y1,
                              float width, uint32_t rgba) {
     /* src/lib.rs:177-192; PietStrokeLine layout src/lib.rs:39-48 (32 bytes) */

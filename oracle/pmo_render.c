@@ -105,6 +105,21 @@ static float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
 static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
+/* Extension D10: coverage of the ellipse inscribed in the bbox, the "shade an ellipse properly"
+ * of PietRender.metal:488-489 with the first-order distance of WebRender's ellipse.glsl that the
+ * comment points to: for F(p) = px^2/rx^2 + py^2/ry^2 - 1, distance ~ F / |grad F|.  binary32,
+ * one rounding per operation, in exactly this order (the HIP kernels do the same):
+ *   ux = px / (rx * rx), uy = py / (ry * ry); g = (px * ux + py * uy) - 1;
+ *   len = 2 * sqrt(ux * ux + uy * uy); alpha = saturate(-(g / len)).
+ * At the centre len = 0 and g = -1: -(g / len) = +inf, alpha = 1.  A bbox without area draws nothing. */
+static float ellipse_alpha(float ddx, float ddy, float rx, float ry) {
+    if (!(rx > 0.0f) || !(ry > 0.0f)) return 0.0f;
+    float ux = ddx / (rx * rx), uy = ddy / (ry * ry);
+    float g = (ddx * ux + ddy * uy) - 1.0f;
+    float len = 2.0f * sqrtf(ux * ux + uy * uy);
+    return saturatef(-(g / len));
+}
+
 /* stroke(), PietRender.metal:49-55 */
 static void stroke_df(float *df, float px, float py, float sx, float sy, float ex, float ey) {
     float lx = ex - sx, ly = ey - sy;
@@ -157,6 +172,7 @@ static int render_pixel_half(const pmo_cmd *cmds, uint32_t x, uint32_t y, uint8_
                 float r = sqrtf(ddx * ddx + ddy * ddy);
                 float circle_r = fminf(cx - x0, cy - y0);
                 float alpha = saturatef(circle_r - r);
+                if (cmd->body[0] & 1u) alpha = ellipse_alpha(ddx, ddy, cx - x0, cy - y0);
                 pmo_half ha = pmo_f2h(alpha);
                 for (int k = 0; k < 3; k++) rgb[k] = pmo_hmix(rgb[k], PMO_H_ZERO, ha);
                 break;
@@ -252,6 +268,7 @@ static int render_pixel_f32(const pmo_cmd *cmds, uint32_t x, uint32_t y, uint8_t
                 float ddx = px - cx, ddy = py - cy;
                 float r = sqrtf(ddx * ddx + ddy * ddy);
                 float alpha = saturatef(fminf(cx - x0, cy - y0) - r);
+                if (cmd->body[0] & 1u) alpha = ellipse_alpha(ddx, ddy, cx - x0, cy - y0);
                 for (int k = 0; k < 3; k++) rgb[k] = mixf(rgb[k], 0.0f, alpha);
                 break;
             }

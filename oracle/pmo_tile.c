@@ -75,9 +75,10 @@ static pmo_cmd *enc_push(tile_enc *e) {
 
 static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
-static void enc_circle(tile_enc *e, const uint16_t bbox[4]) { /* :76-83 */
+static void enc_circle(tile_enc *e, const uint16_t bbox[4], uint32_t ellipse) { /* :76-83 */
     pmo_cmd *c = enc_push(e);
     c->tag = PMO_CMD_CIRCLE;
+    c->body[0] = ellipse; /* extension D10, in the padding word of CmdCirclePacked */
     /* CmdCirclePacked {uint tag; ushort4 bbox}: bbox at byte 8 (ushort4 is 8-aligned) */
     c->body[1] = (uint32_t)bbox[0] | ((uint32_t)bbox[1] << 16);
     c->body[2] = (uint32_t)bbox[2] | ((uint32_t)bbox[3] << 16);
@@ -178,11 +179,12 @@ static void run_group(scene_t *sc, uint32_t gx, uint32_t gy, tile_enc enc[LANES]
                 hit[t] = bbox[2] >= x0[t] && bbox[0] < x0[t] + PMO_TILE_W && bbox[3] >= y0[t] &&
                          bbox[1] < y0[t] + PMO_TILE_H;
             size_t item_ref = (size_t)items_ref + (size_t)ix * PMO_ITEM_SIZE;
-            uint32_t item_type = rd_u32(sc, item_ref) & 0xffffu; /* ushort itemType :216 */
+            uint32_t item_word = rd_u32(sc, item_ref);
+            uint32_t item_type = item_word & 0xffffu; /* ushort itemType :216 */
             switch (item_type) {
                 case PMO_ITEM_CIRCLE: /* :218-222 */
                     for (int t = 0; t < LANES; t++)
-                        if (hit[t]) enc_circle(&enc[t], bbox);
+                        if (hit[t]) enc_circle(&enc[t], bbox, (item_word & PMO_CIRCLE_ELLIPSE) ? 1u : 0u);
                     break;
                 case PMO_ITEM_LINE: { /* :223-247 */
                     uint32_t rgba = rd_u32(sc, item_ref + 8);

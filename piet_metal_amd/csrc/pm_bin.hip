@@ -307,6 +307,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             uint32_t pts = 0, npt = 0, nseg = 0;
             float hw = 0.0f;
             if (tag == kItemCircle) {
+                rgba = (w01v.x & kCircleEllipse) ? kCmdCircleEllipse : 0u;  // (a circle has no colour: the slot carries CmdCircle.flags)
                 aux0 = ibbv.x;
                 aux1 = ibbv.y;
             } else if (tag == kItemLine) {

@@ -194,7 +194,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                     if (ctag == kItemCircle) {  // :218-222
                         n_em = 1;
                         c0.tag = kCmdCircle;
-                        c0.body[0] = 0;
+                        c0.body[0] = L.hrgba[c];  // CmdCircle.flags (extension: bit 0 = ellipse)
                         c0.body[1] = L.haux0[c];
                         c0.body[2] = L.haux1[c];
                         c0.body[3] = 0;

@@ -121,6 +121,11 @@ void Encoder::Circle(double cx, double cy, double r) {
     AddItem(item, ToShortBbox(Rect{cx - r, cy - r, cx + r, cy + r}));
 }
 
+void Encoder::Ellipse(double cx, double cy, double rx, double ry) {
+    PietCircle item{kItemCircle | kCircleEllipse};  // (extension D10: the ellipse inscribed in the bbox)
+    AddItem(item, ToShortBbox(Rect{cx - rx, cy - ry, cx + rx, cy + ry}));
+}
+
 void Encoder::StrokeLine(double x0, double y0, double x1, double y1, float width, uint32_t rgba) {
     PietStrokeLine item{};
     item.item_type = kItemLine;
@@ -236,6 +241,11 @@ int pm_encoder_circle(pm_encoder *e, double cx, double cy, double r) {
     e->enc.Circle(cx, cy, r);
     return e->enc.c_status();
 }
+int pm_encoder_ellipse(pm_encoder *e, double cx, double cy, double rx, double ry) {
+    if (!e) return PM_ERR_INVALID;
+    e->enc.Ellipse(cx, cy, rx, ry);
+    return e->enc.c_status();
+}
 int pm_encoder_stroke_line(pm_encoder *e, double x0, double y0, double x1, double y1, float width,
                            uint32_t rgba) {
     if (!e) return PM_ERR_INVALID;
@@ -286,6 +296,7 @@ int pm_layout_selfcheck(const uint8_t *scene, size_t scene_len, const pm_cmd *cm
             switch (tag & 0xffffu) {
                 case gs::PietItem_Circle:
                     again = gs::PietItem_Circle_pack();
+                    again.tag |= tag & pm::kCircleEllipse;  // (the ellipse bit lives in the tag word's upper half)
                     break;
                 case gs::PietItem_Line: {
                     pm::PietStrokeLine h;
@@ -340,7 +351,7 @@ int pm_layout_selfcheck(const uint8_t *scene, size_t scene_len, const pm_cmd *cm
                 std::memset(&again, 0, sizeof(again));
                 again.tag = c.tag;
                 break;
-            case gp::Cmd_Circle: again = gp::Cmd_Circle_pack(gp::CmdCircle_load(c).bbox); break;
+            case gp::Cmd_Circle: { const gp::CmdCirclePacked q = gp::CmdCircle_load(c); again = gp::Cmd_Circle_pack(q.flags, q.bbox); break; }
             case gp::Cmd_Line: { const gp::CmdLinePacked q = gp::CmdLine_load(c); again = gp::Cmd_Line_pack(q.start, q.end); break; }
             case gp::Cmd_Fill: { const gp::CmdFillPacked q = gp::CmdFill_load(c); again = gp::Cmd_Fill_pack(q.start, q.end); break; }
             case gp::Cmd_Stroke: { const gp::CmdStrokePacked q = gp::CmdStroke_load(c); again = gp::Cmd_Stroke_pack(q.halfWidth, q.rgba_color, q.rg, q.ba); break; }

@@ -23,6 +23,7 @@ public:
     void BeginGroup(size_t n_items);                 // :132
     void EndGroup();                                 // :146
     void Circle(double cx, double cy, double r);     // :167
+    void Ellipse(double cx, double cy, double rx, double ry);  // extension: Circle item + kCircleEllipse
     void StrokeLine(double x0, double y0, double x1, double y1, float width, uint32_t rgba);  // :177
     void Fill(const double *pts_xy, size_t n, uint32_t rgba, uint32_t flags = 0);             // :195 (+ PietFill.flags)
     void Polyline(const double *pts_xy, size_t n, uint32_t rgba, float width);                // :209

@@ -76,6 +76,22 @@ __device__ __forceinline__ _Float16 FillAlpha(_Float16 a, bool even_odd) {
     return static_cast<_Float16>(f);
 }
 
+// Coverage of Cmd_Circle for one pixel (d = pixel - centre; rx, ry = centre - bbox corner): the
+// circle of PietRender.metal:486-490, or -- extension D10, CmdCircle.flags bit 0 -- the ellipse
+// inscribed in the bbox with the first-order distance F / |grad F| of F = x^2/rx^2 + y^2/ry^2 - 1
+// (the WebRender ellipse.glsl form the reference's TODO points to), every step binary32 in the
+// order oracle/pmo_render.c ellipse_alpha() fixes.
+__device__ __forceinline__ float CircleAlpha(float dx, float dy, float rx, float ry, bool ellipse) {
+    if (ellipse) {
+        if (!(rx > 0.0f) || !(ry > 0.0f)) return 0.0f;
+        const float ux = dx / (rx * rx), uy = dy / (ry * ry);
+        const float g = (dx * ux + dy * uy) - 1.0f;
+        const float len = 2.0f * sqrtf(ux * ux + uy * uy);
+        return Sat(-(g / len));
+    }
+    return Sat(fminf(rx, ry) - sqrtf(dx * dx + dy * dy));
+}
+
 __device__ __forceinline__ half2_t Splat(_Float16 v) { half2_t r; r.x = v; r.y = v; return r; }
 
 // ---- row-sparse Fill evaluation -----------------------------------------------------------
@@ -247,13 +263,13 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 const float bx0 = static_cast<float>(cmd.body[1] & 0xffffu), by0 = static_cast<float>(cmd.body[1] >> 16);
                 const float bx1 = static_cast<float>(cmd.body[2] & 0xffffu), by1 = static_cast<float>(cmd.body[2] >> 16);
                 const float cx = bx0 + (bx1 - bx0) * 0.5f, cy = by0 + (by1 - by0) * 0.5f;
-                const float circle_r = fminf(cx - bx0, cy - by0);
+                const bool ellipse = (cmd.body[0] & kCmdCircleEllipse) != 0;
                 const float dy = py - cy;
                 _Float16 alpha[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float dx = (px0 + static_cast<float>(k)) - cx;
-                    alpha[k] = ToHalf(Sat(circle_r - sqrtf(dx * dx + dy * dy)));
+                    alpha[k] = ToHalf(CircleAlpha(dx, dy, cx - bx0, cy - by0, ellipse));
                 }
                 const half2_t zero = Splat(static_cast<_Float16>(0.0f));
                 half2_t a01, a23;
@@ -494,12 +510,12 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
                 const float bx0 = static_cast<float>(cmd.body[1] & 0xffffu), by0 = static_cast<float>(cmd.body[1] >> 16);
                 const float bx1 = static_cast<float>(cmd.body[2] & 0xffffu), by1 = static_cast<float>(cmd.body[2] >> 16);
                 const float cx = bx0 + (bx1 - bx0) * 0.5f, cy = by0 + (by1 - by0) * 0.5f;
-                const float circle_r = fminf(cx - bx0, cy - by0);
+                const bool ellipse = (cmd.body[0] & kCmdCircleEllipse) != 0;
                 const float dy = static_cast<float>(y0 + r4) - cy;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float dx = static_cast<float>(x0 + 4u * g + static_cast<uint32_t>(u)) - cx;
-                    al[u] = ToHalf(Sat(circle_r - sqrtf(dx * dx + dy * dy)));
+                    al[u] = ToHalf(CircleAlpha(dx, dy, cx - bx0, cy - by0, ellipse));
                 }
             } else {  // Solid (:546-549): alpha 1
 #pragma unroll

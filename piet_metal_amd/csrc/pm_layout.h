@@ -37,6 +37,11 @@ enum ItemTag : uint32_t {  // src/lib.rs:70-77
 
 // PietFill.flags (src/lib.rs:54, "will be used for winding number rule", TestApp/SceneEncoder.h:44)
 constexpr uint32_t kFillEvenOdd = 1u;  // even-odd instead of non-zero (PietRender.metal:539-540)
+// Extension (decision D10): bit 16 of a Circle's item_type word (the reference reads the tag as a
+// ushort, PietRender.metal:216) asks for the ellipse inscribed in the item's bbox -- the shading
+// PietRender.metal:488-489 leaves as a TODO.  Travels to the tile's list in CmdCircle.flags.
+constexpr uint32_t kCircleEllipse = 1u << 16;
+constexpr uint32_t kCmdCircleEllipse = 1u;
 
 struct SimpleGroup {  // src/lib.rs:15-20
     uint32_t n_items;

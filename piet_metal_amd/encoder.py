@@ -48,6 +48,11 @@ class Encoder:
     def circle(self, center, radius: float) -> None:
         _lib.check(self._lib.pm_encoder_circle(self._h, center[0], center[1], radius), "circle")
 
+    def ellipse(self, center, rx: float, ry: float) -> None:
+        """Beyond the reference: the ellipse inscribed in the item's bbox (a Circle item with the
+        ellipse bit), shaded as PietRender.metal:488-489 says it should be."""
+        _lib.check(self._lib.pm_encoder_ellipse(self._h, center[0], center[1], rx, ry), "ellipse")
+
     def stroke_line(self, p0, p1, width: float, rgba: int) -> None:
         _lib.check(
             self._lib.pm_encoder_stroke_line(self._h, p0[0], p0[1], p1[0], p1[1], width, rgba & 0xFFFFFFFF),

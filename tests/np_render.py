@@ -80,6 +80,15 @@ def render_tile(cmds, tx, ty, tables):
                 dx, dy = px - cx, py - cy
                 r = np.sqrt(dx * dx + dy * dy)
                 alpha = sat(np.fmin(cx - x0, cy - y0) - r).astype(f16)
+                if b[0] & 1:  # extension D10: the ellipse inscribed in the bbox, F / |grad F|
+                    rx, ry = cx - x0, cy - y0
+                    if rx > 0 and ry > 0:
+                        ux, uy = dx / (rx * rx), dy / (ry * ry)
+                        g = (dx * ux + dy * uy) - f32(1)
+                        ln = f32(2) * np.sqrt(ux * ux + uy * uy)
+                        alpha = sat(-(g / ln)).astype(f16)
+                    else:
+                        alpha = np.zeros((16, 16), f16)
                 for k in range(3):
                     rgb[k] = hmix(rgb[k], f16(0), alpha)
             elif tag == 3:  # Line :495-499 + stroke() :49-55

@@ -92,12 +92,13 @@ def tile_lists(scene: bytes, width: int, height: int):
                 if not (bz >= sx0 and bx < sx0 + stw and bw >= sy0 and by < sy0 + sth):
                     continue
                 item = item_at[ix]
-                tag = u32(item) & 0xFFFF
+                word = u32(item)
+                tag = word & 0xFFFF
                 hits = [bz >= L["x0"] and bx < L["x0"] + TILE_W and bw >= L["y0"] and by < L["y0"] + TILE_H for L in lanes]
                 if tag == 1:  # Circle :218-222
                     for L, hit in zip(lanes, hits):
                         if hit:
-                            L["enc"].push(CIRCLE, 0, bx | (by << 16), bz | (bw << 16))
+                            L["enc"].push(CIRCLE, (word >> 16) & 1, bx | (by << 16), bz | (bw << 16))  # (+ the ellipse bit, extension D10)
                 elif tag == 2:  # Line :223-247
                     rgba, width_ = u32(item + 8), flt(item + 12)
                     s, e = pt(item + 16, 0), pt(item + 16, 1)

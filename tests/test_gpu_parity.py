@@ -515,6 +515,32 @@ def test_even_odd_fills_and_nested_groups(pm, pmo, renderer, seed, n, extent, w,
     assert st["n_items"] == len(inline_ops(tree))
 
 
+def test_ellipses(pm, pmo, renderer):
+    """Extension D10 on the GPU: Circle items with the ellipse bit -- sparse (one wave per tile),
+    piled up (lists longer than a chunk, rendered by a workgroup), degenerate and clipped by the
+    viewport -- pixels and command lists against the oracle; plain circles next to them unchanged."""
+    rng = np.random.default_rng(41)
+    ops = []
+    for _ in range(300):
+        c = rng.uniform(-20, 520, 2)
+        if rng.random() < 0.7:
+            rx, ry = rng.uniform(0.3, 90, 2)
+            if rng.random() < 0.08:
+                rx = 0.0
+            ops.append(("ellipse", float(c[0]), float(c[1]), float(rx), float(ry)))
+        else:
+            ops.append(("circle", float(c[0]), float(c[1]), float(rng.uniform(1, 60))))
+    for k in range(260):  # a pile on a few tiles: > 4 chunks of commands
+        ops.append(("ellipse", 250.0 + 0.1 * k, 240.0 - 0.07 * k, 30.0 + 0.2 * k, 12.0 + 0.05 * k))
+    ops += random_ops(42, 80, extent=500.0)  # fills and strokes in between and on top
+    scene = encode_ops(pm, ops, cap=4 << 20)
+    got = gpu_render(renderer, scene, 512, 500)
+    assert np.array_equal(got, pmo.render(scene, 512, 500))
+    assert_ptcl_equal(renderer, pmo, scene, 512, 500, maxc=2048)
+    only_circles = encode_ops(pm, [op for op in ops if op[0] != "ellipse"], cap=4 << 20)
+    assert np.array_equal(gpu_render(renderer, only_circles, 512, 500), pmo.render(only_circles, 512, 500))
+
+
 def test_even_odd_through_the_device_flatten(pm, pmo, renderer):
     """PM_PATH_EVEN_ODD on a path reaches PietFill.flags through the flatten kernels: scene bytes
     equal the oracle's encoder, pixels equal its render (Tiger, every fill under even-odd)."""

@@ -83,6 +83,8 @@ def _oracle_encode(pmo, ops, cap=1 << 20):
         for op in group:
             if op[0] == "circle":
                 lib.pmo_encoder_circle(C.byref(e), C.c_double(op[1]), C.c_double(op[2]), C.c_double(op[3]))
+            elif op[0] == "ellipse":  # extension: Circle item + ellipse bit
+                lib.pmo_encoder_ellipse(C.byref(e), *[C.c_double(v) for v in op[1:5]])
             elif op[0] == "line":
                 lib.pmo_encoder_stroke_line(C.byref(e), *[C.c_double(v) for v in op[1:5]], C.c_float(op[5]), C.c_uint32(op[6]))
             elif op[0] == "fill":
@@ -142,6 +144,8 @@ def encode_ops(pm, ops, cap=1 << 20):
         for op in group:
             if op[0] == "circle":
                 e.circle((op[1], op[2]), op[3])
+            elif op[0] == "ellipse":
+                e.ellipse((op[1], op[2]), op[3], op[4])
             elif op[0] == "line":
                 e.stroke_line((op[1], op[2]), (op[3], op[4]), op[5], op[6])
             elif op[0] == "fill":
@@ -162,11 +166,17 @@ def encode_ops(pm, ops, cap=1 << 20):
 
 def extend_ops(seed, ops):
     """The extensions on top of a random op list: about a third of the fills take the even-odd
-    rule (and self-overlap, so that the rule shows), and runs of items move into nested groups
-    (up to three levels).  inline_ops() gives the flat list a nested one must render like."""
+    rule (and self-overlap, so that the rule shows), half of the circles become ellipses (some
+    degenerate), and runs of items move into nested groups (up to three levels).  inline_ops()
+    gives the flat list a nested one must render like."""
     rng = np.random.default_rng(seed ^ 0xE0)
     out = []
     for op in ops:
+        if op[0] == "circle" and rng.random() < 0.5:
+            rx, ry = float(rng.uniform(0.2, 60)), float(rng.uniform(0.2, 60))
+            if rng.random() < 0.1:
+                ry = 0.0  # a bbox without height: nothing is drawn
+            op = ("ellipse", op[1], op[2], rx, ry)
         if op[0] == "fill" and rng.random() < 0.35:
             pts = np.asarray(op[1], np.float64)
             if len(pts) >= 3 and rng.random() < 0.7:  # walk the outline twice, the second time shrunk: winding 2 inside

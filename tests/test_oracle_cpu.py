@@ -246,6 +246,44 @@ def test_kat_even_odd_rule(pm, pmo):
     assert (img_nz != img).any()
 
 
+def test_kat_ellipse(pm, pmo):
+    """Extension D10: a Circle item with bit 16 of its tag word set is the ellipse inscribed in its
+    bbox (PietRender.metal:488-489's TODO).  Known answers: centre black, just outside the axes
+    white, mirror symmetry about both axes (the arithmetic is even in dx and dy), area between the
+    ellipses of radii (r - 1) and r (the edge ramp lies inside, as the circle's does), rx == ry
+    agrees with the circle to first order, a bbox without area draws nothing, and the flag travels
+    in CmdCircle's padding word while plain circles keep a zero there."""
+    from test_host_cpu import encode_ops
+
+    cx, cy, rx, ry = 100, 90, 40, 20
+    img = pmo.render(encode_ops(pm, [("ellipse", float(cx), float(cy), float(rx), float(ry))]), 208, 176)
+    assert tuple(img[cy, cx]) == (0, 0, 0, 255)
+    assert img[cy, cx + rx - 2, 0] == 0 and img[cy, cx + rx + 1, 0] == 255
+    assert img[cy + ry - 2, cx, 0] == 0 and img[cy + ry + 1, cx, 0] == 255
+    assert img[cy + ry - 2, cx + rx - 2, 0] == 255  # the bbox corner is outside
+    win = img[cy - ry - 2 : cy + ry + 3, cx - rx - 2 : cx + rx + 3, 0]
+    assert np.array_equal(win, win[::-1]) and np.array_equal(win, win[:, ::-1])
+    lin = np.where(img[:, :, 0] <= 10, img[:, :, 0] / 255.0 / 12.92, ((img[:, :, 0] / 255.0 + 0.055) / 1.055) ** 2.4)
+    area = float((1.0 - lin).sum())
+    assert np.pi * (rx - 1) * (ry - 1) < area < np.pi * rx * ry, area
+    # rx == ry: F / |grad F| = (r^2 - R^2) / 2r, within (r - R)^2 / 2r of the circle's r - R
+    R = 30
+    e = pmo.render(encode_ops(pm, [("ellipse", 64.0, 64.0, float(R), float(R))]), 128, 128)[:, :, 0]
+    c = pmo.render(encode_ops(pm, [("circle", 64.0, 64.0, float(R))]), 128, 128)[:, :, 0]
+    to_lin = lambda v: np.where(v <= 10, v / 255.0 / 12.92, ((v / 255.0 + 0.055) / 1.055) ** 2.4)
+    assert np.abs(to_lin(e) - to_lin(c)).max() < 1.0 / (2 * R) + 0.01 and (e != c).any()
+    assert (pmo.render(encode_ops(pm, [("ellipse", 64.0, 64.0, 30.0, 0.0)]), 128, 128)[:, :, :3] == 255).all()
+    P = pmo.Ptcl(encode_ops(pm, [("ellipse", 40.0, 40.0, 20.0, 9.0), ("circle", 90.0, 40.0, 9.0)]), 128, 80)
+    flags = {}
+    for ty in range(P.tiles_y):
+        for tx in range(P.tiles_x):
+            for c_ in P.cmds(tx, ty):
+                if c_[0] == 2:
+                    flags.setdefault(int(c_[2]) & 0xFFFF, set()).add(int(c_[1]))
+    P.close()
+    assert flags == {20: {1}, 81: {0}}, flags  # keyed by bbox.x0: the ellipse's lists carry 1, the circle's 0
+
+
 def test_nested_groups_render_like_the_inlined_items(pm, pmo):
     """Extension: a PietGroup item stands for its children, in place and in order.  Lists, solid
     colours and pixels of nested scenes equal those of the same items in one flat group, and
