@@ -71,6 +71,14 @@ int pm_encoder_polyline(pm_encoder *e, const double *pts_xy, size_t n_points, ui
  *    PietGroup {item_type, flags, group_ix}); pm_encoder_end_group closes the innermost group.
  *    A scene with groups renders exactly like the same items inlined in paint order. */
 #define PM_FILL_EVEN_ODD 1u
+/* Beyond the reference (src/lib.rs:194, "need to deal with subpaths"): ONE Fill item made of
+ * n_subpaths closed sub-paths (sub_counts[k] points each, back to back in pts_xy) that share a
+ * winding sum -- holes and overlapping contours resolve by fill_flags' rule.  Encoded as PietFill
+ * with flags bit 1 (PM_FILL_COMPOUND); every sub-path is followed by a separator entry
+ * {x = NaN, y = bits of the index of its first point}, n_points counts both. */
+#define PM_FILL_COMPOUND 2u
+int pm_encoder_fill_compound(pm_encoder *e, const double *pts_xy, const uint32_t *sub_counts, size_t n_subpaths, uint32_t rgba,
+                             uint32_t fill_flags);
 /* Beyond the reference (PietRender.metal:488-489, "I should make this shade an ellipse properly"):
  * the ellipse inscribed in the bbox of (cx +- rx, cy +- ry), black like the circle.  Encoded as a
  * Circle item with bit 16 of its item_type word set (the reference reads the tag as a ushort). */

@@ -53,6 +53,12 @@ extern "C" {
  * even-odd formula the reference leaves in a comment (TestApp/PietRender.metal:539-540). */
 #define PMO_ITEM_GROUP 5        /* {item_type, flags, group_ix}: group_ix = offset of a SimpleGroup */
 #define PMO_FILL_EVEN_ODD 1u
+/* Extension (decision D11, "need to deal with subpaths", src/lib.rs:194): PietFill.flags bit 1 = the
+ * point array holds SEVERAL closed sub-paths that share one winding sum and one DrawFill.  Every
+ * sub-path is followed by a separator entry {x = NaN, y = bits of the index of the sub-path's first
+ * point}; n_points counts points and separators.  Segment k runs from point k to point k + 1, or --
+ * when entry k + 1 is a separator -- back to the sub-path's first point; separators start no segment. */
+#define PMO_FILL_COMPOUND 2u
 #define PMO_ITEM_SIZE 32  /* sizeof(union PietItem), src/lib.rs:27-31 */
 #define PMO_BBOX_SIZE 8   /* ShortBbox, src/lib.rs:22-24 */
 #define PMO_GROUP_HDR 8   /* SimpleGroup, src/lib.rs:15-20 */
@@ -90,6 +96,7 @@ typedef struct {
 #define PMO_PATH_FILL 1u
 #define PMO_PATH_STROKE 2u
 #define PMO_PATH_EVEN_ODD 4u
+#define PMO_PATH_COMPOUND 8u /* the sub-paths of a filled path become ONE compound Fill item (holes) */
 
 typedef struct {
     uint32_t el_begin;     /* first element index */
@@ -119,6 +126,9 @@ size_t pmo_encoder_alloc(pmo_encoder *e, size_t size);
 void pmo_encoder_begin_group(pmo_encoder *e, size_t n_items);
 void pmo_encoder_end_group(pmo_encoder *e);
 void pmo_encoder_circle(pmo_encoder *e, double cx, double cy, double r);
+/* sub_counts[n_sub] points per sub-path, pts_xy holds them back to back (extension D11) */
+void pmo_encoder_fill_compound(pmo_encoder *e, const double *pts_xy, const uint32_t *sub_counts, size_t n_sub, uint32_t rgba,
+                               uint32_t fill_flags);
 void pmo_encoder_ellipse(pmo_encoder *e, double cx, double cy, double rx, double ry); /* extension D10 */
 void pmo_encoder_stroke_line(pmo_encoder *e, double x0, double y0, double x1, double y1,
                              float width, uint32_t rgba);

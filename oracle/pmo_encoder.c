@@ -234,6 +234,51 @@ void pmo_encoder_fill_rule(pmo_encoder *e, const double *pts_xy, size_t n_points
     add_item(e, item, 20, sb);
 }
 
+void pmo_encoder_fill_compound(pmo_encoder *e, const double *pts_xy, const uint32_t *sub_counts, size_t n_sub, uint32_t rgba,
+                               uint32_t fill_flags) {
+    /* Extension D11 (pmo.h): the sub-paths' points back to back, a separator after each. */
+    size_t total = 0;
+    for (size_t k = 0; k < n_sub; k++) total += (size_t)sub_counts[k] + 1;
+    size_t points_ix = pmo_encoder_alloc(e, total * 8);
+    size_t dst = points_ix;
+    rect bb = {0, 0, 0, 0};
+    int first = 1;
+    uint32_t at = 0;
+    for (size_t k = 0; k < n_sub; k++) {
+        uint32_t start = at;
+        if (sub_counts[k] == 0) e->error = 1; /* .expect("encoded empty points vector") */
+        for (uint32_t i = 0; i < sub_counts[k]; i++, pts_xy += 2, at++, dst += 8) {
+            double x = pts_xy[0], y = pts_xy[1];
+            if (first) {
+                bb.x0 = bb.x1 = x;
+                bb.y0 = bb.y1 = y;
+                first = 0;
+            } else {
+                bb.x0 = fmin(bb.x0, x);
+                bb.y0 = fmin(bb.y0, y);
+                bb.x1 = fmax(bb.x1, x);
+                bb.y1 = fmax(bb.y1, y);
+            }
+            float f[2] = {(float)x, (float)y};
+            write_bytes(e, dst, f, 8);
+        }
+        uint32_t sep[2] = {0x7fc00000u, start};
+        write_bytes(e, dst, sep, 8);
+        dst += 8;
+        at++;
+    }
+    if (n_sub == 0) e->error = 1;
+    uint8_t item[20];
+    put_u32(item + 0, PMO_ITEM_FILL);
+    put_u32(item + 4, fill_flags | PMO_FILL_COMPOUND);
+    put_u32(item + 8, to_be(rgba));
+    put_u32(item + 12, (uint32_t)total);
+    put_u32(item + 16, (uint32_t)points_ix);
+    uint16_t sb[4];
+    short_bbox(bb, sb);
+    add_item(e, item, 20, sb);
+}
+
 void pmo_encoder_polyline(pmo_encoder *e, const double *pts_xy, size_t n_points, uint32_t rgba,
                           float width) {
     /* src/lib.rs:209-222; PietStrokePolyLine layout src/lib.rs:60-68 (20 bytes) */
@@ -355,10 +400,14 @@ int64_t pmo_scene_from_paths(uint8_t *buf, size_t cap, const pmo_path *paths, si
         if (paths[i].flags & PMO_PATH_FILL) {
             /* encode_path, src/lib.rs:342-347 */
             const double *pp = s.pts;
-            for (int64_t k = 0; k < n_sub; k++) {
-                pmo_encoder_fill_rule(&e, pp, s.sub_counts[k], paths[i].fill_rgba,
-                                      (paths[i].flags & PMO_PATH_EVEN_ODD) ? PMO_FILL_EVEN_ODD : 0u);
-                pp += 2 * (size_t)s.sub_counts[k];
+            const uint32_t rule = (paths[i].flags & PMO_PATH_EVEN_ODD) ? PMO_FILL_EVEN_ODD : 0u;
+            if ((paths[i].flags & PMO_PATH_COMPOUND) && n_sub > 0) {
+                pmo_encoder_fill_compound(&e, pp, s.sub_counts, (size_t)n_sub, paths[i].fill_rgba, rule);
+            } else {
+                for (int64_t k = 0; k < n_sub; k++) {
+                    pmo_encoder_fill_rule(&e, pp, s.sub_counts[k], paths[i].fill_rgba, rule);
+                    pp += 2 * (size_t)s.sub_counts[k];
+                }
             }
         }
         if (paths[i].flags & PMO_PATH_STROKE) {

@@ -55,6 +55,27 @@ static uint16_t rd_u16(scene_t *s, size_t off) {
     return v;
 }
 
+/* Segments of a Fill item.  Plain (the reference, :262-263): point k to point k + 1, the last one
+ * back to point 0.  Compound (extension D11, pmo.h): entries with x = NaN separate sub-paths and
+ * start no segment; a point followed by a separator closes to the index the separator's y holds
+ * (clamped into the array: a malformed scene must not read outside it). */
+static int fill_seg_exists(scene_t *s, size_t pts, int compound, uint32_t k) {
+    if (!compound) return 1;
+    float x = rd_f32(s, pts + (size_t)k * 8);
+    return !(x != x);
+}
+static uint32_t fill_seg_end(scene_t *s, size_t pts, uint32_t n_points, int compound, uint32_t k) {
+    uint32_t nxt = (k + 1 == n_points) ? 0 : k + 1;
+    if (compound) {
+        float x = rd_f32(s, pts + (size_t)nxt * 8);
+        if (x != x) {
+            uint32_t start = rd_u32(s, pts + (size_t)nxt * 8 + 4);
+            nxt = start < n_points ? start : n_points - 1;
+        }
+    }
+    return nxt;
+}
+
 /* ---- TileEncoder (PietRender.metal:69-157) --------------------------------- */
 
 typedef struct {
@@ -215,6 +236,7 @@ static void run_group(scene_t *sc, uint32_t gx, uint32_t gy, tile_enc enc[LANES]
                 case PMO_ITEM_FILL: { /* :248-365 */
                     uint32_t rgba = rd_u32(sc, item_ref + 8);
                     uint32_t even_odd = rd_u32(sc, item_ref + 4) & PMO_FILL_EVEN_ODD; /* PietFill.flags (extension) */
+                    int compound = (rd_u32(sc, item_ref + 4) & PMO_FILL_COMPOUND) != 0; /* sub-paths (extension D11) */
                     uint32_t n_points = rd_u32(sc, item_ref + 12);
                     size_t pts = rd_u32(sc, item_ref + 16);
                     float backdrop[LANES];
@@ -225,8 +247,8 @@ static void run_group(scene_t *sc, uint32_t gx, uint32_t gy, tile_enc enc[LANES]
                         for (uint32_t tix = 0; tix < LANES; tix++) { /* phase 1 :258-295 */
                             int fill_hit = 0;
                             uint32_t fill_ix = j + (tix & 15);
-                            if (fill_ix < n_points) {
-                                uint32_t nxt = (fill_ix + 1 == n_points) ? 0 : fill_ix + 1;
+                            if (fill_ix < n_points && fill_seg_exists(sc, pts, compound, fill_ix)) {
+                                uint32_t nxt = fill_seg_end(sc, pts, n_points, compound, fill_ix);
                                 float stx = rd_f32(sc, pts + (size_t)fill_ix * 8), sty = rd_f32(sc, pts + (size_t)fill_ix * 8 + 4);
                                 float enx = rd_f32(sc, pts + (size_t)nxt * 8), eny = rd_f32(sc, pts + (size_t)nxt * 8 + 4);
                                 float xmin = fminf(stx, enx), ymin = fminf(sty, eny);
@@ -261,7 +283,7 @@ static void run_group(scene_t *sc, uint32_t gx, uint32_t gy, tile_enc enc[LANES]
                             while (fill_vote) {
                                 uint32_t sub = (uint32_t)__builtin_ctz(fill_vote);
                                 uint32_t fill_ix = j + sub;
-                                uint32_t nxt = (fill_ix + 1 == n_points) ? 0 : fill_ix + 1;
+                                uint32_t nxt = fill_seg_end(sc, pts, n_points, compound, fill_ix);
                                 float stx = rd_f32(sc, pts + (size_t)fill_ix * 8), sty = rd_f32(sc, pts + (size_t)fill_ix * 8 + 4);
                                 float enx = rd_f32(sc, pts + (size_t)nxt * 8), eny = rd_f32(sc, pts + (size_t)nxt * 8 + 4);
                                 float xmin = fminf(stx, enx), ymin = fminf(sty, eny);

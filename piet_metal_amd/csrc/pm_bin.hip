@@ -21,6 +21,20 @@ __global__ void pm_index_kernel(const uint8_t *scene, uint32_t n_items, uint32_t
     const uint32_t k0 = (ch - chunk_base[item]) * kChunkSegs;
     const uint32_t k1 = min(k0 + kChunkSegs, nseg);
     float xmin = 0.f, ymin = 0.f, xmax = 0.f, ymax = 0.f;
+    if (tag == kItemFill && (LoadU32(it + 4) & kFillCompound)) {
+        // compound fill: the box of the segments that exist (a chunk of separators only keeps an
+        // empty box no strip row can pass)
+        xmin = ymin = 3.0e38f;
+        xmax = ymax = -3.0e38f;
+        for (uint32_t k = k0; k < k1; ++k) {
+            float2 a, b;
+            if (!FillSegmentEnds(pts, npt, true, k, a, b)) continue;
+            xmin = fminf(xmin, fminf(a.x, b.x)); ymin = fminf(ymin, fminf(a.y, b.y));
+            xmax = fmaxf(xmax, fmaxf(a.x, b.x)); ymax = fmaxf(ymax, fmaxf(a.y, b.y));
+        }
+        chunk_bbox[ch] = make_float4(xmin, ymin, xmax, ymax);
+        return;
+    }
     // points k0 .. k1 (the fill's closing segment wraps to point 0)
     for (uint32_t k = k0; k <= k1; ++k) {
         const uint32_t pi = (tag == kItemFill && k == npt) ? 0u : k;
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                 nch = 1;  // never culled at strip level (PietRender.metal:223-247)
             } else if (tag == kItemFill) {
                 rgba = w23v.x;
-                aux0 = w01v.y & kFillEvenOdd;  // PietFill.flags: the winding rule
+                aux0 = w01v.y & (kFillEvenOdd | kFillCompound);  // PietFill.flags: the winding rule, sub-path separators
                 npt = w23v.y;
                 pts = w4v;
                 nseg = FillSegs(npt);
@@ -447,11 +461,11 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                         const uint32_t ctag = s_ctag[vc];
                         const uint8_t *pts = scene + s_cpts[vc];
                         if (ctag == kItemFill) {
-                            const uint32_t k1 = (k + 1 == s_cnpt[vc]) ? 0u : k + 1;
-                            const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
-                            const float2 b = LoadF2(pts + static_cast<size_t>(k1) * 8);
-                            seg = make_float4(a.x, a.y, b.x, b.y);
-                            vote = VoteFill(seg, y0, sx0);
+                            float2 a, b;
+                            if (FillSegmentEnds(pts, s_cnpt[vc], (s_caux0[vc] & kFillCompound) != 0, k, a, b)) {
+                                seg = make_float4(a.x, a.y, b.x, b.y);
+                                vote = VoteFill(seg, y0, sx0);
+                            }
                         } else if (ctag == kItemPoly) {
                             const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
                             const float2 b = LoadF2(pts + static_cast<size_t>(k + 1) * 8);

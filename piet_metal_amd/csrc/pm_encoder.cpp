@@ -171,6 +171,35 @@ void Encoder::Fill(const double *pts_xy, size_t n, uint32_t rgba, uint32_t flags
     AddItem(item, ToShortBbox(Rect{bb[0], bb[1], bb[2], bb[3]}));
 }
 
+void Encoder::FillCompound(const double *pts_xy, const uint32_t *sub_counts, size_t n_sub, uint32_t rgba, uint32_t flags) {
+    // Extension D11 (pm_layout.h): the sub-paths' points back to back, a separator after each
+    size_t total = 0;
+    for (size_t k = 0; k < n_sub; ++k) total += static_cast<size_t>(sub_counts[k]) + 1;
+    const size_t points_ix = Alloc(total * 2 * sizeof(float));
+    if (n_sub == 0 && status_ == kOk) status_ = kMisuse;
+    Rect bb{0, 0, 0, 0};
+    bool first = true;
+    size_t at = points_ix;
+    uint32_t index = 0;
+    for (size_t k = 0; k < n_sub; ++k) {
+        const uint32_t start = index;
+        if (sub_counts[k] == 0 && status_ == kOk) status_ = kMisuse;  // .expect("encoded empty points vector"), :238
+        for (uint32_t i = 0; i < sub_counts[k]; ++i, pts_xy += 2, ++index, at += 2 * sizeof(float)) {
+            if (first) bb = Rect::FromPoint(pts_xy[0], pts_xy[1]);
+            else bb.UnionPt(pts_xy[0], pts_xy[1]);
+            first = false;
+            const float xy[2] = {static_cast<float>(pts_xy[0]), static_cast<float>(pts_xy[1])};
+            Put(at, xy, sizeof(xy));
+        }
+        const uint32_t sep[2] = {kSubpathSeparatorBits, start};
+        Put(at, sep, sizeof(sep));
+        at += sizeof(sep);
+        ++index;
+    }
+    PietFill item{kItemFill, flags | kFillCompound, ByteSwap(rgba), static_cast<uint32_t>(total), static_cast<uint32_t>(points_ix)};
+    AddItem(item, ToShortBbox(bb));
+}
+
 void Encoder::Polyline(const double *pts_xy, size_t n, uint32_t rgba, float width) {
     double bb[4] = {0, 0, 0, 0};
     const size_t points_ix = EncodePoints(pts_xy, n, bb);
@@ -239,6 +268,12 @@ int pm_encoder_end_group(pm_encoder *e) {
 int pm_encoder_circle(pm_encoder *e, double cx, double cy, double r) {
     if (!e) return PM_ERR_INVALID;
     e->enc.Circle(cx, cy, r);
+    return e->enc.c_status();
+}
+int pm_encoder_fill_compound(pm_encoder *e, const double *pts_xy, const uint32_t *sub_counts, size_t n_subpaths, uint32_t rgba,
+                             uint32_t fill_flags) {
+    if (!e || (n_subpaths && (!pts_xy || !sub_counts))) return PM_ERR_INVALID;
+    e->enc.FillCompound(pts_xy, sub_counts, n_subpaths, rgba, fill_flags & PM_FILL_EVEN_ODD);
     return e->enc.c_status();
 }
 int pm_encoder_ellipse(pm_encoder *e, double cx, double cy, double rx, double ry) {

@@ -26,6 +26,8 @@ public:
     void Ellipse(double cx, double cy, double rx, double ry);  // extension: Circle item + kCircleEllipse
     void StrokeLine(double x0, double y0, double x1, double y1, float width, uint32_t rgba);  // :177
     void Fill(const double *pts_xy, size_t n, uint32_t rgba, uint32_t flags = 0);             // :195 (+ PietFill.flags)
+    // extension: several closed sub-paths under one winding sum (PietFill.flags bit 1, pm_layout.h)
+    void FillCompound(const double *pts_xy, const uint32_t *sub_counts, size_t n_sub, uint32_t rgba, uint32_t flags = 0);
     void Polyline(const double *pts_xy, size_t n, uint32_t rgba, float width);                // :209
     // :224 -- returns points_ix, bbox_out = {x0,y0,x1,y1}
     size_t EncodePoints(const double *pts_xy, size_t n, double bbox_out[4]);

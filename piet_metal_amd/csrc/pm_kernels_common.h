@@ -176,6 +176,23 @@ __device__ __forceinline__ bool VoteFill(float4 s, int y0, int sx0) {
     return hit;
 }
 
+// End points of segment k of a Fill item (pts = its point array, npt entries).  Plain (the
+// reference, PietRender.metal:262-263): point k to point k + 1, the last one back to point 0.
+// Compound (extension D11, pm_layout.h): NaN entries separate sub-paths and start no segment
+// (returns false); a point followed by a separator closes to the index the separator carries,
+// clamped into the array.  The second load happens for closing segments only.
+__device__ __forceinline__ bool FillSegmentEnds(const uint8_t *pts, uint32_t npt, bool compound, uint32_t k, float2 &a, float2 &b) {
+    const uint32_t k1 = (k + 1 == npt) ? 0u : k + 1;
+    a = LoadF2(pts + static_cast<size_t>(k) * 8);
+    b = LoadF2(pts + static_cast<size_t>(k1) * 8);
+    if (compound) {
+        if (a.x != a.x) return false;
+        if (b.x != b.x) b = LoadF2(pts + static_cast<size_t>(min(__float_as_uint(b.y), npt - 1u)) * 8);
+    }
+    return true;
+}
+
+
 // PietRender.metal:374-399.  y_test = row of the lane that votes for this segment
 // (lane = segment index & 31, row = lane >> 4: quirk Q4), sx0/sy0 = group origin.
 __device__ __forceinline__ bool VotePoly(float4 s, float hw, int y_test, int sx0, int sy0) {

@@ -37,6 +37,12 @@ enum ItemTag : uint32_t {  // src/lib.rs:70-77
 
 // PietFill.flags (src/lib.rs:54, "will be used for winding number rule", TestApp/SceneEncoder.h:44)
 constexpr uint32_t kFillEvenOdd = 1u;  // even-odd instead of non-zero (PietRender.metal:539-540)
+// Extension (decision D11, "need to deal with subpaths", src/lib.rs:194): PietFill.flags bit 1 = the
+// point array holds several closed sub-paths that share one winding sum and one DrawFill.  Every
+// sub-path is followed by a separator entry {x = NaN, y = bits of the index of its first point};
+// n_points counts points and separators (FillSegmentEnd in pm_kernels_common.h).
+constexpr uint32_t kFillCompound = 2u;
+constexpr uint32_t kSubpathSeparatorBits = 0x7fc00000u;
 // Extension (decision D10): bit 16 of a Circle's item_type word (the reference reads the tag as a
 // ushort, PietRender.metal:216) asks for the ellipse inscribed in the item's bbox -- the shading
 // PietRender.metal:488-489 leaves as a TODO.  Travels to the tile's list in CmdCircle.flags.

@@ -48,6 +48,15 @@ class Encoder:
     def circle(self, center, radius: float) -> None:
         _lib.check(self._lib.pm_encoder_circle(self._h, center[0], center[1], radius), "circle")
 
+    def fill_compound(self, subpaths, rgba: int, even_odd: bool = False) -> None:
+        """Beyond the reference: ONE Fill item made of several closed sub-paths that share a winding
+        sum (holes); `subpaths` is a sequence of (n, 2) point arrays."""
+        subs = [np.ascontiguousarray(s, np.float64).reshape(-1, 2) for s in subpaths]
+        counts = np.asarray([len(s) for s in subs], np.uint32)
+        pts = np.concatenate(subs) if subs else np.zeros((0, 2), np.float64)
+        _lib.check(self._lib.pm_encoder_fill_compound(self._h, pts.ctypes.data, counts.ctypes.data, len(subs), rgba,
+                                                     _lib.PM_FILL_EVEN_ODD if even_odd else 0), "fill_compound")
+
     def ellipse(self, center, rx: float, ry: float) -> None:
         """Beyond the reference: the ellipse inscribed in the item's bbox (a Circle item with the
         ellipse bit), shaded as PietRender.metal:488-489 says it should be."""

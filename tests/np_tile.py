@@ -120,15 +120,25 @@ def tile_lists(scene: bytes, width: int, height: int):
                     rgba, npts, pix = u32(item + 8), u32(item + 12), u32(item + 16)
                     even_odd = u32(item + 4) & 1  # extension: PietFill.flags bit 0 (src/lib.rs:54)
                     P = lambda k: pt(pix, k)
+                    compound = (u32(item + 4) >> 1) & 1  # extension D11: sub-paths, NaN separators carrying the start index
+
+                    def seg_end(k):  # index of the end point of segment k, or None if entry k is a separator
+                        if compound and np.isnan(P(k)[0]):
+                            return None
+                        n = 0 if k + 1 == npts else k + 1
+                        if compound and np.isnan(P(n)[0]):
+                            n = min(u32(pix + 8 * n + 4), npts - 1)
+                        return n
+
                     backdrop = [f32(0.0)] * 32
                     any_fill = [False] * 32
                     for j in range(0, npts, 16):
                         vote = 0
                         for tix, L in enumerate(lanes):  # phase 1: lane tix looks at segment j + (tix & 15)
                             k = j + (tix & 15)
-                            if k >= npts:
+                            if k >= npts or seg_end(k) is None:
                                 continue
-                            st, en = P(k), P(0 if k + 1 == npts else k + 1)
+                            st, en = P(k), P(seg_end(k))
                             xmin, ymin = min(st[0], en[0]), min(st[1], en[1])
                             xmax, ymax = max(st[0], en[0]), max(st[1], en[1])
                             y0 = L["y0"]
@@ -152,7 +162,7 @@ def tile_lists(scene: bytes, width: int, height: int):
                                 if not hit:
                                     continue
                                 k = j + sub
-                                st, en = P(k), P(0 if k + 1 == npts else k + 1)
+                                st, en = P(k), P(seg_end(k))
                                 xmin, ymin = min(st[0], en[0]), min(st[1], en[1])
                                 xmax, ymax = max(st[0], en[0]), max(st[1], en[1])
                                 x0, y0 = L["x0"], L["y0"]

@@ -515,6 +515,37 @@ def test_even_odd_fills_and_nested_groups(pm, pmo, renderer, seed, n, extent, w,
     assert st["n_items"] == len(inline_ops(tree))
 
 
+def test_compound_fills(pm, pmo, renderer):
+    """Extension D11 on the GPU: Fill items made of several sub-paths (holes, islands, one-point
+    sub-paths, hundreds of sub-paths in one item so that chunks hold nothing but separators),
+    pixels and command lists against the oracle; a malformed separator index stays inside the array."""
+    rng = np.random.default_rng(51)
+    ops = []
+    for _ in range(120):
+        m = int(rng.integers(3, 9))
+        c = rng.uniform(20, 480, 2)
+        pts = c + rng.uniform(-90, 90, (m, 2))
+        subs = [pts, (c + (pts - c) * 0.5)[::-1]]
+        if rng.random() < 0.5:
+            subs.append(pts[:2] + rng.uniform(-40, 40, 2))
+        rgba = int(rng.integers(0, 1 << 32)) | (0xFF if rng.random() < 0.5 else 0)
+        ops.append(("fill_cp_eo" if rng.random() < 0.3 else "fill_cp", subs, rgba))
+    many = [np.array([[x, y], [x + 3.0, y + 0.5], [x + 2.5, y + 3.0]]) for x in np.arange(10.0, 500.0, 7.0) for y in (100.0, 300.0, 303.5)]
+    many += [np.array([[float(x), 250.0]]) for x in range(30)]  # one-point sub-paths: chunks of separators and degenerate segments
+    ops.append(("fill_cp", many, 0x102030FF))
+    ops += random_ops(52, 60, extent=500.0)
+    scene = encode_ops(pm, ops, cap=4 << 20)
+    got = gpu_render(renderer, scene, 512, 500)
+    assert np.array_equal(got, pmo.render(scene, 512, 500))
+    assert_ptcl_equal(renderer, pmo, scene, 512, 500, maxc=2048)
+    # a separator whose index points outside the array is clamped, not followed (both sides)
+    bad = encode_ops(pm, [("fill_cp", [many[0], many[1]], 0x102030FF)]).copy()
+    items = struct.unpack("<I", bad[4:8].tobytes())[0]
+    pix = struct.unpack("<I", bad[items + 16 : items + 20].tobytes())[0]
+    bad[pix + 8 * 3 + 4 : pix + 8 * 3 + 8] = np.frombuffer(struct.pack("<I", 0x7FFFFFFF), np.uint8)
+    assert np.array_equal(gpu_render(renderer, bad, 128, 128), pmo.render(bad, 128, 128))
+
+
 def test_ellipses(pm, pmo, renderer):
     """Extension D10 on the GPU: Circle items with the ellipse bit -- sparse (one wave per tile),
     piled up (lists longer than a chunk, rendered by a workgroup), degenerate and clipped by the

@@ -93,6 +93,12 @@ def _oracle_encode(pmo, ops, cap=1 << 20):
             elif op[0] == "fill_eo":  # extension: PietFill.flags bit 0
                 a = np.ascontiguousarray(op[1], np.float64)
                 lib.pmo_encoder_fill_rule(C.byref(e), C.c_void_p(a.ctypes.data), C.c_size_t(len(a)), C.c_uint32(op[2]), C.c_uint32(1))
+            elif op[0] in ("fill_cp", "fill_cp_eo"):  # extension: compound fill (sub-paths)
+                subs = [np.ascontiguousarray(q, np.float64).reshape(-1, 2) for q in op[1]]
+                a = np.concatenate(subs)
+                cnt = np.asarray([len(q) for q in subs], np.uint32)
+                lib.pmo_encoder_fill_compound(C.byref(e), C.c_void_p(a.ctypes.data), C.c_void_p(cnt.ctypes.data), C.c_size_t(len(subs)),
+                                              C.c_uint32(op[2]), C.c_uint32(1 if op[0] == "fill_cp_eo" else 0))
             elif op[0] == "group":  # extension: nested group
                 emit(op[1])
             else:
@@ -152,6 +158,8 @@ def encode_ops(pm, ops, cap=1 << 20):
                 e.fill(op[1], op[2])
             elif op[0] == "fill_eo":
                 e.fill(op[1], op[2], even_odd=True)
+            elif op[0] in ("fill_cp", "fill_cp_eo"):
+                e.fill_compound(op[1], op[2], even_odd=op[0] == "fill_cp_eo")
             elif op[0] == "group":
                 emit(op[1])
             else:
@@ -172,6 +180,18 @@ def extend_ops(seed, ops):
     rng = np.random.default_rng(seed ^ 0xE0)
     out = []
     for op in ops:
+        if op[0] == "fill" and len(op[1]) >= 3 and rng.random() < 0.3:
+            # compound fill: the outline, a hole (the outline shrunk and reversed), sometimes a third
+            # contour somewhere else and a one-point sub-path
+            pts = np.asarray(op[1], np.float64)
+            c = pts.mean(axis=0)
+            subs = [pts, (c + (pts - c) * float(rng.uniform(0.2, 0.8)))[::-1]]
+            if rng.random() < 0.4:
+                subs.append(pts + rng.uniform(-60, 60, 2))
+            if rng.random() < 0.2:
+                subs.append(pts[:1] + 3.0)
+            out.append(("fill_cp_eo" if rng.random() < 0.3 else "fill_cp", subs, op[2]))
+            continue
         if op[0] == "circle" and rng.random() < 0.5:
             rx, ry = float(rng.uniform(0.2, 60)), float(rng.uniform(0.2, 60))
             if rng.random() < 0.1:

@@ -246,6 +246,43 @@ def test_kat_even_odd_rule(pm, pmo):
     assert (img_nz != img).any()
 
 
+def test_kat_compound_fill(pm, pmo):
+    """Extension D11 ("need to deal with subpaths", src/lib.rs:194): one Fill item made of several
+    closed sub-paths.  Known answers: a reversed inner contour is a hole under the non-zero rule, an
+    equally oriented one is not -- unless the rule is even-odd; the coverage sums are the exact
+    areas; one sub-path alone renders like the plain Fill; two disjoint sub-paths render like two
+    Fills; the separators carry the start index of their sub-path."""
+    from test_host_cpu import encode_ops
+
+    th = np.deg2rad(11.0)
+    rot = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    sq = np.array([[-1, -1], [1, -1], [1, 1], [-1, 1]], np.float64)
+    outer = (sq * 50.0) @ rot.T + (120.3, 110.6)
+    inner = (sq * 20.0) @ rot.T + (120.3, 110.6)
+    W, H = 240, 224
+    cov = lambda ops: pmo.fill_coverage(encode_ops(pm, ops), 0, W, H).astype(np.float64)
+    hole = cov([("fill_cp", [outer, inner[::-1]], 0x203040FF)])
+    same = cov([("fill_cp", [outer, inner], 0x203040FF)])
+    same_eo = cov([("fill_cp_eo", [outer, inner], 0x203040FF)])
+    assert abs(hole.sum() - (100.0 ** 2 - 40.0 ** 2)) < 4.0 and hole[110, 120] == 0.0 and hole[110, 120 + 35] == 1.0
+    assert abs(same.sum() - 100.0 ** 2) < 3.0 and same[110, 120] == 1.0
+    assert abs(same_eo.sum() - (100.0 ** 2 - 40.0 ** 2)) < 6.0 and same_eo[110, 120] == 0.0
+    one = encode_ops(pm, [("fill_cp", [outer], 0x20304080)])
+    plain = encode_ops(pm, [("fill", outer, 0x20304080)])
+    assert not np.array_equal(one, plain) and np.array_equal(pmo.render(one, W, H), pmo.render(plain, W, H))
+    far = outer + (0.0, 0.0)
+    a, b = outer * 0.4 + (10.0, 5.0), outer * 0.4 + (120.0, 100.0)
+    two = pmo.render(encode_ops(pm, [("fill_cp", [a, b], 0x203040FF)]), W, H)
+    assert np.array_equal(two, pmo.render(encode_ops(pm, [("fill", a, 0x203040FF), ("fill", b, 0x203040FF)]), W, H))
+    scene = encode_ops(pm, [("fill_cp", [outer, inner[::-1], far[:1]], 0x203040FF)])
+    items = int(np.frombuffer(scene[4:8].tobytes(), "<u4")[0])
+    flags, npt, pix = (int(v) for v in np.frombuffer(scene[items + 4 : items + 20].tobytes(), "<u4")[[0, 2, 3]])
+    assert flags == 2 and npt == 4 + 1 + 4 + 1 + 1 + 1
+    words = np.frombuffer(scene[pix : pix + 8 * npt].tobytes(), "<u4").reshape(-1, 2)
+    seps = [k for k in range(npt) if words[k, 0] == 0x7FC00000]
+    assert seps == [4, 9, 11] and [int(words[k, 1]) for k in seps] == [0, 5, 10]
+
+
 def test_kat_ellipse(pm, pmo):
     """Extension D10: a Circle item with bit 16 of its tag word set is the ellipse inscribed in its
     bbox (PietRender.metal:488-489's TODO).  Known answers: centre black, just outside the axes
