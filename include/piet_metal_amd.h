@@ -110,6 +110,7 @@ typedef struct {
 #define PM_PATH_FILL 1u
 #define PM_PATH_STROKE 2u
 #define PM_PATH_EVEN_ODD 4u /* fill-rule="evenodd": the fill item gets PM_FILL_EVEN_ODD */
+#define PM_PATH_COMPOUND 8u /* the path's sub-paths become ONE compound Fill item (PM_FILL_COMPOUND): holes work */
 
 typedef struct {
     uint32_t el_begin, el_end; /* element range of this <path> */
@@ -120,8 +121,9 @@ typedef struct {
 } pm_path;                     /* 24 bytes */
 
 #define PM_SVG_REJECT_ARC_PATHS 1 /* drop any path whose data holds A/a */
-#define PM_SVG_SPEC_DEFAULTS 2    /* SVG's initial `fill: black`; default: make_tiger's rule -- only a fill
-                                     property (own or inherited) fills (src/lib.rs:299) */
+#define PM_SVG_SPEC_DEFAULTS 2    /* SVG's initial `fill: black`, and the sub-paths of a path are filled TOGETHER
+                                     (PM_PATH_COMPOUND: holes); default: make_tiger's rules -- only a fill property
+                                     (own or inherited) fills (src/lib.rs:299), every sub-path is its own item (:343) */
 
 /* Beyond what make_tiger reads (d / fill / stroke / stroke-width of every <path>), pm_svg_parse
  * understands: <g>/<svg> nesting with inherited presentation properties, `transform`

@@ -386,7 +386,8 @@ int64_t pmo_scene_from_paths(uint8_t *buf, size_t cap, const pmo_path *paths, si
         int64_t n_sub;
         size_t n_pts;
         if (flatten_grow(els, &paths[i], affine, &s, &n_sub, &n_pts)) goto done;
-        if (paths[i].flags & PMO_PATH_FILL) n_items += (size_t)n_sub;   /* count_fill_items */
+        if (paths[i].flags & PMO_PATH_FILL) /* count_fill_items; a compound fill (extension D11) is one item */
+            n_items += (paths[i].flags & PMO_PATH_COMPOUND) ? (size_t)(n_sub > 0) : (size_t)n_sub;
         if (paths[i].flags & PMO_PATH_STROKE) n_items += (size_t)n_sub; /* count_stroke_items */
     }
     if (n_items_out) *n_items_out = (uint32_t)n_items;

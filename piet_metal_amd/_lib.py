@@ -21,8 +21,9 @@ PM_ERR_SCENE = -5
 PM_ERR_PARSE = -6
 
 PM_EL_MOVE, PM_EL_LINE, PM_EL_QUAD, PM_EL_CURVE, PM_EL_CLOSE = range(5)
-PM_PATH_FILL, PM_PATH_STROKE, PM_PATH_EVEN_ODD = 1, 2, 4
+PM_PATH_FILL, PM_PATH_STROKE, PM_PATH_EVEN_ODD, PM_PATH_COMPOUND = 1, 2, 4, 8
 PM_FILL_EVEN_ODD = 1
+PM_FILL_COMPOUND = 2
 PM_SVG_REJECT_ARC_PATHS = 1
 PM_SVG_SPEC_DEFAULTS = 2
 PM_FMT_RGBA8, PM_FMT_BGRA8 = 0, 1

@@ -190,9 +190,18 @@ __global__ __launch_bounds__(kScanThreads) void KScan(const pm_path *paths, uint
         const uint32_t p = base + threadIdx.x;
         uint32_t vi = 0, vq = 0;
         if (p < n_paths) {
-            const uint32_t mult = ((paths[p].flags & PM_PATH_FILL) ? 1u : 0u) + ((paths[p].flags & PM_PATH_STROKE) ? 1u : 0u);
-            vi = (el_mvoff[paths[p].el_end] - el_mvoff[paths[p].el_begin]) * mult;
-            vq = (el_ptoff[paths[p].el_end] - el_ptoff[paths[p].el_begin]) * mult;
+            const uint32_t n_sub = el_mvoff[paths[p].el_end] - el_mvoff[paths[p].el_begin];
+            const uint32_t n_pts = el_ptoff[paths[p].el_end] - el_ptoff[paths[p].el_begin];
+            if (paths[p].flags & PM_PATH_FILL) {
+                // a compound fill is ONE item; its point array also holds a separator per sub-path
+                const bool compound = (paths[p].flags & PM_PATH_COMPOUND) != 0;
+                vi += compound ? (n_sub ? 1u : 0u) : n_sub;
+                vq += n_pts + (compound ? n_sub : 0u);
+            }
+            if (paths[p].flags & PM_PATH_STROKE) {
+                vi += n_sub;
+                vq += n_pts;
+            }
         }
         uint32_t ti, tq;
         const uint32_t oi = BlockScan1024(vi, s_w, &ti);
@@ -228,8 +237,14 @@ __global__ void KPoints(const pm_path *paths, uint32_t n_paths, const pm_path_el
     const size_t points_start = sizeof(SimpleGroup) + static_cast<size_t>(n_items) * (sizeof(ShortBbox) + kItemSize);
     const bool has_fill = (path.flags & PM_PATH_FILL) != 0;
     const bool has_stroke = (path.flags & PM_PATH_STROKE) != 0;
-    const size_t dst0 = points_start + 8 * (static_cast<size_t>(path_pt_base[p]) + local);
-    const size_t dst1 = dst0 + 8 * static_cast<size_t>(path_pts);  // stroke copy when a fill copy exists
+    // compound fill: the fill copy has a separator after every sub-path, so this element's points
+    // sit `sub` entries further (sub = index of its sub-path), and the stroke copy starts n_sub later
+    const bool compound = has_fill && (path.flags & PM_PATH_COMPOUND) != 0;
+    const uint32_t n_sub_path = el_mvoff[path.el_end] - el_mvoff[path.el_begin];
+    const uint32_t sub = el_mvoff[i] + (tag == PM_EL_MOVE ? 1u : 0u) - el_mvoff[path.el_begin] - 1u;  // (an element before the first MoveTo was rejected by KCount)
+    const size_t base = points_start + 8 * static_cast<size_t>(path_pt_base[p]);
+    const size_t dst0 = base + 8 * (static_cast<size_t>(local) + (compound ? sub : 0u));
+    const size_t dst1 = base + 8 * (static_cast<size_t>(path_pts) + (compound ? n_sub_path : 0u) + local);  // stroke copy when a fill copy exists
     double bx0, by0, bx1, by1;
     auto emit = [&](uint32_t k, double x, double y) {
         if (k == 0) {
@@ -310,7 +325,44 @@ __global__ void KItems(const pm_path *paths, uint32_t n_paths, const pm_path_el 
     const bool has_stroke = (path.flags & PM_PATH_STROKE) != 0;
     uint32_t item = path_item_base[p] + j;
     size_t pts_ix = points_start + 8 * (static_cast<size_t>(path_pt_base[p]) + local);
-    if (has_fill) {
+    if (has_fill && (path.flags & PM_PATH_COMPOUND)) {
+        // Extension D11 (pm_layout.h): the path's sub-paths are ONE Fill item.  Every sub-path's
+        // thread writes the separator that follows its points; the first one also writes the item.
+        const size_t fill_base = points_start + 8 * static_cast<size_t>(path_pt_base[p]);
+        const size_t sep_at = fill_base + 8 * (static_cast<size_t>(el_ptoff[last] - el_ptoff[path.el_begin]) + j);
+        if (sep_at + 8 <= scene_cap) {
+            uint32_t *sep = reinterpret_cast<uint32_t *>(scene + sep_at);
+            sep[0] = kSubpathSeparatorBits;
+            sep[1] = local + j;  // index of this sub-path's first point in the item's array
+        }
+        item = path_item_base[p];
+        if (j == 0 && items_start + (static_cast<size_t>(item) + 1) * kItemSize <= scene_cap) {
+            double ux0 = 0, uy0 = 0, ux1 = 0, uy1 = 0;  // (Rect::union_pt over every point of the path)
+            bool got = false;
+            for (uint32_t i = path.el_begin; i < path.el_end; ++i) {
+                if (el_npts[i] == 0) continue;
+                const double *b = el_bbox + 4 * static_cast<size_t>(i);
+                if (!got) {
+                    ux0 = b[0]; uy0 = b[1]; ux1 = b[2]; uy1 = b[3];
+                    got = true;
+                } else {
+                    ux0 = fmin(ux0, b[0]); uy0 = fmin(uy0, b[1]);
+                    ux1 = fmax(ux1, b[2]); uy1 = fmax(uy1, b[3]);
+                }
+            }
+            ShortBbox sb{SatU16(floor(ux0)), SatU16(floor(uy0)), SatU16(ceil(ux1)), SatU16(ceil(uy1))};
+            *reinterpret_cast<ShortBbox *>(scene + bbox_start + static_cast<size_t>(item) * sizeof(ShortBbox)) = sb;
+            uint32_t *it = reinterpret_cast<uint32_t *>(scene + items_start + static_cast<size_t>(item) * kItemSize);
+            it[0] = kItemFill;
+            it[1] = kFillCompound | ((path.flags & PM_PATH_EVEN_ODD) ? kFillEvenOdd : 0u);
+            it[2] = __builtin_bswap32(path.fill_rgba);
+            it[3] = path_pts + n_sub_path;
+            it[4] = static_cast<uint32_t>(fill_base);
+            it[5] = it[6] = it[7] = 0;
+        }
+        item = path_item_base[p] + 1u + j;
+        pts_ix = fill_base + 8 * (static_cast<size_t>(path_pts) + n_sub_path + local);
+    } else if (has_fill) {
         // Encoder::fill, src/lib.rs:195-207
         if (items_start + (static_cast<size_t>(item) + 1) * kItemSize <= scene_cap) {
             ShortBbox sb{SatU16(floor(bx0)), SatU16(floor(by0)), SatU16(ceil(bx1)), SatU16(ceil(by1))};

@@ -806,6 +806,13 @@ int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
                     if (!st.fill.none && (closed || is_path || name_len == 8 /* polyline fills its implicit closure */)) {
                         path.flags |= PM_PATH_FILL;
                         if (st.even_odd) path.flags |= PM_PATH_EVEN_ODD;
+                        if (flags & PM_SVG_SPEC_DEFAULTS) {
+                            // SVG fills a path's sub-paths TOGETHER (holes, overlaps by the fill rule);
+                            // make_tiger fills them one by one (src/lib.rs:343-347), which stays the default
+                            size_t moves = 0;
+                            for (size_t k = el0; k < out->els.size(); ++k) moves += out->els[k].tag == PM_EL_MOVE;
+                            if (moves > 1) path.flags |= PM_PATH_COMPOUND;
+                        }
                         path.fill_rgba = PaintRgba(st.fill, st.opacity * st.fill_opacity);
                     }
                     if (!st.stroke.none) {

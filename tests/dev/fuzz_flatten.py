@@ -33,6 +33,7 @@ def random_pathset(rng, n_paths, extent):
             if rng.random() < 0.6:
                 els.append((_lib.PM_EL_CLOSE, [0] * 6))
         flags = int(rng.integers(1, 4))  # fill, stroke or both
+        flags |= (4 if rng.random() < 0.3 else 0) | (8 if rng.random() < 0.4 else 0)  # even-odd rule, compound fill
         rgba = lambda: (int(rng.integers(0, 1 << 24)) << 8 | (0xFF if rng.random() < 0.4 else int(rng.integers(1, 255)))) & 0xFFFFFFFF
         width = float(rng.choice([0.05, 0.3, 1.0, 4.0]))
         paths.append((e0, len(els), flags, rgba(), rgba(), width))

@@ -75,7 +75,8 @@ def _short_bbox(x0, y0, x1, y1):
 def scene_from_paths(paths, els, affine) -> bytes:
     """paths: stroke widths ALREADY multiplied by the scale (src/lib.rs:320)."""
     flat = [flatten(els[int(p["el_begin"]) : int(p["el_end"])], affine) for p in paths]
-    n_items = sum(len(s) * (bool(p["flags"] & 1) + bool(p["flags"] & 2)) for p, s in zip(paths, flat))
+    # (extensions: flags bit 2 = even-odd rule, bit 3 = the filled sub-paths form ONE compound item)
+    n_items = sum((min(len(s), 1) if p["flags"] & 8 else len(s)) * bool(p["flags"] & 1) + len(s) * bool(p["flags"] & 2) for p, s in zip(paths, flat))
     item_start = 8 + 8 * n_items
     buf = bytearray(item_start + 32 * n_items)
     struct.pack_into("<II", buf, 0, n_items, item_start)
@@ -99,10 +100,23 @@ def scene_from_paths(paths, els, affine) -> bytes:
 
     be = lambda v: struct.unpack("<I", struct.pack(">I", v & 0xFFFFFFFF))[0]
     for p, subs in zip(paths, flat):
-        if p["flags"] & 1:
+        rule = 1 if p["flags"] & 4 else 0
+        if p["flags"] & 1 and p["flags"] & 8 and subs:
+            # compound fill: points and a separator {NaN, start index} after every sub-path
+            pix = len(buf)
+            allp = [q for pts in subs for q in pts]
+            bb = (min(q[0] for q in allp), min(q[1] for q in allp), max(q[0] for q in allp), max(q[1] for q in allp))
+            at = 0
+            for pts in subs:
+                for (x, y) in pts:
+                    buf += struct.pack("<ff", np.float32(x), np.float32(y))
+                buf += struct.pack("<II", 0x7FC00000, at)
+                at += len(pts) + 1
+            add_item(struct.pack("<5I", 3, 2 | rule, be(int(p["fill_rgba"])), at, pix), _short_bbox(*bb))
+        elif p["flags"] & 1:
             for pts in subs:
                 pix, bb = encode_points(pts)
-                add_item(struct.pack("<5I", 3, 0, be(int(p["fill_rgba"])), len(pts), pix), _short_bbox(*bb))
+                add_item(struct.pack("<5I", 3, rule, be(int(p["fill_rgba"])), len(pts), pix), _short_bbox(*bb))
         if p["flags"] & 2:
             width, rgba = np.float32(p["stroke_width"]), int(p["stroke_rgba"])
             if width < THIN_LINE:

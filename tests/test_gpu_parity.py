@@ -590,6 +590,30 @@ def test_even_odd_through_the_device_flatten(pm, pmo, renderer):
     assert (got != pmo.render(plain, wl.width, wl.height)).any()  # the Tiger has self-overlapping outlines
 
 
+def test_compound_fills_through_the_device_flatten(pm, pmo, renderer):
+    """PM_PATH_COMPOUND: the flatten kernels write ONE Fill item per path, its sub-paths separated
+    in the point array -- scene bytes equal the oracle's encoder, pixels equal its render (Tiger,
+    every filled path compound, with and without the even-odd rule, strokes untouched)."""
+    wl = pm.workloads.tiger(960, 540)
+    for extra in (0, pm._lib.PM_PATH_EVEN_ODD):
+        ps = pm.PathSet(wl.paths.paths.copy(), wl.paths.els)
+        fill = (ps.paths["flags"] & pm._lib.PM_PATH_FILL) != 0
+        ps.paths["flags"] |= np.where(fill, pm._lib.PM_PATH_COMPOUND | extra, 0).astype(np.uint32)
+        renderer.resize(wl.width, wl.height)
+        renderer.flatten_and_encode(ps, wl.affine, wl.width_scale)
+        scene = renderer.download_scene()
+        want_scene, n_items = pmo.scene_from_paths(pmo.scaled_paths(ps.paths, wl.width_scale), ps.els, wl.affine)
+        assert np.array_equal(scene, want_scene)
+        assert renderer.stats()["n_items"] == n_items < 304  # the Tiger has paths with several sub-paths
+        renderer.render()
+        assert np.array_equal(renderer.read_pixels(), pmo.render(scene, wl.width, wl.height))
+        # the view changes, the resident paths are flattened again (animation path)
+        aff2 = tuple(v * 0.7 for v in wl.affine[:4]) + (40.0, 25.0)
+        renderer.reflatten(aff2, wl.width_scale * 0.7)
+        want2, _ = pmo.scene_from_paths(pmo.scaled_paths(ps.paths, wl.width_scale * 0.7), ps.els, aff2)
+        assert np.array_equal(renderer.download_scene(), want2)
+
+
 def test_malformed_nested_groups_are_rejected(pm, renderer):
     good = encode_ops(pm, [("group", [("circle", 50.0, 50.0, 9.0)]), ("circle", 20.0, 20.0, 5.0)])
     renderer.resize(128, 128)
@@ -668,7 +692,7 @@ def test_second_svg_document_end_to_end(pm, pmo, tmp_path):
     out = str(tmp_path / "shapes.png")
     assert cli.main([src, out, "--width", "1200", "--height", "900", "--scale", "3"]) == 0
     ps = pm.PathSet.from_svg(open(src).read(), spec_defaults=True)
-    assert len(ps.paths) == 10 and (ps.paths["flags"] & pm._lib.PM_PATH_EVEN_ODD).any()
+    assert len(ps.paths) == 11 and (ps.paths["flags"] & pm._lib.PM_PATH_EVEN_ODD).any() and (ps.paths["flags"] & pm._lib.PM_PATH_COMPOUND).any()
     scene, n_items = pmo.scene_from_paths(pmo.scaled_paths(ps.paths, 3.0), ps.els, (3.0, 0.0, 0.0, 3.0, 0.0, 0.0))
     want = pmo.render(scene, 1200, 900)
     got = cli.read_png_rgba(out)
@@ -679,6 +703,8 @@ def test_second_svg_document_end_to_end(pm, pmo, tmp_path):
     assert tuple(got[3 * 212, 3 * 103][:3]) == page        # even-odd: the doubly wound core is a hole
     assert tuple(got[3 * 212, 3 * 50][:3]) == (0xC9, 0x2A, 0x2A)   # its ring is painted
     assert tuple(got[3 * 212, 3 * 273][:3]) == (0, 0x80, 0x80)   # the non-zero twin's core is painted (teal)
+    assert tuple(got[3 * 10, 3 * 308][:3]) == page              # the compound path's inner sub-path is a hole
+    assert tuple(got[3 * 4, 3 * 302][:3]) == (0x5F, 0x3D, 0xC4)  # its ring is painted
 
 
 def test_animation_reflatten_resident_paths(pm, pmo, renderer, tmp_path):

@@ -570,6 +570,8 @@ def _svg_walk(svg_text, spec_defaults=False):
         flags, fill_rgba, stroke_rgba, width = 0, 0, 0, 0.0
         if st["fill"] is not None and (closed or tag in ("path", "polyline")):
             flags |= 1 | (4 if st["evenodd"] else 0)
+            if spec_defaults and tag == "path" and len(re.findall(r"[Mm]", props.get("d", ""))) > 1:
+                flags |= 8  # SVG fills the sub-paths of a path together: one compound item
             fill_rgba = (st["fill"] << 8) | int(round(255 * min(1.0, max(0.0, st["op"] * st["fo"]))))
         if st["stroke"] is not None:
             flags |= 2
@@ -613,7 +615,7 @@ def test_svg_document_layer_matches_independent_walker(pm, spec_defaults):
     svg = open(os.path.join(ROOT, "tests", "data", "shapes.svg")).read()
     ps = pm.PathSet.from_svg(svg, spec_defaults=spec_defaults)
     want = _svg_walk(svg, spec_defaults)
-    assert len(ps.paths) == len(want) == 10
+    assert len(ps.paths) == len(want) == 11
     for p, w in zip(ps.paths, want):
         assert int(p["flags"]) == w["flags"], w
         if w["flags"] & 1:

@@ -530,7 +530,8 @@ def test_scene_builder_matches_independent_python_restatement(pm, pmo):
                         els.append((_lib.PM_EL_CURVE, [q[0][0], q[0][1], q[1][0], q[1][1], q[2][0], q[2][1]])); p = q[2]
                     else:
                         els.append((_lib.PM_EL_CLOSE, [0] * 6))
-            paths.append((e0, len(els), int(rng.integers(1, 4)), int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32)),
+            flags = int(rng.integers(1, 4)) | (4 if rng.random() < 0.3 else 0) | (8 if rng.random() < 0.4 else 0)  # (+ even-odd, compound)
+            paths.append((e0, len(els), flags, int(rng.integers(0, 1 << 32)), int(rng.integers(0, 1 << 32)),
                           float(rng.choice([0.05, 0.4, 1.0, 5.0]))))
         E = np.zeros(len(els), pm.PathSet.EL_DTYPE)
         for i, (t, p) in enumerate(els):
