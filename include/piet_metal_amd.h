@@ -130,7 +130,9 @@ typedef struct {
  * (matrix translate scale rotate skewX skewY), `style="..."`, opacity / fill-opacity /
  * stroke-opacity (folded into the items' alpha: no group compositing), fill-rule (evenodd ->
  * PM_PATH_EVEN_ODD), #rgb / #rrggbb / rgb() / basic colour names / none, and rect (rounded too),
- * circle, ellipse, line, polyline, polygon as paths; <defs> and friends are skipped.  Coordinates
+ * circle, ellipse, line, polyline, polygon as paths; <use> (href / xlink:href, x, y: the referenced
+ * element or <symbol>, from anywhere in the document, nested at most 8 deep); <defs> and friends
+ * are not drawn where they stand.  Coordinates
  * come out in the root user space; stroke widths are scaled by sqrt|det| of the matrix. */
 
 typedef struct pm_svg pm_svg;

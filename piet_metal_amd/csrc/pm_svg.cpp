@@ -395,8 +395,9 @@ uint32_t ParseColor(const char *s, size_t len) {  // parse_color, src/lib.rs:375
 // it goes on where the reference stops: <g> nesting with inherited properties, `transform`,
 // `style="..."`, opacity / fill-opacity / stroke-opacity, fill-rule, rgb() and the basic colour
 // names, and the basic shapes (rect, circle, ellipse, line, polyline, polygon) as paths.
+// <use> draws the element (or <symbol>) its href names, wherever that is defined.
 // Not understood (ignored): gradients and patterns (painted as if `none`), clipping, masks,
-// text, <use>, CSS style sheets, units other than user units / px, stroke joins / caps / dashes.
+// text, CSS style sheets, units other than user units / px, stroke joins / caps / dashes.
 
 struct Affine {  // x' = a x + c y + e, y' = b x + d y + f (the SVG matrix(a b c d e f))
     double a = 1, b = 0, c = 0, d = 1, e = 0, f = 0;
@@ -699,16 +700,78 @@ bool IsShape(const char *n, size_t len) {
     return false;
 }
 
-int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
-    const char *p = text;
-    const char *end = text + len;
+// Elements that carry an id: the source range of the whole element (start tag to end tag), for <use>
+struct IdRange {
+    std::string id;
+    const char *begin;
+    const char *end;
+};
+
+// '>' that closes the tag starting at p (quotes respected), or nullptr
+const char *TagEnd(const char *p, const char *end) {
+    char quote = 0;
+    while (p < end && (quote || *p != '>')) {
+        if (quote) {
+            if (*p == quote) quote = 0;
+        } else if (*p == '"' || *p == '\'') {
+            quote = *p;
+        }
+        ++p;
+    }
+    return p < end ? p : nullptr;
+}
+
+void IndexIds(const char *text, const char *end, std::vector<IdRange> *ids) {
+    std::vector<int> open;  // per open element: its entry in ids, or -1
     std::vector<Attr> attrs;
-    std::vector<Style> stack(1);  // [0] = the initial values
-    // SVG's initial fill is black; make_tiger only fills a path that HAS a fill attribute
-    // (src/lib.rs:299).  The Tiger wraps everything in <g fill="none">, where both readings
-    // agree; elsewhere the reference's reading is the default and PM_SVG_SPEC_DEFAULTS the SVG one.
-    stack[0].fill.none = (flags & PM_SVG_SPEC_DEFAULTS) == 0;
-    stack[0].fill.rgb = 0;
+    const char *p = text;
+    while (p < end) {
+        const char *lt = static_cast<const char *>(std::memchr(p, '<', end - p));
+        if (!lt || lt + 1 >= end) break;
+        p = lt + 1;
+        if (end - p >= 3 && std::memcmp(p, "!--", 3) == 0) {
+            const char *q = p + 3;
+            while (q + 2 < end && std::memcmp(q, "-->", 3) != 0) ++q;
+            p = (q + 3 <= end) ? q + 3 : end;
+            continue;
+        }
+        const char *gt = (*p == '?' || *p == '!' || *p == '/') ? static_cast<const char *>(std::memchr(p, '>', end - p)) : TagEnd(p, end);
+        if (!gt) break;
+        if (*p == '/') {
+            if (!open.empty()) {
+                if (open.back() >= 0) (*ids)[open.back()].end = gt + 1;
+                open.pop_back();
+            }
+        } else if (*p != '?' && *p != '!') {
+            const char *n1 = p;
+            while (n1 < gt && !std::isspace(static_cast<unsigned char>(*n1)) && *n1 != '/') ++n1;
+            const bool self_closing = gt > p && gt[-1] == '/';
+            int entry = -1;
+            if (ScanAttrs(n1, gt, &attrs))
+                if (const Attr *a = Find(attrs, "id")) {
+                    entry = static_cast<int>(ids->size());
+                    ids->push_back({std::string(a->val, a->val_len), lt, gt + 1});
+                }
+            if (!self_closing) open.push_back(entry);
+        }
+        p = gt + 1;
+    }
+}
+
+struct Doc {
+    int flags;
+    pm_svg *out;
+    std::vector<IdRange> ids;
+};
+
+// Walks the elements of [text, end) under the inherited style `initial`.  use_depth > 0: the range
+// is the target of a <use> (a <symbol> at its start is entered like a group).
+int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial, int use_depth) {
+    const int flags = doc->flags;
+    pm_svg *out = doc->out;
+    const char *p = text;
+    std::vector<Attr> attrs;
+    std::vector<Style> stack(1, initial);
     std::vector<bool> container;  // open elements: does this one own a stack entry
     while (p < end) {
         const char *lt = static_cast<const char *>(std::memchr(p, '<', end - p));
@@ -753,10 +816,13 @@ int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
         const bool self_closing = q > p && q[-1] == '/';
         const bool is_path = name_len == 4 && std::memcmp(n0, "path", 4) == 0;
         const bool is_shape = !is_path && IsShape(n0, name_len);
+        const bool is_symbol = name_len == 6 && std::memcmp(n0, "symbol", 6) == 0;
+        const bool is_use = name_len == 3 && std::memcmp(n0, "use", 3) == 0;
         const bool is_group = (name_len == 1 && n0[0] == 'g') || (name_len == 3 && std::memcmp(n0, "svg", 3) == 0) ||
-                              (name_len == 1 && n0[0] == 'a') || (name_len == 6 && std::memcmp(n0, "switch", 6) == 0);
+                              (name_len == 1 && n0[0] == 'a') || (name_len == 6 && std::memcmp(n0, "switch", 6) == 0) ||
+                              (is_symbol && use_depth > 0 && lt == text);
         const bool skipped = (name_len == 4 && std::memcmp(n0, "defs", 4) == 0) || (name_len == 8 && std::memcmp(n0, "clipPath", 8) == 0) ||
-                             (name_len == 4 && std::memcmp(n0, "mask", 4) == 0) || (name_len == 6 && std::memcmp(n0, "symbol", 6) == 0) ||
+                             (name_len == 4 && std::memcmp(n0, "mask", 4) == 0) || (is_symbol && !(use_depth > 0 && lt == text)) ||
                              (name_len == 7 && std::memcmp(n0, "pattern", 7) == 0) || (name_len == 6 && std::memcmp(n0, "marker", 6) == 0);
         if (skipped && !self_closing) {
             // definitions are not rendered directly: skip to the matching end tag
@@ -774,6 +840,34 @@ int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
             }
             const char *gt = r < end ? static_cast<const char *>(std::memchr(r, '>', end - r)) : nullptr;
             p = gt ? gt + 1 : end;
+            continue;
+        }
+        if (is_use) {
+            // <use href="#id" x= y=>: the referenced element drawn here, under this element's
+            // inherited properties and transform * translate(x, y) (SVG 1.1 section 5.6; a <symbol>
+            // is entered like a group, its viewBox is not applied).  References nest at most 8 deep.
+            if (!ScanAttrs(p, q, &attrs)) return PM_ERR_PARSE;
+            Style st = stack.back();
+            if (!ApplyElementStyle(attrs, &st)) return PM_ERR_PARSE;
+            Affine shift;
+            if (const Attr *a = Find(attrs, "x")) shift.e = std::strtod(std::string(a->val, a->val_len).c_str(), nullptr);
+            if (const Attr *a = Find(attrs, "y")) shift.f = std::strtod(std::string(a->val, a->val_len).c_str(), nullptr);
+            st.ctm = st.ctm.Then(shift);
+            const Attr *href = Find(attrs, "href");
+            if (!href) href = Find(attrs, "xlink:href");
+            if (href && href->val_len > 1 && href->val[0] == '#' && use_depth < 8) {
+                const std::string id(href->val + 1, href->val_len - 1);
+                for (const IdRange &r : doc->ids)
+                    if (r.id == id) {
+                        if (!(lt >= r.begin && lt < r.end)) {  // (an element cannot use its own ancestor)
+                            const int rc = ParseRange(doc, r.begin, r.end, st, use_depth + 1);
+                            if (rc != PM_OK) return rc;
+                        }
+                        break;
+                    }
+            }
+            if (!self_closing) container.push_back(false);
+            p = q + 1;
             continue;
         }
         if (is_path || is_shape || is_group) {
@@ -833,6 +927,20 @@ int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
         p = q + 1;
     }
     return PM_OK;
+}
+
+int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
+    Doc doc;
+    doc.flags = flags;
+    doc.out = out;
+    IndexIds(text, text + len, &doc.ids);
+    Style initial;
+    // SVG's initial fill is black; make_tiger only fills a path that HAS a fill attribute
+    // (src/lib.rs:299).  The Tiger wraps everything in <g fill="none">, where both readings
+    // agree; elsewhere the reference's reading is the default and PM_SVG_SPEC_DEFAULTS the SVG one.
+    initial.fill.none = (flags & PM_SVG_SPEC_DEFAULTS) == 0;
+    initial.fill.rgb = 0;
+    return ParseRange(&doc, text, text + len, initial, 0);
 }
 
 }  // namespace

@@ -692,7 +692,7 @@ def test_second_svg_document_end_to_end(pm, pmo, tmp_path):
     out = str(tmp_path / "shapes.png")
     assert cli.main([src, out, "--width", "1200", "--height", "900", "--scale", "3"]) == 0
     ps = pm.PathSet.from_svg(open(src).read(), spec_defaults=True)
-    assert len(ps.paths) == 11 and (ps.paths["flags"] & pm._lib.PM_PATH_EVEN_ODD).any() and (ps.paths["flags"] & pm._lib.PM_PATH_COMPOUND).any()
+    assert len(ps.paths) == 16 and (ps.paths["flags"] & pm._lib.PM_PATH_EVEN_ODD).any() and (ps.paths["flags"] & pm._lib.PM_PATH_COMPOUND).any()
     scene, n_items = pmo.scene_from_paths(pmo.scaled_paths(ps.paths, 3.0), ps.els, (3.0, 0.0, 0.0, 3.0, 0.0, 0.0))
     want = pmo.render(scene, 1200, 900)
     got = cli.read_png_rgba(out)
@@ -705,6 +705,8 @@ def test_second_svg_document_end_to_end(pm, pmo, tmp_path):
     assert tuple(got[3 * 212, 3 * 273][:3]) == (0, 0x80, 0x80)   # the non-zero twin's core is painted (teal)
     assert tuple(got[3 * 10, 3 * 308][:3]) == page              # the compound path's inner sub-path is a hole
     assert tuple(got[3 * 4, 3 * 302][:3]) == (0x5F, 0x3D, 0xC4)  # its ring is painted
+    assert tuple(got[3 * 290, 3 * 26][:3]) == (0x0B, 0x72, 0x85)  # <use href="#leaf">: the midrib of the group from <defs>
+    assert tuple(got[3 * 291, 3 * 100][:3]) != page               # <use href="#dot">: the <symbol>, painted with the fill of its <use>
 
 
 def test_animation_reflatten_resident_paths(pm, pmo, renderer, tmp_path):

@@ -510,9 +510,9 @@ def _svg_walk(svg_text, spec_defaults=False):
 
     out = []
 
-    def visit(el, st):
+    def visit(el, st, used=0):
         tag = el.tag.split("}")[-1]
-        if tag in ("defs", "clipPath", "mask", "symbol", "pattern", "marker"):
+        if tag in ("defs", "clipPath", "mask", "pattern", "marker") or (tag == "symbol" and not used):
             return
         st = dict(st)
         props = {k: v for k, v in el.attrib.items()}
@@ -538,9 +538,17 @@ def _svg_walk(svg_text, spec_defaults=False):
                 st["op"] = st["op"] * opac(src["opacity"])
         if "transform" in props:
             st["ctm"] = mat_mul(st["ctm"], transform(props["transform"]))
-        if tag in ("g", "svg", "a", "switch"):
+        if tag in ("g", "svg", "a", "switch", "symbol"):
             for ch in el:
                 visit(ch, st)
+            return
+        if tag == "use":  # the referenced element, here, under this element's properties and transform * translate(x, y)
+            num = lambda k: float(props[k]) if k in props else 0.0
+            st["ctm"] = mat_mul(st["ctm"], [1, 0, 0, 1, num("x"), num("y")])
+            href = props.get("href") or props.get("{http://www.w3.org/1999/xlink}href") or ""
+            target = next((e for e in root.iter() if e.get("id") == href[1:]), None) if href.startswith("#") else None
+            if target is not None and used < 8:
+                visit(target, st, used + 1)
             return
         f = lambda k, dflt=0.0: float(re.match(r"\s*([-+0-9.eE]+)", props[k]).group(1)) if k in props else dflt
         geom, closed = None, True
@@ -615,7 +623,7 @@ def test_svg_document_layer_matches_independent_walker(pm, spec_defaults):
     svg = open(os.path.join(ROOT, "tests", "data", "shapes.svg")).read()
     ps = pm.PathSet.from_svg(svg, spec_defaults=spec_defaults)
     want = _svg_walk(svg, spec_defaults)
-    assert len(ps.paths) == len(want) == 11
+    assert len(ps.paths) == len(want) == 16
     for p, w in zip(ps.paths, want):
         assert int(p["flags"]) == w["flags"], w
         if w["flags"] & 1:
