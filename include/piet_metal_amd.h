@@ -141,6 +141,10 @@ pm_svg *pm_svg_tiger(int flags, int *err); /* the embedded Ghostscript_Tiger.svg
 void pm_svg_free(pm_svg *s);
 size_t pm_svg_n_paths(const pm_svg *s);
 size_t pm_svg_n_els(const pm_svg *s);
+/* The outermost <svg>: returns 1 and fills viewbox = {min-x, min-y, width, height} if it has a valid
+ * viewBox (else 0, viewbox zeroed); width / height = its size attributes in px (0: absent, or a
+ * percentage).  Path coordinates stay in user space: mapping the viewBox to pixels is the caller's affine. */
+int pm_svg_viewbox(const pm_svg *s, double viewbox[4], double *width, double *height);
 const pm_path *pm_svg_paths(const pm_svg *s);
 const pm_path_el *pm_svg_els(const pm_svg *s);
 uint32_t pm_parse_color(const char *s); /* parse_color src/lib.rs:375-385 */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "pm_svg_free": (None, [C.c_void_p]),
     "pm_svg_n_paths": (C.c_size_t, [C.c_void_p]),
     "pm_svg_n_els": (C.c_size_t, [C.c_void_p]),
+    "pm_svg_viewbox": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pm_svg_paths": (C.POINTER(Path), [C.c_void_p]),
     "pm_svg_els": (C.POINTER(PathEl), [C.c_void_p]),
     "pm_parse_color": (C.c_uint32, [C.c_char_p]),

@@ -66,7 +66,7 @@ def main(argv=None) -> int:
     ap.add_argument("output", help="PNG file to write")
     ap.add_argument("--width", type=int, default=1600)
     ap.add_argument("--height", type=int, default=1600)
-    ap.add_argument("--scale", type=float, default=None, help="user units -> pixels (default: height / 200, the Tiger's viewBox)")
+    ap.add_argument("--scale", type=float, default=None, help="user units -> pixels (default: fit the file's viewBox into the viewport; the Tiger: height / 200)")
     ap.add_argument("--offset", type=float, nargs=2, default=None, metavar=("X", "Y"), help="translation in pixels (default: centre horizontally)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--reject-arc-paths", action="store_true", help="skip <path>s that use the arc command (kurbo 0.5.6 question, SURVEY F6)")
@@ -85,6 +85,9 @@ def main(argv=None) -> int:
     scale = args.scale if args.scale is not None else args.height / 200.0
     off = args.offset if args.offset is not None else ((args.width - args.height) / 2.0 if args.scale is None else 0.0, 0.0)
     base = (scale, 0.0, 0.0, scale, float(off[0]), float(off[1]))
+    fit = paths.fit_affine(args.width, args.height) if (args.input != "tiger" and args.scale is None and args.offset is None) else None
+    if fit is not None:  # a file that says where its picture is: show that, centred (xMidYMid meet)
+        base, scale = fit
     with Renderer(args.device) as r:
         r.resize(args.width, args.height)
         nbytes, nitems = r.flatten_and_encode(paths, base, scale)

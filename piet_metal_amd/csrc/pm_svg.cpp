@@ -46,6 +46,10 @@ extern "C" const char pm_tiger_svg_end[];
 struct pm_svg {
     std::vector<pm_path> paths;
     std::vector<pm_path_el> els;
+    // the outermost <svg>: viewBox (if any), width / height in user units (0: absent or a percentage)
+    bool has_viewbox = false, seen_root = false;
+    double viewbox[4] = {0, 0, 0, 0};
+    double width = 0, height = 0;
 };
 
 namespace {
@@ -872,6 +876,43 @@ int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial
         }
         if (is_path || is_shape || is_group) {
             if (!ScanAttrs(p, q, &attrs)) return PM_ERR_PARSE;
+            if (name_len == 3 && n0[0] == 's' && !out->seen_root) {  // the outermost <svg>: where the picture lives
+                out->seen_root = true;
+                auto length = [](const Attr *a) -> double {  // user units / px; a percentage has no meaning here
+                    if (!a) return 0.0;
+                    const std::string v(a->val, a->val_len);
+                    char *rest = nullptr;
+                    const double d = std::strtod(v.c_str(), &rest);
+                    while (rest && *rest && std::isspace(static_cast<unsigned char>(*rest))) ++rest;
+                    const std::string unit = rest ? rest : "";
+                    if (unit.empty() || unit == "px") return d > 0 ? d : 0.0;
+                    if (unit == "pt") return d * (96.0 / 72.0);
+                    if (unit == "in") return d * 96.0;
+                    if (unit == "mm") return d * (96.0 / 25.4);
+                    if (unit == "cm") return d * (96.0 / 2.54);
+                    return 0.0;
+                };
+                out->width = length(Find(attrs, "width"));
+                out->height = length(Find(attrs, "height"));
+                if (const Attr *vb = Find(attrs, "viewBox")) {
+                    std::string v(vb->val, vb->val_len);
+                    for (char &ch : v)
+                        if (ch == ',') ch = ' ';
+                    double n[4];
+                    const char *c = v.c_str();
+                    int got = 0;
+                    for (; got < 4; ++got) {
+                        char *e2 = nullptr;
+                        n[got] = std::strtod(c, &e2);
+                        if (e2 == c) break;
+                        c = e2;
+                    }
+                    if (got == 4 && n[2] > 0 && n[3] > 0) {
+                        out->has_viewbox = true;
+                        std::memcpy(out->viewbox, n, sizeof(n));
+                    }
+                }
+            }
             Style st = stack.back();
             if (!ApplyElementStyle(attrs, &st)) return PM_ERR_PARSE;
             if (is_group) {
@@ -976,6 +1017,13 @@ size_t pm_svg_n_paths(const pm_svg *s) { return s ? s->paths.size() : 0; }
 size_t pm_svg_n_els(const pm_svg *s) { return s ? s->els.size() : 0; }
 const pm_path *pm_svg_paths(const pm_svg *s) { return s ? s->paths.data() : nullptr; }
 const pm_path_el *pm_svg_els(const pm_svg *s) { return s ? s->els.data() : nullptr; }
+int pm_svg_viewbox(const pm_svg *s, double viewbox[4], double *width, double *height) {
+    if (!s) return 0;
+    if (viewbox) std::memcpy(viewbox, s->viewbox, sizeof(s->viewbox));
+    if (width) *width = s->width;
+    if (height) *height = s->height;
+    return s->has_viewbox ? 1 : 0;
+}
 uint32_t pm_parse_color(const char *s) { return s ? ParseColor(s, std::strlen(s)) : 0xff00ff80u; }
 
 }  // extern "C"

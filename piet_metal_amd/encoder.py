@@ -140,9 +140,27 @@ class PathSet:
             npaths, nels = lib.pm_svg_n_paths(h), lib.pm_svg_n_els(h)
             paths = np.frombuffer(C.string_at(lib.pm_svg_paths(h), npaths * 24), dtype=_PATH_DTYPE).copy() if npaths else np.zeros(0, _PATH_DTYPE)
             els = np.frombuffer(C.string_at(lib.pm_svg_els(h), nels * 56), dtype=_EL_DTYPE).copy() if nels else np.zeros(0, _EL_DTYPE)
+            vb, w, hh = (C.c_double * 4)(), C.c_double(0), C.c_double(0)
+            has_vb = lib.pm_svg_viewbox(h, vb, C.byref(w), C.byref(hh))
         finally:
             lib.pm_svg_free(h)
-        return cls(paths, els)
+        ps = cls(paths, els)
+        ps.viewbox = tuple(vb) if has_vb else None  # the outermost <svg>'s viewBox (user units)
+        ps.size = (w.value, hh.value)                # its width / height in px (0: not given)
+        return ps
+
+    def fit_affine(self, width: int, height: int):
+        """(affine, scale) that shows the document's viewBox (or its width x height) centred in a
+        width x height viewport, aspect ratio kept (SVG's default preserveAspectRatio xMidYMid meet);
+        None when the document gives neither."""
+        vb = getattr(self, "viewbox", None)
+        if vb is None:
+            w, h = getattr(self, "size", (0.0, 0.0))
+            if not (w > 0 and h > 0):
+                return None
+            vb = (0.0, 0.0, w, h)
+        s = min(width / vb[2], height / vb[3])
+        return (s, 0.0, 0.0, s, (width - s * vb[2]) / 2.0 - s * vb[0], (height - s * vb[3]) / 2.0 - s * vb[1]), s
 
     @classmethod
     def from_svg(cls, text: bytes | str, reject_arc_paths: bool = False, spec_defaults: bool = False) -> "PathSet":

@@ -707,6 +707,10 @@ def test_second_svg_document_end_to_end(pm, pmo, tmp_path):
     assert tuple(got[3 * 4, 3 * 302][:3]) == (0x5F, 0x3D, 0xC4)  # its ring is painted
     assert tuple(got[3 * 290, 3 * 26][:3]) == (0x0B, 0x72, 0x85)  # <use href="#leaf">: the midrib of the group from <defs>
     assert tuple(got[3 * 291, 3 * 100][:3]) != page               # <use href="#dot">: the <symbol>, painted with the fill of its <use>
+    # without --scale the CLI fits the document's viewBox (400 x 300) into the viewport, centred
+    assert cli.main([src, out, "--width", "1000", "--height", "600"]) == 0
+    scene2, _ = pmo.scene_from_paths(pmo.scaled_paths(ps.paths, 2.0), ps.els, (2.0, 0.0, 0.0, 2.0, 100.0, 0.0))
+    assert np.array_equal(cli.read_png_rgba(out), pmo.render(scene2, 1000, 600))
 
 
 def test_animation_reflatten_resident_paths(pm, pmo, renderer, tmp_path):

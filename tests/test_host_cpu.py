@@ -613,6 +613,24 @@ def _bez(p0, els_row, t):
             mt ** 3 * p0[1] + 3 * mt * mt * t * P[1] + 3 * mt * t * t * P[3] + t ** 3 * P[5])
 
 
+def test_svg_viewbox_and_fit(pm):
+    """The outermost <svg>'s viewBox and size come through the ABI; fit_affine maps the viewBox into a
+    viewport like preserveAspectRatio="xMidYMid meet"; units of width / height are converted to px."""
+    ps = pm.PathSet.from_svg(open(os.path.join(ROOT, "tests", "data", "shapes.svg")).read())
+    assert ps.viewbox == (0.0, 0.0, 400.0, 300.0) and ps.size == (400.0, 300.0)
+    aff, s = ps.fit_affine(1200, 600)
+    assert s == 2.0 and aff == (2.0, 0.0, 0.0, 2.0, 200.0, 0.0)
+    ps = pm.PathSet.from_svg('<svg viewBox="10,20 50 100" width="100%"><svg viewBox="0 0 1 1"><path d="M0 0h1v1z" fill="red"/></svg></svg>')
+    assert ps.viewbox == (10.0, 20.0, 50.0, 100.0) and ps.size == (0.0, 0.0)  # the OUTERMOST element counts
+    aff, s = ps.fit_affine(200, 200)
+    assert s == 2.0 and aff == (2.0, 0.0, 0.0, 2.0, 50.0 - 20.0, -40.0)
+    ps = pm.PathSet.from_svg('<svg width="2in" height="36pt" viewBox="0 0 0 5"><rect width="5" height="5" fill="red"/></svg>')
+    assert ps.viewbox is None and ps.size == (192.0, 48.0)  # a viewBox without area is ignored
+    assert ps.fit_affine(96, 96)[1] == 0.5
+    assert pm.PathSet.from_svg('<svg><rect width="5" height="5" fill="red"/></svg>').fit_affine(10, 10) is None
+    assert pm.PathSet.tiger().viewbox == (0.0, 0.0, 200.0, 200.0)
+
+
 @pytest.mark.parametrize("spec_defaults", [False, True])
 def test_svg_document_layer_matches_independent_walker(pm, spec_defaults):
     """tests/data/shapes.svg (nested groups, transforms, style, opacity, both fill rules, every basic
