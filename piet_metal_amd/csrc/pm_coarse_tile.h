@@ -75,7 +75,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
         // (Requesting the NEXT record's pair here as well saves 0.4 us per tile at 128 VGPRs and
         //  costs more than that in spills at the 96 the fused kernel is built for.)
         const uint4 hdr = Scalar4(*reinterpret_cast<const uint4 *>(P.arena + rec));
-        const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * lane);
+        const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * Opaque(lane));
         const uint32_t next = hdr.x;
         const uint32_t ncand = hdr.y;
         const uint32_t mask_dwords = (ncand + 3u) & ~3u;
@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
         const uint32_t n_slots = hdr.w;
         // (the first 128 words of the scan are requested now: they arrive with the candidate records
         //  instead of costing a memory round trip of their own when the first round asks for them)
-        uint2 mv_first = make_uint2(0u, 0u);
+        uint2 mv_first = make_uint2(OpaqueZero(), OpaqueZero());
         if (2u * lane < n_slots) mv_first = *reinterpret_cast<const uint2 *>(meta + 2u * lane);
         uint32_t scan_pos = 0;  // next segment to scan
         uint32_t ring_cnt = 0;  // relevant segments found so far (ring write position)
@@ -220,7 +220,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                             const uint32_t i0 = scan_pos + 2u * lane;
                             uint2 mv = mv_first;
                             if (scan_pos != 0) {
-                                mv = make_uint2(0u, 0u);
+                                mv = make_uint2(OpaqueZero(), OpaqueZero());
                                 if (i0 < cnt_x) mv = *reinterpret_cast<const uint2 *>(meta + st_x + i0);
                             }
                             const uint32_t ma[2] = {mv.x, mv.y};

@@ -92,6 +92,14 @@ __device__ __forceinline__ float CircleAlpha(float dx, float dy, float rx, float
     return Sat(fminf(rx, ry) - sqrtf(dx * dx + dy * dy));
 }
 
+// "no stroke yet" (renderKernel's df = 1e9, :471).  Materialized where it is used: as a plain
+// literal the compiler hoists four copies of it out of the tile loop and then spills them.
+__device__ __forceinline__ float FarAway() {
+    float v;
+    asm volatile("v_mov_b32 %0, 0x4e6e6b28" : "=v"(v));
+    return v;
+}
+
 __device__ __forceinline__ half2_t Splat(_Float16 v) { half2_t r; r.x = v; r.y = v; return r; }
 
 // ---- row-sparse Fill evaluation -----------------------------------------------------------
@@ -301,7 +309,7 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     alpha[k] = ToHalf(Sat(half_width + 0.5f - st.df[k]));
-                    st.df[k] = 1e9f;
+                    st.df[k] = FarAway();
                 }
                 half2_t a01, a23;
                 a01.x = alpha[0]; a01.y = alpha[1]; a23.x = alpha[2]; a23.y = alpha[3];
@@ -477,7 +485,7 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
             unsigned long long t_i = 0;
             if (kProf) t_i = wall_clock64();
             half2_t sa01 = Splat(static_cast<_Float16>(0.0f)), sa23 = sa01;
-            float df[4] = {1e9f, 1e9f, 1e9f, 1e9f};
+            float df[4] = {FarAway(), FarAway(), FarAway(), FarAway()};
             if (s0 == 0) {  // the chunk opens inside an item: its accumulators so far
                 const uint2 cs = S.carry_sa[parity][lane];
                 const float4 cd = S.carry_df[parity][lane];
@@ -660,8 +668,8 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                 PixelRGB s1;
                 s1.r = s1.g = s1.b = static_cast<_Float16>(1.0f);
                 if (wave == 0) {  // no item is open when a list starts
-                    S.carry_sa[0][lane] = make_uint2(0u, 0u);
-                    S.carry_df[0][lane] = make_float4(1e9f, 1e9f, 1e9f, 1e9f);
+                    S.carry_sa[0][lane] = make_uint2(OpaqueZero(), OpaqueZero());
+                    S.carry_df[0][lane] = make_float4(FarAway(), FarAway(), FarAway(), FarAway());
                 }
                 uint32_t parity = 0;
                 for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk, parity ^= 1u) {
@@ -691,14 +699,14 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                 st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = Splat(static_cast<_Float16>(1.0f));
                 st.sa01 = st.sa23 = Splat(static_cast<_Float16>(0.0f));
 #pragma unroll
-                for (int k = 0; k < 4; ++k) st.df[k] = 1e9f;
+                for (int k = 0; k < 4; ++k) st.df[k] = FarAway();
                 for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk) {
                     const uint32_t m = min(kSpChunk, n_cmd - c0);
                     WaveSync();
                     {
                         const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
                         uint2 *l = reinterpret_cast<uint2 *>(cmds);
-                        for (uint32_t w = lane; w < 3u * m; w += 64u) l[w] = g[w];
+                        for (uint32_t w = Opaque(lane); w < 3u * m; w += 64u) l[w] = g[w];  // (Opaque: no hoisted address to spill)
                     }
                     WaveSync();
                     InterpretSparse(S, cmds, S.w[wave].f.fill_ix, m, x0, y0, st);
