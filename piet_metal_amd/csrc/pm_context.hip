@@ -174,7 +174,7 @@ struct pm_ctx {
     bool fused = true;       // pm_fine_kernel<true>: each tile's list is built and interpreted by the same wave(s)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
     uint32_t heavy_stream = 32, vheavy_stream = 96;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
-    uint32_t coarse_wg_per_cu = 5, fine_wg_per_cu = 4;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
+    uint32_t coarse_wg_per_cu = 5, fine_wg_per_cu = 5;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
 
@@ -922,7 +922,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->vheavy_stream = static_cast<uint32_t>(EnvInt("PM_VHEAVY_STREAM", 96, 1, 1 << 20));
     c->fold_clear = EnvInt("PM_FOLD_CLEAR", 1, 0, 1) != 0;
     c->fused = EnvInt("PM_FUSED", 1, 0, 1) != 0;
-    c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 4, 1, 16));
+    c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 5, 1, 16));
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
     for (auto &s : c->slot) {
