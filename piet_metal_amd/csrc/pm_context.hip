@@ -148,6 +148,7 @@ int EnvInt(const char *name, int dflt, int lo, int hi) {
 struct FrameSlot {
     uint8_t *d_fb = nullptr;  // this slot's framebuffer (pm_render); pm_render_to uses the caller's
     uint32_t *d_arena = nullptr;
+    uint32_t arena_cap = 0;  // dwords allocated for this slot (allocated when the slot is first used)
     uint32_t *d_striprow = nullptr;
     uint4 *d_queue = nullptr;
     uint32_t *d_tile_state = nullptr;
@@ -210,6 +211,7 @@ struct pm_ctx {
     uint32_t row_total = 0;
     bool use_row_lists = false;
     uint32_t arena_cap = 0;         // dwords per slot
+    uint64_t ptcl_want = 0;         // commands a slot's list arena starts with / was grown to
     bool arena_dirty = true;
 
     std::vector<FrameSlot> slot;
@@ -310,6 +312,27 @@ int ValidateScene(const uint8_t *meta, size_t meta_len, size_t scene_bytes, uint
     return PM_OK;
 }
 
+// A slot's binning arena and command-list arena, allocated (or grown to what EnsureArena asked for)
+// when the slot is about to be used.
+int EnsureSlotBuffers(pm_ctx *c, FrameSlot *s) {
+    if (!s->d_arena || s->arena_cap < c->arena_cap) {
+        if (s->d_arena) (void)hipFree(s->d_arena);  // (hipFree waits for the device: nothing is using it any more)
+        s->d_arena = nullptr;
+        s->arena_cap = 0;
+        PM_TRY(hipMalloc(&s->d_arena, static_cast<size_t>(std::max<uint32_t>(c->arena_cap, pm::kArenaBase)) * sizeof(uint32_t)));
+        s->arena_cap = c->arena_cap;
+    }
+    if (!s->d_ptcl || s->ptcl_cap < c->ptcl_want) {
+        if (s->d_ptcl) (void)hipFree(s->d_ptcl);
+        s->d_ptcl = nullptr;
+        s->ptcl_cap = 0;
+        const uint64_t cmds = std::max<uint64_t>(c->ptcl_want, 64);
+        PM_TRY(hipMalloc(&s->d_ptcl, cmds * sizeof(pm::Cmd)));
+        s->ptcl_cap = static_cast<uint32_t>(cmds);
+    }
+    return PM_OK;
+}
+
 // Exact upper bound (dwords) of what pm_bin_kernel can allocate for this scene,
 // viewport and band: every (strip row, candidate item) costs a candidate record
 // plus 16 B per stream element, every (strip row, batch) a header.
@@ -347,7 +370,7 @@ void StripRowBounds(const pm_ctx *c, std::vector<uint64_t> *need) {
 }
 
 int EnsureArena(pm_ctx *c) {
-    if (!c->arena_dirty && c->slot[0].d_arena) return PM_OK;
+    if (!c->arena_dirty && c->arena_cap != 0) return PM_OK;
     if (c->item_meta.empty() || c->tiles_x == 0) return PM_OK;  // nothing to size against yet
     const WallTimer timer;
     PM_TRY(SyncAll(c) == PM_OK ? hipSuccess : hipErrorUnknown);
@@ -369,22 +392,15 @@ int EnsureArena(pm_ctx *c) {
     //  demand creeps from frame to frame, and re-allocating four 100 MB arenas costs milliseconds)
     const uint64_t alloc_dwords = total <= c->arena_cap ? c->arena_cap : (c->arena_cap == 0 ? total : std::min<uint64_t>(0xfffffff0ull, total + total / 4));
     c->sr_empty_dwords = static_cast<uint32_t>((static_cast<uint64_t>(pm::kRecHdrDwords + 3u) * ((c->n_items + 255u) / 256u) + 3u) & ~3ull);
-    for (auto &s : c->slot) {
-        if (!s.d_arena || total > c->arena_cap) {
-            if (s.d_arena) (void)hipFree(s.d_arena);
-            s.d_arena = nullptr;
-            PM_TRY(hipMalloc(&s.d_arena, alloc_dwords * sizeof(uint32_t)));
-        }
-        if (!s.d_ptcl) {
-            // Command-list arena: lists are sized from what binning actually found, so there is no
-            // static bound; start generously (HBM is 288 GB) and let pm_sync grow it on overflow.
-            uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
-            if (const char *v = std::getenv("PM_PTCL_INITIAL_CMDS"))  // tests: force the overflow -> grow -> re-render path
-                cmds = std::max<uint64_t>(64, std::strtoull(v, nullptr, 10));
-            cmds = std::min<uint64_t>(cmds, 0x7fffffffull);
-            PM_TRY(hipMalloc(&s.d_ptcl, cmds * sizeof(pm::Cmd)));
-            s.ptcl_cap = static_cast<uint32_t>(cmds);
-        }
+    // (the slots' arenas themselves are allocated when a slot is first used, EnsureSlotBuffers: the
+    //  first frame of a scene pays for one arena, not for four -- hundreds of MB each at 8K)
+    if (c->ptcl_want == 0) {
+        // Command-list arena: lists are sized from what binning actually found, so there is no
+        // static bound; start generously (HBM is 288 GB) and let pm_sync grow it on overflow.
+        uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
+        if (const char *v = std::getenv("PM_PTCL_INITIAL_CMDS"))  // tests: force the overflow -> grow -> re-render path
+            cmds = std::max<uint64_t>(64, std::strtoull(v, nullptr, 10));
+        c->ptcl_want = std::min<uint64_t>(cmds, 0x7fffffffull);
     }
     c->arena_cap = std::max<uint32_t>(c->arena_cap, static_cast<uint32_t>(alloc_dwords));
     // The strip rows some item's bbox reaches get a workgroup of pm_bin_kernel each; the others are
@@ -516,8 +532,12 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->fb = fb;
     p->fb_stride = static_cast<uint32_t>(stride);
     p->fb_vec16 = ((reinterpret_cast<uintptr_t>(fb) & 15u) == 0 && (stride & 15u) == 0) ? 1u : 0u;
+    {
+        const int rb = EnsureSlotBuffers(c, s);
+        if (rb != PM_OK) return rb;
+    }
     p->arena = s->d_arena;
-    p->arena_cap = c->arena_cap;
+    p->arena_cap = s->arena_cap;
     p->sr_desc = c->d_sr_desc;
     p->n_sr_active = c->n_sr_active;
     p->sr_empty_dwords = c->sr_empty_dwords;
@@ -1160,13 +1180,8 @@ int pm_sync(pm_ctx *c) {
         }
         if (redo.empty()) return PM_OK;
         want = std::min<uint64_t>(0x7fffffffull, want);
-        if (want <= c->slot[0].ptcl_cap) break;
-        for (auto &t : c->slot) {
-            if (t.d_ptcl) (void)hipFree(t.d_ptcl);
-            t.d_ptcl = nullptr;
-            PM_TRY(hipMalloc(&t.d_ptcl, want * sizeof(pm::Cmd)));
-            t.ptcl_cap = static_cast<uint32_t>(want);
-        }
+        if (want <= c->ptcl_want) break;
+        c->ptcl_want = want;  // (every slot grows when it is used next, EnsureSlotBuffers)
         // render the damaged targets again on the context's own streams (a caller's stream may be
         // gone by now; the next pass of this loop waits for them and checks them again)
         for (const pm::FrameParams &p : redo) {
