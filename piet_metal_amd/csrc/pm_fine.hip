@@ -235,6 +235,39 @@ __device__ __forceinline__ uint32_t PrepareFills(SparseLds &S, Cmd *cmds, const 
     return min(pos, nfill);
 }
 
+// A run of `run` consecutive Fill commands from command i on, all of them prepared (passes 1 and 2
+// done): pass 3 for the run.  The row masks of four commands are fetched together, then their
+// contributions, so that the LDS latencies overlap and no tag is dispatched inside the run; the
+// adds keep list order (binary16 addition is not associative).
+__device__ __forceinline__ void AddFillRun(const WaveFineLds &W, const Cmd *cmds, uint32_t i, uint32_t run, uint32_t row, uint32_t g,
+                                           half2_t &sa01, half2_t &sa23) {
+    const uint32_t below = (1u << row) - 1u;
+#pragma unroll 1
+    for (uint32_t r = 0; r < run; r += 4u) {
+        uint32_t hdr[4];  // row mask | first fragment << 16 (pass 1)
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) hdr[k] = (r + k < run) ? cmds[i + r + k].body[0] : 0u;
+        uint2 v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            v[k] = make_uint2(0u, 0u);
+            if ((hdr[k] >> row) & 1u) v[k] = W.contrib[(hdr[k] >> 16) + static_cast<uint32_t>(__popc(hdr[k] & below))][g];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            if ((hdr[k] >> row) & 1u) {
+                sa01 = sa01 + Half2FromBits(v[k].x);
+                sa23 = sa23 + Half2FromBits(v[k].y);
+            }
+    }
+}
+
+// Fill commands in a row from command i on (bit i of fm, the chunk's Fill mask, is set)
+__device__ __forceinline__ uint32_t FillRunLength(uint64_t fm, uint32_t i) {
+    const uint64_t rest = ~(fm >> i);
+    return rest ? static_cast<uint32_t>(__builtin_ctzll(rest)) : 64u - i;
+}
+
 // Pixels of one lane, whole-tile layout, signedArea packed (the half adds are per element)
 struct PixelStateS {
     half2_t r01, r23, g01, g23, b01, b23;
@@ -318,14 +351,10 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
             }
             case kCmdFill: {
                 if (fo >= prepared) prepared = PrepareFills(S, cmds, fill_ix, nfill, fo, x0, y0);  // uniform
-                ++fo;
-                const uint32_t hdr = cmds[i].body[0];  // row mask | first fragment << 16 (pass 1)
-                if ((hdr >> row) & 1u) {
-                    const uint32_t f = (hdr >> 16) + static_cast<uint32_t>(__popc(hdr & ((1u << row) - 1u)));
-                    const uint2 v = S.w[WaveId()].f.contrib[f][g];
-                    st.sa01 = st.sa01 + Half2FromBits(v.x);
-                    st.sa23 = st.sa23 + Half2FromBits(v.y);
-                }
+                const uint32_t run = min(FillRunLength(fm, i), prepared - fo);  // >= 1
+                AddFillRun(S.w[WaveId()].f, cmds, i, run, row, g, st.sa01, st.sa23);
+                fo += run;
+                i += run - 1u;
                 break;
             }
             case kCmdFillEdge: {
@@ -397,14 +426,10 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const u
         const Cmd cmd = cmds[i];
         if (cmd.tag == kCmdFill) {
             if (fo >= prepared) prepared = PrepareFills(S, cmds, fill_ix, flimit, fo, x0, y0);  // uniform
-            ++fo;
-            const uint32_t hdr = cmds[i].body[0];
-            if ((hdr >> row) & 1u) {
-                const uint32_t f = (hdr >> 16) + static_cast<uint32_t>(__popc(hdr & ((1u << row) - 1u)));
-                const uint2 v = S.w[WaveId()].f.contrib[f][g];
-                sa01 = sa01 + Half2FromBits(v.x);
-                sa23 = sa23 + Half2FromBits(v.y);
-            }
+            const uint32_t run = min(min(FillRunLength(fm, i), e - i), prepared - fo);  // >= 1
+            AddFillRun(S.w[WaveId()].f, cmds, i, run, row, g, sa01, sa23);
+            fo += run;
+            i += run - 1u;
         } else if (cmd.tag == kCmdFillEdge) {
             const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
             const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
