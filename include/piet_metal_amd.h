@@ -135,6 +135,14 @@ typedef struct {
  * are not drawn where they stand.  Coordinates
  * come out in the root user space; stroke widths are scaled by sqrt|det| of the matrix. */
 
+/* Beyond the reference (src/lib.rs:194, "need to deal with subpaths and also want curves"): the
+ * encoder takes a whole kurbo-style path -- what make_tiger's encode_path / encode_path_stroke do
+ * (src/lib.rs:342-367) for one BezPath under the identity transform: flatten.rs on the host
+ * (tolerance 0.1), then one Fill per sub-path (or ONE compound Fill with PM_FILL_COMPOUND) resp. one
+ * poly-line per sub-path with the thin-line rule.  Same bytes as pm_flatten_and_encode on that path. */
+int pm_encoder_fill_path(pm_encoder *e, const pm_path_el *els, size_t n_els, uint32_t rgba, uint32_t fill_flags);
+int pm_encoder_stroke_path(pm_encoder *e, const pm_path_el *els, size_t n_els, uint32_t rgba, float width);
+
 typedef struct pm_svg pm_svg;
 pm_svg *pm_svg_parse(const char *text, size_t len, int flags, int *err);
 pm_svg *pm_svg_tiger(int flags, int *err); /* the embedded Ghostscript_Tiger.svg (src/lib.rs:288) */

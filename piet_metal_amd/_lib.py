@@ -82,6 +82,8 @@ SIGNATURES = {
     "pm_encoder_circle": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
     "pm_encoder_ellipse": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]),
     "pm_encoder_fill_compound": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]),
+    "pm_encoder_fill_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]),
+    "pm_encoder_stroke_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_float]),
     "pm_encoder_stroke_line": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_float, C.c_uint32]),
     "pm_encoder_fill": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]),
     "pm_encoder_fill_rule": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]),

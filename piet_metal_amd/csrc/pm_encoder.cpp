@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <vector>
 #include <new>
 
 namespace pm {
@@ -270,6 +271,116 @@ int pm_encoder_circle(pm_encoder *e, double cx, double cy, double r) {
     e->enc.Circle(cx, cy, r);
     return e->enc.c_status();
 }
+// ---- paths with curves (src/lib.rs:194: "Signature will change, need to deal with subpaths and
+//      also want curves") -------------------------------------------------------------------
+// encode_path / encode_path_stroke of make_tiger (src/lib.rs:342-367) for ONE kurbo BezPath under
+// the identity transform: flatten.rs:10-47 on the host (tolerance 0.1, src/lib.rs:330), then the
+// encoder calls.  Same arithmetic, in binary64, as the device flatten kernels (pm_flatten.hip) and
+// the oracle: the three produce the same bytes.  This is the convenience API for callers that build
+// scenes item by item; whole documents go through pm_flatten_and_encode on the device.
+namespace {
+
+uint64_t HostSubdivisionCount(double x) {  // kurbo to_quads: the smallest n >= 1 with n^6 >= x (no libm dependency)
+    if (!(x > 1.0)) return 1;
+    if (x > 1e54) return 1ull << 30;
+    const double g = std::ceil(std::pow(x, 1.0 / 6.0));
+    uint64_t n = g >= 1.0 ? static_cast<uint64_t>(g) : 1;
+    auto p6 = [](uint64_t v) {
+        const double d = static_cast<double>(v);
+        return ((d * d) * (d * d)) * (d * d);
+    };
+    while (n > 1 && p6(n - 1) >= x) --n;
+    while (p6(n) < x) ++n;
+    return n;
+}
+
+double HostCubicEval(double p0, double p1, double p2, double p3, double t) {  // kurbo CubicBez::eval
+    const double mt = 1.0 - t;
+    return p0 * (mt * mt * mt) + (p1 * (mt * mt * 3.0) + (p2 * (mt * 3.0) + p3 * t) * t) * t;
+}
+
+// false: a LineTo / CurveTo before any MoveTo (the reference panics: cur_path.as_mut().unwrap())
+bool HostFlatten(const pm_path_el *els, size_t n_els, std::vector<double> *pts, std::vector<uint32_t> *sub_counts) {
+    constexpr double kTolerance = 0.1;  // src/lib.rs:330
+    bool open = false;
+    double lx = 0.0, ly = 0.0;
+    for (size_t i = 0; i < n_els; ++i) {
+        const pm_path_el &el = els[i];
+        if (el.tag == PM_EL_MOVE) {
+            sub_counts->push_back(1);
+            open = true;
+            lx = el.p[0];
+            ly = el.p[1];
+            pts->push_back(lx);
+            pts->push_back(ly);
+        } else if (el.tag == PM_EL_LINE) {
+            if (!open) return false;
+            lx = el.p[0];
+            ly = el.p[1];
+            pts->push_back(lx);
+            pts->push_back(ly);
+            sub_counts->back() += 1;
+        } else if (el.tag == PM_EL_CURVE) {
+            if (!open) return false;
+            const double accuracy = kTolerance * 1e-2;  // flatten.rs:35
+            const double max_hypot2 = 432.0 * accuracy * accuracy;
+            const double ax = el.p[0] * 3.0 - lx, ay = el.p[1] * 3.0 - ly;
+            const double bx = el.p[2] * 3.0 - el.p[4], by = el.p[3] * 3.0 - el.p[5];
+            const double dx = bx - ax, dy = by - ay;
+            const uint64_t n = HostSubdivisionCount((dx * dx + dy * dy) / max_hypot2);
+            for (uint64_t k = 0; k < n; ++k) {
+                const double t1 = static_cast<double>(k + 1) / static_cast<double>(n);
+                pts->push_back(HostCubicEval(lx, el.p[0], el.p[2], el.p[4], t1));
+                pts->push_back(HostCubicEval(ly, el.p[1], el.p[3], el.p[5], t1));
+            }
+            sub_counts->back() += static_cast<uint32_t>(n);
+            lx = el.p[4];
+            ly = el.p[5];
+        }  // QuadTo, ClosePath: `_ => ()`, flatten.rs:40
+    }
+    return true;
+}
+
+}  // namespace
+
+int pm_encoder_fill_path(pm_encoder *e, const pm_path_el *els, size_t n_els, uint32_t rgba, uint32_t fill_flags) {
+    if (!e || (n_els && !els)) return PM_ERR_INVALID;
+    std::vector<double> pts;
+    std::vector<uint32_t> subs;
+    if (!HostFlatten(els, n_els, &pts, &subs)) return PM_ERR_INVALID;
+    const uint32_t rule = fill_flags & PM_FILL_EVEN_ODD;
+    if ((fill_flags & PM_FILL_COMPOUND) && !subs.empty()) {
+        e->enc.FillCompound(pts.data(), subs.data(), subs.size(), rgba, rule);
+    } else {
+        const double *pp = pts.data();
+        for (uint32_t n : subs) {  // encode_path: one Fill per sub-path, src/lib.rs:343-347
+            e->enc.Fill(pp, n, rgba, rule);
+            pp += 2 * static_cast<size_t>(n);
+        }
+    }
+    return e->enc.c_status();
+}
+
+int pm_encoder_stroke_path(pm_encoder *e, const pm_path_el *els, size_t n_els, uint32_t rgba, float width) {
+    if (!e || (n_els && !els)) return PM_ERR_INVALID;
+    std::vector<double> pts;
+    std::vector<uint32_t> subs;
+    if (!HostFlatten(els, n_els, &pts, &subs)) return PM_ERR_INVALID;
+    constexpr float kThinLine = 0.7f;  // src/lib.rs:351
+    if (width < kThinLine) {           // encode_path_stroke, src/lib.rs:353-362
+        float alpha = static_cast<float>(rgba & 0xffu);
+        alpha = alpha * std::sqrt(width / kThinLine);
+        rgba = (rgba & ~0xffu) | static_cast<uint32_t>(alpha);
+        width = kThinLine;
+    }
+    const double *pp = pts.data();
+    for (uint32_t n : subs) {
+        e->enc.Polyline(pp, n, rgba, width);
+        pp += 2 * static_cast<size_t>(n);
+    }
+    return e->enc.c_status();
+}
+
 int pm_encoder_fill_compound(pm_encoder *e, const double *pts_xy, const uint32_t *sub_counts, size_t n_subpaths, uint32_t rgba,
                              uint32_t fill_flags) {
     if (!e || (n_subpaths && (!pts_xy || !sub_counts))) return PM_ERR_INVALID;

@@ -57,6 +57,18 @@ class Encoder:
         _lib.check(self._lib.pm_encoder_fill_compound(self._h, pts.ctypes.data, counts.ctypes.data, len(subs), rgba,
                                                      _lib.PM_FILL_EVEN_ODD if even_odd else 0), "fill_compound")
 
+    def fill_path(self, els: np.ndarray, rgba: int, even_odd: bool = False, compound: bool = False) -> None:
+        """Beyond the reference: a path with curves and sub-paths (PathSet.EL_DTYPE elements), flattened
+        on the host like make_tiger's encode_path; compound=True: ONE Fill item, holes are holes."""
+        els = np.ascontiguousarray(els, dtype=_EL_DTYPE)
+        flags = (_lib.PM_FILL_EVEN_ODD if even_odd else 0) | (_lib.PM_FILL_COMPOUND if compound else 0)
+        _lib.check(self._lib.pm_encoder_fill_path(self._h, els.ctypes.data, len(els), rgba & 0xFFFFFFFF, flags), "fill_path")
+
+    def stroke_path(self, els: np.ndarray, rgba: int, width: float) -> None:
+        """A path's sub-paths as poly-lines, with the thin-line rule of encode_path_stroke."""
+        els = np.ascontiguousarray(els, dtype=_EL_DTYPE)
+        _lib.check(self._lib.pm_encoder_stroke_path(self._h, els.ctypes.data, len(els), rgba & 0xFFFFFFFF, float(width)), "stroke_path")
+
     def ellipse(self, center, rx: float, ry: float) -> None:
         """Beyond the reference: the ellipse inscribed in the item's bbox (a Circle item with the
         ellipse bit), shaded as PietRender.metal:488-489 says it should be."""

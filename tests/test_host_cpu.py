@@ -613,6 +613,37 @@ def _bez(p0, els_row, t):
             mt ** 3 * p0[1] + 3 * mt * mt * t * P[1] + 3 * mt * t * t * P[3] + t ** 3 * P[5])
 
 
+def test_encoder_paths_with_curves_match_the_flatten_pipeline(pm, pmo):
+    """pm_encoder_fill_path / pm_encoder_stroke_path (host flatten + encode of one path with curves
+    and sub-paths: the signature src/lib.rs:194 anticipates) item by item against the oracle's
+    make_tiger restatement on whole documents under the identity transform: the same scene bytes --
+    the Tiger (fills, strokes, thin lines, arcs as cubics) and shapes.svg with SVG semantics
+    (compound fills, even-odd)."""
+    docs = [pm.PathSet.tiger(), pm.PathSet.from_svg(open(os.path.join(ROOT, "tests", "data", "shapes.svg")).read(), spec_defaults=True)]
+    ident = (1.0, 0.0, 0.0, 1.0, 0.0, 0.0)
+    for ps in docs:
+        want, n_items = pmo.scene_from_paths(pmo.scaled_paths(ps.paths, 1.0), ps.els, ident)
+        buf = np.zeros(len(want) + 4096, np.uint8)
+        e = pm.Encoder(buf)
+        e.begin_group(n_items)
+        for p in ps.paths:
+            els = ps.els[int(p["el_begin"]) : int(p["el_end"])]
+            fl = int(p["flags"])
+            if fl & pm._lib.PM_PATH_FILL:
+                e.fill_path(els, int(p["fill_rgba"]), even_odd=bool(fl & pm._lib.PM_PATH_EVEN_ODD), compound=bool(fl & pm._lib.PM_PATH_COMPOUND))
+            if fl & pm._lib.PM_PATH_STROKE:
+                e.stroke_path(els, int(p["stroke_rgba"]), float(p["stroke_width"]))
+        e.end_group()
+        assert np.array_equal(buf[: e.bytes_used], want)
+    # a LineTo before any MoveTo is an error (the reference panics), not a guess
+    bad = np.zeros(1, pm.PathSet.EL_DTYPE)
+    bad["tag"][0] = pm._lib.PM_EL_LINE
+    e = pm.Encoder(np.zeros(1024, np.uint8))
+    e.begin_group(1)
+    with pytest.raises(pm.PietMetalError):
+        e.fill_path(bad, 0xFF)
+
+
 def test_svg_viewbox_and_fit(pm):
     """The outermost <svg>'s viewBox and size come through the ABI; fit_affine maps the viewBox into a
     viewport like preserveAspectRatio="xMidYMid meet"; units of width / height are converted to px."""
