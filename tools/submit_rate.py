@@ -1,9 +1,9 @@
-"""How fast can the host submit frames?  (pm_render = 3 launches + 1 event record)"""
+"""How fast can the host submit frames?  (pm_render = 2 launches)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import piet_metal_amd as pm
 r = pm.Renderer(0)
-for wl in (pm.workloads.config1_rect(), pm.workloads.tiger(3840, 2160)):
+for wl in (pm.workloads.config1_rect(), pm.workloads.tiger(1920, 1080, fills_only=True), pm.workloads.tiger(3840, 2160)):
     r.resize(wl.width, wl.height)
     r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
     for _ in range(50): r.render()
