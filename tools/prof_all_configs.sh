@@ -1,4 +1,5 @@
 #!/bin/bash
+# Profile rounds of all bench workloads: tools/prof_round.sh for the Tiger (r02_c) and configs 2, 4, 5 (r02c_cfgN)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
