@@ -44,7 +44,11 @@ extern "C" {
 /* Drop-in for include/piet_metal.h:3 (impl src/lib.rs:387-393): fills `buf`
  * with the Ghostscript Tiger scene at scale 8, flattened ON DEVICE 0 and copied
  * back.  Same signature, no status channel (errors leave buf untouched and are
- * readable through pm_last_error()). */
+ * readable through pm_last_error()).
+ * PARITY UNPINNED: the bytes equal the in-repo oracle's (oracle/, a restatement of make_tiger +
+ * flatten.rs + the kurbo 0.5.6 / roxmltree steps they call), not a buffer produced by the Rust
+ * encoder -- none can be produced in this image; the Tiger's 6 arc paths and the current point
+ * after `Z` are product-defined. */
 void init_test_scene(uint8_t *buf, ssize_t buf_size);
 
 /* Encoder, mirrors `impl Encoder` (src/lib.rs:103-254) method for method.
