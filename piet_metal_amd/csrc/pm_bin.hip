@@ -178,6 +178,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     const float fy0 = static_cast<float>(y0), fy1 = static_cast<float>(y0 + static_cast<int>(kTileH));
     const float fsy0 = static_cast<float>(sy0), fsy1 = static_cast<float>(sy0 + static_cast<int>(kGroupH));
 
+    if (blockIdx.x == 0 && tid < kTicketParts) PM_PP(ctr_next)->ticket[tid].count = 0;
     if (blockIdx.x == 0 && tid == 0) {
         // The counters of the NEXT frame (the other parity) are idle now: reset them
         // here so that no separate memset launch is needed.

@@ -16,6 +16,8 @@ namespace pm {
 // one long and one short tile instead of whatever the strip rows' atomics happened to interleave.
 constexpr uint32_t kClasses = 8;
 
+constexpr uint32_t kTicketParts = 128;  // decks of the drawn part of the tile hand-out (pm_fine_kernel)
+
 // Per-frame counters; two copies alternate between frames so that frame N's binning
 // kernel can reset frame N+1's copy (no memset launch on the critical path).
 struct Counters {
@@ -31,6 +33,10 @@ struct Counters {
     uint32_t arena_top;  // dwords of binning records written (statistics)
     uint32_t overflow;   // set if the command-list arena ran out
     uint32_t pad4[30];
+    struct {
+        uint32_t count;  // cards drawn from this deck of tiles (pm_fine_kernel's hand-out)
+        uint32_t pad[31];
+    } ticket[kTicketParts];
 };
 
 // Arena record written by pm_bin_kernel for one (strip row, batch of <=256 items):
@@ -107,6 +113,7 @@ struct FrameParams {
     uint32_t split_mode;           // fine kernel: 0 = one wave per tile always, 1 = a workgroup per tile with a long list
     uint32_t class_thr[kClasses - 1];  // descending: a tile with more stream elements than class_thr[c] is in class <= c
     uint32_t n_heavy_classes;          // classes 0 .. n-1 are rendered by a whole workgroup per tile (long lists)
+    uint32_t handout_static;           // 1: every pass of the tile kernel is handed out statically (other frames in flight)
     // large scenes: per-tile-row item lists written each frame by pm_rowcull_kernel
     uint32_t use_row_lists;
     const uint32_t *row_base;      // [band rows + 1] list offsets (host-computed sizes)

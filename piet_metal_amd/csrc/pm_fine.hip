@@ -641,23 +641,58 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
         return pass * n_waves + ((pass & 1u) ? (n_waves - 1u - wave_global) : wave_global);
     };
     const uint64_t lanes_below = (1ull << lane) - 1ull;
+    // Hand-out.  The passes that hold workgroup tiles (at least the first) are static, snake order
+    // over the sorted slots as before.  The slots after them -- the shortest lists -- are dealt in
+    // kTicketParts interleaved decks (slot n_static + p + kTicketParts * j is card j of deck p); a
+    // wave that has finished its static share draws from deck wave_global % kTicketParts until the
+    // deck is empty.  Per-tile times vary by 2x around what the estimates predict, so a wave's
+    // second tile lands on whoever is free instead of on whoever the snake says (one counter for
+    // the whole grid would cap at ~90 draws/us; 128 counters in 128 cache lines cost nothing
+    // measurable, tools/probes/atomic_probe.hip).
+    // P.handout_static: the host saw other frames in flight -- with neighbours filling the idle
+    // SIMDs a drawn hand-out only adds contention (sustained throughput -3.5 %), alone it ends the
+    // launch 4.6 us earlier.
+    const uint32_t static_passes = P.handout_static ? 0x7fffffffu / n_waves : max(1u, (s_h + n_waves - 1u) / n_waves);
+    const uint32_t n_static = static_passes * n_waves;
+    const uint32_t part = wave_global % kTicketParts;
+    uint32_t *const deck_ctr = &P.ctr_cur->ticket[part].count;
     uint32_t slot = pass_slot(0);
     uint4 qe = make_uint4(0u, 0u, 0u, 0u);
     uint32_t qix = 0;
-    if (slot < n_slots) {
+    bool have = slot < n_slots;
+    if (have) {
         qix = slot_entry(slot);
         qe = P.queue[qix];
     }
-    for (uint32_t pass = 0; pass * n_waves < n_slots; ++pass) {
+    for (uint32_t pass = 0; have; ++pass) {
         const uint32_t cur_slot = slot;
         const uint4 cur = Scalar4(qe);
         uint4 *const qentry = P.queue + qix;
-        slot = pass_slot(pass + 1u);
-        if ((pass + 1u) * n_waves < n_slots && slot < n_slots) {
-            qix = slot_entry(slot);
-            qe = P.queue[qix];
+        const bool draws = pass + 1u >= static_passes;  // the next tile is a drawn one
+        if (!draws) {
+            slot = pass_slot(pass + 1u);
+            have = slot < n_slots;
+            if (have) {
+                qix = slot_entry(slot);
+                qe = P.queue[qix];
+            }
         }
-        if (cur_slot >= n_slots) continue;
+        // (called once per tile, when only the encoding of its pixels is left: a card in hand is a
+        //  tile nobody else can take)
+        // (issuing the draw earlier, when the last chunk is staged, and looking at it here was
+        //  measured: no difference -- what a drawn hand-out costs is that every wave stays busy)
+        auto next_card = [&]() {
+            if (!draws) return;
+            uint32_t j = 0;
+            if (lane == 0) j = __hip_atomic_fetch_add(deck_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            j = __builtin_amdgcn_readfirstlane(j);
+            slot = n_static + part + kTicketParts * j;
+            have = slot < n_slots;
+            if (have) {
+                qix = slot_entry(slot);
+                qe = P.queue[qix];
+            }
+        };
         const bool wg_mode = cur_slot < s_h && sh != 0;  // uniform over the workgroup (slots are aligned)
         const uint32_t tile = cur.x;
         unsigned long long t_begin = 0;
@@ -678,6 +713,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
             }
             if (kProf) prof.c = wall_clock64();
         }
+        if (n_cmd == 0) next_card();
         if (n_cmd != 0) {  // 0: the coarse kernel found one opaque colour and wrote it
             const uint32_t *src = reinterpret_cast<const uint32_t *>(P.ptcl + cur.y);
             const uint32_t tx = tile % P.tiles_x;
@@ -710,6 +746,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                 }
                 __syncthreads();  // the other waves may still read this wave's alpha images
                 __builtin_amdgcn_s_setprio(0);
+                next_card();
                 if (pyi < P.height && pxi < P.width) {
                     uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + (pix >> 4)) * P.fb_stride + static_cast<size_t>(pxi) * 4;
                     *reinterpret_cast<uint32_t *>(dst) = enc(s1.r, s1.g, s1.b);
@@ -736,6 +773,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                     WaveSync();
                     InterpretSparse(S, cmds, S.w[wave].f.fill_ix, m, x0, y0, st);
                 }
+                next_card();
                 if (pyi < P.height && pxi < P.width) {
                     uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
                     uint4 out;
