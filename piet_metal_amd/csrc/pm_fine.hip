@@ -92,13 +92,19 @@ __device__ __forceinline__ float CircleAlpha(float dx, float dy, float rx, float
     return Sat(fminf(rx, ry) - sqrtf(dx * dx + dy * dy));
 }
 
-// "no stroke yet" (renderKernel's df = 1e9, :471).  Materialized where it is used: as a plain
-// literal the compiler hoists four copies of it out of the tile loop and then spills them.
+// The distance field is kept SQUARED between its Line commands and the Stroke that consumes it:
+// df = min(1e9, sqrt(d_1), sqrt(d_2), ...) (renderKernel :471, :495-499) equals
+// min(1e9, sqrt(min(d_1, d_2, ...))) bit for bit, because a correctly rounded sqrt is monotone and
+// min picks one of its arguments -- one sqrt per Stroke and pixel instead of one per Line and pixel
+// (47 ns each for a lone wave, profiles/r02_issue_probe.txt).  "No line yet" is +infinity,
+// materialized where it is used: as a plain literal the compiler hoists four copies of it out of
+// the tile loop and then spills them.
 __device__ __forceinline__ float FarAway() {
     float v;
-    asm volatile("v_mov_b32 %0, 0x4e6e6b28" : "=v"(v));
+    asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(v));
     return v;
 }
+__device__ __forceinline__ float StrokeDistance(float d2) { return fminf(1e9f, sqrtf(d2)); }
 
 __device__ __forceinline__ half2_t Splat(_Float16 v) { half2_t r; r.x = v; r.y = v; return r; }
 
@@ -332,7 +338,7 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                     const float dx = (px0 + static_cast<float>(k)) - sx;
                     const float t = Sat((lx * dx + lydy) / den);
                     const float fx = lx * t - dx, fy = ly * t - dy;
-                    st.df[k] = fminf(st.df[k], sqrtf(fx * fx + fy * fy));
+                    st.df[k] = fminf(st.df[k], fx * fx + fy * fy);  // (squared: see FarAway)
                 }
                 break;
             }
@@ -341,7 +347,7 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 _Float16 alpha[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    alpha[k] = ToHalf(Sat(half_width + 0.5f - st.df[k]));
+                    alpha[k] = ToHalf(Sat(half_width + 0.5f - StrokeDistance(st.df[k])));
                     st.df[k] = FarAway();
                 }
                 half2_t a01, a23;
@@ -449,7 +455,7 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const u
                 const float dx = (px0 + static_cast<float>(k)) - sx;
                 const float t = Sat((lx * dx + lydy) / den);
                 const float fx = lx * t - dx, fy = ly * t - dy;
-                df[k] = fminf(df[k], sqrtf(fx * fx + fy * fy));
+                df[k] = fminf(df[k], fx * fx + fy * fy);  // (squared: see FarAway)
             }
         }
     }
@@ -538,7 +544,7 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
             } else if (cmd.tag == kCmdStroke) {  // :500-504
                 const float half_width = __uint_as_float(cmd.body[0]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) al[u] = ToHalf(Sat(half_width + 0.5f - df[u]));
+                for (int u = 0; u < 4; ++u) al[u] = ToHalf(Sat(half_width + 0.5f - StrokeDistance(df[u])));
             } else if (cmd.tag == kCmdCircle) {  // :481-490
                 const float bx0 = static_cast<float>(cmd.body[1] & 0xffffu), by0 = static_cast<float>(cmd.body[1] >> 16);
                 const float bx1 = static_cast<float>(cmd.body[2] & 0xffffu), by1 = static_cast<float>(cmd.body[2] >> 16);
