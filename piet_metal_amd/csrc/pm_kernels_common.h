@@ -6,8 +6,8 @@
 //   renderKernel TestApp/PietRender.metal:457-566  (+ stroke/renderDf :49-60)
 //   composite    TestApp/PietRender.metal:16-44
 //
-// Decomposition (NOT the reference's thread-per-tile / 256 MiB tile buffer) -- one kernel per
-// level of parallelism, launched back to back on the frame's stream by pm_context.hip:
+// Decomposition (NOT the reference's thread-per-tile / 256 MiB tile buffer) -- a frame is TWO
+// launches, back to back on the frame's stream (pm_context.hip):
 //
 //   pm_index_kernel   (once per scene) float bounding box of every chunk of 8 consecutive
 //       segments -- the segment-level analogue of the ShortBbox array the encoder builds per item.
@@ -22,23 +22,24 @@
 //         (PietRender.metal:258-295 fills, :374-399 polylines), the 16-bit mask of tiles the
 //         segment can matter to, and for fills the backdrop step;
 //       - per (item, tile) counts and backdrops, the TileEncoder solid rule per tile, the
-//         command-list space of every tile and its place in one of three class queues.
-//   (clearing)        pixels of the tiles binning resolved (background / one opaque colour): extra
-//       workgroups of pm_fine_kernel's launch (or pm_clear_kernel with PM_FOLD_CLEAR=0).
-//   pm_coarse_kernel  persistent; ONE WAVE PER QUEUED TILE, no workgroup barriers.
-//       - candidates are filtered by a per-tile hit bit; the record's slots carrying the tile's
-//         bit are gathered in paint order; each lane runs the reference's "phase 2" test for
-//         (tile, segment) (:302-357, :406-440) and emits 0..3 commands; ballots / mbcnt prefix
-//         ranks give every command its slot in the tile's command list in HBM (the reference's
-//         24-byte Cmd records);
-//       - opaque-solid detection (TileEncoder::encodeSolid/end) restarts the list; Bail tiles are
-//         written as one constant here.
-//   pm_fine_kernel    persistent; interprets a tile's command list (renderKernel) for its 256
-//       pixels with 1, 4 or 16 waves by list length.  Everything that only depends on y
-//       (segment window, the two divides of the area integral, FillEdge) is computed once per
-//       lane, colour blending runs as packed half2 math, and each lane finishes with one
-//       16-byte store.  Accumulators are binary16 exactly where the source declares `half`;
-//       commands are applied in list order (half accumulation is order dependent).
+//         command-list space of every tile and its place in one of eight cost-class queues.
+//   pm_fine_kernel<fused>   persistent; per queued tile, by the wave(s) that will render it:
+//       - CoarseTile (pm_coarse_tile.h; ONE WAVE, no workgroup barriers): candidates are filtered
+//         by a per-tile hit bit; the record's slots carrying the tile's bit are gathered in paint
+//         order; each lane runs the reference's "phase 2" test for (tile, segment) (:302-357,
+//         :406-440) and emits 0..3 commands; ballots / mbcnt prefix ranks give every command its
+//         slot in the tile's command list in HBM (the reference's 24-byte Cmd records);
+//         opaque-solid detection (TileEncoder::encodeSolid/end) restarts the list; Bail tiles are
+//         written as one constant there;
+//       - renderKernel over the list for the tile's 256 pixels: one wave (4 px per lane, row-sparse
+//         Fill evaluation), or the workgroup's four waves for a long list (items evaluated in
+//         parallel into binary16 alpha images, blended in list order).  Accumulators are binary16
+//         exactly where the source declares `half`; commands are applied in list order (half
+//         accumulation is order dependent);
+//       - extra workgroups of the same launch write the pixels of the tiles binning resolved
+//         (background / one opaque colour): the composite for tiles that never get a list.
+//   pm_coarse_kernel  CoarseTile as a launch of its own (PM_FUSED=0, and the list-capture hooks
+//       behind pm_debug_capture_ptcl / pm_fill_coverage); pm_clear_kernel likewise (PM_FOLD_CLEAR=0).
 //
 // Compile with -ffp-contract=off: every source-level f32/f16 operation is one
 // IEEE rounding, as in the oracle.
