@@ -412,7 +412,9 @@ int EnsureArena(pm_ctx *c) {
         if (((need[i] + 3u) & ~3ull) != c->sr_empty_dwords) desc.push_back(make_uint4(static_cast<uint32_t>(i), base[i], base[i + 1], 0u));
     // heaviest strip rows first (their arena need is the work estimate): the launch's span is its
     // longest workgroup, and that one should not start in the second wave of workgroups
-    if (EnvInt("PM_BIN_SORT", 0, 0, 1))  // (measured: +2.5 us when the heavy rows share CUs -- off)
+    // (measured: +2.5 us -- so is a snake order over CU periods, and natural order with the lightest
+    //  rows last gains nothing: neighbouring strip rows share data and belong together)
+    if (EnvInt("PM_BIN_SORT", 0, 0, 1))
         std::stable_sort(desc.begin(), desc.end(), [](const uint4 &a, const uint4 &b) { return a.z - a.y > b.z - b.y; });
     if (desc.empty()) desc.push_back(make_uint4(0u, base[0], need.empty() ? base[0] : base[1], 0u));
     c->n_sr_active = static_cast<uint32_t>(desc.size());
