@@ -616,7 +616,16 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
             cls_end[k] = run;
         }
     }
-    const uint32_t wave_global = blockIdx.x * kWaves + wave;
+    // Which workgroup of the hand-out this block is: blocks are dispatched round robin over the 8
+    // XCDs (block b runs on XCD b % 8, tools/probes/atomic_probe.hip), and neighbouring slots are
+    // tiles of one strip row that read the same binning record -- so runs of four workgroups (16
+    // slots) are dealt to the XCDs instead of single ones, and a record is fetched into one L2, not four.
+    uint32_t wg = blockIdx.x;
+    if ((P.fine_grid & 31u) == 0u) {
+        const uint32_t xcd = wg & 7u, i = wg >> 3;
+        wg = (((i >> 2) << 3) + xcd) * 4u + (i & 3u);
+    }
+    const uint32_t wave_global = wg * kWaves + wave;
     const uint32_t n_waves = P.fine_grid * kWaves;
     const uint32_t n_tiles = cls_end[kClasses - 1];
     const uint32_t n_heavy = P.n_heavy_classes ? cls_end[min(P.n_heavy_classes, kClasses) - 1u] : 0u;
