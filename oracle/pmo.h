@@ -177,6 +177,8 @@ typedef struct pmo_ptcl pmo_ptcl; /* per-tile command lists for one viewport */
 pmo_ptcl *pmo_ptcl_build(const uint8_t *scene, size_t scene_len, uint32_t width, uint32_t height);
 void pmo_ptcl_free(pmo_ptcl *p);
 uint32_t pmo_ptcl_tiles_x(const pmo_ptcl *p);
+/* tile-group rows [gy0, gy1) only (2 tile rows per group row); the other tiles stay empty */
+pmo_ptcl *pmo_ptcl_build_rows(const uint8_t *scene, size_t scene_len, uint32_t width, uint32_t height, uint32_t gy0, uint32_t gy1);
 uint32_t pmo_ptcl_tiles_y(const pmo_ptcl *p);
 /* Number of commands of tile (tx,ty) including the terminating End, or 1 for a
  * Bail tile (list is then just {Bail}). */

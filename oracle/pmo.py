@@ -45,6 +45,8 @@ def load() -> C.CDLL:
     lib.pmo_scene_from_paths.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     lib.pmo_ptcl_build.restype = C.c_void_p
     lib.pmo_ptcl_build.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]
+    lib.pmo_ptcl_build_rows.restype = C.c_void_p
+    lib.pmo_ptcl_build_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.pmo_ptcl_free.argtypes = [C.c_void_p]
     lib.pmo_ptcl_tiles_x.restype = C.c_uint32
     lib.pmo_ptcl_tiles_x.argtypes = [C.c_void_p]
@@ -115,10 +117,13 @@ def scaled_paths(paths: np.ndarray, width_scale: float) -> np.ndarray:
 class Ptcl:
     """Per-tile command lists (tileKernel output) for one viewport."""
 
-    def __init__(self, scene: np.ndarray, width: int, height: int):
+    def __init__(self, scene: np.ndarray, width: int, height: int, group_rows: tuple[int, int] | None = None):
         self._lib = load()
         scene = np.ascontiguousarray(scene, dtype=np.uint8)
-        self._h = self._lib.pmo_ptcl_build(scene.ctypes.data, scene.size, width, height)
+        if group_rows is None:
+            self._h = self._lib.pmo_ptcl_build(scene.ctypes.data, scene.size, width, height)
+        else:  # a slice of the tile pass: tile-group rows [a, b) = tile rows [2a, 2b)
+            self._h = self._lib.pmo_ptcl_build_rows(scene.ctypes.data, scene.size, width, height, group_rows[0], group_rows[1])
         if not self._h:
             raise RuntimeError("oracle tileKernel failed (scene out of bounds?)")
         self.width, self.height = width, height

@@ -413,7 +413,10 @@ static void run_group(scene_t *sc, uint32_t gx, uint32_t gy, tile_enc enc[LANES]
     }
 }
 
-pmo_ptcl *pmo_ptcl_build(const uint8_t *scene, size_t scene_len, uint32_t width, uint32_t height) {
+/* Tile-group rows [gy0, gy1) only (a group row = PMO_TILER_GROUP_H tile rows; the other tiles stay
+ * empty): threadgroups are independent, so a host with many cores can run the tile pass of one
+ * frame in slices (bench.py's all-cores CPU baseline). */
+pmo_ptcl *pmo_ptcl_build_rows(const uint8_t *scene, size_t scene_len, uint32_t width, uint32_t height, uint32_t gy0, uint32_t gy1) {
     if (scene_len < 8) return NULL;
     pmo_ptcl *p = (pmo_ptcl *)calloc(1, sizeof(*p));
     /* PietRenderer.m:63-67 */
@@ -459,7 +462,8 @@ pmo_ptcl *pmo_ptcl_build(const uint8_t *scene, size_t scene_len, uint32_t width,
     scene_t sc = {scene, scene_len, 0, root};
     tile_enc enc[LANES];
     memset(enc, 0, sizeof(enc));
-    for (uint32_t gy = 0; gy < groups_y; gy++) {
+    if (gy1 > groups_y) gy1 = groups_y;
+    for (uint32_t gy = gy0; gy < gy1; gy++) {
         for (uint32_t gx = 0; gx < groups_x; gx++) {
             run_group(&sc, gx, gy, enc);
             for (uint32_t t = 0; t < LANES; t++) {
@@ -482,6 +486,10 @@ pmo_ptcl *pmo_ptcl_build(const uint8_t *scene, size_t scene_len, uint32_t width,
         return NULL;
     }
     return p;
+}
+
+pmo_ptcl *pmo_ptcl_build(const uint8_t *scene, size_t scene_len, uint32_t width, uint32_t height) {
+    return pmo_ptcl_build_rows(scene, scene_len, width, height, 0, 0xffffffffu);
 }
 
 void pmo_ptcl_free(pmo_ptcl *p) {

@@ -367,6 +367,30 @@ def test_empty_and_degenerate_scenes(pmo):
         assert (pmo.render(scene, 48, 48) == 255).all()
 
 
+def test_tile_pass_in_slices_equals_the_whole_frame(pm, pmo):
+    """pmo_ptcl_build_rows: threadgroups are independent, so the tile pass of a frame can be cut into
+    slices of tile-group rows (bench.py's all-cores CPU baseline does): lists and pixels of the
+    slices equal the whole frame's."""
+    wl = pm.workloads.tiger(700, 410)
+    scene, _ = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
+    want = pmo.render(scene, 700, 410)
+    whole = pmo.Ptcl(scene, 700, 410)
+    tiles_y = (410 + 15) // 16
+    groups_y = (tiles_y + 1) // 2
+    got = np.zeros_like(want)
+    for a in range(0, groups_y, 3):
+        b = min(a + 3, groups_y)
+        P = pmo.Ptcl(scene, 700, 410, group_rows=(a, b))
+        rows = P.render_rows(2 * a, min(2 * b, tiles_y))
+        got[32 * a : 32 * a + rows.shape[0]] = rows
+        for ty in range(2 * a, min(2 * b, tiles_y)):
+            for tx in range(P.tiles_x):
+                assert np.array_equal(P.cmds(tx, ty), whole.cmds(tx, ty)) and P.solid(tx, ty) == whole.solid(tx, ty)
+        P.close()
+    whole.close()
+    assert np.array_equal(got, want)
+
+
 def test_viewport_not_multiple_of_tile(pmo):
     s = pmo.scene_cardioid()
     big = pmo.render(s, 2048, 1536)
