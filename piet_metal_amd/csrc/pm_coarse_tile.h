@@ -479,5 +479,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
     return solid_color ? 0u : n_pending;
 }
 
+#undef PM_CT_TICK
+
 }  // namespace
 }  // namespace pm
