@@ -44,9 +44,20 @@ struct CoarseTicks {
 #define PM_CT_TICK(v) \
     if (kProf) v = wall_clock64()
 
+// lds_chunks != nullptr (a tile the whole workgroup will render): the first kLdsChunks * 64 commands
+// of the list are ALSO left in LDS, 64 per chunk, chunk k at lds_chunks + k * lds_stride bytes -- the
+// staged-command areas of the workgroup's other waves, idle while this wave builds the list.  The
+// renderer then starts from LDS instead of reading the list back chunk by chunk.
+constexpr uint32_t kLdsChunks = 3;
+
 template <bool kCapture, bool kProf = false>
 __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &L, uint4 *const qentry, const uint4 qe,
-                                               const uint32_t lane, const uint64_t lanes_below, CoarseTicks *ticks = nullptr) {
+                                               const uint32_t lane, const uint64_t lanes_below, CoarseTicks *ticks = nullptr,
+                                               uint8_t *const lds_chunks = nullptr, const uint32_t lds_stride = 0) {
+    auto lds_put = [&](uint32_t q, const Cmd &c) {
+        if (lds_chunks != nullptr && q < kLdsChunks * 64u)
+            *reinterpret_cast<Cmd *>(lds_chunks + (q >> 6) * lds_stride + (q & 63u) * static_cast<uint32_t>(sizeof(Cmd))) = c;
+    };
     unsigned long long tk0 = 0, tk1 = 0;
     const uint32_t tile = qe.x;
     if (qe.y == 0xffffffffu) {  // the command-list arena overflowed (pm_sync re-renders the frame)
@@ -399,6 +410,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                     if (n_em >= 1) {
                         if (p >= first_kept) {
                             out_cmds[base + p] = c0;
+                            lds_put(base + p, c0);
                             if (kCapture) {
                                 const uint32_t li = list_len + p - first_kept;
                                 if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = c0;
@@ -409,6 +421,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                     if (n_em == 2) {
                         if (p >= first_kept) {
                             out_cmds[base + p] = c1;
+                            lds_put(base + p, c1);
                             if (kCapture) {
                                 const uint32_t li = list_len + p - first_kept;
                                 if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = c1;
@@ -418,6 +431,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                     }
                     if (has_fin && p >= first_kept) {
                         out_cmds[base + p] = fin;
+                        lds_put(base + p, fin);
                         if (kCapture) {
                             const uint32_t li = list_len + p - first_kept;
                             if (li < P.dbg_max) {

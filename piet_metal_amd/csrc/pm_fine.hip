@@ -717,7 +717,10 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
         uint32_t n_cmd = cur.w;
         if (kFused) {
             // (wave 0 of a workgroup-mode tile has wave == 0: its region is S.w[0] either way)
-            if (!wg_mode || wave == 0) n_cmd = CoarseTile<false, kProf>(P, S.w[wave].c, qentry, cur, lane, lanes_below, &ct);
+            // (a workgroup tile: chunks 0..2 of the list also go to the staged-command areas of waves 1..3)
+            if (!wg_mode || wave == 0)
+                n_cmd = CoarseTile<false, kProf>(P, S.w[wave].c, qentry, cur, lane, lanes_below, &ct,
+                                                 wg_mode ? reinterpret_cast<uint8_t *>(S.w[1].f.cmds) : nullptr, static_cast<uint32_t>(sizeof(WaveLds)));
             if (wg_mode) {
                 if (wave == 0 && lane == 0) S.wg_ncmd[pass & 1u] = n_cmd;
                 __syncthreads();  // (workgroup-scope release/acquire: the list wave 0 wrote is visible)
@@ -750,14 +753,17 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                 uint32_t parity = 0;
                 for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk, parity ^= 1u) {
                     const uint32_t m = min(kSpChunk, n_cmd - c0);
-                    __syncthreads();  // the previous chunk (or tile) is done with the shared arrays
-                    {
+                    Cmd *chunk = S.w[0].f.cmds;
+                    if (!kFused || c0 != 0) __syncthreads();  // the previous chunk (or tile) is done with the shared tables
+                    if (kFused && c0 < kLdsChunks * kSpChunk) {
+                        chunk = S.w[1u + c0 / kSpChunk].f.cmds;  // CoarseTile left it there (visible since the barrier after it)
+                    } else {
                         const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
                         uint2 *l = reinterpret_cast<uint2 *>(S.w[0].f.cmds);
                         for (uint32_t w = threadIdx.x; w < 3u * m; w += kThreads) l[w] = g[w];
+                        __syncthreads();
                     }
-                    __syncthreads();
-                    RenderChunkWG<kProf>(S, S.w[0].f.cmds, S.w[wave].f.fill_ix, m, parity, x0, y0, pix, s1, prof);
+                    RenderChunkWG<kProf>(S, chunk, S.w[wave].f.fill_ix, m, parity, x0, y0, pix, s1, prof);
                 }
                 __syncthreads();  // the other waves may still read this wave's alpha images
                 __builtin_amdgcn_s_setprio(0);
