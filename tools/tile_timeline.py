@@ -11,8 +11,11 @@ if len(sys.argv) > 2:  # only a band of tile rows: the tiles of the band without
     r.set_band(int(sys.argv[1]), int(sys.argv[2]))
 for _ in range(3):
     r.render()
+    if os.environ.get("PM_TIMELINE_LONE", "1") != "0":
+        r.sync()  # every frame alone: the hand-out and the class thresholds of a lone frame
 r.sync()
 t = r.time_tiles()
+t = t[t[:, 0] > 0]  # (rows of slots the replay did not reach stay zero)
 start, end = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
 tile = (t[:, 2] & 0x7fffffff).astype(np.int64); quarter = (t[:, 2] >> 31).astype(bool)
 wave = (t[:, 3] >> 32).astype(np.int64); ncmd = (t[:, 3] & 0xffffffff).astype(np.int64)
@@ -52,3 +55,7 @@ if t.shape[1] >= 12 and (t[:, 11] > 0).any():
     w = np.argsort(-coarse)[:3]
     for i in w:
         print(f"   slot {i} ncmd {ncmd[i]} list {coarse[i]:.1f} us: " + ", ".join(f"{k} {v[i]:.1f}" for k, v in stages.items()) + f", rounds {rounds[i]}, records {records[i]}")
+
+last = np.argsort(-end)[:10]
+print("slots that end last:")
+for i in last: print(f"  slot {i} tile {tile[i]} q={quarter[i]} ncmd {ncmd[i]} start {(start[i]-t0)*us:.1f} end {(end[i]-t0)*us:.1f} dur {dur[i]:.1f} list {coarse[i]:.1f}")
