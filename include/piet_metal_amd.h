@@ -133,7 +133,7 @@ typedef struct {
  * understands: <g>/<svg> nesting with inherited presentation properties, `transform`
  * (matrix translate scale rotate skewX skewY), `style="..."`, opacity / fill-opacity /
  * stroke-opacity (folded into the items' alpha: no group compositing), fill-rule (evenodd ->
- * PM_PATH_EVEN_ODD), #rgb / #rrggbb / rgb() / basic colour names / none, and rect (rounded too),
+ * PM_PATH_EVEN_ODD), #rgb / #rrggbb / rgb() / the 147 colour keywords / none, and rect (rounded too),
  * circle, ellipse, line, polyline, polygon as paths; <use> (href / xlink:href, x, y: the referenced
  * element or <symbol>, from anywhere in the document, nested at most 8 deep); <defs> and friends
  * are not drawn where they stand.  Coordinates

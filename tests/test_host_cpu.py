@@ -644,6 +644,22 @@ def test_encoder_paths_with_curves_match_the_flatten_pipeline(pm, pmo):
         e.fill_path(bad, 0xFF)
 
 
+def test_svg_colour_keywords_match_an_independent_table(pm):
+    """The 147 colour keywords of SVG 1.1 against Pillow's table (an independent source)."""
+    ImageColor = pytest.importorskip("PIL.ImageColor")
+    checked = 0
+    for name in ImageColor.colormap:
+        if name == "rebeccapurple":  # CSS4, not SVG 1.1: unknown keywords leave the inherited paint
+            ps = pm.PathSet.from_svg('<svg><rect width="5" height="5" fill="%s"/></svg>' % name)
+            assert len(ps.paths) == 0
+            continue
+        r, g, b = ImageColor.getrgb(name)[:3]
+        ps = pm.PathSet.from_svg('<svg><rect width="5" height="5" fill="%s"/></svg>' % name)
+        assert int(ps.paths[0]["fill_rgba"]) == ((r << 24) | (g << 16) | (b << 8) | 0xFF), name
+        checked += 1
+    assert checked == 147
+
+
 def test_svg_viewbox_and_fit(pm):
     """The outermost <svg>'s viewBox and size come through the ABI; fit_affine maps the viewBox into a
     viewport like preserveAspectRatio="xMidYMid meet"; units of width / height are converted to px."""
