@@ -131,7 +131,8 @@ typedef struct {
 
 /* Beyond what make_tiger reads (d / fill / stroke / stroke-width of every <path>), pm_svg_parse
  * understands: <g>/<svg> nesting with inherited presentation properties, `transform`
- * (matrix translate scale rotate skewX skewY), `style="..."`, opacity / fill-opacity /
+ * (matrix translate scale rotate skewX skewY), `style="..."`, <style> sheets with element / .class /
+ * #id selectors (presentation attributes < element < class < id rules < style attribute), opacity / fill-opacity /
  * stroke-opacity (folded into the items' alpha: no group compositing), fill-rule (evenodd ->
  * PM_PATH_EVEN_ODD), #rgb / #rrggbb / rgb() / the 147 colour keywords / none, and rect (rounded too),
  * circle, ellipse, line, polyline, polygon as paths; <use> (href / xlink:href, x, y: the referenced

@@ -401,7 +401,8 @@ uint32_t ParseColor(const char *s, size_t len) {  // parse_color, src/lib.rs:375
 // names, and the basic shapes (rect, circle, ellipse, line, polyline, polygon) as paths.
 // <use> draws the element (or <symbol>) its href names, wherever that is defined.
 // Not understood (ignored): gradients and patterns (painted as if `none`), clipping, masks,
-// text, CSS style sheets, units other than user units / px, stroke joins / caps / dashes.
+// text, CSS selectors beyond element / .class / #id, units other than user units / px, stroke
+// joins / caps / dashes.
 
 struct Affine {  // x' = a x + c y + e, y' = b x + d y + f (the SVG matrix(a b c d e f))
     double a = 1, b = 0, c = 0, d = 1, e = 0, f = 0;
@@ -599,25 +600,100 @@ void ApplyProperty(const std::string &name, const std::string &value, Style *st)
     }
 }
 
-bool ApplyElementStyle(const std::vector<Attr> &attrs, Style *st) {
+// A <style> sheet, as far as this front-end reads one: rules whose selector is a bare element name,
+// .class or #id (comma lists allowed; anything else -- combinators, attributes, pseudo classes, @rules
+// -- is skipped).  Cascade: presentation attributes < element rules < class rules < id rules < the
+// style attribute (CSS 2.1 section 6.4.3 for these selectors; later rules win within a kind).
+struct CssRule {
+    int kind;  // 0 element, 1 class, 2 id
+    std::string name, decls;
+};
+
+void ApplyDeclarations(const char *p, const char *end, Style *st, double *opacity_factor) {
+    while (p < end) {
+        const char *semi = static_cast<const char *>(std::memchr(p, ';', end - p));
+        const char *de = semi ? semi : end;
+        const char *colon = static_cast<const char *>(std::memchr(p, ':', de - p));
+        if (colon) {
+            const std::string name = Trim(p, colon - p), value = Trim(colon + 1, de - colon - 1);
+            if (name == "opacity") *opacity_factor = ParseOpacity(value, 1.0);  // (the last declaration wins, then it multiplies once)
+            else ApplyProperty(name, value, st);
+        }
+        p = de + 1;
+    }
+}
+
+void ParseStyleSheet(const char *p, const char *end, std::vector<CssRule> *rules) {
+    std::string css;
+    while (p < end) {  // drop comments and CDATA markers
+        if (end - p >= 2 && p[0] == '/' && p[1] == '*') {
+            const char *q = p + 2;
+            while (q + 1 < end && !(q[0] == '*' && q[1] == '/')) ++q;
+            p = q + 2 <= end ? q + 2 : end;
+        } else if (end - p >= 9 && std::memcmp(p, "<![CDATA[", 9) == 0) {
+            p += 9;
+        } else if (end - p >= 3 && std::memcmp(p, "]]>", 3) == 0) {
+            p += 3;
+        } else {
+            css.push_back(*p++);
+        }
+    }
+    size_t at = 0;
+    while (at < css.size()) {
+        const size_t open = css.find('{', at);
+        if (open == std::string::npos) break;
+        const size_t close = css.find('}', open);
+        if (close == std::string::npos) break;
+        const std::string sel = css.substr(at, open - at), decls = css.substr(open + 1, close - open - 1);
+        at = close + 1;
+        size_t s0 = 0;
+        while (s0 <= sel.size()) {
+            size_t comma = sel.find(',', s0);
+            if (comma == std::string::npos) comma = sel.size();
+            const std::string one = Trim(sel.c_str() + s0, comma - s0);
+            s0 = comma + 1;
+            if (one.empty()) continue;
+            const int kind = one[0] == '.' ? 1 : (one[0] == '#' ? 2 : 0);
+            const std::string name = kind ? one.substr(1) : one;
+            bool simple = !name.empty();
+            for (char ch : name)
+                if (!(std::isalnum(static_cast<unsigned char>(ch)) || ch == '-' || ch == '_')) simple = false;
+            if (simple) rules->push_back({kind, name, decls});
+        }
+    }
+}
+
+bool ApplyElementStyle(const std::vector<Attr> &attrs, Style *st, const std::vector<CssRule> *css = nullptr, const char *el_name = nullptr,
+                       size_t el_name_len = 0) {
     static const char *kProps[] = {"fill", "stroke", "stroke-width", "fill-rule", "fill-opacity", "stroke-opacity"};
     for (const char *pn : kProps)
         if (const Attr *a = Find(attrs, pn)) ApplyProperty(pn, Trim(a->val, a->val_len), st);
-    if (const Attr *a = Find(attrs, "opacity")) st->opacity *= ParseOpacity(Trim(a->val, a->val_len), 1.0);  // not inherited: it multiplies
-    if (const Attr *a = Find(attrs, "style")) {
-        const char *p = a->val, *end = a->val + a->val_len;
-        while (p < end) {
-            const char *semi = static_cast<const char *>(std::memchr(p, ';', end - p));
-            const char *de = semi ? semi : end;
-            const char *colon = static_cast<const char *>(std::memchr(p, ':', de - p));
-            if (colon) {
-                const std::string name = Trim(p, colon - p), value = Trim(colon + 1, de - colon - 1);
-                if (name == "opacity") st->opacity *= ParseOpacity(value, 1.0);
-                else ApplyProperty(name, value, st);
+    double opacity_factor = 1.0;  // not inherited: the element's own value multiplies the ancestors'
+    if (const Attr *a = Find(attrs, "opacity")) opacity_factor = ParseOpacity(Trim(a->val, a->val_len), 1.0);
+    if (css && !css->empty()) {
+        const Attr *cls = Find(attrs, "class"), *id = Find(attrs, "id");
+        for (int kind = 0; kind < 3; ++kind)
+            for (const CssRule &r : *css) {
+                if (r.kind != kind) continue;
+                bool match = false;
+                if (kind == 0) {
+                    match = el_name && r.name.size() == el_name_len && std::memcmp(r.name.data(), el_name, el_name_len) == 0;
+                } else if (kind == 2) {
+                    match = id && r.name.size() == id->val_len && std::memcmp(r.name.data(), id->val, id->val_len) == 0;
+                } else if (cls) {
+                    const char *c = cls->val, *ce = cls->val + cls->val_len;
+                    while (c < ce && !match) {
+                        while (c < ce && std::isspace(static_cast<unsigned char>(*c))) ++c;
+                        const char *w = c;
+                        while (c < ce && !std::isspace(static_cast<unsigned char>(*c))) ++c;
+                        match = static_cast<size_t>(c - w) == r.name.size() && std::memcmp(w, r.name.data(), r.name.size()) == 0;
+                    }
+                }
+                if (match) ApplyDeclarations(r.decls.data(), r.decls.data() + r.decls.size(), st, &opacity_factor);
             }
-            p = de + 1;
-        }
     }
+    if (const Attr *a = Find(attrs, "style")) ApplyDeclarations(a->val, a->val + a->val_len, st, &opacity_factor);
+    st->opacity *= opacity_factor;
     if (const Attr *a = Find(attrs, "transform")) {
         Affine t;
         if (!ParseTransform(std::string(a->val, a->val_len), &t)) return false;
@@ -791,6 +867,7 @@ struct Doc {
     int flags;
     pm_svg *out;
     std::vector<IdRange> ids;
+    std::vector<CssRule> css;
 };
 
 // Walks the elements of [text, end) under the inherited style `initial`.  use_depth > 0: the range
@@ -877,7 +954,7 @@ int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial
             // is entered like a group, its viewBox is not applied).  References nest at most 8 deep.
             if (!ScanAttrs(p, q, &attrs)) return PM_ERR_PARSE;
             Style st = stack.back();
-            if (!ApplyElementStyle(attrs, &st)) return PM_ERR_PARSE;
+            if (!ApplyElementStyle(attrs, &st, &doc->css, n0, name_len)) return PM_ERR_PARSE;
             Affine shift;
             if (const Attr *a = Find(attrs, "x")) shift.e = std::strtod(std::string(a->val, a->val_len).c_str(), nullptr);
             if (const Attr *a = Find(attrs, "y")) shift.f = std::strtod(std::string(a->val, a->val_len).c_str(), nullptr);
@@ -939,7 +1016,7 @@ int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial
                 }
             }
             Style st = stack.back();
-            if (!ApplyElementStyle(attrs, &st)) return PM_ERR_PARSE;
+            if (!ApplyElementStyle(attrs, &st, &doc->css, n0, name_len)) return PM_ERR_PARSE;
             if (is_group) {
                 if (!self_closing) {
                     stack.push_back(st);
@@ -1000,6 +1077,21 @@ int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
     doc.flags = flags;
     doc.out = out;
     IndexIds(text, text + len, &doc.ids);
+    for (const char *p = text, *end = text + len; p < end;) {  // every <style> element of the document
+        const char *st0 = static_cast<const char *>(std::memchr(p, '<', end - p));
+        if (!st0) break;
+        if (end - st0 >= 7 && std::memcmp(st0, "<style", 6) == 0 && (st0[6] == '>' || std::isspace(static_cast<unsigned char>(st0[6])))) {
+            const char *gt = TagEnd(st0 + 1, end);
+            if (!gt) break;
+            const char *body = gt + 1;
+            const char *close = body;
+            while (close + 8 <= end && std::memcmp(close, "</style>", 8) != 0) ++close;
+            if (gt[-1] != '/' && close + 8 <= end) ParseStyleSheet(body, close, &doc.css);
+            p = close;
+        } else {
+            p = st0 + 1;
+        }
+    }
     Style initial;
     // SVG's initial fill is black; make_tiger only fills a path that HAS a fill attribute
     // (src/lib.rs:299).  The Tiger wraps everything in <g fill="none">, where both readings

@@ -692,7 +692,7 @@ def test_second_svg_document_end_to_end(pm, pmo, tmp_path):
     out = str(tmp_path / "shapes.png")
     assert cli.main([src, out, "--width", "1200", "--height", "900", "--scale", "3"]) == 0
     ps = pm.PathSet.from_svg(open(src).read(), spec_defaults=True)
-    assert len(ps.paths) == 16 and (ps.paths["flags"] & pm._lib.PM_PATH_EVEN_ODD).any() and (ps.paths["flags"] & pm._lib.PM_PATH_COMPOUND).any()
+    assert len(ps.paths) == 21 and (ps.paths["flags"] & pm._lib.PM_PATH_EVEN_ODD).any() and (ps.paths["flags"] & pm._lib.PM_PATH_COMPOUND).any()
     scene, n_items = pmo.scene_from_paths(pmo.scaled_paths(ps.paths, 3.0), ps.els, (3.0, 0.0, 0.0, 3.0, 0.0, 0.0))
     want = pmo.render(scene, 1200, 900)
     got = cli.read_png_rgba(out)

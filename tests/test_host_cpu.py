@@ -516,16 +516,28 @@ def _svg_walk(svg_text, spec_defaults=False):
             return
         st = dict(st)
         props = {k: v for k, v in el.attrib.items()}
-        decl = {}
-        for d in props.get("style", "").split(";"):
-            if ":" in d:
-                k, v = d.split(":", 1)
-                decl[k.strip()] = v.strip()
-        for k in ("fill", "stroke"):
-            for src in (props, decl):
+
+        def decls_of(text):
+            d = {}
+            for part in text.split(";"):
+                if ":" in part:
+                    k, v = part.split(":", 1)
+                    d[k.strip()] = v.strip()
+            return d
+
+        # cascade: presentation attributes < element rules < class rules < id rules < style attribute
+        sources = [props]
+        classes = props.get("class", "").split()
+        for kind in (0, 1, 2):
+            for rk, rname, rdecl in sheet:
+                if rk == kind and ((kind == 0 and rname == tag) or (kind == 1 and rname in classes) or (kind == 2 and rname == props.get("id"))):
+                    sources.append(decls_of(rdecl))
+        sources.append(decls_of(props.get("style", "")))
+        own_opacity = None
+        for src in sources:
+            for k in ("fill", "stroke"):
                 if k in src:
                     st[k] = paint(src[k], st[k])
-        for src in (props, decl):
             if "stroke-width" in src:
                 st["width"] = float(np.float32(float(src["stroke-width"])))
             if "fill-rule" in src:
@@ -535,7 +547,9 @@ def _svg_walk(svg_text, spec_defaults=False):
             if "stroke-opacity" in src:
                 st["so"] = opac(src["stroke-opacity"])
             if "opacity" in src:
-                st["op"] = st["op"] * opac(src["opacity"])
+                own_opacity = opac(src["opacity"])
+        if own_opacity is not None:
+            st["op"] = st["op"] * own_opacity
         if "transform" in props:
             st["ctm"] = mat_mul(st["ctm"], transform(props["transform"]))
         if tag in ("g", "svg", "a", "switch", "symbol"):
@@ -591,6 +605,15 @@ def _svg_walk(svg_text, spec_defaults=False):
             out.append({"flags": flags, "fill": fill_rgba, "stroke": stroke_rgba, "width": width, "geom": geom, "ctm": st["ctm"]})
 
     root = ET.fromstring(svg_text)
+    sheet = []  # (kind, name, declarations) of the <style> rules with a simple selector, in document order
+    for el in root.iter():
+        if el.tag.split("}")[-1] == "style":
+            css = re.sub(r"/\*.*?\*/", "", el.text or "", flags=re.S)
+            for sel, body in re.findall(r"([^{}]+)\{([^{}]*)\}", css):
+                for one in sel.split(","):
+                    one = one.strip()
+                    if re.fullmatch(r"[.#]?[A-Za-z0-9_-]+", one):
+                        sheet.append((1 if one[0] == "." else 2 if one[0] == "#" else 0, one.lstrip(".#"), body))
     visit(root, {"fill": 0 if spec_defaults else None, "stroke": None, "width": 1.0, "evenodd": False, "fo": 1.0, "so": 1.0, "op": 1.0,
                  "ctm": [1, 0, 0, 1, 0, 0]})
     return out
@@ -688,7 +711,7 @@ def test_svg_document_layer_matches_independent_walker(pm, spec_defaults):
     svg = open(os.path.join(ROOT, "tests", "data", "shapes.svg")).read()
     ps = pm.PathSet.from_svg(svg, spec_defaults=spec_defaults)
     want = _svg_walk(svg, spec_defaults)
-    assert len(ps.paths) == len(want) == 16
+    assert len(ps.paths) == len(want) == 21
     for p, w in zip(ps.paths, want):
         assert int(p["flags"]) == w["flags"], w
         if w["flags"] & 1:
