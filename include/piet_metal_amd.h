@@ -125,6 +125,8 @@ typedef struct {
 } pm_path;                     /* 24 bytes */
 
 #define PM_SVG_REJECT_ARC_PATHS 1 /* drop any path whose data holds A/a */
+#define PM_SVG_FLAT_GRADIENTS 4   /* url(#gradient) paints become ONE colour, the mean of the gradient's stops (the renderer has
+                                     no gradients; default: such a paint is `none`, the element is not drawn with it) */
 #define PM_SVG_SPEC_DEFAULTS 2    /* SVG's initial `fill: black`, and the sub-paths of a path are filled TOGETHER
                                      (PM_PATH_COMPOUND: holes); default: make_tiger's rules -- only a fill property
                                      (own or inherited) fills (src/lib.rs:299), every sub-path is its own item (:343) */

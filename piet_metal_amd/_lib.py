@@ -26,6 +26,7 @@ PM_FILL_EVEN_ODD = 1
 PM_FILL_COMPOUND = 2
 PM_SVG_REJECT_ARC_PATHS = 1
 PM_SVG_SPEC_DEFAULTS = 2
+PM_SVG_FLAT_GRADIENTS = 4
 PM_FMT_RGBA8, PM_FMT_BGRA8 = 0, 1
 
 

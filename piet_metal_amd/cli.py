@@ -71,6 +71,7 @@ def main(argv=None) -> int:
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--reject-arc-paths", action="store_true", help="skip <path>s that use the arc command (kurbo 0.5.6 question, SURVEY F6)")
     ap.add_argument("--reference-fill-rule", action="store_true", help="files: only a fill property fills (make_tiger, src/lib.rs:299) instead of SVG's initial black")
+    ap.add_argument("--no-flat-gradients", action="store_true", help="files: do not draw gradient paints at all (default: as the mean colour of their stops)")
     ap.add_argument("--frames", type=int, default=1, help="render an animation of this many frames (output NAME-###.png)")
     ap.add_argument("--spin", type=float, default=360.0, help="--frames: total rotation about the viewport centre, degrees")
     args = ap.parse_args(argv)
@@ -81,7 +82,7 @@ def main(argv=None) -> int:
         paths = PathSet.tiger(args.reject_arc_paths)
     else:
         with open(args.input, "rb") as f:
-            paths = PathSet.from_svg(f.read(), args.reject_arc_paths, spec_defaults=not args.reference_fill_rule)
+            paths = PathSet.from_svg(f.read(), args.reject_arc_paths, spec_defaults=not args.reference_fill_rule, flat_gradients=not args.no_flat_gradients)
     scale = args.scale if args.scale is not None else args.height / 200.0
     off = args.offset if args.offset is not None else ((args.width - args.height) / 2.0 if args.scale is None else 0.0, 0.0)
     base = (scale, 0.0, 0.0, scale, float(off[0]), float(off[1]))

@@ -400,7 +400,8 @@ uint32_t ParseColor(const char *s, size_t len) {  // parse_color, src/lib.rs:375
 // `style="..."`, opacity / fill-opacity / stroke-opacity, fill-rule, rgb() and the basic colour
 // names, and the basic shapes (rect, circle, ellipse, line, polyline, polygon) as paths.
 // <use> draws the element (or <symbol>) its href names, wherever that is defined.
-// Not understood (ignored): gradients and patterns (painted as if `none`), clipping, masks,
+// Not understood (ignored): patterns and -- unless PM_SVG_FLAT_GRADIENTS turns them into their mean
+// colour -- gradients (painted as if `none`), clipping, masks,
 // text, CSS selectors beyond element / .class / #id, units other than user units / px, stroke
 // joins / caps / dashes.
 
@@ -425,6 +426,7 @@ struct Paint {
 struct Style {
     Paint fill, stroke;
     float stroke_width = 1.0f;
+    double fill_server_alpha = 1.0, stroke_server_alpha = 1.0;  // mean stop-opacity of a flattened gradient paint
     double opacity = 1.0, fill_opacity = 1.0, stroke_opacity = 1.0;  // opacity: product of the ancestors'
     bool even_odd = false;
     Affine ctm;
@@ -436,7 +438,16 @@ std::string Trim(const char *s, size_t n) {
     return std::string(s, n);
 }
 
-bool ParsePaint(const std::string &v, Paint *out) {
+// url(#id) paints: with PM_SVG_FLAT_GRADIENTS the document layer installs a resolver that turns a
+// gradient into ONE colour (the mean of its stops) -- the renderer has no gradients, and a flat
+// stand-in is closer to the picture than nothing.  Without it a url() paint is `none`.
+struct PaintServerResolver {
+    virtual bool Resolve(const std::string &id, uint32_t *rgb, double *alpha) const = 0;
+    virtual ~PaintServerResolver() = default;
+};
+thread_local const PaintServerResolver *t_paint_servers = nullptr;
+
+bool ParsePaint(const std::string &v, Paint *out, double *server_alpha = nullptr) {
     // the 147 colour keywords of SVG 1.1 (section 4.4)
     static const struct { const char *name; uint32_t rgb; } kNames[] = {
         {"aliceblue", 0xf0f8ff}, {"antiquewhite", 0xfaebd7}, {"aqua", 0x00ffff}, {"aquamarine", 0x7fffd4}, {"azure", 0xf0ffff}, {"beige", 0xf5f5dc},
@@ -469,6 +480,21 @@ bool ParsePaint(const std::string &v, Paint *out) {
         {"violet", 0xee82ee}, {"wheat", 0xf5deb3}, {"white", 0xffffff}, {"whitesmoke", 0xf5f5f5}, {"yellow", 0xffff00}, {"yellowgreen", 0x9acd32},
     };
     if (v.empty() || v == "inherit" || v == "currentColor") return false;  // leave the inherited value
+    if (v.compare(0, 4, "url(") == 0 && t_paint_servers) {
+        size_t a = v.find('#'), b = v.find(')');
+        if (a != std::string::npos && b != std::string::npos && b > a + 1) {
+            std::string id = Trim(v.c_str() + a + 1, b - a - 1);
+            if (!id.empty() && (id.back() == '"' || id.back() == '\'')) id.pop_back();
+            uint32_t rgb = 0;
+            double alpha = 1.0;
+            if (t_paint_servers->Resolve(id, &rgb, &alpha)) {
+                out->none = false;
+                out->rgb = rgb;
+                if (server_alpha) *server_alpha = alpha;
+                return true;
+            }
+        }
+    }
     if (v == "none" || v == "transparent" || v.compare(0, 4, "url(") == 0) {
         out->none = true;
         return true;
@@ -585,9 +611,11 @@ double ParseLength(const Attr *a, double dflt = 0.0) {
 // One presentation property, from an attribute or a `style` declaration (which wins, CSS cascade).
 void ApplyProperty(const std::string &name, const std::string &value, Style *st) {
     if (name == "fill") {
-        (void)ParsePaint(value, &st->fill);
+        double a = 1.0;
+        if (ParsePaint(value, &st->fill, &a)) st->fill_server_alpha = a;
     } else if (name == "stroke") {
-        (void)ParsePaint(value, &st->stroke);
+        double a = 1.0;
+        if (ParsePaint(value, &st->stroke, &a)) st->stroke_server_alpha = a;
     } else if (name == "stroke-width") {
         st->stroke_width = std::strtof(value.c_str(), nullptr);  // f32::from_str, src/lib.rs:320
     } else if (name == "fill-rule") {
@@ -870,6 +898,84 @@ struct Doc {
     std::vector<CssRule> css;
 };
 
+// PM_SVG_FLAT_GRADIENTS: a <linearGradient> / <radialGradient> as one colour -- the arithmetic mean
+// of its stops' colours (sRGB components) and of their stop-opacity; a gradient without stops takes
+// those of the gradient its href names.
+struct GradientResolver : PaintServerResolver {
+    const Doc *doc = nullptr;
+    bool Stops(const std::string &id, int depth, double sum[4], int *n) const {
+        for (const IdRange &r : doc->ids) {
+            if (r.id != id) continue;
+            const char *p = r.begin + 1;
+            const char *n1 = p;
+            while (n1 < r.end && !std::isspace(static_cast<unsigned char>(*n1)) && *n1 != '>' && *n1 != '/') ++n1;
+            const std::string el(p, n1 - p);
+            if (el != "linearGradient" && el != "radialGradient") return false;
+            std::vector<Attr> attrs;
+            for (const char *q = r.begin; q < r.end;) {
+                const char *lt = static_cast<const char *>(std::memchr(q, '<', r.end - q));
+                if (!lt || r.end - lt < 6) break;
+                q = lt + 1;
+                if (std::memcmp(lt, "<stop", 5) != 0 || !(std::isspace(static_cast<unsigned char>(lt[5])) || lt[5] == '/' || lt[5] == '>')) continue;
+                const char *gt = TagEnd(lt + 1, r.end);
+                if (!gt) break;
+                if (!ScanAttrs(lt + 5, gt, &attrs)) continue;
+                Style st;  // stop-color / stop-opacity: presentation attributes or style declarations
+                Paint c;
+                c.none = false;
+                c.rgb = 0;  // initial stop-color: black
+                double op = 1.0;
+                auto take = [&](const std::string &name, const std::string &value) {
+                    if (name == "stop-color") (void)ParsePaint(value, &c);
+                    else if (name == "stop-opacity") op = ParseOpacity(value, op);
+                };
+                if (const Attr *a = Find(attrs, "stop-color")) take("stop-color", Trim(a->val, a->val_len));
+                if (const Attr *a = Find(attrs, "stop-opacity")) take("stop-opacity", Trim(a->val, a->val_len));
+                if (const Attr *a = Find(attrs, "style")) {
+                    const char *d = a->val, *de = a->val + a->val_len;
+                    while (d < de) {
+                        const char *semi = static_cast<const char *>(std::memchr(d, ';', de - d));
+                        const char *e2 = semi ? semi : de;
+                        const char *colon = static_cast<const char *>(std::memchr(d, ':', e2 - d));
+                        if (colon) take(Trim(d, colon - d), Trim(colon + 1, e2 - colon - 1));
+                        d = e2 + 1;
+                    }
+                }
+                if (c.none) continue;
+                sum[0] += (c.rgb >> 16) & 0xffu;
+                sum[1] += (c.rgb >> 8) & 0xffu;
+                sum[2] += c.rgb & 0xffu;
+                sum[3] += op;
+                *n += 1;
+                q = gt + 1;
+            }
+            if (*n == 0 && depth < 4) {  // inherit the stops of the referenced gradient
+                const char *gt = TagEnd(r.begin + 1, r.end);
+                if (gt && ScanAttrs(n1, gt, &attrs)) {
+                    const Attr *h = Find(attrs, "href");
+                    if (!h) h = Find(attrs, "xlink:href");
+                    if (h && h->val_len > 1 && h->val[0] == '#') return Stops(std::string(h->val + 1, h->val_len - 1), depth + 1, sum, n);
+                }
+            }
+            return *n > 0;
+        }
+        return false;
+    }
+    bool Resolve(const std::string &id, uint32_t *rgb, double *alpha) const override {
+        double sum[4] = {0, 0, 0, 0};
+        int n = 0;
+        const PaintServerResolver *saved = t_paint_servers;
+        t_paint_servers = nullptr;  // (stop colours are plain colours)
+        const bool ok = Stops(id, 0, sum, &n);
+        t_paint_servers = saved;
+        if (!ok) return false;
+        const auto ch = [&](double v) { return static_cast<uint32_t>(std::lround(v / n)); };
+        *rgb = (ch(sum[0]) << 16) | (ch(sum[1]) << 8) | ch(sum[2]);
+        *alpha = sum[3] / n;
+        return true;
+    }
+};
+
 // Walks the elements of [text, end) under the inherited style `initial`.  use_depth > 0: the range
 // is the target of a <use> (a <symbol> at its start is entered like a group).
 int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial, int use_depth) {
@@ -1050,11 +1156,11 @@ int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial
                             for (size_t k = el0; k < out->els.size(); ++k) moves += out->els[k].tag == PM_EL_MOVE;
                             if (moves > 1) path.flags |= PM_PATH_COMPOUND;
                         }
-                        path.fill_rgba = PaintRgba(st.fill, st.opacity * st.fill_opacity);
+                        path.fill_rgba = PaintRgba(st.fill, st.opacity * st.fill_opacity * st.fill_server_alpha);
                     }
                     if (!st.stroke.none) {
                         path.flags |= PM_PATH_STROKE;
-                        path.stroke_rgba = PaintRgba(st.stroke, st.opacity * st.stroke_opacity);
+                        path.stroke_rgba = PaintRgba(st.stroke, st.opacity * st.stroke_opacity * st.stroke_server_alpha);
                         // widths scale with the geometric mean of the matrix's stretch (exact for similarities)
                         const double det = std::fabs(st.ctm.a * st.ctm.d - st.ctm.b * st.ctm.c);
                         path.stroke_width = st.ctm.IsIdentity() ? st.stroke_width : static_cast<float>(st.stroke_width * std::sqrt(det));
@@ -1098,7 +1204,12 @@ int ParseDocument(const char *text, size_t len, int flags, pm_svg *out) {
     // agree; elsewhere the reference's reading is the default and PM_SVG_SPEC_DEFAULTS the SVG one.
     initial.fill.none = (flags & PM_SVG_SPEC_DEFAULTS) == 0;
     initial.fill.rgb = 0;
-    return ParseRange(&doc, text, text + len, initial, 0);
+    GradientResolver gradients;
+    gradients.doc = &doc;
+    t_paint_servers = (flags & PM_SVG_FLAT_GRADIENTS) ? &gradients : nullptr;
+    const int rc = ParseRange(&doc, text, text + len, initial, 0);
+    t_paint_servers = nullptr;
+    return rc;
 }
 
 }  // namespace

@@ -175,13 +175,15 @@ class PathSet:
         return (s, 0.0, 0.0, s, (width - s * vb[2]) / 2.0 - s * vb[0], (height - s * vb[3]) / 2.0 - s * vb[1]), s
 
     @classmethod
-    def from_svg(cls, text: bytes | str, reject_arc_paths: bool = False, spec_defaults: bool = False) -> "PathSet":
+    def from_svg(cls, text: bytes | str, reject_arc_paths: bool = False, spec_defaults: bool = False, flat_gradients: bool = False) -> "PathSet":
         """Parse an SVG document.  spec_defaults: SVG's initial `fill: black` instead of the
-        reference's rule that only a fill property fills (src/lib.rs:299)."""
+        reference's rule that only a fill property fills (src/lib.rs:299); flat_gradients: a
+        url(#gradient) paint becomes the mean colour of the gradient's stops instead of `none`."""
         lib = _lib.load()
         data = text.encode() if isinstance(text, str) else bytes(text)
         err = C.c_int(0)
         flags = (_lib.PM_SVG_REJECT_ARC_PATHS if reject_arc_paths else 0) | (_lib.PM_SVG_SPEC_DEFAULTS if spec_defaults else 0)
+        flags |= _lib.PM_SVG_FLAT_GRADIENTS if flat_gradients else 0
         h = lib.pm_svg_parse(data, len(data), flags, C.byref(err))
         if not h:
             raise _lib.PietMetalError(err.value, "pm_svg_parse")

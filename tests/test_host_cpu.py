@@ -683,6 +683,28 @@ def test_svg_colour_keywords_match_an_independent_table(pm):
     assert checked == 147
 
 
+def test_svg_gradient_paints_flattened_to_their_mean(pm):
+    """PM_SVG_FLAT_GRADIENTS: url(#gradient) becomes the mean of the stops (colour per sRGB component,
+    stop-opacity folded into the item's alpha); stops are inherited through href; without the flag,
+    and for references that are not gradients, the paint is `none`."""
+    svg = '''<svg xmlns="http://www.w3.org/2000/svg" xmlns:xlink="http://www.w3.org/1999/xlink">
+      <defs>
+        <linearGradient id="g1"><stop offset="0" stop-color="#ff0000"/><stop offset="1" style="stop-color:#0000ff;stop-opacity:0.5"/></linearGradient>
+        <radialGradient id="g2" xlink:href="#g1" r="3"/>
+        <linearGradient id="g3"><stop offset="0" stop-color="white"/><stop offset=".5" stop-color="rgb(0,0,0)"/><stop offset="1"/></linearGradient>
+        <rect id="notagradient" width="1" height="1"/>
+      </defs>
+      <rect width="5" height="5" fill="url(#g1)"/>
+      <rect width="5" height="5" fill="url(#g2)" stroke="url(#nope)" fill-opacity="0.5"/>
+      <g fill="url('#g3')"><rect width="5" height="5"/><rect width="5" height="5" fill="#123456"/></g>
+      <rect width="5" height="5" fill="url(#notagradient)"/>
+    </svg>'''
+    assert len(pm.PathSet.from_svg(svg).paths) == 1  # only the plain colour draws
+    ps = pm.PathSet.from_svg(svg, flat_gradients=True)
+    assert [int(p["flags"]) for p in ps.paths] == [1, 1, 1, 1]
+    assert [hex(int(p["fill_rgba"])) for p in ps.paths] == ["0x800080bf", "0x80008060", "0x555555ff", "0x123456ff"]
+
+
 def test_svg_viewbox_and_fit(pm):
     """The outermost <svg>'s viewBox and size come through the ABI; fit_affine maps the viewBox into a
     viewport like preserveAspectRatio="xMidYMid meet"; units of width / height are converted to px."""
