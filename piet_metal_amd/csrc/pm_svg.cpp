@@ -507,25 +507,62 @@ bool ParsePaint(const std::string &v, Paint *out, double *server_alpha = nullptr
         out->rgb = c >> 8;
         return true;
     }
-    if (v.compare(0, 4, "rgb(") == 0) {
-        double ch[3] = {0, 0, 0};
-        const char *p = v.c_str() + 4;
-        for (int i = 0; i < 3; ++i) {
+    const bool is_rgb = v.compare(0, 4, "rgb(") == 0, is_rgba = v.compare(0, 5, "rgba(") == 0;
+    if (is_rgb || is_rgba) {  // CSS colour functions; an alpha channel folds into the item's alpha
+        double ch[4] = {0, 0, 0, 1};
+        const char *p = v.c_str() + (is_rgba ? 5 : 4);
+        for (int i = 0; i < (is_rgba ? 4 : 3); ++i) {
             char *q = nullptr;
             ch[i] = std::strtod(p, &q);
             if (q == p) return false;
             p = q;
             while (std::isspace(static_cast<unsigned char>(*p))) ++p;
             if (*p == '%') {
-                ch[i] = ch[i] * 255.0 / 100.0;
+                ch[i] = i < 3 ? ch[i] * 255.0 / 100.0 : ch[i] / 100.0;
                 ++p;
             }
-            while (*p == ',' || std::isspace(static_cast<unsigned char>(*p))) ++p;
+            while (*p == ',' || *p == '/' || std::isspace(static_cast<unsigned char>(*p))) ++p;
         }
         uint32_t rgb = 0;
         for (int i = 0; i < 3; ++i) rgb = (rgb << 8) | static_cast<uint32_t>(std::lround(std::fmin(255.0, std::fmax(0.0, ch[i]))));
         out->none = false;
         out->rgb = rgb;
+        if (server_alpha) *server_alpha = std::fmin(1.0, std::fmax(0.0, ch[3]));
+        return true;
+    }
+    const bool is_hsl = v.compare(0, 4, "hsl(") == 0, is_hsla = v.compare(0, 5, "hsla(") == 0;
+    if (is_hsl || is_hsla) {  // CSS Color 3, section 4.2.4
+        double ch[4] = {0, 0, 0, 1};
+        const char *p = v.c_str() + (is_hsla ? 5 : 4);
+        for (int i = 0; i < (is_hsla ? 4 : 3); ++i) {
+            char *q = nullptr;
+            ch[i] = std::strtod(p, &q);
+            if (q == p) return false;
+            p = q;
+            while (*p && (std::isalpha(static_cast<unsigned char>(*p)) || std::isspace(static_cast<unsigned char>(*p)))) ++p;  // "deg"
+            if (*p == '%') {
+                if (i == 3) ch[i] /= 100.0;
+                ++p;
+            }
+            while (*p == ',' || *p == '/' || std::isspace(static_cast<unsigned char>(*p))) ++p;
+        }
+        const double h = std::fmod(std::fmod(ch[0], 360.0) + 360.0, 360.0) / 360.0;
+        const double sat = std::fmin(1.0, std::fmax(0.0, ch[1] / 100.0)), l = std::fmin(1.0, std::fmax(0.0, ch[2] / 100.0));
+        const double m2 = l <= 0.5 ? l * (sat + 1.0) : l + sat - l * sat, m1 = l * 2.0 - m2;
+        auto hue = [&](double t) {
+            if (t < 0) t += 1;
+            if (t > 1) t -= 1;
+            if (t * 6 < 1) return m1 + (m2 - m1) * t * 6;
+            if (t * 2 < 1) return m2;
+            if (t * 3 < 2) return m1 + (m2 - m1) * (2.0 / 3.0 - t) * 6;
+            return m1;
+        };
+        const double rgbf[3] = {hue(h + 1.0 / 3.0), hue(h), hue(h - 1.0 / 3.0)};
+        uint32_t rgb = 0;
+        for (int i = 0; i < 3; ++i) rgb = (rgb << 8) | static_cast<uint32_t>(std::lround(255.0 * rgbf[i]));
+        out->none = false;
+        out->rgb = rgb;
+        if (server_alpha) *server_alpha = std::fmin(1.0, std::fmax(0.0, ch[3]));
         return true;
     }
     for (const auto &n : kNames)

@@ -683,6 +683,21 @@ def test_svg_colour_keywords_match_an_independent_table(pm):
     assert checked == 147
 
 
+def test_svg_colour_functions(pm):
+    """rgb() / rgba() / hsl() / hsla(): colours against Pillow's conversions, alpha channels folded
+    into the item's alpha."""
+    ImageColor = pytest.importorskip("PIL.ImageColor")
+    rng = np.random.default_rng(3)
+    cases = ["rgb(10%, 20%, 30%)", "rgb(12, 200, 255)", "hsl(0,100%,50%)", "hsl(120, 100%, 25%)"]
+    cases += ["hsl(%d, %d%%, %d%%)" % (rng.integers(0, 360), rng.integers(0, 101), rng.integers(0, 101)) for _ in range(60)]
+    for c in cases:
+        ps = pm.PathSet.from_svg('<svg><rect width="5" height="5" fill="%s"/></svg>' % c)
+        r, g, b = ImageColor.getrgb(c)[:3]
+        assert int(ps.paths[0]["fill_rgba"]) == ((r << 24) | (g << 16) | (b << 8) | 0xFF), c
+    ps = pm.PathSet.from_svg('<svg><rect width="5" height="5" fill="rgba(255, 0, 0, 0.5)" stroke="hsla(240,100%,50%,25%)" opacity="0.5"/></svg>')
+    assert int(ps.paths[0]["fill_rgba"]) == 0xFF000040 and int(ps.paths[0]["stroke_rgba"]) == 0x0000FF20
+
+
 def test_svg_gradient_paints_flattened_to_their_mean(pm):
     """PM_SVG_FLAT_GRADIENTS: url(#gradient) becomes the mean of the stops (colour per sRGB component,
     stop-opacity folded into the item's alpha); stops are inherited through href; without the flag,
