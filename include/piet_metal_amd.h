@@ -139,7 +139,8 @@ typedef struct {
  * PM_PATH_EVEN_ODD), #rgb / #rrggbb / rgb() rgba() hsl() hsla() / the 147 colour keywords / none, and rect (rounded too),
  * circle, ellipse, line, polyline, polygon as paths; <use> (href / xlink:href, x, y: the referenced
  * element or <symbol>, from anywhere in the document, nested at most 8 deep); <defs> and friends
- * are not drawn where they stand.  Coordinates
+ * are not drawn where they stand; lengths in px / pt / pc / mm / cm / in and percentages of the outermost
+ * viewBox.  Coordinates
  * come out in the root user space; stroke widths are scaled by sqrt|det| of the matrix. */
 
 /* Beyond the reference (src/lib.rs:194, "need to deal with subpaths and also want curves"): the

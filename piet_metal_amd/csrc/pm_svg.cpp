@@ -637,12 +637,30 @@ double ParseOpacity(const std::string &v, double dflt) {
     return std::fmin(1.0, std::fmax(0.0, x));
 }
 
-double ParseLength(const Attr *a, double dflt = 0.0) {
-    if (!a) return dflt;
-    const std::string v(a->val, a->val_len);
+// A length (SVG 1.1 section 7.10) in user units: px and bare numbers as they are, the absolute units
+// at 96 per inch, em / ex as 16 / 8 (there is no font), a percentage of `ref` (the viewBox width,
+// height or normalised diagonal the caller passes; 0 when the document gives none).
+double LengthFromString(const std::string &v, double dflt, double ref) {
     char *q = nullptr;
     const double x = std::strtod(v.c_str(), &q);
-    return q == v.c_str() ? dflt : x;  // a trailing "px" is user units; other units are not converted
+    if (q == v.c_str()) return dflt;
+    while (*q && std::isspace(static_cast<unsigned char>(*q))) ++q;
+    const std::string unit = Trim(q, std::strlen(q));
+    if (unit.empty() || unit == "px") return x;
+    if (unit == "%") return x * ref / 100.0;
+    if (unit == "pt") return x * (96.0 / 72.0);
+    if (unit == "pc") return x * 16.0;
+    if (unit == "mm") return x * (96.0 / 25.4);
+    if (unit == "cm") return x * (96.0 / 2.54);
+    if (unit == "in") return x * 96.0;
+    if (unit == "em") return x * 16.0;
+    if (unit == "ex") return x * 8.0;
+    return x;
+}
+
+double ParseLength(const Attr *a, double dflt = 0.0, double ref = 0.0) {
+    if (!a) return dflt;
+    return LengthFromString(std::string(a->val, a->val_len), dflt, ref);
 }
 
 // One presentation property, from an attribute or a `style` declaration (which wins, CSS cascade).
@@ -654,7 +672,7 @@ void ApplyProperty(const std::string &name, const std::string &value, Style *st)
         double a = 1.0;
         if (ParsePaint(value, &st->stroke, &a)) st->stroke_server_alpha = a;
     } else if (name == "stroke-width") {
-        st->stroke_width = std::strtof(value.c_str(), nullptr);  // f32::from_str, src/lib.rs:320
+        st->stroke_width = static_cast<float>(LengthFromString(value, 0.0, 0.0));  // f32::from_str, src/lib.rs:320 (+ units)
     } else if (name == "fill-rule") {
         if (value == "evenodd") st->even_odd = true;
         else if (value == "nonzero") st->even_odd = false;
@@ -784,7 +802,12 @@ void TransformEls(std::vector<pm_path_el> *els, size_t el0, const Affine &m) {
 }
 
 // basic shapes as path elements (SVG 1.1 section 9); false = the shape renders nothing
-bool ShapeToEls(const char *name, size_t name_len, const std::vector<Attr> &attrs, std::vector<pm_path_el> *els, bool *closed) {
+// (vw, vh: what percentages refer to -- the outermost viewBox, or the document's width / height)
+bool ShapeToEls(const char *name, size_t name_len, const std::vector<Attr> &attrs, double vw, double vh, std::vector<pm_path_el> *els,
+                bool *closed) {
+    const double vd = std::sqrt((vw * vw + vh * vh) / 2.0);  // 7.10: percentages of "other" lengths
+    auto X = [&](const char *k, double dflt = 0.0) { return ParseLength(Find(attrs, k), dflt, vw); };
+    auto Y = [&](const char *k, double dflt = 0.0) { return ParseLength(Find(attrs, k), dflt, vh); };
     PathBuilder out{els};
     const std::string n(name, name_len);
     *closed = true;
@@ -799,11 +822,11 @@ bool ShapeToEls(const char *name, size_t name_len, const std::vector<Attr> &attr
         return true;
     };
     if (n == "rect") {
-        const double x = ParseLength(Find(attrs, "x")), y = ParseLength(Find(attrs, "y"));
-        const double w = ParseLength(Find(attrs, "width")), h = ParseLength(Find(attrs, "height"));
+        const double x = X("x"), y = Y("y");
+        const double w = X("width"), h = Y("height");
         if (!(w > 0.0) || !(h > 0.0)) return false;
         const Attr *arx = Find(attrs, "rx"), *ary = Find(attrs, "ry");
-        double rx = ParseLength(arx, -1.0), ry = ParseLength(ary, -1.0);
+        double rx = ParseLength(arx, -1.0, vw), ry = ParseLength(ary, -1.0, vh);
         if (rx < 0.0 && ry < 0.0) rx = ry = 0.0;
         else if (rx < 0.0) rx = ry;
         else if (ry < 0.0) ry = rx;
@@ -830,15 +853,15 @@ bool ShapeToEls(const char *name, size_t name_len, const std::vector<Attr> &attr
         return true;
     }
     if (n == "circle") {
-        const double r = ParseLength(Find(attrs, "r"));
-        return ellipse(ParseLength(Find(attrs, "cx")), ParseLength(Find(attrs, "cy")), r, r);
+        const double r = ParseLength(Find(attrs, "r"), 0.0, vd);
+        return ellipse(X("cx"), Y("cy"), r, r);
     }
     if (n == "ellipse")
-        return ellipse(ParseLength(Find(attrs, "cx")), ParseLength(Find(attrs, "cy")), ParseLength(Find(attrs, "rx")), ParseLength(Find(attrs, "ry")));
+        return ellipse(X("cx"), Y("cy"), X("rx"), Y("ry"));
     if (n == "line") {
         *closed = false;
-        out.Push(PM_EL_MOVE, ParseLength(Find(attrs, "x1")), ParseLength(Find(attrs, "y1")));
-        out.Push(PM_EL_LINE, ParseLength(Find(attrs, "x2")), ParseLength(Find(attrs, "y2")));
+        out.Push(PM_EL_MOVE, X("x1"), Y("y1"));
+        out.Push(PM_EL_LINE, X("x2"), Y("y2"));
         return true;
     }
     if (n == "polyline" || n == "polygon") {
@@ -1174,7 +1197,8 @@ int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial
                     ok = ParsePathData(d->val, d->val_len, &out->els, &has_arc);
                     if (has_arc && (flags & PM_SVG_REJECT_ARC_PATHS)) ok = false;
                 } else {
-                    ok = ShapeToEls(n0, name_len, attrs, &out->els, &closed);
+                    ok = ShapeToEls(n0, name_len, attrs, out->has_viewbox ? out->viewbox[2] : out->width,
+                                    out->has_viewbox ? out->viewbox[3] : out->height, &out->els, &closed);
                 }
                 if (!ok) {
                     out->els.resize(el0);  // `if let Ok(ref bp) = ...` skips the path, src/lib.rs:296

@@ -683,6 +683,24 @@ def test_svg_colour_keywords_match_an_independent_table(pm):
     assert checked == 147
 
 
+def test_svg_lengths_units_and_percentages(pm):
+    """SVG 1.1 section 7.10: absolute units at 96 per inch, percentages of the outermost viewBox
+    (width for x-like, height for y-like, sqrt((w^2 + h^2) / 2) for radii), on shapes and stroke widths."""
+    ps = pm.PathSet.from_svg('<svg viewBox="0 0 200 100"><rect width="100%" height="50%" fill="red"/>'
+                             '<circle cx="50%" cy="50%" r="10%" fill="blue"/>'
+                             '<line x1="1in" y1="12pt" x2="10mm" y2="2pc" stroke="#000" stroke-width="1.5pt"/></svg>')
+    els = lambda k: ps.els[int(ps.paths[k]["el_begin"]) : int(ps.paths[k]["el_end"])]
+    assert [tuple(e["p"][:2]) for e in els(0)[:4]] == [(0.0, 0.0), (200.0, 0.0), (200.0, 50.0), (0.0, 50.0)]
+    r = 0.1 * math.sqrt((200.0 ** 2 + 100.0 ** 2) / 2.0)
+    assert tuple(els(1)[0]["p"][:2]) == pytest.approx((100.0 + r, 50.0))
+    assert tuple(els(2)[0]["p"][:2]) == (96.0, 16.0) and tuple(els(2)[1]["p"][:2]) == pytest.approx((10 * 96 / 25.4, 32.0))
+    assert float(ps.paths[2]["stroke_width"]) == 2.0
+    # without a viewBox the document's own size is the reference; without either a percentage is nothing
+    ps = pm.PathSet.from_svg('<svg width="300" height="150"><rect width="50%" height="100%" fill="red"/></svg>')
+    assert tuple(ps.els[2]["p"][:2]) == (150.0, 150.0)
+    assert len(pm.PathSet.from_svg('<svg><rect width="50%" height="100%" fill="red"/></svg>').paths) == 0
+
+
 def test_svg_colour_functions(pm):
     """rgb() / rgba() / hsl() / hsla(): colours against Pillow's conversions, alpha channels folded
     into the item's alpha."""
