@@ -672,7 +672,12 @@ void ApplyProperty(const std::string &name, const std::string &value, Style *st)
         double a = 1.0;
         if (ParsePaint(value, &st->stroke, &a)) st->stroke_server_alpha = a;
     } else if (name == "stroke-width") {
-        st->stroke_width = static_cast<float>(LengthFromString(value, 0.0, 0.0));  // f32::from_str, src/lib.rs:320 (+ units)
+        // f32::from_str, src/lib.rs:320: a bare number is parsed as binary32 (no double rounding); only
+        // a value that carries a unit goes through the conversion
+        char *rest = nullptr;
+        const float plain = std::strtof(value.c_str(), &rest);
+        while (rest && *rest && std::isspace(static_cast<unsigned char>(*rest))) ++rest;
+        st->stroke_width = (rest && *rest) ? static_cast<float>(LengthFromString(value, 0.0, 0.0)) : plain;
     } else if (name == "fill-rule") {
         if (value == "evenodd") st->even_odd = true;
         else if (value == "nonzero") st->even_odd = false;
