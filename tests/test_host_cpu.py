@@ -6,6 +6,7 @@ import math
 import os
 import re
 import struct
+import sys
 
 import numpy as np
 import pytest
@@ -681,6 +682,16 @@ def test_svg_colour_keywords_match_an_independent_table(pm):
         assert int(ps.paths[0]["fill_rgba"]) == ((r << 24) | (g << 16) | (b << 8) | 0xFF), name
         checked += 1
     assert checked == 147
+
+
+def test_svg_parser_survives_mutated_documents(pm):
+    """tests/dev/fuzz_svg.py: 1 500 mutated copies of shapes.svg and of the Tiger's head -- every one is
+    either parsed or rejected with an error code (no crash, no hang)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "dev"))
+    import fuzz_svg
+
+    ok, err, _ = fuzz_svg.run(7, 1500)
+    assert ok + err == 1500 and ok > 100 and err > 100
 
 
 def test_svg_lengths_units_and_percentages(pm):
