@@ -597,7 +597,9 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
 //
 // kFused: the wave (or, for a long list, wave 0 of the workgroup) first builds the tile's list with
 // CoarseTile -- pm_coarse_kernel's body -- and interprets it straight away: no launch boundary
-// between the two stages, and the list is read back while it is still in L2.
+// between the two stages; a single wave reads its list back while it is still in L2, a workgroup
+// finds the first three chunks in LDS (CoarseTile drops them into the waiting waves' staging areas).
+// Blocks beyond P.fine_grid write the pixels of the tiles binning resolved (ClearStripRow).
 // kProf: the developer timeline build (pm_debug_time_tiles); P.dbg_time is only read there.
 template <bool kFused, bool kProf>
 __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
