@@ -135,7 +135,7 @@ typedef struct {
  * understands: <g>/<svg> nesting with inherited presentation properties, `transform`
  * (matrix translate scale rotate skewX skewY), `style="..."`, <style> sheets with element / .class /
  * #id selectors (presentation attributes < element < class < id rules < style attribute), opacity / fill-opacity /
- * stroke-opacity (folded into the items' alpha: no group compositing), fill-rule (evenodd ->
+ * stroke-opacity (folded into the items' alpha: no group compositing), display: none / visibility, fill-rule (evenodd ->
  * PM_PATH_EVEN_ODD), #rgb / #rrggbb / rgb() rgba() hsl() hsla() / the 147 colour keywords / none, and rect (rounded too),
  * circle, ellipse, line, polyline, polygon as paths; <use> (href / xlink:href, x, y: the referenced
  * element or <symbol>, from anywhere in the document, nested at most 8 deep); <defs> and friends

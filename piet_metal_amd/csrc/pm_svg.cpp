@@ -429,6 +429,8 @@ struct Style {
     double fill_server_alpha = 1.0, stroke_server_alpha = 1.0;  // mean stop-opacity of a flattened gradient paint
     double opacity = 1.0, fill_opacity = 1.0, stroke_opacity = 1.0;  // opacity: product of the ancestors'
     bool even_odd = false;
+    bool display_none = false;  // `display: none` on the element or an ancestor: nothing of the subtree is drawn
+    bool hidden = false;        // `visibility: hidden | collapse` (inherited; a descendant may turn it back on)
     Affine ctm;
 };
 
@@ -681,6 +683,11 @@ void ApplyProperty(const std::string &name, const std::string &value, Style *st)
     } else if (name == "fill-rule") {
         if (value == "evenodd") st->even_odd = true;
         else if (value == "nonzero") st->even_odd = false;
+    } else if (name == "display") {
+        if (value == "none") st->display_none = true;  // (sticky: descendants cannot undo it, SVG 1.1 section 11.5)
+    } else if (name == "visibility") {
+        if (value == "hidden" || value == "collapse") st->hidden = true;
+        else if (value == "visible") st->hidden = false;
     } else if (name == "fill-opacity") {
         st->fill_opacity = ParseOpacity(value, st->fill_opacity);
     } else if (name == "stroke-opacity") {
@@ -753,7 +760,7 @@ void ParseStyleSheet(const char *p, const char *end, std::vector<CssRule> *rules
 
 bool ApplyElementStyle(const std::vector<Attr> &attrs, Style *st, const std::vector<CssRule> *css = nullptr, const char *el_name = nullptr,
                        size_t el_name_len = 0) {
-    static const char *kProps[] = {"fill", "stroke", "stroke-width", "fill-rule", "fill-opacity", "stroke-opacity"};
+    static const char *kProps[] = {"fill", "stroke", "stroke-width", "fill-rule", "fill-opacity", "stroke-opacity", "display", "visibility"};
     for (const char *pn : kProps)
         if (const Attr *a = Find(attrs, pn)) ApplyProperty(pn, Trim(a->val, a->val_len), st);
     double opacity_factor = 1.0;  // not inherited: the element's own value multiplies the ancestors'
@@ -1212,7 +1219,8 @@ int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial
                     pm_path path{};
                     path.el_begin = static_cast<uint32_t>(el0);
                     path.el_end = static_cast<uint32_t>(out->els.size());
-                    if (!st.fill.none && (closed || is_path || name_len == 8 /* polyline fills its implicit closure */)) {
+                    const bool shown = !st.display_none && !st.hidden;
+                    if (shown && !st.fill.none && (closed || is_path || name_len == 8 /* polyline fills its implicit closure */)) {
                         path.flags |= PM_PATH_FILL;
                         if (st.even_odd) path.flags |= PM_PATH_EVEN_ODD;
                         if (flags & PM_SVG_SPEC_DEFAULTS) {
@@ -1224,7 +1232,7 @@ int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial
                         }
                         path.fill_rgba = PaintRgba(st.fill, st.opacity * st.fill_opacity * st.fill_server_alpha);
                     }
-                    if (!st.stroke.none) {
+                    if (shown && !st.stroke.none) {
                         path.flags |= PM_PATH_STROKE;
                         path.stroke_rgba = PaintRgba(st.stroke, st.opacity * st.stroke_opacity * st.stroke_server_alpha);
                         // widths scale with the geometric mean of the matrix's stretch (exact for similarities)

@@ -694,6 +694,18 @@ def test_svg_parser_survives_mutated_documents(pm):
     assert ok + err == 1500 and ok > 100 and err > 100
 
 
+def test_svg_display_and_visibility(pm):
+    """`display: none` removes an element and its subtree (descendants cannot undo it); `visibility`
+    is inherited and a descendant may turn it back on; both through attributes, style and sheets."""
+    svg = '''<svg><style>.off { display: none } .ghost { visibility: hidden }</style>
+      <g display="none"><rect width="5" height="5" fill="red" display="inline"/></g>
+      <g class="ghost"><rect width="5" height="5" fill="green"/><rect width="6" height="6" fill="blue" visibility="visible"/></g>
+      <rect width="7" height="7" fill="black" style="display:none"/><rect class="off" width="7" height="7" fill="black"/>
+      <rect width="8" height="8" fill="#123" stroke="#456" visibility="collapse"/><rect width="8" height="8" fill="#123"/></svg>'''
+    ps = pm.PathSet.from_svg(svg)
+    assert [hex(int(p["fill_rgba"])) for p in ps.paths] == ["0xffff", "0x112233ff"]
+
+
 def test_svg_lengths_units_and_percentages(pm):
     """SVG 1.1 section 7.10: absolute units at 96 per inch, percentages of the outermost viewBox
     (width for x-like, height for y-like, sqrt((w^2 + h^2) / 2) for radii), on shapes and stroke widths."""
