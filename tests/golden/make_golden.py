@@ -76,9 +76,39 @@ def big_main():
             json.dump(out, f, indent=1, sort_keys=True)
 
 
+def ext_scenes():
+    """The scenes that pin the encoder extensions (even-odd, nested groups, ellipses, compound fills,
+    DESIGN.md 2 decisions D9-D11) and the SVG document layer: name -> (scene bytes, width, height)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_cpu import _oracle_encode, extend_ops, random_ops
+
+    out = {}
+    for seed, n, extent, w, h in [(82, 160, 300.0, 320, 304), (91, 260, 600.0, 640, 576)]:
+        out[f"extended_ops_{seed}"] = (_oracle_encode(pmo, extend_ops(seed, random_ops(seed, n, extent=extent))), w, h)
+    svg = open(os.path.join(ROOT, "tests", "data", "shapes.svg")).read()
+    for spec in (False, True):
+        ps = pm.PathSet.from_svg(svg, spec_defaults=spec)
+        scene, _ = pmo.scene_from_paths(pmo.scaled_paths(ps.paths, 3.0), ps.els, (3.0, 0.0, 0.0, 3.0, 0.0, 0.0))
+        out["shapes_svg_x3_" + ("svg_rules" if spec else "tiger_rules")] = (scene, 1200, 900)
+    return out
+
+
+def ext_main():
+    """python tests/golden/make_golden.py --ext : pins of the extension scenes (merged into golden.json)."""
+    path = os.path.join(os.path.dirname(__file__), "golden.json")
+    out = json.load(open(path))
+    for name, (scene, w, h) in ext_scenes().items():
+        out[name] = scene_entry(scene, w, h)
+        print(name, out[name], flush=True)
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def main():
     if "--big" in sys.argv:
         return big_main()
+    if "--ext" in sys.argv:
+        return ext_main()
     out = {}
     out["path_test_512x832"] = scene_entry(pmo.scene_path_test(), 512, 832)
     out["cardioid_2048x1536"] = scene_entry(pmo.scene_cardioid(), 2048, 1536)

@@ -223,6 +223,24 @@ def test_config4_blobs_reduced_vs_oracle_and_full_properties(pm, pmo, renderer):
     P.close()
 
 
+def test_extension_scenes_against_committed_goldens(pm, pmo, renderer, golden):
+    """The pins of the extension scenes (tests/golden/make_golden.py --ext): the GPU's pixels and
+    per-tile command lists against the COMMITTED hashes, not only against today's oracle."""
+    from test_oracle_cpu import _extension_scenes
+
+    for name, (scene, w, h) in _extension_scenes(pm, pmo).items():
+        got = gpu_render(renderer, scene, w, h)
+        assert sha(got) == golden[name]["rgba_sha256"], name
+        counts, _solid, cmds = renderer.capture_ptcl(golden[name]["max_cmds_per_tile"])
+        hsh = hashlib.sha256()
+        for ty in range(counts.shape[0]):
+            for tx in range(counts.shape[1]):
+                n = int(counts[ty, tx])
+                hsh.update(np.uint32(n).tobytes())
+                hsh.update(np.ascontiguousarray(cmds[ty, tx, :n]).tobytes())
+        assert hsh.hexdigest() == golden[name]["ptcl_sha256"], name
+
+
 @pytest.mark.parametrize("cfg", ["config4", "config5"])
 def test_baseline_configs_4_and_5_full_size_goldens(pm, pmo, renderer, golden, cfg):
     """BASELINE configs 4 (10 k blobs, 4096^2) and 5 (25 Tigers, 8192^2) at FULL size against the

@@ -4,6 +4,7 @@ so these are the pins this repo creates ("parity unpinned" upstream)."""
 import hashlib
 import json
 import os
+import sys
 import struct
 
 import numpy as np
@@ -74,6 +75,24 @@ def test_golden_tiger_4k_scene_and_lists(pm, pmo, golden):
     wl = pm.workloads.tiger(3840, 2160)
     scene, _ = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
     check_scene(pmo, golden, "tiger_3840x2160", scene, with_image=False)
+
+
+def _extension_scenes(pm, pmo):
+    sys.path.insert(0, GOLD)
+    import make_golden
+
+    make_golden.pm, make_golden.pmo = pm, pmo
+    return make_golden.ext_scenes()
+
+
+def test_golden_extension_scenes(pm, pmo, golden):
+    """The committed pins of the encoder extensions (even-odd, nested groups, ellipses, compound fills:
+    decisions D9-D11) and of the SVG document layer (shapes.svg under both rule sets): scene bytes,
+    command lists and pixels of the oracle today equal what was committed -- so the oracle and the
+    product cannot drift TOGETHER on semantics that have no reference to fall back on."""
+    for name, (scene, w, h) in _extension_scenes(pm, pmo).items():
+        assert golden[name]["viewport"] == [w, h]
+        check_scene(pmo, golden, name, scene)
 
 
 def test_luts_pinned(pmo, golden):
