@@ -1,0 +1,45 @@
+// Register pins: the few places where the kernels tell the gfx950 register allocator / instruction
+// selector what it must not do.  Kept apart from the kernels because they are written in GCN
+// assembler constraints ("v" = a VGPR); tests/emu/ supplies its own pm_pin.h with the same
+// functions in plain C++ when it runs the kernels lane by lane on the CPU (test infrastructure).
+#pragma once
+
+#include <cstdint>
+
+namespace pm {
+namespace {
+
+// Values the compiler must not hoist out of the tile loops (it keeps hoisted copies live across a
+// whole tile and then spills them): a zero, and a lane index it cannot see through.
+__device__ __forceinline__ uint32_t OpaqueZero() {
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t Opaque(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// A value that is the result of f32 arithmetic, pinned in a register before it is converted or
+// compared: instruction selection otherwise folds the producing operation into the consumer
+// (v_fma_mixlo_f16 rounds ONCE to binary16 where the source rounds to f32 first).
+__device__ __forceinline__ void PinF32(float &x) { asm volatile("" : "+v"(x)); }
+
+// +infinity materialized where it is used (as a literal the compiler hoists copies of it out of
+// the tile loop and spills them).
+__device__ __forceinline__ float OpaqueInfinity() {
+    float v;
+    asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(v));
+    return v;
+}
+
+// Eight loaded values that must all have arrived before any of them is looked at: keeps the
+// compiler from sinking the loads into the branches that use them (one round trip, not three).
+__device__ __forceinline__ void PinLoaded8(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t &a3, uint32_t &a4, uint32_t &a5,
+                                           uint32_t &a6, uint32_t &a7) {
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+}
+
+}  // namespace
+}  // namespace pm

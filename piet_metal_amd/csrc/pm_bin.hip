@@ -1,6 +1,7 @@
 // pm_index_kernel, pm_rowcull_kernel, pm_bin_kernel: scene index and the strip-level half of tileKernel
 // (see pm_kernels_common.h for the decomposition and the rules shared by the three files)
 #include "pm_kernels_common.h"
+#include <pm_params.h>  // gfx950/pm_params.h: kernel arguments held in a VGPR, read with v_readlane
 
 namespace pm {
 
@@ -92,40 +93,6 @@ __global__ __launch_bounds__(kBinThreads) void pm_rowcull_kernel(FrameParams P) 
 // =====================================================================================
 
 namespace {
-
-// The kernel arguments, one dword per lane.  pm_bin_kernel is short of SGPRs: left to the
-// compiler, every late use of a FrameParams field becomes its own s_load + s_waitcnt (each a
-// 0.2 us scalar round trip, a dozen of them before the first useful load).  Instead the
-// whole struct is fetched with ONE vector load at entry and fields are picked out with
-// v_readlane -- no memory traffic, no waits.
-struct ParamRegs {
-    uint32_t w[(sizeof(FrameParams) / 4 + 63) / 64];
-};
-
-__device__ __forceinline__ ParamRegs LoadParams(const FrameParams &P) {
-    static_assert(sizeof(FrameParams) % 4 == 0, "FrameParams is read dword-wise");
-    ParamRegs r;
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(&P);
-    const uint32_t lane = LaneId();
-#pragma unroll
-    for (uint32_t k = 0; k < sizeof(r.w) / 4; ++k) {
-        const uint32_t ix = k * 64u + lane;
-        r.w[k] = ix < sizeof(FrameParams) / 4 ? src[ix] : 0u;
-    }
-    return r;
-}
-
-template <size_t kOff>
-__device__ __forceinline__ uint32_t ParamU32(const ParamRegs &r) {
-    static_assert(kOff % 4 == 0 && kOff < sizeof(FrameParams), "field offset");
-    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(r.w[kOff / 256]), static_cast<int>((kOff / 4) & 63)));
-}
-
-template <typename T, size_t kOff>
-__device__ __forceinline__ T ParamPtr(const ParamRegs &r) {
-    const uint64_t lo = ParamU32<kOff>(r), hi = ParamU32<kOff + 4>(r);
-    return reinterpret_cast<T>(lo | (hi << 32));
-}
 
 #define PM_PU(field) ParamU32<offsetof(FrameParams, field)>(PR)
 #define PM_PP(field) ParamPtr<decltype(FrameParams::field), offsetof(FrameParams, field)>(PR)
@@ -312,7 +279,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             uint32_t cbase = PM_PP(chunk_base)[idx];
             {   // keep the compiler from sinking any of these loads into the tag branches below
                 uint32_t a0 = w01.x, a1 = w01.y, a2 = w23.x, a3 = w23.y, a4 = w4, a5 = ibb.x, a6 = ibb.y;
-                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(cbase));
+                PinLoaded8(a0, a1, a2, a3, a4, a5, a6, cbase);
                 w01v = make_uint2(a0, a1);
                 w23v = make_uint2(a2, a3);
                 w4v = a4;

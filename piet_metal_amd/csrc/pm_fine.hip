@@ -50,7 +50,7 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 // Measured on gfx950: 958 of 16.7 M random products differ (tools/probes/mix_probe.hip); a
 // 2 000-scene fuzz run found two pixels off by one because of it.
 __device__ __forceinline__ _Float16 ToHalf(float x) {
-    asm volatile("" : "+v"(x));
+    PinF32(x);
     return static_cast<_Float16>(x);
 }
 
@@ -72,7 +72,7 @@ __device__ __forceinline__ _Float16 FillAlpha(_Float16 a, bool even_odd) {
         return __builtin_fabsf16(v);
     }
     float f = fminf(fabsf(static_cast<float>(a)), 1.0f);
-    asm volatile("" : "+v"(f));
+    PinF32(f);
     return static_cast<_Float16>(f);
 }
 
@@ -99,11 +99,7 @@ __device__ __forceinline__ float CircleAlpha(float dx, float dy, float rx, float
 // (47 ns each for a lone wave, profiles/r02_issue_probe.txt).  "No line yet" is +infinity,
 // materialized where it is used: as a plain literal the compiler hoists four copies of it out of
 // the tile loop and then spills them.
-__device__ __forceinline__ float FarAway() {
-    float v;
-    asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(v));
-    return v;
-}
+__device__ __forceinline__ float FarAway() { return OpaqueInfinity(); }
 __device__ __forceinline__ float StrokeDistance(float d2) { return fminf(1e9f, sqrtf(d2)); }
 
 __device__ __forceinline__ half2_t Splat(_Float16 v) { half2_t r; r.x = v; r.y = v; return r; }

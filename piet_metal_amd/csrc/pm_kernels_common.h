@@ -51,6 +51,7 @@
 #include <cstddef>
 
 #include "pm_device.h"
+#include <pm_pin.h>  // gfx950/pm_pin.h: register pins (GCN asm constraints)
 
 namespace pm {
 
@@ -75,18 +76,6 @@ constexpr uint32_t kBatch = 256;   // candidate items per binning batch
 
 // wave index in the workgroup, as a scalar (the compiler cannot prove threadIdx.x >> 6 uniform)
 __device__ __forceinline__ uint32_t WaveId() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
-
-// Values the compiler must not hoist out of the tile loops (it keeps hoisted copies live across a
-// whole tile and then spills them): a zero, and a lane index it cannot see through.
-__device__ __forceinline__ uint32_t OpaqueZero() {
-    uint32_t v;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(v));
-    return v;
-}
-__device__ __forceinline__ uint32_t Opaque(uint32_t v) {
-    asm volatile("" : "+v"(v));
-    return v;
-}
 
 // a 16-byte value every lane loaded from the same address, moved to scalar registers
 __device__ __forceinline__ uint4 Scalar4(uint4 v) {

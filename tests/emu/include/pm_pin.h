@@ -1,0 +1,25 @@
+// TEST INFRASTRUCTURE: plain-C++ stand-in for piet_metal_amd/csrc/gfx950/pm_pin.h (register pins
+// written as GCN asm constraints) when the kernels run lane by lane on the CPU (tests/emu/).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+
+namespace pm {
+namespace {
+
+inline uint32_t OpaqueZero() { return 0u; }
+inline uint32_t Opaque(uint32_t v) { return v; }
+inline void PinF32(float &x) {  // (a compiler barrier is all a CPU build needs: no v_fma_mix here)
+    asm volatile("" : "+x"(x));
+}
+inline float OpaqueInfinity() {
+    const uint32_t b = 0x7f800000u;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+inline void PinLoaded8(uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &) {}
+
+}  // namespace
+}  // namespace pm
