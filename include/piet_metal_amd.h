@@ -57,6 +57,15 @@ typedef struct pm_encoder pm_encoder;
 pm_encoder *pm_encoder_new(uint8_t *buf, size_t cap);                 /* Encoder::new      :104 */
 void pm_encoder_free(pm_encoder *e);
 size_t pm_encoder_alloc(pm_encoder *e, size_t size);                  /* Encoder::alloc    :114 */
+/* Encoder::write_struct :122 (`pub unsafe fn write_struct<T>(&mut self, ix: usize, s: &T)`): copies the
+ * `len` bytes of a #[repr(C)] value to offset `ix` of the scene buffer.  The Rust slice index panics
+ * past the end; here nothing is written and PM_ERR_CAPACITY is returned (and stays the encoder's status). */
+int pm_encoder_write_struct(pm_encoder *e, size_t ix, const void *src, size_t len);
+/* Encoder::encode_points :224 (`pub fn encode_points(&mut self, points: &[Point]) -> (usize, Rect)`):
+ * allocates n_points (f32, f32) pairs, writes the points rounded to f32 and returns their offset in
+ * *points_ix and the f64 bounding box {x0, y0, x1, y1} in bbox.  An empty slice is the reference's
+ * .expect("encoded empty points vector") panic: PM_ERR_INVALID. */
+int pm_encoder_encode_points(pm_encoder *e, const double *pts_xy, size_t n_points, size_t *points_ix, double bbox[4]);
 int pm_encoder_begin_group(pm_encoder *e, size_t n_items);            /* begin_group       :132 */
 int pm_encoder_end_group(pm_encoder *e);                              /* end_group         :146 */
 int pm_encoder_circle(pm_encoder *e, double cx, double cy, double r); /* circle            :167 */
@@ -212,7 +221,13 @@ int pm_sync(pm_ctx *c);
 
 #define PM_FMT_RGBA8 0
 #define PM_FMT_BGRA8 1 /* the reference drawable's byte order, PietRenderer.m:29 */
-/* Read the (band of the) framebuffer back: height rows of width*4 bytes. */
+/* Byte order in which pm_render / pm_render_to STORE pixels from now on: PM_FMT_RGBA8 (default) or
+ * PM_FMT_BGRA8 = MTLPixelFormatBGRA8Unorm, what the reference's renderKernel writes into
+ * (view.colorPixelFormat, PietRenderer.m:29) -- a caller-owned BGRA surface is then filled directly,
+ * no swizzle pass.  Same pixels, R and B exchanged. */
+int pm_set_target_format(pm_ctx *c, int fmt);
+/* Read the (band of the) framebuffer back: height rows of width*4 bytes, in byte order `fmt`
+ * (swizzled on the host if the frame was stored in the other order). */
 int pm_read_pixels(pm_ctx *c, uint8_t *dst, size_t dst_stride, int fmt);
 void *pm_framebuffer_device_ptr(pm_ctx *c, size_t *stride_bytes, uint32_t *rows);
 void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes);

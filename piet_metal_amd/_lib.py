@@ -78,6 +78,8 @@ SIGNATURES = {
     "pm_encoder_new": (C.c_void_p, [C.c_void_p, C.c_size_t]),
     "pm_encoder_free": (None, [C.c_void_p]),
     "pm_encoder_alloc": (C.c_size_t, [C.c_void_p, C.c_size_t]),
+    "pm_encoder_write_struct": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "pm_encoder_encode_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_double)]),
     "pm_encoder_begin_group": (C.c_int, [C.c_void_p, C.c_size_t]),
     "pm_encoder_end_group": (C.c_int, [C.c_void_p]),
     "pm_encoder_circle": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_double]),
@@ -115,6 +117,7 @@ SIGNATURES = {
     "pm_render": (C.c_int, [C.c_void_p]),
     "pm_render_to": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pm_sync": (C.c_int, [C.c_void_p]),
+    "pm_set_target_format": (C.c_int, [C.c_void_p, C.c_int]),
     "pm_read_pixels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "pm_framebuffer_device_ptr": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     "pm_scene_device_ptr": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),

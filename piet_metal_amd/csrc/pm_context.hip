@@ -162,6 +162,7 @@ struct FrameSlot {
     uint32_t parity = 0;
     hipEvent_t ev_done = nullptr;  // end of the slot's last frame
     bool in_flight = false;        // a frame using this slot was submitted; ev_done marks its end
+    bool needs_check = false;      // ... and pm_sync has not yet looked at its overflow flag (SyncAll only waits)
     pm::FrameParams params{};
     hipStream_t frame_stream = nullptr;  // stream the slot's last frame ran on (compared, never dereferenced, if user_stream)
     bool user_stream = false;            // the frame ran on a caller-owned stream: ev_done was recorded behind it at submit
@@ -174,6 +175,7 @@ struct pm_ctx {
     bool fold_clear = true;  // pm_fine_kernel's launch also writes the resolved tiles (no pm_clear_kernel launch)
     bool fused = true;       // pm_fine_kernel<true>: each tile's list is built and interpreted by the same wave(s)
     int handout = 0;         // tile hand-out: 0 = drawn for a lone frame, static when frames overlap; 1 = static; 2 = drawn
+    int target_fmt = PM_FMT_RGBA8;  // byte order the kernels store pixels in (pm_set_target_format)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
     uint32_t heavy_stream = 32, heavy_stream_lone = 24, vheavy_stream = 96;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
     uint32_t coarse_wg_per_cu = 5, fine_wg_per_cu = 5;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
@@ -264,6 +266,7 @@ void FreeViewport(pm_ctx *c) {
         s.d_queue = nullptr;
         s.d_striprow = s.d_tile_state = s.d_tile_ptcl = s.d_tile_ncmd = nullptr;
         s.in_flight = false;
+        s.needs_check = false;
     }
     c->last_slot = -1;
 }
@@ -543,6 +546,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->fb = fb;
     p->fb_stride = static_cast<uint32_t>(stride);
     p->fb_vec16 = ((reinterpret_cast<uintptr_t>(fb) & 15u) == 0 && (stride & 15u) == 0) ? 1u : 0u;
+    p->fb_bgra = c->target_fmt == PM_FMT_BGRA8 ? 1u : 0u;
     {
         const int rb = EnsureSlotBuffers(c, s);
         if (rb != PM_OK) return rb;
@@ -601,6 +605,7 @@ uint32_t FineGrid(const pm_ctx *c) {
 void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t frame_stream) {
     FrameSlot *s = &c->slot[si];
     s->in_flight = true;
+    s->needs_check = true;
     s->user_stream = false;
     s->params = p;
     s->frame_stream = frame_stream;
@@ -1166,6 +1171,12 @@ int pm_render_to(pm_ctx *c, void *dev_framebuffer, size_t stride_bytes, void *hi
 // most recent frame overflowed is rendered again, oldest first, so that after PM_OK every
 // framebuffer handed to this context holds a complete frame.  (A caller that synchronises only
 // its own stream never learns of an overflow: pm_sync is the status channel.)
+int pm_set_target_format(pm_ctx *c, int fmt) {
+    if (!c || (fmt != PM_FMT_RGBA8 && fmt != PM_FMT_BGRA8)) return PM_ERR_INVALID;
+    c->target_fmt = fmt;  // (frames already submitted keep the order they were submitted with)
+    return PM_OK;
+}
+
 int pm_sync(pm_ctx *c) {
     if (!c) return PM_ERR_INVALID;
     PM_TRY(hipSetDevice(c->device));
@@ -1182,7 +1193,9 @@ int pm_sync(pm_ctx *c) {
         for (size_t k = 0; k < c->slot.size(); ++k) {
             const int si = static_cast<int>((c->frame + k) % c->slot.size());  // slot c->frame % n holds the oldest frame
             const FrameSlot &s = c->slot[si];
-            if (!s.in_flight) continue;
+            // (not `in_flight`: every call that waits for the device clears that -- pm_get_stats,
+            //  pm_frame_latency, ... -- and a frame with holes must not slip through behind them)
+            if (!s.needs_check) continue;
             if (own_fb(s.params.fb)) {
                 if (si != c->last_slot) continue;
             } else {
@@ -1193,6 +1206,7 @@ int pm_sync(pm_ctx *c) {
         }
         int r = SyncAll(c);
         if (r != PM_OK) return r;
+        for (auto &t : c->slot) t.needs_check = false;  // (the frames left out of `latest` were superseded on their target)
         std::vector<pm::FrameParams> redo;
         uint64_t want = 0;
         for (int si : latest) {
@@ -1226,7 +1240,7 @@ int pm_read_pixels(pm_ctx *c, uint8_t *dst, size_t dst_stride, int fmt) {
     const FrameSlot *s = &c->slot[c->last_slot];
     const uint32_t rows = std::min(BandRows(c) * pm::kTileH, c->height - c->row0 * pm::kTileH);
     PM_TRY(hipMemcpy2D(dst, dst_stride, s->params.fb, s->params.fb_stride, static_cast<size_t>(c->width) * 4, rows, hipMemcpyDeviceToHost));
-    if (fmt == PM_FMT_BGRA8) {
+    if ((fmt == PM_FMT_BGRA8) != (s->params.fb_bgra != 0)) {  // the frame was stored in the other byte order
         for (uint32_t y = 0; y < rows; ++y) {
             uint8_t *row = dst + static_cast<size_t>(y) * dst_stride;
             for (uint32_t x = 0; x < c->width; ++x) std::swap(row[4 * x], row[4 * x + 2]);

@@ -91,6 +91,7 @@ struct FrameParams {
     uint8_t *fb;          // band framebuffer, RGBA8, row 0 = pixel row row0*16
     uint32_t fb_stride;
     uint32_t fb_vec16;    // 1 if fb and stride are 16-byte aligned
+    uint32_t fb_bgra;     // 1: pixels are stored B,G,R,A (MTLPixelFormatBGRA8Unorm, PietRenderer.m:29) instead of R,G,B,A
     uint32_t *arena;
     uint32_t arena_cap;   // dwords
     const uint4 *sr_desc;     // [n_sr_active] {strip row, its private arena region begin, end, 0}

@@ -414,6 +414,21 @@ int pm_encoder_polyline(pm_encoder *e, const double *pts_xy, size_t n_points, ui
     e->enc.Polyline(pts_xy, n_points, rgba, width);
     return e->enc.c_status();
 }
+int pm_encoder_write_struct(pm_encoder *e, size_t ix, const void *src, size_t len) {
+    if (!e || (!src && len)) return PM_ERR_INVALID;
+    e->enc.WriteStruct(ix, src, len);
+    return e->enc.c_status();
+}
+
+int pm_encoder_encode_points(pm_encoder *e, const double *pts_xy, size_t n_points, size_t *points_ix, double bbox[4]) {
+    if (!e || (!pts_xy && n_points)) return PM_ERR_INVALID;
+    double bb[4] = {0.0, 0.0, 0.0, 0.0};
+    const size_t ix = e->enc.EncodePoints(pts_xy, n_points, bb);
+    if (points_ix) *points_ix = ix;
+    if (bbox) std::memcpy(bbox, bb, sizeof(bb));
+    return e->enc.c_status();
+}
+
 size_t pm_encoder_bytes_used(const pm_encoder *e) { return e ? e->enc.bytes_used() : 0; }
 
 // Developer / test hook for the generated layout code (pm_layout_gen.h): reads `scene` through

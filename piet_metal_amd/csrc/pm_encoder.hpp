@@ -32,6 +32,10 @@ public:
     // :224 -- returns points_ix, bbox_out = {x0,y0,x1,y1}
     size_t EncodePoints(const double *pts_xy, size_t n, double bbox_out[4]);
 
+    // :122 write_struct -- `len` raw bytes at offset `at` of the buffer (bounds-checked: the Rust slice
+    // index panics, here the status turns kCapacity and nothing is written)
+    void WriteStruct(size_t at, const void *src, size_t len) { Put(at, src, len); }
+
     size_t bytes_used() const { return free_space_; }
     bool ok() const { return status_ == kOk; }
     int c_status() const {

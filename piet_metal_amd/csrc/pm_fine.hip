@@ -16,8 +16,9 @@ __device__ __forceinline__ void ClearStripRow(const FrameParams &P, uint32_t str
     const uint32_t t = lane >> 2;  // tile of this lane's 4 pixels
     const uint32_t tx = strip * kStripTiles + t;
     if (tx >= P.tiles_x) return;
-    const uint32_t col = P.tile_state[row_rel * P.tiles_x + tx];
-    if (col == 0) return;  // queued: the tile kernels write it
+    const uint32_t state = P.tile_state[row_rel * P.tiles_x + tx];
+    if (state == 0) return;  // queued: the tile kernels write it
+    const uint32_t col = StoreOrder(state, P.fb_bgra);
     const uint32_t px = strip * kGroupW + lane * 4u;
     const uint32_t y0 = (P.row0 + row_rel) * kTileH;
     // 16 pixel rows x 1024 B per strip row: thread -> (row = it*4 + wave, 16 B = 4 px at lane*4)
@@ -636,10 +637,12 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     // linear -> sRGB + unorm8 (:563-565): the 65,536-entry table of decision D2.  (A compact
     // LDS-resident form of the table was measured slower: twelve byte loads per lane are fewer
     // instructions than twelve decodes.)
+    const bool bgra = P.fb_bgra != 0;  // (uniform: the swap is two selects per pixel)
     auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {
-        return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, r)]) |
+        const _Float16 lo = bgra ? b : r, hi = bgra ? r : b;
+        return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, lo)]) |
                (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
-               (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, b)]) << 16) | 0xff000000u;
+               (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, hi)]) << 16) | 0xff000000u;
     };
     // slot -> queue entry
     auto slot_entry = [&](uint32_t slot) -> uint32_t {

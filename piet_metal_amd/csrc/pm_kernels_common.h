@@ -141,6 +141,12 @@ __device__ __forceinline__ bool Straddles(float s00, float s01, float s10, float
     return s00 * s01 + s00 * s10 + s00 * s11 < 3.0f;
 }
 
+// A stored RGBA8 pixel (R in the low byte) in the target's byte order: R and B change places for a
+// BGRA8 target (the reference's drawable, PietRenderer.m:29).
+__device__ __forceinline__ uint32_t StoreOrder(uint32_t rgba, uint32_t bgra) {
+    return bgra ? ((rgba & 0xff00ff00u) | ((rgba & 0xffu) << 16) | ((rgba >> 16) & 0xffu)) : rgba;
+}
+
 __device__ __forceinline__ uint32_t LoadU32(const uint8_t *p) { return *reinterpret_cast<const uint32_t *>(p); }
 __device__ __forceinline__ float2 LoadF2(const uint8_t *p) { return *reinterpret_cast<const float2 *>(p); }
 

@@ -38,6 +38,19 @@ class Encoder:
     def alloc(self, size: int) -> int:
         return int(self._lib.pm_encoder_alloc(self._h, size))
 
+    def write_struct(self, ix: int, data: bytes) -> None:
+        """Encoder::write_struct (src/lib.rs:122): raw bytes of a #[repr(C)] value at offset ix."""
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        _lib.check(self._lib.pm_encoder_write_struct(self._h, ix, buf, len(data)), "pm_encoder_write_struct")
+
+    def encode_points(self, points):
+        """Encoder::encode_points (src/lib.rs:224) -> (points_ix, (x0, y0, x1, y1))."""
+        pts = np.ascontiguousarray(points, dtype=np.float64).reshape(-1, 2)
+        ix = C.c_size_t(0)
+        bb = (C.c_double * 4)()
+        _lib.check(self._lib.pm_encoder_encode_points(self._h, pts.ctypes.data, len(pts), C.byref(ix), bb), "pm_encoder_encode_points")
+        return int(ix.value), tuple(bb)
+
     def begin_group(self, n_items: int) -> None:
         """`Encoder::begin_group`; inside an open group it starts a nested group (extension)."""
         _lib.check(self._lib.pm_encoder_begin_group(self._h, n_items), "begin_group")

@@ -127,6 +127,11 @@ class Renderer:
     def sync(self) -> None:
         _lib.check(self._lib.pm_sync(self._h), "pm_sync")
 
+    def set_target_format(self, bgra: bool) -> None:
+        """Byte order the kernels store pixels in from now on: RGBA8 (default) or BGRA8, the
+        reference drawable's MTLPixelFormatBGRA8Unorm (PietRenderer.m:29)."""
+        _lib.check(self._lib.pm_set_target_format(self._h, _lib.PM_FMT_BGRA8 if bgra else _lib.PM_FMT_RGBA8), "pm_set_target_format")
+
     def read_pixels(self, bgra: bool = False) -> np.ndarray:
         out = np.zeros((self.band_pixel_rows, self.width, 4), np.uint8)
         _lib.check(

@@ -104,7 +104,31 @@ def ext_main():
         json.dump(out, f, indent=1, sort_keys=True)
 
 
+def fnv1a64(a) -> str:
+    h = 0xCBF29CE484222325
+    for b in np.ascontiguousarray(a).tobytes():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return f"{h:016x}"
+
+
+def cabi_main():
+    """python tests/golden/make_golden.py --cabi : what tests/cabi_smoke.c (a plain-C consumer of the
+    C ABI) must print -- the cardioid scene rendered at 1024x768 by the oracle, hashed with the
+    FNV-1a the C program carries (merged into golden.json)."""
+    path = os.path.join(os.path.dirname(__file__), "golden.json")
+    out = json.load(open(path))
+    scene = pmo.scene_cardioid()
+    img = pmo.render(scene, 1024, 768)
+    out["cabi_smoke"] = {"viewport": [1024, 768], "scene_bytes": int(scene.size), "scene_fnv1a64": fnv1a64(scene),
+                         "rgba_fnv1a64": fnv1a64(img), "bgra_fnv1a64": fnv1a64(img[:, :, [2, 1, 0, 3]]), "rgba_sha256": sha(img)}
+    print(out["cabi_smoke"])
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 def main():
+    if "--cabi" in sys.argv:
+        return cabi_main()
     if "--big" in sys.argv:
         return big_main()
     if "--ext" in sys.argv:

@@ -322,6 +322,34 @@ def test_render_to_torch_tensor_on_torch_stream(pm, pmo, renderer):
     assert np.array_equal(t[:270].cpu().numpy(), pmo.render(scene, 480, 270))
 
 
+def test_bgra8_target_is_the_rgba_frame_with_r_and_b_exchanged(pm, pmo, renderer):
+    """The reference's renderKernel writes a BGRA8Unorm drawable (PietRenderer.m:29): with
+    pm_set_target_format(BGRA8) the kernels store that byte order themselves -- interpreted tiles,
+    tiles resolved to one colour by binning or by the list builder -- into the context's framebuffer
+    and into a caller-owned one."""
+    import torch
+
+    wl = pm.workloads.tiger(640, 360)
+    renderer.resize(wl.width, wl.height)
+    renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    want = pmo.render(renderer.download_scene(), wl.width, wl.height)
+    try:
+        renderer.set_target_format(bgra=True)
+        renderer.render()
+        assert np.array_equal(renderer.read_pixels(bgra=True), want[:, :, [2, 1, 0, 3]])
+        assert np.array_equal(renderer.read_pixels(), want)  # swizzled back on the host
+        if torch.cuda.is_available():  # (always on the GPU box; the CPU emulation of tests/emu has no torch device)
+            t = torch.zeros((368, wl.width, 4), dtype=torch.uint8, device="cuda:0")
+            renderer.render_to(t, None)
+            renderer.sync()
+            assert np.array_equal(t[: wl.height].cpu().numpy(), want[:, :, [2, 1, 0, 3]])
+    finally:
+        renderer.set_target_format(bgra=False)
+    renderer.render()
+    assert np.array_equal(renderer.read_pixels(), want)
+    assert np.array_equal(renderer.read_pixels(bgra=True), want[:, :, [2, 1, 0, 3]])
+
+
 def test_back_to_back_frames_and_timing_api(pm, pmo, renderer):
     scene = pmo.scene_cardioid()
     renderer.resize(1024, 768)
@@ -420,6 +448,30 @@ def test_c_abi_gather_single_rank(pm, pmo, renderer):
         comm.close()
 
 
+def test_plain_c_consumer_of_the_c_abi(pm, golden, tmp_path):
+    """tests/cabi_smoke.c: C11, built with gcc against include/piet_metal_amd.h alone (calling
+    conventions and struct layouts as a C compiler sees them, not as ctypes was told), linked to the
+    library, run as its own process: encoder -> pinned scene buffer -> upload -> render -> read back,
+    RGBA8 and BGRA8 targets, hashes against the oracle's (tests/golden/make_golden.py --cabi)."""
+    import subprocess
+
+    from piet_metal_amd import _lib
+
+    lib = _lib.load()._name  # the library this test session runs on
+    exe = str(tmp_path / "cabi_smoke")
+    rocm = "/opt/rocm/lib"
+    subprocess.check_call(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cabi_smoke.c"), "-o", exe, lib, "-lm",
+                           f"-Wl,-rpath,{os.path.dirname(lib)}", f"-Wl,-rpath,{rocm}", f"-Wl,-rpath-link,{rocm}"])
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=600).stdout
+    got = dict(line.split()[:2] for line in out.splitlines() if line and not line.startswith("tiles"))
+    g = golden["cabi_smoke"]
+    assert int(got["scene_bytes"]) == g["scene_bytes"] and out.split()[3] == g["scene_fnv1a64"], out
+    assert got["rgba_fnv1a64"] == g["rgba_fnv1a64"], out
+    assert got["bgra_fnv1a64"] == g["bgra_fnv1a64"], out
+    assert "overflow 0" in out
+
+
 def test_command_list_arena_overflow_grows_and_rerenders(pm, pmo, monkeypatch):
     """Lists are sized from what binning finds, so the arena can run out: pm_sync must notice,
     grow it and render the frame again (also with several frames in flight)."""
@@ -439,6 +491,26 @@ def test_command_list_arena_overflow_grows_and_rerenders(pm, pmo, monkeypatch):
         for _ in range(3):
             r.render()
         assert np.array_equal(r.read_pixels(), want)
+    finally:
+        r.close()
+
+
+def test_overflow_is_not_hidden_by_calls_that_wait_for_the_device(pm, pmo, monkeypatch):
+    """pm_get_stats / pm_frame_latency / ... wait for the device themselves; a frame whose
+    command-list arena ran out must still be found and repaired by the next pm_sync / pm_read_pixels
+    (round-2 advisor finding: render -> stats -> read_pixels returned a frame with holes)."""
+    monkeypatch.setenv("PM_PTCL_INITIAL_CMDS", "2048")
+    r = pm.Renderer(0)
+    try:
+        wl = pm.workloads.tiger(640, 360)
+        r.resize(wl.width, wl.height)
+        r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        want = pmo.render(r.download_scene(), wl.width, wl.height)
+        r.render()
+        st = r.stats()  # waits for the device (SyncAll) before anybody looked at the overflow flag
+        assert st["overflow"] == 1
+        assert np.array_equal(r.read_pixels(), want)
+        assert r.stats()["overflow"] == 0
     finally:
         r.close()
 

@@ -288,6 +288,35 @@ def test_encoder_misuse_is_an_error_not_a_crash(pm):
         e4.fill(np.zeros((0, 2)), 0xFF)
 
 
+def test_encoder_write_struct_and_encode_points(pm):
+    """The two remaining `pub` methods of Encoder (src/lib.rs:122 write_struct, :224 encode_points): a Fill
+    item assembled by hand from them is byte for byte what Encoder::fill (:195-207) writes."""
+    import struct
+
+    pts = [(10.25, 20.5), (300.125, 25.0), (150.0, 270.75), (0.1, 99.9)]
+    a = np.zeros(512, np.uint8)
+    ea = pm.Encoder(a)
+    ea.begin_group(1)
+    ea.fill(pts, 0x11223344)
+    ea.end_group()
+    b = np.zeros(512, np.uint8)
+    eb = pm.Encoder(b)
+    eb.begin_group(1)
+    ix, bb = eb.encode_points(pts)
+    assert ix == 8 + 8 + 32 and bb == (0.1, 20.5, 300.125, 270.75)  # f64 box of the points (Rect::from_points / union_pt)
+    # ShortBbox::from_rect (:88-97): floor / ceil;  PietFill {item_type 3, flags, rgba_color (byte-swapped, :200), n_points, points_ix}
+    eb.write_struct(8, struct.pack("<4H", 0, 20, 301, 271))
+    eb.write_struct(16, struct.pack("<5I", 3, 0, 0x44332211, len(pts), ix))
+    assert eb.bytes_used == ea.bytes_used and a.tobytes() == b.tobytes()
+    # the Rust slice index panics past the end of the buffer: an error code here, nothing written
+    with pytest.raises(pm.PietMetalError) as ei:
+        eb.write_struct(510, b"\x01\x02\x03\x04")
+    assert ei.value.status == pm._lib.PM_ERR_CAPACITY and b[510] == 0
+    e4 = pm.Encoder(np.zeros(64, np.uint8))
+    with pytest.raises(pm.PietMetalError):  # .expect("encoded empty points vector"), :238
+        e4.encode_points(np.zeros((0, 2)))
+
+
 def test_bbox_rules(pm):
     # fill: floor/ceil of the point box; polyline/line: inflated by width/2; clamp to u16
     buf = np.zeros(4096, np.uint8)
