@@ -193,6 +193,8 @@ int pm_set_band(pm_ctx *c, uint32_t tile_row0, uint32_t tile_row1);
 
 /* _sceneBuf.contents (PietRenderer.m:52-53, :204): pinned host staging buffer the
  * caller encodes into; pm_upload_scene makes `bytes` of it resident in HBM. */
+/* The pointer stays valid until pm_scene_reserve asks for more (or pm_destroy): uploads, device
+ * flattening and nested-group scenes grow only the device copy. */
 uint8_t *pm_scene_buffer(pm_ctx *c, size_t *cap);
 int pm_scene_reserve(pm_ctx *c, size_t cap);
 int pm_upload_scene(pm_ctx *c, size_t bytes);

@@ -183,9 +183,10 @@ struct pm_ctx {
     int n_cus = 0;
 
     // scene
-    uint8_t *h_scene = nullptr;  // pinned staging
-    size_t scene_cap = 0;
+    uint8_t *h_scene = nullptr;  // pinned staging (pm_scene_buffer): only pm_scene_reserve moves it
+    size_t scene_cap = 0;        // its capacity
     uint8_t *d_scene = nullptr;
+    size_t dev_scene_cap = 0;    // >= scene_cap: the device copy also grows on its own (flat groups, device flatten)
     size_t scene_bytes = 0;       // resident bytes (with the flat form of nested groups appended)
     size_t user_scene_bytes = 0;  // what the caller uploaded / the flatten kernels wrote
     uint32_t dev_bbox_ix = 8, dev_items_ix = 0;  // the drawn group's ShortBbox / item arrays in d_scene
@@ -421,12 +422,9 @@ int EnsureArena(pm_ctx *c) {
     std::vector<uint4> desc;
     for (size_t i = 0; i < need.size(); ++i)
         if (((need[i] + 3u) & ~3ull) != c->sr_empty_dwords) desc.push_back(make_uint4(static_cast<uint32_t>(i), base[i], base[i + 1], 0u));
-    // heaviest strip rows first (their arena need is the work estimate): the launch's span is its
-    // longest workgroup, and that one should not start in the second wave of workgroups
-    // (measured: +2.5 us -- so is a snake order over CU periods, and natural order with the lightest
-    //  rows last gains nothing: neighbouring strip rows share data and belong together)
-    if (EnvInt("PM_BIN_SORT", 0, 0, 1))
-        std::stable_sort(desc.begin(), desc.end(), [](const uint4 &a, const uint4 &b) { return a.z - a.y > b.z - b.y; });
+    // (strip rows stay in their natural order: heaviest-first was measured 2.5 us slower -- the heavy
+    //  ones then share CUs -- and so was a snake order over CU periods; neighbouring strip rows share
+    //  data and belong together)
     if (desc.empty()) desc.push_back(make_uint4(0u, base[0], need.empty() ? base[0] : base[1], 0u));
     c->n_sr_active = static_cast<uint32_t>(desc.size());
     if (desc.size() > c->sr_desc_cap) {  // (grow only: an animation re-sizes every frame)
@@ -732,7 +730,7 @@ void InvalidateScene(pm_ctx *c) {
     c->arena_dirty = true;
 }
 
-int ReserveScene(pm_ctx *c, size_t cap, size_t keep_bytes);
+int ReserveDevice(pm_ctx *c, size_t cap, size_t keep_bytes);
 
 // Nested groups (extension, src/lib.rs:148): a scene with PietGroup items renders like the same
 // items inlined depth first, in paint order.  The kernels only ever see a flat group, so the
@@ -741,10 +739,11 @@ int ReserveScene(pm_ctx *c, size_t cap, size_t keep_bytes);
 struct FlatGroup {
     std::vector<uint8_t> boxes, items;
     uint32_t n = 0;
+    uint64_t visits = 0;  // groups entered: a DAG of (empty) groups shared by many parents is cut off too
 };
 
 bool FlattenGroup(const uint8_t *sc, size_t len, uint64_t group, int depth, FlatGroup *out) {
-    if (depth > 32 || group + 8 > len || (group & 3u)) return false;
+    if (depth > 32 || group + 8 > len || (group & 3u) || ++out->visits > (1u << 24)) return false;
     uint32_t n, items_ix;
     std::memcpy(&n, sc + group, 4);
     std::memcpy(&items_ix, sc + group + 4, 4);
@@ -808,9 +807,10 @@ int SetScene(pm_ctx *c, size_t bytes, const uint8_t *host) {
         std::memcpy(blk.data() + (root - bytes), ghdr, 8);
         std::memcpy(blk.data() + (root - bytes) + 8, flat.boxes.data(), flat.boxes.size());
         std::memcpy(blk.data() + (root - bytes) + 8 + 8ull * n, flat.items.data(), flat.items.size());
-        if (total > c->scene_cap) {
+        if (total > c->dev_scene_cap) {
             PM_TRY(hipStreamSynchronize(c->stream));  // the upload of the scene bytes is still in flight
-            const int rr = ReserveScene(c, total + (total >> 3), bytes);
+            // (device copy only: the pinned buffer the caller encodes into stays where it is)
+            const int rr = ReserveDevice(c, total + (total >> 3), bytes);
             if (rr != PM_OK) {
                 InvalidateScene(c);
                 return rr;
@@ -856,33 +856,48 @@ int SetScene(pm_ctx *c, size_t bytes, const uint8_t *host) {
     return PM_OK;
 }
 
-int ReserveScene(pm_ctx *c, size_t cap, size_t keep_bytes = 0) {
-    if (cap <= c->scene_cap) return PM_OK;
-    keep_bytes = std::max(keep_bytes, c->scene_bytes);
+int CheckSceneCap(size_t cap) {
     if (cap > 0xffffffffull) {  // offsets in the scene format (and in the kernels' bounds checks) are u32
         SetError("scene buffers are limited to 4 GiB - 1 (u32 offsets in the scene format)");
         return PM_ERR_CAPACITY;
     }
-    uint8_t *h = nullptr, *d = nullptr;
-    PM_TRY(hipHostMalloc(&h, cap, hipHostMallocDefault));
-    hipError_t e = hipMalloc(&d, cap);
-    if (e != hipSuccess) {
-        (void)hipHostFree(h);
-        return HipFail(e, "hipMalloc(scene)");
-    }
-    std::memset(h, 0, cap);
-    if (c->h_scene) {
-        std::memcpy(h, c->h_scene, c->scene_cap);
-        (void)hipHostFree(c->h_scene);
-    }
+    return PM_OK;
+}
+
+// Grows the device copy of the scene (keeping its first keep_bytes).  The pinned host buffer is not
+// touched: a pointer pm_scene_buffer returned stays valid (round-2 advisor finding).
+int ReserveDevice(pm_ctx *c, size_t cap, size_t keep_bytes = 0) {
+    if (cap <= c->dev_scene_cap) return PM_OK;
+    keep_bytes = std::max(keep_bytes, c->scene_bytes);
+    const int rc = CheckSceneCap(cap);
+    if (rc != PM_OK) return rc;
+    uint8_t *d = nullptr;
+    PM_TRY(hipMalloc(&d, cap));
     if (c->d_scene) {
-        if (keep_bytes) (void)hipMemcpy(d, c->d_scene, std::min(keep_bytes, c->scene_cap), hipMemcpyDeviceToDevice);
+        if (keep_bytes) (void)hipMemcpy(d, c->d_scene, std::min(keep_bytes, c->dev_scene_cap), hipMemcpyDeviceToDevice);
         (void)hipFree(c->d_scene);
     }
-    c->h_scene = h;
     c->d_scene = d;
-    c->scene_cap = cap;
+    c->dev_scene_cap = cap;
     return PM_OK;
+}
+
+// pm_create / pm_scene_reserve: the pinned host buffer AND the device copy.
+int ReserveScene(pm_ctx *c, size_t cap) {
+    if (cap > c->scene_cap) {
+        const int rc = CheckSceneCap(cap);
+        if (rc != PM_OK) return rc;
+        uint8_t *h = nullptr;
+        PM_TRY(hipHostMalloc(&h, cap, hipHostMallocDefault));
+        std::memset(h, 0, cap);
+        if (c->h_scene) {
+            std::memcpy(h, c->h_scene, c->scene_cap);
+            (void)hipHostFree(c->h_scene);
+        }
+        c->h_scene = h;
+        c->scene_cap = cap;
+    }
+    return ReserveDevice(c, cap);
 }
 
 }  // namespace
@@ -1111,13 +1126,13 @@ int FlattenAndEncode(pm_ctx *c, bool resident, const pm_path *paths, size_t n_pa
     InvalidateScene(c);  // the kernels below overwrite d_scene
     const WallTimer timer;
     int r = pm::FlattenEncodeOnDevice(c->stream, &c->flatten_cache, resident, paths, n_paths, els, n_els, affine, width_scale, c->d_scene,
-                                      c->scene_cap, &bytes, &items, &he);
-    if (r == PM_ERR_CAPACITY && bytes > c->scene_cap) {
-        // grow the scene buffers and retry once
-        const int rr = ReserveScene(c, bytes + (bytes >> 3));
+                                      c->dev_scene_cap, &bytes, &items, &he);
+    if (r == PM_ERR_CAPACITY && bytes > c->dev_scene_cap) {
+        // grow the device copy (the kernels write it; nothing is staged on the host) and retry once
+        const int rr = ReserveDevice(c, bytes + (bytes >> 3));
         if (rr != PM_OK) return rr;
         r = pm::FlattenEncodeOnDevice(c->stream, &c->flatten_cache, resident, paths, n_paths, els, n_els, affine, width_scale, c->d_scene,
-                                      c->scene_cap, &bytes, &items, &he);
+                                      c->dev_scene_cap, &bytes, &items, &he);
     }
     if (r == PM_ERR_HIP) return HipFail(he, "flatten kernels");
     if (r != PM_OK) {
@@ -1482,8 +1497,8 @@ int pm_fill_coverage(pm_ctx *c, uint32_t item_ix, float *dst, size_t dst_stride_
     std::memcpy(mini, hdr, 8);
     std::memcpy(mini + 8, meta + 8 + 8ull * item_ix, 8);
     std::memcpy(mini + 16, item, 32);
-    if (root + sizeof(mini) > c->scene_cap) {
-        r = ReserveScene(c, root + sizeof(mini) + 4096, c->scene_bytes);
+    if (root + sizeof(mini) > c->dev_scene_cap) {
+        r = ReserveDevice(c, root + sizeof(mini) + 4096, c->scene_bytes);
         if (r != PM_OK) return r;
     }
     PM_TRY(hipMemcpy(c->d_scene + root, mini, sizeof(mini), hipMemcpyHostToDevice));
@@ -1588,8 +1603,15 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
         p.dbg_solid = d_solid;
         p.dbg_cmds = d_cmds;
         p.dbg_max = max_cmds_per_tile;
-        pm::LaunchCoarse(p, CoarseGrid(c), true, c->stream);  // replays the last frame's queues
-        e = hipStreamSynchronize(c->stream);
+        if (c->fused) {
+            // the frame path's own kernel, capture switched on (it rebuilds the same lists and renders
+            // the same pixels: idempotent); the frame's hand-out counters are spent: deal again
+            e = hipMemsetAsync(&p.ctr_cur->ticket, 0, sizeof(p.ctr_cur->ticket), c->stream);
+            pm::LaunchFine(p, 0u, true, c->stream);
+        } else {
+            pm::LaunchCoarse(p, CoarseGrid(c), true, c->stream);  // replays the last frame's queues
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(counts, d_counts, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(solid, d_solid, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);

@@ -299,8 +299,10 @@ double HostCubicEval(double p0, double p1, double p2, double p3, double t) {  //
     return p0 * (mt * mt * mt) + (p1 * (mt * mt * 3.0) + (p2 * (mt * 3.0) + p3 * t) * t) * t;
 }
 
-// false: a LineTo / CurveTo before any MoveTo (the reference panics: cur_path.as_mut().unwrap())
-bool HostFlatten(const pm_path_el *els, size_t n_els, std::vector<double> *pts, std::vector<uint32_t> *sub_counts) {
+// PM_ERR_INVALID: a LineTo / CurveTo before any MoveTo (the reference panics: cur_path.as_mut().unwrap()).
+// PM_ERR_CAPACITY: more points than `max_points` -- what the encoder's buffer could still hold; an
+// extreme (or NaN-adjacent) curve asks for up to 2^30 subdivisions, which must not be generated first.
+int HostFlatten(const pm_path_el *els, size_t n_els, size_t max_points, std::vector<double> *pts, std::vector<uint32_t> *sub_counts) {
     constexpr double kTolerance = 0.1;  // src/lib.rs:330
     bool open = false;
     double lx = 0.0, ly = 0.0;
@@ -314,20 +316,21 @@ bool HostFlatten(const pm_path_el *els, size_t n_els, std::vector<double> *pts, 
             pts->push_back(lx);
             pts->push_back(ly);
         } else if (el.tag == PM_EL_LINE) {
-            if (!open) return false;
+            if (!open) return PM_ERR_INVALID;
             lx = el.p[0];
             ly = el.p[1];
             pts->push_back(lx);
             pts->push_back(ly);
             sub_counts->back() += 1;
         } else if (el.tag == PM_EL_CURVE) {
-            if (!open) return false;
+            if (!open) return PM_ERR_INVALID;
             const double accuracy = kTolerance * 1e-2;  // flatten.rs:35
             const double max_hypot2 = 432.0 * accuracy * accuracy;
             const double ax = el.p[0] * 3.0 - lx, ay = el.p[1] * 3.0 - ly;
             const double bx = el.p[2] * 3.0 - el.p[4], by = el.p[3] * 3.0 - el.p[5];
             const double dx = bx - ax, dy = by - ay;
             const uint64_t n = HostSubdivisionCount((dx * dx + dy * dy) / max_hypot2);
+            if (pts->size() / 2 + n > max_points) return PM_ERR_CAPACITY;
             for (uint64_t k = 0; k < n; ++k) {
                 const double t1 = static_cast<double>(k + 1) / static_cast<double>(n);
                 pts->push_back(HostCubicEval(lx, el.p[0], el.p[2], el.p[4], t1));
@@ -338,7 +341,7 @@ bool HostFlatten(const pm_path_el *els, size_t n_els, std::vector<double> *pts, 
             ly = el.p[5];
         }  // QuadTo, ClosePath: `_ => ()`, flatten.rs:40
     }
-    return true;
+    return PM_OK;
 }
 
 }  // namespace
@@ -347,7 +350,7 @@ int pm_encoder_fill_path(pm_encoder *e, const pm_path_el *els, size_t n_els, uin
     if (!e || (n_els && !els)) return PM_ERR_INVALID;
     std::vector<double> pts;
     std::vector<uint32_t> subs;
-    if (!HostFlatten(els, n_els, &pts, &subs)) return PM_ERR_INVALID;
+    if (const int fr = HostFlatten(els, n_els, e->enc.bytes_free() / 8, &pts, &subs)) return fr;
     const uint32_t rule = fill_flags & PM_FILL_EVEN_ODD;
     if ((fill_flags & PM_FILL_COMPOUND) && !subs.empty()) {
         e->enc.FillCompound(pts.data(), subs.data(), subs.size(), rgba, rule);
@@ -365,7 +368,7 @@ int pm_encoder_stroke_path(pm_encoder *e, const pm_path_el *els, size_t n_els, u
     if (!e || (n_els && !els)) return PM_ERR_INVALID;
     std::vector<double> pts;
     std::vector<uint32_t> subs;
-    if (!HostFlatten(els, n_els, &pts, &subs)) return PM_ERR_INVALID;
+    if (const int fr = HostFlatten(els, n_els, e->enc.bytes_free() / 8, &pts, &subs)) return fr;
     constexpr float kThinLine = 0.7f;  // src/lib.rs:351
     if (width < kThinLine) {           // encode_path_stroke, src/lib.rs:353-362
         float alpha = static_cast<float>(rgba & 0xffu);

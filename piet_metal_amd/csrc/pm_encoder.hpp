@@ -37,6 +37,7 @@ public:
     void WriteStruct(size_t at, const void *src, size_t len) { Put(at, src, len); }
 
     size_t bytes_used() const { return free_space_; }
+    size_t bytes_free() const { return free_space_ < cap_ ? cap_ - free_space_ : 0; }
     bool ok() const { return status_ == kOk; }
     int c_status() const {
         return status_ == kOk ? PM_OK : (status_ == kCapacity ? PM_ERR_CAPACITY : PM_ERR_INVALID);

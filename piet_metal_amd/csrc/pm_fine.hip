@@ -598,7 +598,9 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
 // finds the first three chunks in LDS (CoarseTile drops them into the waiting waves' staging areas).
 // Blocks beyond P.fine_grid write the pixels of the tiles binning resolved (ClearStripRow).
 // kProf: the developer timeline build (pm_debug_time_tiles); P.dbg_time is only read there.
-template <bool kFused, bool kProf>
+// kCapture (pm_debug_capture_ptcl): the fused kernel also records every list it builds in the
+// reference's layout -- the lists of the frame path itself, LDS drop into the waiting waves included.
+template <bool kFused, bool kProf, bool kCapture = false>
 __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     __shared__ SparseLds S;
     if (blockIdx.x >= P.fine_grid) {
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     const uint64_t lanes_below = (1ull << lane) - 1ull;
     // Hand-out.  The passes that hold workgroup tiles (at least the first) are static, snake order
     // over the sorted slots as before.  The slots after them -- the shortest lists -- are dealt in
-    // kTicketParts interleaved decks (slot n_static + p + kTicketParts * j is card j of deck p); a
+    // n_decks = min(kTicketParts, waves) interleaved decks (slot n_static + p + n_decks * j is card j of deck p); a
     // wave that has finished its static share draws from deck wave_global % kTicketParts until the
     // deck is empty.  Per-tile times vary by 2x around what the estimates predict, so a wave's
     // second tile lands on whoever is free instead of on whoever the snake says (one counter for
@@ -670,7 +672,10 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     // launch 4.6 us earlier.
     const uint32_t static_passes = P.handout_static ? 0x7fffffffu / n_waves : max(1u, (s_h + n_waves - 1u) / n_waves);
     const uint32_t n_static = static_passes * n_waves;
-    const uint32_t part = wave_global % kTicketParts;
+    // (a grid with fewer waves than decks -- a small device or partition -- uses as many decks as it
+    //  has waves: a deck nobody draws from would leave its tiles unrendered)
+    const uint32_t n_decks = min(kTicketParts, n_waves);
+    const uint32_t part = wave_global % n_decks;
     uint32_t *const deck_ctr = &P.ctr_cur->ticket[part].count;
     uint32_t slot = pass_slot(0);
     uint4 qe = make_uint4(0u, 0u, 0u, 0u);
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
             uint32_t j = 0;
             if (lane == 0) j = __hip_atomic_fetch_add(deck_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             j = __builtin_amdgcn_readfirstlane(j);
-            slot = n_static + part + kTicketParts * j;
+            slot = n_static + part + n_decks * j;
             have = slot < n_slots;
             if (have) {
                 qix = slot_entry(slot);
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
             // (wave 0 of a workgroup-mode tile has wave == 0: its region is S.w[0] either way)
             // (a workgroup tile: chunks 0..2 of the list also go to the staged-command areas of waves 1..3)
             if (!wg_mode || wave == 0)
-                n_cmd = CoarseTile<false, kProf>(P, S.w[wave].c, qentry, cur, lane, lanes_below, &ct,
+                n_cmd = CoarseTile<kCapture, kProf>(P, S.w[wave].c, qentry, cur, lane, lanes_below, &ct,
                                                  wg_mode ? reinterpret_cast<uint8_t *>(S.w[1].f.cmds) : nullptr, static_cast<uint32_t>(sizeof(WaveLds)));
             if (wg_mode) {
                 if (wave == 0 && lane == 0) S.wg_ncmd[pass & 1u] = n_cmd;
@@ -902,7 +907,9 @@ void LaunchCoverage(const FrameParams &p, uint32_t n_tiles, const uint32_t *tile
 
 void LaunchFine(const FrameParams &p, uint32_t clear_blocks, bool fused, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
     const dim3 grid(p.fine_grid + clear_blocks), block(kThreads);
-    if (p.dbg_time) {
+    if (fused && p.dbg_counts) {  // list capture from the frame path's own kernel
+        PM_LAUNCH((pm_fine_kernel<true, false, true>), grid, block, stream, t0, t1, p);
+    } else if (p.dbg_time) {
         if (fused)
             PM_LAUNCH((pm_fine_kernel<true, true>), grid, block, stream, t0, t1, p);
         else

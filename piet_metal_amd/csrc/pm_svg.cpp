@@ -963,9 +963,14 @@ void IndexIds(const char *text, const char *end, std::vector<IdRange> *ids) {
     }
 }
 
+// Work a hostile document may ask for is bounded: <use> nests 8 deep, so k references per level
+// would expand to k^8 elements; every expansion counts against this budget.
+constexpr uint64_t kMaxUseExpansions = 1u << 20;
+
 struct Doc {
     int flags;
     pm_svg *out;
+    uint64_t use_expansions = 0;
     std::vector<IdRange> ids;
     std::vector<CssRule> css;
 };
@@ -1118,7 +1123,7 @@ int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial
                 const char *nx = static_cast<const char *>(std::memchr(r, '<', end - r));
                 if (!nx) { r = end; break; }
                 if (static_cast<size_t>(end - nx) >= close.size() && std::memcmp(nx, close.c_str(), close.size()) == 0) --depth;
-                else if (static_cast<size_t>(end - nx) >= open.size() && std::memcmp(nx, open.c_str(), open.size()) == 0 &&
+                else if (static_cast<size_t>(end - nx) > open.size() && std::memcmp(nx, open.c_str(), open.size()) == 0 &&
                          (nx[open.size()] == '>' || std::isspace(static_cast<unsigned char>(nx[open.size()])))) ++depth;
                 r = nx + 1;
             }
@@ -1144,6 +1149,7 @@ int ParseRange(Doc *doc, const char *text, const char *end, const Style &initial
                 for (const IdRange &r : doc->ids)
                     if (r.id == id) {
                         if (!(lt >= r.begin && lt < r.end)) {  // (an element cannot use its own ancestor)
+                            if (++doc->use_expansions > kMaxUseExpansions) return PM_ERR_PARSE;
                             const int rc = ParseRange(doc, r.begin, r.end, st, use_depth + 1);
                             if (rc != PM_OK) return rc;
                         }

@@ -1,0 +1,54 @@
+"""The HIP kernels' LOGIC on a box without a GPU: tests/emu/ compiles piet_metal_amd/csrc/*.hip as plain
+C++ against a stand-in hip_runtime.h and runs every lane of every workgroup as a fiber with wave64
+cross-lane semantics (ballot, readlane, DPP, bpermute, barriers).  Here a subset of the gpu-marked
+parity tests -- the very same test functions the GPU box runs against libpiet_metal_amd.so -- runs
+against that emulated library and the oracle.
+
+Test infrastructure only: the product never loads the emulated library (tests/conftest.py swaps it in
+under PM_TEST_EMU=1 and refuses to when a GPU is present); nothing measured comes from it; data races,
+register pressure and instruction selection are invisible to it.  The parity claims rest on the -m gpu
+run on the MI355X."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SUBSET = ("random_scenes or many_items or longer_than or empty_scene or even_odd_fills_and_nested_groups and 31 or compound_fills "
+          "or ellipses or bgra8 or plain_c or not_hidden or overflow_grows or reference_scenes and not 1536 and not 1501 "
+          "or fuzz_regressions and 20206 or both_fine or failed_scene or malformed or pointer_survives")
+
+
+def _run(k, extra_env=None, workers="4"):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the gpu-marked tests run on the real library")
+    env = dict(os.environ, PM_TEST_EMU="1")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k", k,
+           "-p", "no:cacheprovider"]
+    if workers:
+        cmd += ["-n", workers]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-4000:] + p.stderr[-2000:]
+    return p.stdout
+
+
+def test_parity_subset_under_wave64_emulation(built):
+    out = _run(SUBSET)
+    assert " passed" in out and "failed" not in out
+
+
+def test_every_frame_path_switch_under_emulation(built):
+    out = _run("every_frame_path or persistent_grid")
+    assert " passed" in out and "failed" not in out
+
+
+def test_tiny_device_fewer_waves_than_handout_decks(built):
+    """Two CUs x one workgroup = 8 waves < the 128 decks of the drawn hand-out (round-2 advisor
+    finding: decks nobody draws from left their tiles unrendered)."""
+    out = _run("persistent_grid_sizes and 1-1-1 or every_frame_path and 2-1-1", {"PM_EMU_CUS": "2"}, workers="")
+    assert " passed" in out and "failed" not in out

@@ -589,6 +589,56 @@ def test_both_fine_modes_agree_with_the_oracle(pm, pmo, monkeypatch, split, heav
         r.close()
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("fold_clear", ["1", "0"])
+@pytest.mark.parametrize("handout", ["0", "1", "2"])
+def test_every_frame_path_switch_agrees_with_the_oracle(pm, pmo, monkeypatch, fused, fold_clear, handout):
+    """The frame path has switches (pm_create reads them): list building fused into the tile kernel or
+    as its own launch (PM_FUSED), resolved tiles cleared by the tile kernel's launch or by
+    pm_clear_kernel (PM_FOLD_CLEAR), tiles dealt statically or drawn (PM_HANDOUT).  Every combination
+    renders the same bytes and builds the same lists -- captured from the kernel that built them."""
+    monkeypatch.setenv("PM_FUSED", fused)
+    monkeypatch.setenv("PM_FOLD_CLEAR", fold_clear)
+    monkeypatch.setenv("PM_HANDOUT", handout)
+    r = pm.Renderer(0)
+    try:
+        wl = pm.workloads.tiger(480, 270)
+        r.resize(wl.width, wl.height)
+        r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        scene = r.download_scene()
+        for _ in range(3):  # (frames in flight: the hand-out decision of PM_HANDOUT=0 depends on it)
+            r.render()
+        assert np.array_equal(r.read_pixels(), pmo.render(scene, wl.width, wl.height))
+        assert_ptcl_equal(r, pmo, scene, wl.width, wl.height)
+        ops = random_ops(77, 300, extent=500.0)
+        scene2 = encode_ops(pm, ops)
+        got = gpu_render(r, scene2, 517, 500)
+        assert np.array_equal(got, pmo.render(scene2, 517, 500))
+        assert_ptcl_equal(r, pmo, scene2, 517, 500)
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("coarse_wg,fine_wg,fused", [("1", "1", "1"), ("7", "3", "0"), ("2", "9", "1")])
+def test_persistent_grid_sizes(pm, pmo, monkeypatch, coarse_wg, fine_wg, fused):
+    """PM_COARSE_WG_PER_CU / PM_FINE_WG_PER_CU size the persistent grids; the hand-out must cover
+    every queued tile whatever the grid (few workgroups: many passes; many: empty ones)."""
+    monkeypatch.setenv("PM_COARSE_WG_PER_CU", coarse_wg)
+    monkeypatch.setenv("PM_FINE_WG_PER_CU", fine_wg)
+    monkeypatch.setenv("PM_FUSED", fused)
+    r = pm.Renderer(0)
+    try:
+        wl = pm.workloads.tiger(960, 540)
+        r.resize(wl.width, wl.height)
+        r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        scene = r.download_scene()
+        r.render()
+        assert np.array_equal(r.read_pixels(), pmo.render(scene, wl.width, wl.height))
+        assert_ptcl_equal(r, pmo, scene, wl.width, wl.height)
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("seed,n,extent,w,h", [(31, 200, 500.0, 520, 500), (32, 400, 300.0, 330, 310), (33, 60, 1500.0, 1400, 900)])
 def test_even_odd_fills_and_nested_groups(pm, pmo, renderer, seed, n, extent, w, h):
     """The encoder extensions end to end on the GPU: scenes with even-odd fills (PietFill.flags)
@@ -760,6 +810,32 @@ def test_f32_coverage_matches_the_f32_reference(pm, pmo, renderer):
     assert worst == 0
     with pytest.raises(pm.PietMetalError):
         renderer.fill_coverage(10 ** 6)
+
+
+def test_scene_buffer_pointer_survives_device_side_growth(pm, pmo):
+    """A C host caches pm_scene_buffer's pointer like the reference caches _sceneBuf.contents
+    (PietRenderer.m:204).  Calls that need more DEVICE room than the buffer has (here pm_fill_coverage
+    appending its one-item group behind a scene that fills the buffer) must grow the device copy only
+    (round-2 advisor finding: the pinned buffer used to be reallocated under the caller)."""
+    r = pm.Renderer(0)
+    try:
+        buf = r.scene_buffer()
+        p0, cap = buf.ctypes.data, buf.size
+        scene = pmo.scene_path_test()
+        buf[: scene.size] = scene
+        r.resize(128, 832)
+        r.upload_scene(cap)  # (the bytes behind the scene are padding nothing refers to)
+        got = r.fill_coverage(0)
+        want = pmo.fill_coverage(scene, 0, 128, 832)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        again = r.scene_buffer()
+        assert again.ctypes.data == p0 and again.size == cap
+        buf[: scene.size] = scene  # the cached pointer is still writable memory of the context
+        r.upload_scene(scene.size)
+        r.render()
+        assert np.array_equal(r.read_pixels(), pmo.render(scene, 128, 832))
+    finally:
+        r.close()
 
 
 def test_cli_renders_svg_to_png(pm, pmo, tmp_path):
