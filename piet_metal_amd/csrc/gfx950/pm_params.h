@@ -8,6 +8,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <type_traits>
 
 namespace pm {
 namespace {
@@ -35,10 +36,16 @@ __device__ __forceinline__ uint32_t ParamU32(const ParamRegs &r) {
     return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(r.w[kOff / 256]), static_cast<int>((kOff / 4) & 63)));
 }
 
+// A pointer rebuilt from two dwords has no address space the compiler could know: every access
+// through it would be a FLAT operation, which counts against the LDS counter as well (it might be an
+// LDS address) and drags a vmcnt(0) into every LDS-only barrier.  All pointers in FrameParams point to
+// device memory: the value is made as a GLOBAL (address space 1) pointer first, and address-space
+// inference turns the accesses behind the cast back to generic into global_load / global_store.
 template <typename T, size_t kOff>
 __device__ __forceinline__ T ParamPtr(const ParamRegs &r) {
     const uint64_t lo = ParamU32<kOff>(r), hi = ParamU32<kOff + 4>(r);
-    return reinterpret_cast<T>(lo | (hi << 32));
+    typedef __attribute__((address_space(1))) std::remove_pointer_t<T> *GlobalPtr;
+    return (T)(GlobalPtr)(lo | (hi << 32));
 }
 
 }  // namespace

@@ -41,5 +41,15 @@ __device__ __forceinline__ void PinLoaded8(uint32_t &a0, uint32_t &a1, uint32_t 
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
 }
 
+// v_writelane_b32: a wave-uniform value into lane kLane of a VGPR (one instruction; the compiler has
+// no builtin for it and would otherwise build `lane == kLane ? s : v` from a compare and a select).
+template <uint32_t kLane>
+__device__ __forceinline__ void WriteLane(uint32_t &v, uint32_t uniform_value) {
+    // (readfirstlane: a value the compiler cannot PROVE uniform would be handed over in a VGPR; it folds
+    //  away for values already in SGPRs)
+    const uint32_t sv = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(uniform_value)));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sv), "n"(kLane));
+}
+
 }  // namespace
 }  // namespace pm

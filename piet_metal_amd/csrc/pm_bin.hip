@@ -99,34 +99,55 @@ namespace {
 
 }  // namespace
 
-template <bool kProfile>
-__global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
-    const ParamRegs PR = LoadParams(P);
-    __shared__ uint32_t s_part[kBinWaves];
-    __shared__ uint32_t s_cidx[kThreads];   // candidate item index
-    __shared__ uint32_t s_cmask[kThreads];  // candidate per-tile hit mask (16 bits)
-    __shared__ uint32_t s_ctag[kThreads];
-    __shared__ uint32_t s_cpts[kThreads];   // points_ix (or byte offset of start/end for lines)
-    __shared__ uint32_t s_cnseg[kThreads];  // segments of the item
-    __shared__ uint32_t s_cnpt[kThreads];
-    __shared__ float s_chw[kThreads];       // 0.5*width + 0.5 for polylines
-    __shared__ uint32_t s_cchunk[kThreads]; // first chunk-table entry of the item
-    __shared__ uint32_t s_choff[kThreads + 1];  // chunk-stream offsets
+// The binning workgroup's LDS, ONE object: every array is then a constant offset from the same base
+// and an access costs `tid * 4` plus an immediate (as separate __shared__ arrays each one gets its own
+// hoisted base + index register, and a dozen of them end up in scratch).
+constexpr uint32_t kCtStride = kStripTiles + 1;  // row stride 17: a thread per candidate walking its row, and 16 lanes adding to one row, are both free of bank conflicts
+constexpr uint32_t kSurvLds = 1024;
+struct BinLds {
+    uint32_t s_part[kBinWaves];
+    uint32_t s_cidx[kThreads];   // candidate item index
+    uint32_t s_cmask[kThreads];  // candidate per-tile hit mask (16 bits)
+    uint32_t s_ctag[kThreads];
+    uint32_t s_cpts[kThreads];   // points_ix (or byte offset of start/end for lines)
+    uint32_t s_cnseg[kThreads];  // segments of the item
+    uint32_t s_cnpt[kThreads];
+    float s_chw[kThreads];       // 0.5*width + 0.5 for polylines
+    uint32_t s_cchunk[kThreads]; // first chunk-table entry of the item
+    uint32_t s_choff[kThreads + 1];  // chunk-stream offsets
     // per (candidate, tile): backdrop steps << 20 | relevant segments.  Row stride 17: a thread per
     // candidate walking its row, and 16 lanes adding to one row, are both free of bank conflicts.
-    constexpr uint32_t kCtStride = kStripTiles + 1;
-    __shared__ uint32_t s_ct[kThreads * kCtStride];
-    __shared__ uint32_t s_surv[kBinWaves][256];  // [0][..]: surviving chunks of one round (c << 24 | j); later scratch  // surviving chunks of one wave round: c << 24 | j
-    __shared__ uint32_t s_est[kStripTiles];  // per tile: stream elements the tile kernel will see
+    uint32_t s_ct[kThreads * kCtStride];
+    uint32_t s_surv[kSurvLds];  // surviving chunks of the record (c << 24 | j), while they fit
+    uint32_t s_est[kStripTiles];  // per tile: stream elements the tile kernel will see
     // per tile, in paint order across batches: the last candidate that can emit anything, and the
     // last one that is nothing but an opaque Solid (backdrop-only fill, alpha 0xff).  If they
     // coincide the tile's list is {Solid(opaque)} -> Bail: the tile is that colour, written here.
-    __shared__ uint32_t s_last_kept[kStripTiles];
-    __shared__ uint32_t s_last_solid[kStripTiles];
-    __shared__ uint32_t s_solid_rgba[kStripTiles];
-    __shared__ uint32_t s_crgba[kThreads], s_caux0[kThreads], s_caux1[kThreads];  // candidate colour / payload
-    __shared__ uint32_t s_lut[256];  // sRGB->linear half bits | a/255 half bits << 16
+    uint32_t s_last_kept[kStripTiles];
+    uint32_t s_last_solid[kStripTiles];
+    uint32_t s_solid_rgba[kStripTiles];
+    uint32_t s_crgba[kThreads], s_caux0[kThreads], s_caux1[kThreads];  // candidate colour / payload
+    uint32_t s_lut[256];  // sRGB->linear half bits | a/255 half bits << 16
+    // per tile, across the records of the strip row: the tile's first piece {quad, candidates | segments << 9}
+    // and its latest piece (whose header is patched when a later record adds one)
+    uint32_t s_head_q[kStripTiles], s_head_n[kStripTiles], s_prev_q[kStripTiles];
+    uint32_t s_piece_q[kStripTiles];  // this record's piece of the tile (quad index, 0 = none)
+    uint32_t s_piece_n[kStripTiles];  // its candidates | segments << 9
+    uint32_t s_wcnt[kBinWaves][kStripTiles];  // relevant segments per tile in each wave's share of the slots
+    // finalisation, per wave of candidates and tile: candidates that can emit, their relevant segments,
+    // pseudo elements (candidates without segments), last candidate that can emit / last opaque Solid (index + 1)
+    uint32_t s_wh[kBinWaves][kStripTiles], s_we[kBinWaves][kStripTiles];
+    uint32_t s_wlk[kBinWaves][kStripTiles], s_wls[kBinWaves][kStripTiles];
+    uint32_t s_whub[kBinWaves][kStripTiles];  // per wave of candidates and tile: candidates whose bbox reaches the tile
+    uint32_t s_alloc[2];  // {first quad of this record's pieces (0xffffffff: the tile arena ran out), overflow seen}
+    unsigned long long s_stamp[14];  // developer timeline (kProfile builds)
 
+};
+
+template <bool kProfile>
+__global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
+    const ParamRegs PR = LoadParams(P);
+    __shared__ BinLds L;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = LaneId();
     const uint32_t wave = tid >> 6;
@@ -141,9 +162,12 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     const int sx0 = static_cast<int>(strip * kGroupW);
     const int y0 = static_cast<int>(ty * kTileH);
     const int sy0 = y0 & ~static_cast<int>(kGroupH - 1);
-    const float fsx0 = static_cast<float>(sx0), fsx1 = static_cast<float>(sx0 + static_cast<int>(kGroupW));
-    const float fy0 = static_cast<float>(y0), fy1 = static_cast<float>(y0 + static_cast<int>(kTileH));
-    const float fsy0 = static_cast<float>(sy0), fsy1 = static_cast<float>(sy0 + static_cast<int>(kGroupH));
+    // (wave-uniform floats: converted on the vector unit, then kept in SGPRs -- as VGPRs they are live
+    //  through the whole kernel and end up spilled)
+    auto uniform_f = [](int v) { return __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(static_cast<float>(v)))))); };
+    const float fsx0 = uniform_f(sx0), fsx1 = uniform_f(sx0 + static_cast<int>(kGroupW));
+    const float fy0 = uniform_f(y0), fy1 = uniform_f(y0 + static_cast<int>(kTileH));
+    const float fsy0 = uniform_f(sy0), fsy1 = uniform_f(sy0 + static_cast<int>(kGroupH));
 
     if (blockIdx.x == 0 && tid < kTicketParts) PM_PP(ctr_next)->ticket[tid].count = 0;
     if (blockIdx.x == 0 && tid == 0) {
@@ -159,21 +183,29 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     // that the profiled kernel keeps the register allocation of the production one.
     // slots: 0 entry, 1 item scan done, 2 first record's headers done, 3 last segment stream done,
     //        4 last record finalised, 5 queues done, 6 chunks tested (count), 7 exit
+    // (the clocks go to LDS and leave for memory in one burst when the wave ends: a global store per
+    //  stamp would sit in front of the next loads -- vector memory operations complete in order -- and
+    //  charge every phase a store acknowledgement)
     auto stamp = [&](uint32_t k) {
         if (kProfile) {
-            if (tid == 0) PM_PP(dbg_bin)[12ull * sr + k] = wall_clock64();
+            if (tid == 0) L.s_stamp[k] = wall_clock64();
         }
     };
     bool prof_first = true;
     uint32_t prof_chunks = 0;
+    if (kProfile && tid < 14) L.s_stamp[tid] = 0;
     stamp(0);
     if (tid < kStripTiles) {
-        s_est[tid] = 0;
-        s_last_kept[tid] = 0;
-        s_last_solid[tid] = 0;
-        s_solid_rgba[tid] = 0;
+        L.s_est[tid] = 0;
+        L.s_last_kept[tid] = 0;
+        L.s_last_solid[tid] = 0;
+        L.s_solid_rgba[tid] = 0;
+        L.s_head_q[tid] = 0;
+        L.s_head_n[tid] = 0;
+        L.s_prev_q[tid] = 0;
     }
-    __syncthreads();
+    if (tid == 0) L.s_alloc[1] = 0;
+    LdsBarrier();
 
     const uint8_t *scene = PM_PP(scene);
     // wave-uniform values are pinned to SGPRs (readfirstlane): the record pointers and loop
@@ -185,8 +217,67 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     uint32_t cursor = __builtin_amdgcn_readfirstlane(srd.y);
     const uint32_t region_begin = cursor;
     const uint32_t region_end = __builtin_amdgcn_readfirstlane(srd.z);
-    uint32_t head = 0;       // first record of this strip row
-    uint32_t prev_rec = 0;   // record whose `next` field is still open
+
+    // ---- the strip row's tail (one wave): queue the tiles with something to draw, mark the others ----
+    // Lane t owns tile t of the strip row; the class masks are ballots, the command-list offsets a
+    // wave scan, and the atomics' results travel by v_readlane.
+    bool tail_done = false;
+    auto RowTail = [&]() {
+        const uint32_t tiles_here = min(kStripTiles, PM_PU(tiles_x) - strip * kStripTiles);
+        const bool tile_lane = lane < tiles_here;
+        const uint32_t est = tile_lane ? L.s_est[lane & (kStripTiles - 1u)] : 0u;
+        // {Solid(opaque)} -> Bail: the tile is one opaque colour (TileEncoder::end, :144-151)
+        const bool is_solid = est != 0 && L.s_last_kept[lane & (kStripTiles - 1u)] == L.s_last_solid[lane & (kStripTiles - 1u)];
+        const bool is_queued = est != 0 && !is_solid;
+        // cost class of the tile's list (0 = longest): the number of thresholds the estimate does not exceed
+        static_assert(kClasses == 8, "seven thresholds spelled out below");
+#define PM_THR(k) ((est <= ParamU32<offsetof(FrameParams, class_thr) + 4 * (k)>(PR)) ? 1u : 0u)
+        const uint32_t cls = PM_THR(0) + PM_THR(1) + PM_THR(2) + PM_THR(3) + PM_THR(4) + PM_THR(5) + PM_THR(6);
+#undef PM_THR
+        uint32_t my_mask = 0;    // queued tiles of this lane's class
+        uint32_t lane_cnt = 0;   // lane c < kClasses: tiles of class c in this strip row
+        ForClasses([&](auto kc) {
+            constexpr uint32_t k = decltype(kc)::value;
+            const uint32_t mk = static_cast<uint32_t>(__ballot(is_queued && cls == k));
+            if (cls == k) my_mask = mk;
+            WriteLane<k>(lane_cnt, static_cast<uint32_t>(__popc(mk)));
+        });
+        // command-list space of a queued tile, in quads: an element emits at most 2 commands + its
+        // item's closing command, plus End; 24 bytes each
+        const uint32_t slots = is_queued ? ((3u * est + 1u) * kCmdQuadsNum + kCmdQuadsDen - 1u) / kCmdQuadsDen : 0u;
+        const uint32_t slots_incl = WaveInclusiveScan(slots);
+        const uint32_t qtotal = WaveLast(slots_incl);
+        // tile-arena space and the class queue positions: ONE atomic instruction, a lane per counter
+        uint32_t qres = 0;
+        if (qtotal) {  // uniform
+            if (lane < kClasses && lane_cnt) qres = atomicAdd(&PM_PP(ctr_cur)->cls[lane].count, lane_cnt);
+            if (lane == kClasses) qres = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, qtotal);
+        }
+        // tiles with nothing to draw are background: no item touches them, or every touching
+        // item lost all its segments in phase 1 (the reference writes Bail/white for them).  Their
+        // pixels are written by the clearing workgroups of the tile kernel's launch from tile_state:
+        // 25 MB of stores per 4K frame that would otherwise stall these latency-bound workgroups in bursts.
+        const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + lane;
+        if (tile_lane)  // what this kernel decided per tile: 0 = queued, else the tile's colour
+            PM_PP(tile_state)[tile] = is_queued ? 0u : (is_solid ? L.s_solid_rgba[lane] : 0xffffffffu);
+        if (!qtotal) return;
+        const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), kClasses)) + 1u;  // (quad 0 stays unused: 0 = "no piece")
+        const uint32_t q_base = static_cast<uint32_t>(__shfl(static_cast<int>(qres), static_cast<int>(cls)));  // my class's queue position
+        // (L.s_alloc[1]: an earlier record of this strip row found the tile arena full -- its pieces do not exist)
+        const bool fits = base + qtotal <= PM_PU(tarena_cap) && base + qtotal >= base && L.s_alloc[1] == 0u;
+        // (on overflow the tiles are still queued but marked "no list": the tile kernels skip
+        //  them, the frame has holes, and pm_sync re-renders it with a larger arena)
+        if (!fits && lane == 0) PM_PP(ctr_cur)->overflow = 1;
+        if (is_queued) {
+            const uint32_t list_slot = fits ? base + (slots_incl - slots) : 0xffffffffu;
+            PM_PP(tile_ptcl)[tile] = list_slot;
+            // A queue entry is everything the tile kernels need to start: {tile, first quad of its
+            // command list, its first piece, that piece's candidates | segments << 9}
+            const uint4 entry = make_uint4(tile, list_slot, L.s_head_q[lane], L.s_head_n[lane]);
+            const uint32_t below = (1u << lane) - 1u;
+            PM_PP(queue)[cls * PM_PU(queue_cap) + q_base + __popc(my_mask & below)] = entry;
+        }
+    };
 
     // Records hold up to kBatch CANDIDATES (not items): item bboxes are scanned kBatch at a time
     // and the survivors accumulate; a record is cut only when the next scan step would not fit.
@@ -218,7 +309,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         it_next = band_item[tid];
     }
     // the two colour tables ride along with the first bbox load (finalisation reads them from LDS)
-    if (n_band) s_lut[tid] = PM_PP(lut_srgb2lin)[tid] | (PM_PP(lut_unorm2h)[tid] << 16);
+    if (n_band) L.s_lut[tid] = PM_PP(lut_srgb2lin)[tid] | (PM_PP(lut_unorm2h)[tid] << 16);
     for (uint32_t ib = 0;; ib += kBatch) {
         const bool more = ib < n_band;  // uniform
         const uint32_t j = ib + tid;
@@ -244,13 +335,13 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         }
         uint32_t nb = 0;
         uint32_t cpos = 0;
-        if (more) cpos = BlockRank<kBinWaves>(cand, s_part, &nb);
+        if (more) cpos = BlockRank<kBinWaves>(cand, L.s_part, &nb);
         nb = __builtin_amdgcn_readfirstlane(nb);
         if (more && ncand + nb <= kBatch) {
             // append and keep scanning
             if (cand) {
-                s_cidx[ncand + cpos] = i;
-                s_cmask[ncand + cpos] = mask;
+                L.s_cidx[ncand + cpos] = i;
+                L.s_cmask[ncand + cpos] = mask;
             }
             ncand += nb;
             continue;
@@ -259,14 +350,14 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             if (!more) break;
             continue;  // (nb > kBatch cannot happen: a scan step tests kBatch items)
         }
-        __syncthreads();  // the appended candidates are visible
+        LdsBarrier();  // the appended candidates are visible
         if (kProfile && prof_first) stamp(1);  // first record starts (item scan done)
 
         // ---- candidate headers + chunk-stream offsets ---------------------------------
         uint32_t nch = 0;
         if (tid < ncand) {
             uint32_t tag = 0, rgba = 0, aux0 = 0, aux1 = 0;
-            const uint32_t idx = s_cidx[tid];
+            const uint32_t idx = L.s_cidx[tid];
             const uint8_t *item = scene + items_ix + static_cast<size_t>(idx) * kItemSize;
             // the first 20 bytes of the item, its bbox and its chunk-table entry: all loads are
             // issued before any of them is looked at (one round trip instead of a tag-dependent two)
@@ -316,385 +407,541 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             } else {
                 tag = 0;
             }
-            s_ctag[tid] = tag;
-            s_crgba[tid] = rgba;
-            s_caux0[tid] = aux0;
-            s_caux1[tid] = aux1;
-            s_cpts[tid] = pts;
-            s_cnpt[tid] = npt;
-            s_cnseg[tid] = nseg;
-            s_chw[tid] = hw;
-            s_cchunk[tid] = cbase;
+            L.s_ctag[tid] = tag;
+            L.s_crgba[tid] = rgba;
+            L.s_caux0[tid] = aux0;
+            L.s_caux1[tid] = aux1;
+            L.s_cpts[tid] = pts;
+            L.s_cnpt[tid] = npt;
+            L.s_cnseg[tid] = nseg;
+            L.s_chw[tid] = hw;
+            L.s_cchunk[tid] = cbase;
 #pragma unroll
-            for (uint32_t t = 0; t < kStripTiles; ++t) s_ct[tid * kCtStride + t] = 0;
+            for (uint32_t t = 0; t < kStripTiles; ++t) L.s_ct[tid * kCtStride + t] = 0;
+        }
+        {   // per tile: how many of the wave's candidates reach it with their bbox (an upper bound of the
+            // candidates of the tile's piece); the per-share segment counters start at zero
+            const uint32_t cm = tid < ncand ? L.s_cmask[tid] : 0u;
+            uint32_t hub = 0;
+            ForStripTiles([&](auto tc) {
+                constexpr uint32_t t = decltype(tc)::value;
+                WriteLane<t>(hub, static_cast<uint32_t>(__popcll(__ballot((cm >> t) & 1u))));
+            });
+            if (lane < kStripTiles) {
+                L.s_whub[wave][lane] = hub;
+                L.s_wcnt[wave][lane] = 0;
+            }
         }
         uint32_t total_ch;
-        const uint32_t choff = BlockExclusiveScan<kBinWaves>(nch, s_part, &total_ch);
+        const uint32_t choff = BlockExclusiveScan<kBinWaves>(nch, L.s_part, &total_ch);
         total_ch = __builtin_amdgcn_readfirstlane(total_ch);
-        if (tid < ncand) s_choff[tid] = choff;
-        if (tid == 0) s_choff[ncand] = total_ch;
+        if (tid < ncand) L.s_choff[tid] = choff;
+        if (tid == 0) L.s_choff[ncand] = total_ch;
 
-        // ---- the record (uniform arithmetic, no allocation traffic) -----------------------
-        const uint32_t mask_dwords = (ncand + 3u) & ~3u;
+        // ---- the record: segment slots + meta words (uniform arithmetic, no allocation traffic) ----
         const uint32_t rec = cursor;
-        const uint32_t size = kRecHdrDwords + mask_dwords + (kCandDwords + kCtDwords) * ncand + 5u * kChunkSegs * total_ch;
+        const uint32_t size = kSlotDwords * kChunkSegs * total_ch;
         if (rec + size > region_end) {  // cannot happen unless the host bound is wrong
             if (tid == 0) PM_PP(ctr_cur)->overflow = 1;
             break;
         }
         cursor += size;
-        uint32_t *hdr = PM_PP(arena) + rec;
-        uint32_t *mask_tab = hdr + kRecHdrDwords;
-        uint32_t *cand_rec = mask_tab + mask_dwords;
-        uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
-        float4 *segs = reinterpret_cast<float4 *>(ct_tab + kCtDwords * ncand);
+        float4 *segs = reinterpret_cast<float4 *>(PM_PP(arena) + rec);
         uint32_t *meta = reinterpret_cast<uint32_t *>(segs + kChunkSegs * total_ch);
-        if (tid == 0) {
-            if (prev_rec) PM_PP(arena)[prev_rec] = rec;
-            hdr[0] = 0;  // next
-            hdr[1] = ncand;
-            hdr[2] = total_ch;
-        }
-        if (head == 0) head = rec;
-        prev_rec = rec;
-        __syncthreads();  // s_choff, s_c* visible to every wave
+        LdsBarrier();  // L.s_choff, s_c* visible to every wave
         if (kProfile && prof_first) stamp(2);  // headers + scan done
-        prof_first = false;
 
-        // ---- chunk stream -> surviving chunks -> segment votes ---------------------------------
-        // Block rounds of 256 chunks: chunks whose box cannot reach the strip row are dropped and
+        // ---- chunk stream -> surviving chunks ------------------------------------------------------
+        // Block rounds of 1024 chunks: chunks whose box cannot reach the strip row are dropped and
         // the survivors get consecutive indices (paint order).  Every surviving chunk OWNS
         // kChunkSegs segment slots (slot = chunk_index * kChunkSegs + segment_in_chunk), so the
-        // expansion needs no compaction at all: each lane votes one segment (phase 1), writes
-        // its slot's meta word (0 = no vote) and, if voted, the segment -- and the four waves
-        // simply split the round's elements evenly.
+        // expansion needs no compaction at all.  The list of survivors (c << 24 | j) lives in LDS;
+        // beyond kSurvLds surviving chunks it continues in the first meta word of the chunk's own
+        // slots (read before the vote overwrites it).
         uint32_t sbase = 0;  // surviving chunks so far
         constexpr uint32_t kCPL = 4;  // chunks tested per lane per round: fewer rounds, fewer barriers
         for (uint32_t r0 = 0; r0 < total_ch; r0 += kBinThreads * kCPL) {
             const uint32_t eb = r0 + kCPL * tid;  // this lane's consecutive chunks (stream order)
-            if (kProfile && r0 == 0) stamp(8);
+            if (kProfile && prof_first && r0 == 0) stamp(8);
             uint32_t svb = 0;
             uint32_t pk[kCPL];
             if (eb < total_ch) {
-                uint32_t c = FindOwner(s_choff, ncand, eb);
+                uint32_t c = FindOwner(L.s_choff, ncand, eb);
                 uint32_t cc[kCPL];
                 float4 bb[kCPL];
 #pragma unroll
                 for (uint32_t u = 0; u < kCPL; ++u) {
                     const uint32_t e = eb + u;
-                    while (c + 1 < ncand && s_choff[c + 1] <= e) ++c;  // owners only move forward
+                    while (c + 1 < ncand && L.s_choff[c + 1] <= e) ++c;  // owners only move forward
                     cc[u] = c;
-                    const uint32_t j = e - s_choff[c];
+                    const uint32_t j = e - L.s_choff[c];
                     pk[u] = (c << 24) | j;
                     bb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < total_ch && s_ctag[c] != kItemLine) bb[u] = PM_PP(chunk_bbox)[s_cchunk[c] + j];
+                    if (e < total_ch && L.s_ctag[c] != kItemLine) bb[u] = PM_PP(chunk_bbox)[L.s_cchunk[c] + j];
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < kCPL; ++u) {
                     if (eb + u >= total_ch) continue;
-                    const uint32_t ctag = s_ctag[cc[u]];
+                    const uint32_t ctag = L.s_ctag[cc[u]];
                     bool sv;
                     if (ctag == kItemLine) {
                         sv = true;
                     } else if (ctag == kItemFill) {  // necessary part of :264-265 for any segment of the chunk
                         sv = bb[u].w >= fy0 && bb[u].y < fy1 && bb[u].x < fsx1;
                     } else {  // necessary part of :378-379
-                        const float hw = s_chw[cc[u]];
+                        const float hw = L.s_chw[cc[u]];
                         sv = bb[u].w > fsy0 - hw && bb[u].y < fsy1 + hw && bb[u].z > fsx0 - hw && bb[u].x < fsx1 + hw;
                     }
                     if (sv) svb |= 1u << u;
                 }
             }
             uint32_t ns;
-            uint32_t srank = BlockExclusiveScan<kBinWaves>(static_cast<uint32_t>(__popc(svb)), s_part, &ns);
+            uint32_t srank = BlockExclusiveScan<kBinWaves>(static_cast<uint32_t>(__popc(svb)), L.s_part, &ns);
             ns = __builtin_amdgcn_readfirstlane(ns);
-            if (kProfile && r0 == 0) stamp(9);
-            if (ns == 0) continue;  // uniform
+            if (kProfile && prof_first && r0 == 0) stamp(9);
 #pragma unroll
             for (uint32_t u = 0; u < kCPL; ++u)
-                if ((svb >> u) & 1u) (&s_surv[0][0])[srank++] = pk[u];
-            __syncthreads();
-            const uint32_t n_el = ns * kChunkSegs;
-            if (kProfile && r0 == 0) stamp(10);
-            for (uint32_t f0 = wave * 64u; f0 < n_el; f0 += kBinThreads) {
-                const uint32_t f = f0 + lane;
-                bool vote = false;
-                uint32_t vc = 0;
-                float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (f < n_el) {
-                    const uint32_t spk = (&s_surv[0][0])[f / kChunkSegs];
+                if ((svb >> u) & 1u) {
+                    const uint32_t ix = sbase + srank++;
+                    if (ix < kSurvLds) L.s_surv[ix] = pk[u];
+                    else meta[ix * kChunkSegs] = pk[u];
+                }
+            sbase += ns;
+        }
+        const uint32_t n_slots = sbase * kChunkSegs;  // slots of the record in use
+        if (sbase > kSurvLds) __syncthreads();  // (survivors beyond the LDS list sit in global memory, written by any wave)
+        else LdsBarrier();        // the survivor list is complete
+        if (kProfile && prof_first) {
+            stamp(10);
+            if (tid == 0) L.s_stamp[6] = n_slots;  // (slot 6: segment slots of the first record)
+        }
+
+        // ---- segment votes: a wave owns a CONTIGUOUS share of the slots (so that what it counts and
+        //      later places follows slot = paint order); each lane votes one segment (phase 1), writes
+        //      its slot's meta word (0 = no vote) and, if voted, the segment -------------------------------
+        const uint32_t q_share = ((n_slots + kBinWaves * 64u - 1u) / (kBinWaves * 64u)) * 64u;  // slots per wave, a multiple of 64
+        const uint32_t w_lo = min(n_slots, wave * q_share), w_hi = min(n_slots, w_lo + q_share);
+        {
+            // The loop is software-pipelined by hand: the NEXT round's segment end points are requested
+            // before this round's votes are computed and stored.  Vector memory operations complete in
+            // order, so a wait for loads issued BEFORE the stores does not wait for the stores'
+            // acknowledgements (microseconds), and the loads' own latency runs under the arithmetic.
+            // fetch: slot f -> its candidate, segment index, item type (0: no segment there) and the two end
+            // points as the item stores them (a compound fill's separators are sorted out by the consumer)
+            auto fetch = [&](uint32_t f, uint32_t &vc, uint32_t &k, uint32_t &ctag, float2 &a, float2 &b) {
+                vc = 0;
+                k = 0;
+                ctag = 0;
+                a = b = make_float2(0.f, 0.f);
+                if (f < w_hi) {
+                    const uint32_t six = f / kChunkSegs;
+                    const uint32_t spk = six < kSurvLds ? L.s_surv[six] : meta[six * kChunkSegs];
                     vc = spk >> 24;
-                    const uint32_t k = (spk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
-                    if (k < s_cnseg[vc]) {
-                        const uint32_t ctag = s_ctag[vc];
-                        const uint8_t *pts = scene + s_cpts[vc];
-                        if (ctag == kItemFill) {
-                            float2 a, b;
-                            if (FillSegmentEnds(pts, s_cnpt[vc], (s_caux0[vc] & kFillCompound) != 0, k, a, b)) {
-                                seg = make_float4(a.x, a.y, b.x, b.y);
-                                vote = VoteFill(seg, y0, sx0);
-                            }
-                        } else if (ctag == kItemPoly) {
-                            const float2 a = LoadF2(pts + static_cast<size_t>(k) * 8);
-                            const float2 b = LoadF2(pts + static_cast<size_t>(k + 1) * 8);
-                            seg = make_float4(a.x, a.y, b.x, b.y);
-                            const int y_test = sy0 + static_cast<int>(((k & 31u) >> 4) * kTileH);
-                            vote = VotePoly(seg, s_chw[vc], y_test, sx0, sy0);
-                        } else {  // line
-                            const float2 a = LoadF2(pts);
-                            const float2 b = LoadF2(pts + 8);
-                            seg = make_float4(a.x, a.y, b.x, b.y);
-                            vote = true;
-                        }
+                    k = (spk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
+                    if (k < L.s_cnseg[vc]) {
+                        ctag = L.s_ctag[vc];
+                        const uint8_t *pts = scene + L.s_cpts[vc];
+                        // Fill: point k to point k + 1, the last one back to point 0 (:262-263); polyline:
+                        // k to k + 1 (:376-377); line: its start and end sit in the item itself
+                        uint32_t ka = k, kb = k + 1u;
+                        if (ctag == kItemFill && kb == L.s_cnpt[vc]) kb = 0u;
+                        if (ctag == kItemLine) ka = 0u, kb = 1u;
+                        a = LoadF2(pts + static_cast<size_t>(ka) * 8);
+                        b = LoadF2(pts + static_cast<size_t>(kb) * 8);
                     }
+                }
+            };
+            uint32_t vc_n, k_n, ctag_n;
+            float2 a_n, b_n;
+            fetch(w_lo + lane, vc_n, k_n, ctag_n, a_n, b_n);
+            for (uint32_t f0 = w_lo; f0 < w_hi; f0 += 64u) {
+                const uint32_t f = f0 + lane;
+                const uint32_t vc = vc_n, k = k_n, ctag_f = ctag_n;
+                float2 a = a_n, b = b_n;
+                fetch(f + 64u, vc_n, k_n, ctag_n, a_n, b_n);
+                bool vote = false;
+                float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ctag_f == kItemFill) {
+                    bool exists = true;
+                    if (L.s_caux0[vc] & kFillCompound) {
+                        // compound (extension D11, pm_layout.h): NaN entries separate sub-paths and start no
+                        // segment; a point followed by a separator closes to the index the separator carries
+                        if (a.x != a.x) exists = false;
+                        else if (b.x != b.x)
+                            b = LoadF2(scene + L.s_cpts[vc] + static_cast<size_t>(min(__float_as_uint(b.y), L.s_cnpt[vc] - 1u)) * 8);
+                    }
+                    if (exists) {
+                        seg = make_float4(a.x, a.y, b.x, b.y);
+                        vote = VoteFill(seg, y0, sx0);
+                    }
+                } else if (ctag_f == kItemPoly) {
+                    seg = make_float4(a.x, a.y, b.x, b.y);
+                    const int y_test = sy0 + static_cast<int>(((k & 31u) >> 4) * kTileH);
+                    vote = VotePoly(seg, L.s_chw[vc], y_test, sx0, sy0);
+                } else if (ctag_f == kItemLine) {
+                    seg = make_float4(a.x, a.y, b.x, b.y);
+                    vote = true;
                 }
                 uint32_t mword = 0;
-                if (f < n_el) {
-                    const uint32_t slot = sbase * kChunkSegs + f;
+                if (f < w_hi) {
                     if (vote) {
-                // Per tile of the strip: (a) can this segment emit a command there -- the
-                // x/box pre-conditions of phase 2 (:334, :349-350, :416-417); (b) for fills,
-                // the backdrop term of :326-333, which the reference accumulates per tile over
-                // EVERY voted segment of the row, is summed once per (item, tile) here.
-                const uint32_t ctag = s_ctag[vc];
-                const uint32_t hm = s_cmask[vc];
-                uint32_t M = 0;
-                const float xmin = fminf(seg.x, seg.z), ymin = fminf(seg.y, seg.w);
-                const float xmax = fmaxf(seg.x, seg.z), ymax = fmaxf(seg.y, seg.w);
-                if (ctag == kItemFill) {
-                    // xmin < fx1 and xmax > fx0 against integer tile edges: exact in integers
-                    const int fl = static_cast<int>(floorf(fmaxf(fminf(xmin, 1048576.0f), -1048576.0f)));
-                    const int ce = static_cast<int>(ceilf(fmaxf(fminf(xmax, 1048576.0f), -1048576.0f)));
-                    const int t_lo = max(0, (fl - sx0) >> 4);                 // first t with x0+16 > xmin
-                    const int t_hi = min(15, ((ce - sx0 + 15) >> 4) - 1);      // last t with x0 < xmax
-                    if (t_hi >= t_lo) M = ((2u << t_hi) - 1u) & ~((1u << t_lo) - 1u);
-                    if (ymin <= fy0) {
-                        // backdrop: sign(line(x0, y0)) == sign(a) holds on a suffix of the tiles
-                        // (every rounding in a*x0 + y0*b + c is monotone in x0), so one bisection
-                        // finds the first tile; there s00 is the same expression, i.e. sign(a).
-                        const float a = seg.w - seg.y;
-                        const float b = seg.x - seg.z;
-                        const float cc = -(a * seg.x + b * seg.y);
-                        const float sa = Sgn(a);
-                        const float yb = fy0 * b;
-                        if (sa != 0.0f) {
-                            int lo = 0, hi = 16;  // first t in [0,16] where the predicate holds
-                            while (lo < hi) {
-                                const int mid = (lo + hi) >> 1;
-                                const float fxm = static_cast<float>(sx0 + mid * static_cast<int>(kTileW));
-                                if (Sgn(a * fxm + yb + cc) == sa) hi = mid; else lo = mid + 1;
+                        // Per tile of the strip: (a) can this segment emit a command there -- the
+                        // x/box pre-conditions of phase 2 (:334, :349-350, :416-417); (b) for fills,
+                        // the backdrop term of :326-333, which the reference accumulates per tile over
+                        // EVERY voted segment of the row, is summed once per (item, tile) here.
+                        const uint32_t ctag = L.s_ctag[vc];
+                        const uint32_t hm = L.s_cmask[vc];
+                        uint32_t M = 0;
+                        const float xmin = fminf(seg.x, seg.z), ymin = fminf(seg.y, seg.w);
+                        const float xmax = fmaxf(seg.x, seg.z), ymax = fmaxf(seg.y, seg.w);
+                        if (ctag == kItemFill) {
+                            // xmin < fx1 and xmax > fx0 against integer tile edges: exact in integers
+                            const int fl = static_cast<int>(floorf(fmaxf(fminf(xmin, 1048576.0f), -1048576.0f)));
+                            const int ce = static_cast<int>(ceilf(fmaxf(fminf(xmax, 1048576.0f), -1048576.0f)));
+                            const int t_lo = max(0, (fl - sx0) >> 4);                 // first t with x0+16 > xmin
+                            const int t_hi = min(15, ((ce - sx0 + 15) >> 4) - 1);      // last t with x0 < xmax
+                            if (t_hi >= t_lo) M = ((2u << t_hi) - 1u) & ~((1u << t_lo) - 1u);
+                            if (ymin <= fy0) {
+                                // backdrop: sign(line(x0, y0)) == sign(a) holds on a suffix of the tiles
+                                // (every rounding in a*x0 + y0*b + c is monotone in x0), so one bisection
+                                // finds the first tile; there s00 is the same expression, i.e. sign(a).
+                                const float a = seg.w - seg.y;
+                                const float b = seg.x - seg.z;
+                                const float cc = -(a * seg.x + b * seg.y);
+                                const float sa = Sgn(a);
+                                const float yb = fy0 * b;
+                                if (sa != 0.0f) {
+                                    int lo = 0, hi = 16;  // first t in [0,16] where the predicate holds
+                                    while (lo < hi) {
+                                        const int mid = (lo + hi) >> 1;
+                                        const float fxm = static_cast<float>(sx0 + mid * static_cast<int>(kTileW));
+                                        if (Sgn(a * fxm + yb + cc) == sa) hi = mid; else lo = mid + 1;
+                                    }
+                                    if (lo < 16) atomicAdd(&L.s_ct[vc * kCtStride + lo], static_cast<uint32_t>(-static_cast<int>(sa)) << kCtShift);
+                                }
                             }
-                            if (lo < 16) atomicAdd(&s_ct[vc * kCtStride + lo], static_cast<uint32_t>(-static_cast<int>(sa)) << kCtShift);
+                        } else if (ctag == kItemPoly) {
+                            const float hw = L.s_chw[vc];
+                            if (ymax > fy0 - hw && ymin < fy1 + hw) {
+                                // tiles t with xmax > fx0(t) - hw && xmin < fx1(t) + hw (:416-417).  Both
+                                // bounds are monotone in t (tile edges are integers, every rounding is
+                                // monotone): the first holds on a prefix of the tiles, the second on a
+                                // suffix -- two bisections with the very expressions, no table of 17 edges.
+                                int lo = 0, hi = 16;  // tiles where the first condition holds: [0, lo)
+                                while (lo < hi) {
+                                    const int mid = (lo + hi) >> 1;
+                                    if (xmax > static_cast<float>(sx0 + mid * static_cast<int>(kTileW)) - hw) lo = mid + 1; else hi = mid;
+                                }
+                                const int t_end = lo;
+                                lo = 0, hi = 16;      // ... the second: [lo, 16)
+                                while (lo < hi) {
+                                    const int mid = (lo + hi) >> 1;
+                                    if (xmin < static_cast<float>(sx0 + (mid + 1) * static_cast<int>(kTileW)) + hw) hi = mid; else lo = mid + 1;
+                                }
+                                if (lo < t_end) M = ((1u << t_end) - 1u) & ~((1u << lo) - 1u);
+                            }
+                        } else {
+                            M = 0xffffu;  // a line is tested by every tile its bbox hits (:223-247)
                         }
-                    }
-                } else if (ctag == kItemPoly) {
-                    const float hw = s_chw[vc];
-                    if (ymax > fy0 - hw && ymin < fy1 + hw) {
-#pragma unroll 4
-                        for (uint32_t t = 0; t < kStripTiles; ++t) {
-                            const float fx0 = static_cast<float>(sx0 + static_cast<int>(t * kTileW));
-                            const float fx1 = static_cast<float>(sx0 + static_cast<int>((t + 1) * kTileW));
-                            if (xmax > fx0 - hw && xmin < fx1 + hw) M |= 1u << t;
-                        }
-                    }
-                } else {
-                    M = 0xffffu;  // a line is tested by every tile its bbox hits (:223-247)
-                }
-                M &= hm;
-                        segs[slot] = seg;
+                        M &= hm;
+                        segs[f] = seg;
                         mword = M | (vc << 16) | 0x80000000u;  // bit 31: a voted segment lives here
                     }
-                    meta[slot] = mword;
+                    meta[f] = mword;
                 }
                 // relevant-segment counts per (candidate, tile).  The 8 lanes of a chunk share one
                 // candidate: spread the 16 tile bits to 16 nibbles (64 bits), add the 8 lanes with
                 // three DPP steps (8 <= 15 fits a nibble), and let lane j of the chunk add the counts
                 // of tiles 2j and 2j+1 -- ~40 instructions instead of 16 ballots per distinct candidate.
+                const uint32_t mm = mword & 0xffffu;
                 {
                     static_assert(kChunkSegs == 8, "one chunk = 8 lanes");
-                    const uint32_t mm = mword & 0xffffu;
                     uint32_t lo8 = SpreadNibbles(mm & 0xffu), hi8 = SpreadNibbles(mm >> 8);
                     lo8 += DppQuadXor1(lo8); hi8 += DppQuadXor1(hi8);
                     lo8 += DppQuadXor2(lo8); hi8 += DppQuadXor2(hi8);
                     lo8 += DppHalfMirror(lo8); hi8 += DppHalfMirror(hi8);
                     const uint32_t j = lane & 7u;
                     const uint32_t two = (((j < 4u) ? lo8 : hi8) >> (8u * (j & 3u))) & 0xffu;
-                    if (f < n_el && two) {
-                        uint32_t *row = &s_ct[vc * kCtStride + 2u * j];
-                        if (two & 15u) atomicAdd(row, two & 15u);
-                        if (two >> 4) atomicAdd(row + 1, two >> 4);
+                    if (f < w_hi && two) {
+                        // (and per wave share and tile: what the scatter below starts from)
+                        uint32_t *row = &L.s_ct[vc * kCtStride + 2u * j];
+                        uint32_t *wrow = &L.s_wcnt[wave][2u * j];
+                        if (two & 15u) {
+                            atomicAdd(row, two & 15u);
+                            atomicAdd(wrow, two & 15u);
+                        }
+                        if (two >> 4) {
+                            atomicAdd(row + 1, two >> 4);
+                            atomicAdd(wrow + 1, two >> 4);
+                        }
                     }
                 }
             }
-            if (kProfile && r0 == 0) {
-                stamp(11);
-                if (tid == 0) PM_PP(dbg_bin)[12ull * sr + 6] = n_el;  // (slot 6: elements of round 0)
-            }
-            sbase += ns;
-            __syncthreads();  // s_surv is rewritten by the next round
         }
-        if (tid == 0) hdr[3] = sbase * kChunkSegs;  // slots the tile kernel has to scan
-        __syncthreads();  // every wave's s_ct contributions are in
+        LdsBarrier();  // every wave's L.s_ct contributions and L.s_wcnt are in
         stamp(3);  // segment stream done
         if (kProfile) prof_chunks += total_ch;
 
-        // ---- candidate records, per-(candidate, tile) table, mask table ------------------------
-        if (tid < mask_dwords) {
-            uint32_t w0 = 0;
-            if (tid < ncand) {
-                // keep a hit bit only where the candidate can emit something: a relevant
-                // segment, a non-zero backdrop (Solid / DrawFill), or a circle
-                uint32_t hm = 0;
-                int run = 0;  // backdrop steps were recorded at the first tile they apply to
-                const uint32_t cm = s_cmask[tid];
-                const uint32_t tag = s_ctag[tid], rgba = s_crgba[tid];
-                const bool opaque = (rgba & 0xff000000u) == 0xff000000u;
-                const bool even_odd = tag == kItemFill && (s_caux0[tid] & kFillEvenOdd) != 0;
-                uint4 *ctw = reinterpret_cast<uint4 *>(ct_tab + kCtDwords * tid);
-#pragma unroll 1
-                for (uint32_t q = 0; q < 4; ++q) {
-                    uint32_t ct[4];
+        // ---- the tiles' pieces of this record: reserved NOW (tail wave), so that the atomic's round trip
+        //      runs under the candidates pass.  Segments per tile are known (L.s_wcnt); candidates only by
+        //      their upper bound (bbox masks, L.s_whub): a piece is {header, segments, candidates} and the
+        //      slack sits unused behind the candidates it really gets ----------------------------------------
+        constexpr uint32_t kTailWave = kBinWaves - 1;  // (its share of the slots is the one that may be short)
+        uint32_t nrel_t = 0, pq_rel = 0, alloc_q = 0, alloc_total = 0;  // tail wave, lane t < 16
+        if (wave == kTailWave) {
+            uint32_t nhub = 0;
+            if (lane < kStripTiles) {
 #pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k) {
-                        const uint32_t t = 4 * q + k;
-                        const uint32_t raw = s_ct[tid * kCtStride + t];
-                        const uint32_t cnt = raw & kCtCountMask;
-                        run += static_cast<int>(raw) >> kCtShift;
-                        ct[k] = (static_cast<uint32_t>(run) << kCtShift) | cnt;
-                        // a tile wholly inside a fill is covered if its winding is non-zero / odd
-                        const bool pseudo = tag == kItemCircle || (tag == kItemFill && (even_odd ? (run & 1) != 0 : run != 0));
-                        uint32_t n_el = cnt ? cnt : (pseudo ? 1u : 0u);
-                        if (!((cm >> t) & 1u) || tag == 0) n_el = 0;
-                        if (n_el) hm |= 1u << t;
-                        // for the per-tile pass below: elements | "is nothing but an opaque Solid" << 31
-                        s_ct[tid * kCtStride + t] = n_el | ((n_el && tag == kItemFill && cnt == 0 && opaque) ? 0x80000000u : 0u);
-                    }
-                    ctw[q] = make_uint4(ct[0], ct[1], ct[2], ct[3]);
+                for (uint32_t w = 0; w < static_cast<uint32_t>(kBinWaves); ++w) {
+                    nrel_t += L.s_wcnt[w][lane];
+                    nhub += L.s_whub[w][lane];
                 }
-                w0 = tag | (hm << 16);
-                const uint32_t rg = (s_lut[rgba & 0xffu] & 0xffffu) | (s_lut[(rgba >> 8) & 0xffu] << 16);
-                const uint32_t ba = (s_lut[(rgba >> 16) & 0xffu] & 0xffffu) | (s_lut[rgba >> 24] & 0xffff0000u);
-                uint4 *cr = reinterpret_cast<uint4 *>(cand_rec + kCandDwords * tid);
-                cr[0] = make_uint4(w0, rgba, s_caux0[tid], s_caux1[tid]);
-                cr[1] = make_uint4(s_cidx[tid], 0u, rg, ba);
-                s_cpts[tid] = rgba;  // (points offsets are no longer needed) colour for the solid test
             }
-            mask_tab[tid] = w0;
+            const uint32_t quads = nhub ? 1u + nrel_t + 2u * nhub : 0u;
+            const uint32_t incl = WaveInclusiveScan(quads);
+            alloc_total = WaveLast(incl);
+            pq_rel = incl - quads;
+            if (alloc_total && lane == 0) alloc_q = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, alloc_total);  // (looked at after the pass below)
         }
-        __syncthreads();
-        // ---- per tile, in paint order: elements queued, last candidate that can emit, last one
-        //      that is nothing but an opaque Solid.  thread = (tile, slice of the candidates)
+
+        // ---- candidates pass, thread = candidate.  Per tile of the strip: the backdrop (prefix of the
+        //      recorded steps), whether the candidate can emit anything there (its hit bit), whether it
+        //      is nothing but an opaque Solid; ballots over the wave's candidates give, per tile, the
+        //      candidates of its piece, the pseudo elements (candidates without segments), the last
+        //      candidate that can emit and the last opaque Solid ---------------------------------------------
+        uint32_t hm = 0;  // this candidate's hit bits
         {
-            const uint32_t t = tid & (kStripTiles - 1u), sl = tid >> 4;
-            uint32_t est_p = 0, lk = 0, ls = 0;
-            for (uint32_t c = sl; c < ncand; c += kThreads / kStripTiles) {
-                const uint32_t v = s_ct[c * kCtStride + t];
-                if (v) {
-                    est_p += v & 0x7fffffffu;
-                    lk = c + 1u;
-                    if (v >> 31) ls = c + 1u;
+            uint32_t wh = 0, we = 0, wlk = 0, wls = 0;  // lane t < 16: this wave's totals for tile t
+            if (wave * 64u < ncand) {  // uniform: the wave holds candidates
+                // (Opaque: LDS addresses derived from it are made here, not at kernel entry and spilled)
+                const uint32_t tid = Opaque(threadIdx.x);
+                // (threads beyond the candidates read stale rows: with an empty bbox mask nothing of it counts)
+                const uint32_t cm = tid < ncand ? L.s_cmask[tid] : 0u;
+                const uint32_t tag = L.s_ctag[tid], rgba = L.s_crgba[tid];
+                const uint32_t fill_bit = tag == kItemFill ? 1u : 0u;
+                const uint32_t circle_bit = tag == kItemCircle ? 1u : 0u;
+                const uint32_t opaque_bit = (rgba & 0xff000000u) == 0xff000000u ? fill_bit : 0u;
+                // a tile wholly inside a fill is covered if its winding is non-zero (all bits) / odd (bit 0)
+                const uint32_t rule = (L.s_caux0[tid] & kFillEvenOdd) ? 1u : 0xffffffffu;
+                uint32_t *const ct_row = &L.s_ct[tid * kCtStride];
+                uint32_t sm = 0, zm = 0;  // nothing but an opaque Solid / hit without segments
+                int run = 0;  // backdrop steps were recorded at the first tile they apply to
+                ForStripTiles([&](auto tc) {
+                    constexpr uint32_t t = decltype(tc)::value;
+                    const uint32_t raw = ct_row[t];
+                    const uint32_t cnt = raw & kCtCountMask;
+                    run += static_cast<int>(raw) >> kCtShift;
+                    ct_row[t] = (static_cast<uint32_t>(run) << kCtShift) | cnt;
+                    const uint32_t inside = (static_cast<uint32_t>(run) & rule) != 0u ? fill_bit : 0u;
+                    // a hit bit only where the candidate can emit something: a relevant segment, a
+                    // non-zero backdrop (Solid / DrawFill), or a circle
+                    const uint32_t some = (cnt != 0u ? 1u : 0u) | inside | circle_bit;
+                    const uint32_t hit = some & (cm >> t) & 1u;
+                    const uint32_t nos = cnt == 0u ? hit : 0u;
+                    hm |= hit << t;
+                    zm |= nos << t;
+                    sm |= (nos & opaque_bit) << t;
+                });
+                const uint32_t wbase = WaveId() * 64u + 64u;
+                ForStripTiles([&](auto tc) {
+                    constexpr uint32_t t = decltype(tc)::value;
+                    const uint64_t bh = __ballot((hm >> t) & 1u), bz = __ballot((zm >> t) & 1u), bs = __ballot((sm >> t) & 1u);
+                    WriteLane<t>(wh, static_cast<uint32_t>(__popcll(bh)));
+                    WriteLane<t>(we, static_cast<uint32_t>(__popcll(bz)));
+                    WriteLane<t>(wlk, bh ? wbase - static_cast<uint32_t>(__builtin_clzll(bh)) : 0u);  // candidate index + 1
+                    WriteLane<t>(wls, bs ? wbase - static_cast<uint32_t>(__builtin_clzll(bs)) : 0u);
+                });
+                if (tid < ncand) {
+                    L.s_cmask[tid] = hm | (sm << 16);
+                    // the colour already through unpack_unorm4x8_srgb_to_half
+                    L.s_cpts[tid] = (L.s_lut[rgba & 0xffu] & 0xffffu) | (L.s_lut[(rgba >> 8) & 0xffu] << 16);         // rg
+                    L.s_cnpt[tid] = (L.s_lut[(rgba >> 16) & 0xffu] & 0xffffu) | (L.s_lut[rgba >> 24] & 0xffff0000u);  // ba
                 }
             }
-            uint32_t *part = &s_surv[0][0];  // (free during finalisation) [3][16 slices][16 tiles]
-            part[sl * kStripTiles + t] = est_p;
-            part[256 + sl * kStripTiles + t] = lk;
-            part[512 + sl * kStripTiles + t] = ls;
-            __syncthreads();
-            if (tid < kStripTiles) {
-                uint32_t est = 0, lkm = 0, lsm = 0;
+            if (lane < kStripTiles) {
+                L.s_wh[wave][lane] = wh;
+                L.s_we[wave][lane] = we;
+                L.s_wlk[wave][lane] = wlk;
+                L.s_wls[wave][lane] = wls;
+            }
+        }
+        // the tail wave: where the pieces went
+        if (wave == kTailWave) {
+            uint32_t base_q = 1u;
+            if (alloc_total) {  // uniform
+                base_q = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(alloc_q))) + 1u;  // (quad 0 stays unused: 0 = "no piece")
+                if (!(base_q + alloc_total <= PM_PU(tarena_cap) && base_q + alloc_total >= base_q)) base_q = 0xffffffffu;
+            }
+            if (lane < kStripTiles) {
+                L.s_piece_q[lane] = base_q != 0xffffffffu ? base_q + pq_rel : 0u;
+                L.s_piece_n[lane] = nrel_t;  // (segments; the candidates of the piece are known after the barrier)
+            }
+            if (lane == 0) {
+                L.s_alloc[0] = base_q;
+                if (base_q == 0xffffffffu) L.s_alloc[1] = 1u;
+            }
+        }
+        LdsBarrier();  // hit bits, per-wave totals, pieces
+        if (kProfile) stamp(12);
+        const uint32_t base_q = L.s_alloc[0];
+        const bool last_record = !more;  // uniform
+        // ---- the tail wave: piece headers, the strip row's running estimates; after the strip row's
+        //      LAST record also the row's tail -- classes, command-list space, queue entries -- while
+        //      the other waves already place candidates and segments --------------------------------------
+        if (wave == kTailWave) {
+            uint32_t nh = 0, ne = 0, lkm = 0, lsm = 0;
+            uint32_t hdr_q = 0, hdr_prev = 0, hdr_n = 0;
+            if (lane < kStripTiles) {
 #pragma unroll
-                for (uint32_t q = 0; q < kThreads / kStripTiles; ++q) {
-                    est += part[q * kStripTiles + tid];
-                    lkm = max(lkm, part[256 + q * kStripTiles + tid]);
-                    lsm = max(lsm, part[512 + q * kStripTiles + tid]);
+                for (uint32_t w = 0; w < static_cast<uint32_t>(kBinWaves); ++w) {
+                    nh += L.s_wh[w][lane];
+                    ne += L.s_we[w][lane];
+                    lkm = max(lkm, L.s_wlk[w][lane]);
+                    lsm = max(lsm, L.s_wls[w][lane]);
                 }
-                s_est[tid] += est;
-                if (lkm) s_last_kept[tid] = s_cidx[lkm - 1u] + 1u;  // records come in paint order
+                L.s_est[lane] += nrel_t + ne;
+                if (lkm) L.s_last_kept[lane] = L.s_cidx[lkm - 1u] + 1u;  // records come in paint order
                 if (lsm) {
-                    s_last_solid[tid] = s_cidx[lsm - 1u] + 1u;
-                    s_solid_rgba[tid] = s_cpts[lsm - 1u];
+                    L.s_last_solid[lane] = L.s_cidx[lsm - 1u] + 1u;
+                    L.s_solid_rgba[lane] = L.s_crgba[lsm - 1u];
+                }
+                if (nh && base_q != 0xffffffffu) {
+                    // this piece's header (no successor yet); the tile's previous piece learns about it
+                    // (the stores follow the tail's atomic: an atomic issued after them would wait for them)
+                    const uint32_t pq = base_q + pq_rel;
+                    const uint32_t pn = nh | (nrel_t << kPieceHitBits);
+                    hdr_q = pq;
+                    hdr_prev = L.s_prev_q[lane];
+                    hdr_n = pn;
+                    if (!hdr_prev) {
+                        L.s_head_q[lane] = pq;
+                        L.s_head_n[lane] = pn;
+                    }
+                    L.s_prev_q[lane] = pq;
+                }
+            }
+            if (last_record) RowTail();
+            if (hdr_q) {
+                PM_PP(tarena)[hdr_q] = make_uint4(0u, 0u, 0u, 0u);
+                if (hdr_prev) *reinterpret_cast<uint2 *>(PM_PP(tarena) + hdr_prev) = make_uint2(hdr_q, hdr_n);
+            }
+        }
+        if (base_q != 0xffffffffu) {  // uniform (else: the tile arena ran out; the strip row's tiles are marked "no list")
+            // (the scatter's first slots are requested before the candidate entries are stored: loads
+            //  issued after stores wait for the stores' acknowledgements)
+            uint32_t mw_n = 0;
+            float4 seg_n = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w_lo + lane < w_hi) {
+                mw_n = meta[w_lo + lane];  // (this wave wrote it)
+                seg_n = segs[w_lo + lane];
+            }
+            // ---- candidate entries, thread = candidate: its rank among the tile's candidates is a
+            //      ballot away; two quads per (candidate, tile) behind the piece's segments ------------------
+            if (wave * 64u < ncand) {  // uniform
+                const uint32_t tid = Opaque(threadIdx.x);
+                const bool is_c = tid < ncand;
+                uint4 e0 = make_uint4(0u, 0u, 0u, 0u);
+                uint32_t e1y = 0, e1z = 0, e1w = 0;
+                if (is_c) {
+                    e0 = make_uint4(L.s_ctag[tid], L.s_crgba[tid], L.s_caux0[tid], L.s_caux1[tid]);
+                    e1y = L.s_cidx[tid];
+                    e1z = L.s_cpts[tid];
+                    e1w = L.s_cnpt[tid];
+                }
+                // lane t < 16: quad of the first candidate entry this wave writes for tile t
+                uint32_t cq = 0;
+                if (lane < kStripTiles) {
+                    uint32_t before = 0;
+                    for (uint32_t w = 0; w < wave; ++w) before += L.s_wh[w][lane];
+                    cq = L.s_piece_q[lane] + 1u + L.s_piece_n[lane] + 2u * before;
+                }
+                const uint32_t *const ct_row = &L.s_ct[(is_c ? tid : 0u) * kCtStride];
+                ForStripTiles([&](auto tc) {
+                    constexpr uint32_t t = decltype(tc)::value;
+                    const bool hit = (hm >> t) & 1u;
+                    const uint64_t bh = __ballot(hit);
+                    const uint32_t q0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cq), static_cast<int>(t)));
+                    if (hit) {
+                        uint4 *e = PM_PP(tarena) + q0 + 2u * RankBelow(bh);
+                        e[0] = e0;
+                        e[1] = make_uint4(ct_row[t], e1y, e1z, e1w);
+                    }
+                });
+            }
+            // ---- scatter: every relevant (segment, tile) pair to its place in the tile's piece; lane
+            //      t < 16 keeps the quad of the next segment of tile t written by this wave.  The next
+            //      round's slots are fetched while this round's are placed ------------------------------------
+            {
+                uint32_t next_q = 0;
+                if (lane < kStripTiles) {
+                    uint32_t before = 0;
+                    for (uint32_t w = 0; w < wave; ++w) before += L.s_wcnt[w][lane];
+                    next_q = L.s_piece_q[lane] + 1u + before;
+                }
+                for (uint32_t f0 = w_lo; f0 < w_hi; f0 += 64u) {
+                    const uint32_t mm = mw_n & 0xffffu;
+                    const float4 seg = seg_n;
+                    const uint32_t fn = f0 + 64u + lane;
+                    mw_n = 0;
+                    if (fn < w_hi) {
+                        mw_n = meta[fn];
+                        seg_n = segs[fn];
+                    }
+                    // the tiles present among the 64 slots, one round each
+                    uint32_t present = 0;
+                    {
+                        uint32_t u = mm;  // OR over the wave (DPP within rows, then the row totals)
+                        u |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), 0x111, 0xf, 0xf, true));
+                        u |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), 0x112, 0xf, 0xf, true));
+                        u |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), 0x114, 0xf, 0xf, true));
+                        u |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), 0x118, 0xf, 0xf, true));
+                        present = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(u), 15)) |
+                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(u), 31)) |
+                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(u), 47)) |
+                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(u), 63));
+                    }
+                    while (present) {  // uniform
+                        const uint32_t t = static_cast<uint32_t>(__builtin_ctz(present));
+                        present &= present - 1u;
+                        const bool mine = (mm >> t) & 1u;
+                        const uint64_t b = __ballot(mine);
+                        const uint32_t q0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(next_q), static_cast<int>(t)));
+                        if (mine) *reinterpret_cast<float4 *>(PM_PP(tarena) + q0 + RankBelow(b)) = seg;
+                        if (lane == t) next_q += static_cast<uint32_t>(__popcll(b));
+                    }
                 }
             }
         }
-        __syncthreads();  // s_c* arrays are rewritten by the next record
-        stamp(4);  // record finalised
+        if (!more) {  // the strip row's last record: nothing left to wait for (its stores drain on their own)
+            tail_done = true;
+            stamp(4);  // record finalised
+            break;
+        }
+        LdsBarrier();  // s_c* arrays are rewritten by the next record
+        stamp(4);
+        prof_first = false;
         ncand = 0;
-        if (!more) break;
         if (cand) {  // the scan step that did not fit opens the next record
-            s_cidx[cpos] = i;
-            s_cmask[cpos] = mask;
+            L.s_cidx[cpos] = i;
+            L.s_cmask[cpos] = mask;
         }
         ncand = nb;
     }
-    if (tid == 0) {
-        PM_PP(striprow_head)[sr] = head;
-        atomicAdd(&PM_PP(ctr_cur)->arena_top, cursor - region_begin);  // dwords used (stats only)
+    if (tid == 0) atomicAdd(&PM_PP(ctr_cur)->arena_top, cursor - region_begin);  // dwords used (stats only)
+    // the strip row's tail, unless its last record took care of it
+    if (!tail_done) {  // uniform
+        LdsBarrier();  // L.s_est, s_last_*, s_head_* of the last record are in
+        if (wave == kBinWaves - 1) RowTail();
     }
-
-    // ---- queue the tiles with something to draw, mark the others --------------------------
-    // One wave is enough: lane t owns tile t of the strip row; the class masks are ballots, the
-    // command-list offsets a wave scan, and the atomics' results travel by v_readlane.
-    __syncthreads();  // s_est, s_last_* of the last record are in
-    if (wave != 0) return;
-    const uint32_t tiles_here = min(kStripTiles, PM_PU(tiles_x) - strip * kStripTiles);
-    const bool tile_lane = lane < tiles_here;
-    const uint32_t est = tile_lane ? s_est[lane] : 0u;
-    // {Solid(opaque)} -> Bail: the tile is one opaque colour (TileEncoder::end, :144-151)
-    const bool is_solid = est != 0 && s_last_kept[lane & (kStripTiles - 1u)] == s_last_solid[lane & (kStripTiles - 1u)];
-    const bool is_queued = est != 0 && !is_solid;
-    // cost class of the tile's list (0 = longest): the number of thresholds the estimate does not exceed
-    static_assert(kClasses == 8, "seven thresholds spelled out below");
-#define PM_THR(k) ((est <= ParamU32<offsetof(FrameParams, class_thr) + 4 * (k)>(PR)) ? 1u : 0u)
-    const uint32_t cls = PM_THR(0) + PM_THR(1) + PM_THR(2) + PM_THR(3) + PM_THR(4) + PM_THR(5) + PM_THR(6);
-#undef PM_THR
-    uint32_t my_mask = 0;    // queued tiles of this lane's class
-    uint32_t lane_cnt = 0;   // lane c < kClasses: tiles of class c in this strip row
-    uint32_t queued = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kClasses; ++k) {
-        const uint32_t mk = static_cast<uint32_t>(__ballot(is_queued && cls == k));
-        if (cls == k) my_mask = mk;
-        if (lane == k) lane_cnt = static_cast<uint32_t>(__popc(mk));
-        queued |= mk;
-    }
-    // command-list slots of a queued tile: an element emits at most 2 commands + its item's
-    // closing command, plus End
-    const uint32_t slots = is_queued ? 3u * est + 1u : 0u;
-    const uint32_t slots_incl = WaveInclusiveScan(slots);
-    const uint32_t qtotal = WaveLast(slots_incl);
-    // list space and the class queue positions: ONE atomic instruction, a lane per counter
-    uint32_t qres = 0;
-    if (queued) {  // uniform
-        if (lane < kClasses && lane_cnt) qres = atomicAdd(&PM_PP(ctr_cur)->cls[lane].count, lane_cnt);
-        if (lane == kClasses) qres = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, qtotal);
-    }
-    // tiles with nothing to draw are background: no item touches them, or every touching
-    // item lost all its segments in phase 1 (the reference writes Bail/white for them).  Their
-    // pixels are written by pm_clear_kernel from tile_state: 25 MB of stores per 4K frame that
-    // would otherwise stall these latency-bound workgroups in bursts.
-    const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + lane;
-    if (tile_lane)  // what this kernel decided per tile: 0 = queued, else the tile's colour
-        PM_PP(tile_state)[tile] = is_queued ? 0u : (is_solid ? s_solid_rgba[lane] : 0xffffffffu);
-    if (queued) {
-        const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), kClasses));
-        const uint32_t q_base = static_cast<uint32_t>(__shfl(static_cast<int>(qres), static_cast<int>(cls)));  // my class's queue position
-        const bool fits = base + qtotal <= PM_PU(ptcl_cap) && base + qtotal >= base;
-        // (on overflow the tiles are still queued but marked "no list": the tile kernels skip
-        //  them, the frame has holes, and pm_sync re-renders it with a larger arena)
-        if (!fits && lane == 0) PM_PP(ctr_cur)->overflow = 1;
-        if (is_queued) {
-            const uint32_t list_slot = fits ? base + (slots_incl - slots) : 0xffffffffu;
-            PM_PP(tile_ptcl)[tile] = list_slot;
-            // A queue entry is everything the tile kernels need to start: {tile, first command
-            // slot, first binning record of the strip row, commands written (pm_coarse_kernel)}
-            const uint4 entry = make_uint4(tile, list_slot, head, 0u);
-            const uint32_t below = (1u << lane) - 1u;
-            PM_PP(queue)[cls * PM_PU(queue_cap) + q_base + __popc(my_mask & below)] = entry;
-        }
-    }
-    stamp(5);  // queues + list slots done
     (void)prof_chunks;
-    stamp(7);
+    if (kProfile) {
+        // wave 0's stamps (0 entry, 1 item scan done, 2 first record's headers done, 8 / 9 chunk tests of
+        // round 0, 10 survivors listed (6: slots), 3 votes done, 12 candidates pass done, 4 entries +
+        // scatter done, 7 exit), then the tail wave's own end (14)
+        stamp(7);
+        if (tid < 14) PM_PP(dbg_bin)[16ull * sr + tid] = L.s_stamp[tid];
+        if (wave == kBinWaves - 1 && lane == 0) PM_PP(dbg_bin)[16ull * sr + 14] = wall_clock64();
+    }
 }
 
 // =====================================================================================

@@ -39,9 +39,8 @@ __global__ __launch_bounds__(kThreads, PM_COARSE_WPS) void pm_coarse_kernel(Fram
 #pragma unroll
         for (uint32_t k = 1; k < kClasses; ++k)
             if (slot >= cls_end[k - 1]) qix = k * P.queue_cap + (slot - cls_end[k - 1]);
-        uint4 *const qentry = P.queue + qix;
-        const uint4 qe = Scalar4(*qentry);
-        CoarseTile<kCapture>(P, L, qentry, qe, lane, lanes_below);
+        const uint4 qe = Scalar4(P.queue[qix]);
+        CoarseTile<kCapture>(P, L, qe, lane, lanes_below);
         WaveSync();  // L reuse by the next tile
     }
 }

@@ -8,17 +8,15 @@ namespace pm {
 namespace {
 
 constexpr uint32_t kWaveCands = 64;  // candidates handled per pass
-constexpr uint32_t kRing = 256;      // >= 64 (one round) + 127 (scan overshoot), power of two
 
 struct CoarseLds {
-    uint32_t ring[kRing];     // indices of the record's segments relevant to this tile
-    uint8_t hidx[kThreads];   // candidates of the record that hit this tile (indices)
+    float4 segw[64];          // the first 64 segments of a piece, fetched together with its candidates
     uint32_t htag[kWaveCands];
     uint32_t hrgba[kWaveCands];
     uint32_t haux0[kWaveCands];
     uint32_t haux1[kWaveCands];
     uint32_t hrel[kWaveCands];   // relevant segments of the candidate in this tile
-    uint32_t hwoff[kWaveCands];  // index of its first relevant segment (ring position)
+    uint32_t hwoff[kWaveCands];  // index of its first relevant segment in the piece
     uint32_t hcnt[kWaveCands];   // stream elements (relevant segments, or 1 pseudo element)
     uint32_t hrg[kWaveCands];
     uint32_t hba[kWaveCands];
@@ -33,11 +31,11 @@ struct CoarseLds {
 // interpret -- empty, Bail tile already painted here, or arena overflow).
 // Developer timeline (kProf instantiations only): 10 ns ticks per stage of the list building
 struct CoarseTicks {
-    unsigned long long hdr = 0;    // record header + mask table + candidates that hit the tile
-    unsigned long long cand = 0;   // candidate records + their scans
+    unsigned long long hdr = 0;    // (unused since the tile's piece arrives in one batch of loads)
+    unsigned long long cand = 0;   // piece header + candidates + first segments: loads and scans
     unsigned long long owner = 0;  // round: owners of the stream elements
-    unsigned long long scan = 0;   // round: worklist of relevant segments (meta scan)
-    unsigned long long seg = 0;    // round: segment load + phase-2 tests
+    unsigned long long scan = 0;   // (unused: binning leaves the tile's segments in paint order)
+    unsigned long long seg = 0;    // round: segment fetch + phase-2 tests
     unsigned long long emit = 0;   // round: closing commands, slots, stores
     unsigned long long rounds = 0, records = 0;
 };
@@ -51,7 +49,7 @@ struct CoarseTicks {
 constexpr uint32_t kLdsChunks = 3;
 
 template <bool kCapture, bool kProf = false>
-__device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &L, uint4 *const qentry, const uint4 qe,
+__device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &L, const uint4 qe,
                                                const uint32_t lane, const uint64_t lanes_below, CoarseTicks *ticks = nullptr,
                                                uint8_t *const lds_chunks = nullptr, const uint32_t lds_stride = 0) {
     auto lds_put = [&](uint32_t q, const Cmd &c) {
@@ -61,10 +59,10 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
     unsigned long long tk0 = 0, tk1 = 0;
     const uint32_t tile = qe.x;
     if (qe.y == 0xffffffffu) {  // the command-list arena overflowed (pm_sync re-renders the frame)
-        if (lane == 0) qentry->w = 0;
+        if (lane == 0) P.tile_ncmd[tile] = 0;
         return 0;
     }
-    Cmd *const out_cmds = P.ptcl + qe.y;  // this tile's private command slots
+    Cmd *const out_cmds = reinterpret_cast<Cmd *>(P.tarena + qe.y);  // this tile's private command slots
     const uint32_t tx = tile % P.tiles_x;
     const uint32_t ty_rel = tile / P.tiles_x;
     const uint32_t ty = P.row0 + ty_rel;
@@ -73,86 +71,48 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
     const float fx0 = static_cast<float>(x0), fy0 = static_cast<float>(y0);
     const float fx1 = static_cast<float>(x0 + static_cast<int>(kTileW));
     const float fy1 = static_cast<float>(y0 + static_cast<int>(kTileH));
-    const uint32_t tbit = tx & (kStripTiles - 1);
 
     uint32_t solid_color = 0xffffffffu;  // TileEncoder::solidColor (:74)
     uint32_t n_pending = 0;              // commands written to the tile's list so far
     uint32_t list_len = 0;               // logical list length since tileBegin (capture)
 
-    uint32_t rec = qe.z;  // (= striprow_head[sr])
-    while (rec != 0) {
+    // The tile's pieces, one per binning record of its strip row (almost always one): the candidates
+    // that can emit here and their relevant segments, contiguous and in paint order.
+    uint32_t piece = qe.z;
+    uint32_t piece_n = qe.w;
+    while (piece != 0) {
         PM_CT_TICK(tk0);
-        // header and mask table sit next to each other: all loads are in flight together.
-        // (Requesting the NEXT record's pair here as well saves 0.4 us per tile at 128 VGPRs and
-        //  costs more than that in spills at the 96 the fused kernel is built for.)
-        const uint4 hdr = Scalar4(*reinterpret_cast<const uint4 *>(P.arena + rec));
-        const uint4 mk = *reinterpret_cast<const uint4 *>(P.arena + rec + kRecHdrDwords + 4u * Opaque(lane));
-        const uint32_t next = hdr.x;
-        const uint32_t ncand = hdr.y;
-        const uint32_t mask_dwords = (ncand + 3u) & ~3u;
-        const uint32_t *cand_rec = P.arena + rec + kRecHdrDwords + mask_dwords;
-        const uint32_t *ct_tab = cand_rec + kCandDwords * ncand;
-        const float4 *segs = reinterpret_cast<const float4 *>(ct_tab + kCtDwords * ncand);
-        const uint32_t *meta = reinterpret_cast<const uint32_t *>(segs + kChunkSegs * hdr.z);
-        // Worklist of the segments that matter to THIS tile: the record's segment slots are
-        // scanned linearly (2 meta words per lane per step, independent loads) and the slots
-        // carrying this tile's bit are kept, in paint order, in a small LDS ring.
-        const uint32_t n_slots = hdr.w;
-        // (the first 128 words of the scan are requested now: they arrive with the candidate records
-        //  instead of costing a memory round trip of their own when the first round asks for them)
-        uint2 mv_first = make_uint2(OpaqueZero(), OpaqueZero());
-        if (2u * lane < n_slots) mv_first = *reinterpret_cast<const uint2 *>(meta + 2u * lane);
-        uint32_t scan_pos = 0;  // next segment to scan
-        uint32_t ring_cnt = 0;  // relevant segments found so far (ring write position)
+        const uint32_t nhit = piece_n & kPieceHitMask, nrel = piece_n >> kPieceHitBits;
+        const uint4 *const pc = P.tarena + piece;
+        const float4 *const segs = reinterpret_cast<const float4 *>(pc + 1u);  // {header, segments, candidates}
+        const uint4 *const cands = pc + 1u + nrel;
+        // header (the next piece), the first 64 candidates and the first 64 segments: all in flight together
+        const uint4 hdr = Scalar4(*pc);
+        float4 seg_first = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (Opaque(lane) < nrel) seg_first = segs[Opaque(lane)];
         uint32_t rel_done = 0;  // relevant segments owned by earlier candidate passes
-
-        // ---- candidates that hit this tile, in paint order (lane owns 4 consecutive) ------
-        const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
-        uint32_t hbits = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k)
-            if (4u * lane + k < ncand && ((mw[k] >> (16 + tbit)) & 1u)) hbits |= 1u << k;
-        const uint32_t hcount = __popc(hbits);
-        const uint32_t hincl = WaveInclusiveScan(hcount);
-        const uint32_t nhit = WaveLast(hincl);
-        if (kProf) {
-            tk1 = wall_clock64();
-            ticks->hdr += tk1 - tk0;
-            ticks->records += 1;
-        }
-        if (nhit == 0) {
-            rec = next;
-            continue;
-        }
-        WaveSync();
-        {
-            uint32_t hp = hincl - hcount;
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k)
-                if ((hbits >> k) & 1u) L.hidx[hp++] = static_cast<uint8_t>(4u * lane + k);
-        }
-        WaveSync();
+        if (kProf) ticks->records += 1;
 
         for (uint32_t cb = 0; cb < nhit; cb += kWaveCands) {
-            PM_CT_TICK(tk0);
+            if (cb != 0) PM_CT_TICK(tk0);
             const uint32_t nh = min(kWaveCands, nhit - cb);
             if (lane < nh) {
-                const uint4 *cr = reinterpret_cast<const uint4 *>(cand_rec + kCandDwords * L.hidx[cb + lane]);
+                const uint4 *cr = cands + 2u * (cb + lane);
                 const uint4 a = cr[0];
                 const uint4 b = cr[1];
                 L.htag[lane] = a.x & 0xffffu;
                 L.hrgba[lane] = a.y;
                 L.haux0[lane] = a.z;
                 L.haux1[lane] = a.w;
-                const uint32_t ct = ct_tab[kCtDwords * L.hidx[cb + lane] + tbit];
-                const uint32_t rel = ct & kCtCountMask;
+                const uint32_t rel = b.x & kCtCountMask;
                 L.hrel[lane] = rel;
                 L.hcnt[lane] = rel ? rel : 1u;  // circle / backdrop-only fill: one pseudo element
                 L.hrg[lane] = b.z;
                 L.hba[lane] = b.w;
-                L.backdrop[lane] = static_cast<int>(ct) >> kCtShift;
+                L.backdrop[lane] = static_cast<int>(b.x) >> kCtShift;
                 L.any[lane] = 0;
             }
+            if (cb == 0) L.segw[lane] = seg_first;
             WaveSync();
             uint32_t stream_len, pass_rel;
             {
@@ -218,49 +178,16 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                     ticks->owner += tk1 - tk0;
                     ticks->rounds += 1;
                 }
-                // make sure the ring holds every relevant segment this round needs
-                {
-                    const bool wants = (e < stream_len) && ctag != kItemCircle && L.hrel[c] != 0;
-                    const uint64_t wm = __ballot(wants);
-                    if (wm) {
-                        const uint32_t my_need = wants ? (L.hwoff[c] + (e - L.hoff[c]) + 1u) : 0u;
-                        const uint32_t need = WaveAtHighest(my_need, wm);
-                        while (ring_cnt < need && scan_pos < n_slots) {
-                            const uint32_t cnt_x = n_slots;
-                            const uint32_t st_x = 0;
-                            const uint32_t i0 = scan_pos + 2u * lane;
-                            uint2 mv = mv_first;
-                            if (scan_pos != 0) {
-                                mv = make_uint2(OpaqueZero(), OpaqueZero());
-                                if (i0 < cnt_x) mv = *reinterpret_cast<const uint2 *>(meta + st_x + i0);
-                            }
-                            const uint32_t ma[2] = {mv.x, mv.y};
-                            uint32_t rb = 0;
-#pragma unroll
-                            for (uint32_t q = 0; q < 2; ++q)
-                                if (i0 + q < cnt_x && ((ma[q] >> tbit) & 1u)) rb |= 1u << q;
-                            const uint32_t rc = __popc(rb);
-                            const uint32_t rincl = WaveInclusiveScan(rc);
-                            uint32_t wp = ring_cnt + rincl - rc;
-#pragma unroll
-                            for (uint32_t q = 0; q < 2; ++q)
-                                if ((rb >> q) & 1u) L.ring[(wp++) & (kRing - 1u)] = st_x + i0 + q;
-                            ring_cnt += WaveLast(rincl);
-                            scan_pos += 128u;
-                        }
-                        WaveSync();
-                    }
-                }
-                if (kProf) {
-                    tk0 = wall_clock64();
-                    ticks->scan += tk0 - tk1;
-                }
+                if (kProf) tk0 = tk1;
                 if (e < stream_len) {
                     if (ctag == kItemFill && L.hrel[c] == 0) {
                         // backdrop-only fill: nothing to test, the closing command decides
                     } else if (ctag != kItemCircle) {
-                        const uint32_t k = e - L.hoff[c];
-                        const float4 s = segs[L.ring[(L.hwoff[c] + k) & (kRing - 1u)]];
+                        // the element's segment: position hwoff + k of the piece (the first 64 are in LDS already)
+                        const uint32_t si = L.hwoff[c] + (e - L.hoff[c]);
+                        float4 s;
+                        if (si < 64u) s = L.segw[si];
+                        else s = segs[si];
                         const float a = s.w - s.y;
                         const float b = s.x - s.z;
                         const float cc = -(a * s.x + b * s.y);
@@ -453,13 +380,13 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
             }
             rel_done += pass_rel;
         }
-        rec = next;
+        piece = hdr.x;
+        piece_n = hdr.y;
     }
 
     // ---- TileEncoder::end() (:144-151): Bail tiles are finished here (composite :34-44) ----
     if (lane == 0) {
-        P.tile_ncmd[tile] = solid_color ? 0u : n_pending;
-        qentry->w = solid_color ? 0u : n_pending;  // what pm_fine_kernel reads
+        P.tile_ncmd[tile] = solid_color ? 0u : n_pending;  // what a stand-alone pm_fine_kernel reads
     }
     if (solid_color != 0) {
         // the tile is one opaque colour, bytes as stored: 64 lanes x 16 B = the whole tile

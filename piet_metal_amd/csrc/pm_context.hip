@@ -149,13 +149,12 @@ struct FrameSlot {
     uint8_t *d_fb = nullptr;  // this slot's framebuffer (pm_render); pm_render_to uses the caller's
     uint32_t *d_arena = nullptr;
     uint32_t arena_cap = 0;  // dwords allocated for this slot (allocated when the slot is first used)
-    uint32_t *d_striprow = nullptr;
     uint4 *d_queue = nullptr;
     uint32_t *d_tile_state = nullptr;
     uint32_t *d_tile_ptcl = nullptr;
     uint32_t *d_tile_ncmd = nullptr;
-    pm::Cmd *d_ptcl = nullptr;
-    uint32_t ptcl_cap = 0;  // commands
+    uint4 *d_ptcl = nullptr;  // tile arena: per-tile pieces + command lists
+    uint32_t ptcl_cap = 0;    // quads (16 B)
     uint2 *d_row_bbox = nullptr;  // per-tile-row item lists of this slot's frame (large scenes)
     uint32_t *d_row_item = nullptr;
     pm::Counters *d_ctr = nullptr;  // two: a frame's binning kernel zeroes the one the slot's next frame uses
@@ -258,14 +257,13 @@ int SyncAll(pm_ctx *c) {
 void FreeViewport(pm_ctx *c) {
     for (auto &s : c->slot) {
         if (s.d_fb) (void)hipFree(s.d_fb);
-        if (s.d_striprow) (void)hipFree(s.d_striprow);
         if (s.d_queue) (void)hipFree(s.d_queue);
         if (s.d_tile_state) (void)hipFree(s.d_tile_state);
         if (s.d_tile_ptcl) (void)hipFree(s.d_tile_ptcl);
         if (s.d_tile_ncmd) (void)hipFree(s.d_tile_ncmd);
         s.d_fb = nullptr;
         s.d_queue = nullptr;
-        s.d_striprow = s.d_tile_state = s.d_tile_ptcl = s.d_tile_ncmd = nullptr;
+        s.d_tile_state = s.d_tile_ptcl = s.d_tile_ncmd = nullptr;
         s.in_flight = false;
         s.needs_check = false;
     }
@@ -280,7 +278,6 @@ int AllocViewport(pm_ctx *c) {
     const size_t tiles = BandTiles(c);
     for (auto &s : c->slot) {
         PM_TRY(hipMalloc(&s.d_fb, std::max<size_t>(c->fb_bytes, 16)));
-        PM_TRY(hipMalloc(&s.d_striprow, std::max<size_t>(static_cast<size_t>(rows) * c->strips_x, 1) * sizeof(uint32_t)));
         PM_TRY(hipMalloc(&s.d_queue, pm::kClasses * tiles * sizeof(uint4)));  // one queue per cost class
         PM_TRY(hipMalloc(&s.d_tile_state, tiles * sizeof(uint32_t)));
         PM_TRY(hipMalloc(&s.d_tile_ptcl, tiles * sizeof(uint32_t)));
@@ -339,27 +336,24 @@ int EnsureSlotBuffers(pm_ctx *c, FrameSlot *s) {
         if (s->d_ptcl) (void)hipFree(s->d_ptcl);
         s->d_ptcl = nullptr;
         s->ptcl_cap = 0;
-        const uint64_t cmds = std::max<uint64_t>(c->ptcl_want, 64);
-        PM_TRY(hipMalloc(&s->d_ptcl, cmds * sizeof(pm::Cmd)));
-        s->ptcl_cap = static_cast<uint32_t>(cmds);
+        const uint64_t quads = std::max<uint64_t>(c->ptcl_want, 64);
+        PM_TRY(hipMalloc(&s->d_ptcl, quads * sizeof(uint4)));
+        s->ptcl_cap = static_cast<uint32_t>(quads);
     }
     return PM_OK;
 }
 
-// Exact upper bound (dwords) of what pm_bin_kernel can allocate for this scene,
-// viewport and band: every (strip row, candidate item) costs a candidate record
-// plus 16 B per stream element, every (strip row, batch) a header.
-// Worst-case arena demand of every strip row of the band (dwords): each batch of 256 items
-// costs a header (+ mask-table padding), every candidate item a mask word + its record +
-// its per-tile table + 16 segment slots (16 B) and 16 meta words per chunk.  The binning
-// kernel bump-allocates inside these private regions, so the bound must be exact or larger.
+// Worst-case binning-arena demand of every strip row of the band (dwords): every candidate item
+// costs kChunkSegs segment slots (16 B) + meta words per chunk (every chunk surviving), plus a token
+// amount that tells a strip row some item reaches from one nothing reaches.  The binning kernel
+// bump-allocates inside these private regions, so the bound must be exact or larger.
 void StripRowBounds(const pm_ctx *c, std::vector<uint64_t> *need) {
     const uint8_t *meta = c->item_meta.data();
     uint32_t n, items_ix;
     std::memcpy(&n, meta, 4);
     std::memcpy(&items_ix, meta + 4, 4);
     const uint32_t rows = BandRows(c);
-    need->assign(static_cast<size_t>(rows) * c->strips_x, static_cast<uint64_t>(pm::kRecHdrDwords + 3u) * ((n + 255u) / 256u));
+    need->assign(static_cast<size_t>(rows) * c->strips_x, 0);
     for (uint32_t i = 0; i < n; ++i) {
         uint16_t bb[4];
         std::memcpy(bb, meta + 8 + 8ull * i, 8);
@@ -373,7 +367,7 @@ void StripRowBounds(const pm_ctx *c, std::vector<uint64_t> *need) {
         if (tag == pm::kItemPoly && npt >= 2) nseg = npt - 1;
         if (tag == pm::kItemLine) nseg = 1;
         const uint64_t nch = (nseg + pm::kChunkSegs - 1) / pm::kChunkSegs;
-        const uint64_t per = 1u + pm::kCandDwords + pm::kCtDwords + 5ull * pm::kChunkSegs * nch;
+        const uint64_t per = 4u + static_cast<uint64_t>(pm::kSlotDwords) * pm::kChunkSegs * nch;
         // strips: bz >= sx0 && bx < sx0 + 256 ; rows: bw >= y0 && by < y0 + 16
         const int64_t s_lo = bb[0] / 256, s_hi = std::min<int64_t>(bb[2] / 256, static_cast<int64_t>(c->strips_x) - 1);
         const int64_t r_lo = std::max<int64_t>(bb[1] / 16, c->row0), r_hi = std::min<int64_t>(bb[3] / 16, static_cast<int64_t>(c->row1) - 1);
@@ -404,16 +398,17 @@ int EnsureArena(pm_ctx *c) {
     // (exact for a context's first scene; a quarter of headroom when it has to GROW: an animation's
     //  demand creeps from frame to frame, and re-allocating four 100 MB arenas costs milliseconds)
     const uint64_t alloc_dwords = total <= c->arena_cap ? c->arena_cap : (c->arena_cap == 0 ? total : std::min<uint64_t>(0xfffffff0ull, total + total / 4));
-    c->sr_empty_dwords = static_cast<uint32_t>((static_cast<uint64_t>(pm::kRecHdrDwords + 3u) * ((c->n_items + 255u) / 256u) + 3u) & ~3ull);
+    c->sr_empty_dwords = 0;  // (a strip row no item's bbox reaches has nothing reserved)
     // (the slots' arenas themselves are allocated when a slot is first used, EnsureSlotBuffers: the
     //  first frame of a scene pays for one arena, not for four -- hundreds of MB each at 8K)
     if (c->ptcl_want == 0) {
-        // Command-list arena: lists are sized from what binning actually found, so there is no
-        // static bound; start generously (HBM is 288 GB) and let pm_sync grow it on overflow.
+        // Tile arena (per-tile pieces + command lists, 16-byte quads): sized from what binning
+        // actually finds, so there is no static bound; start generously (HBM is 288 GB) and let
+        // pm_sync grow it on overflow.
         uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
         if (const char *v = std::getenv("PM_PTCL_INITIAL_CMDS"))  // tests: force the overflow -> grow -> re-render path
             cmds = std::max<uint64_t>(64, std::strtoull(v, nullptr, 10));
-        c->ptcl_want = std::min<uint64_t>(cmds, 0x7fffffffull);
+        c->ptcl_want = std::min<uint64_t>(cmds * pm::kCmdQuadsNum / pm::kCmdQuadsDen, 0x7fffffffull);
     }
     c->arena_cap = std::max<uint32_t>(c->arena_cap, static_cast<uint32_t>(alloc_dwords));
     // The strip rows some item's bbox reaches get a workgroup of pm_bin_kernel each; the others are
@@ -437,7 +432,6 @@ int EnsureArena(pm_ctx *c) {
     PM_TRY(hipMemcpy(c->d_sr_desc, desc.data(), desc.size() * sizeof(uint4), hipMemcpyHostToDevice));
     for (auto &s : c->slot) {
         PM_TRY(hipMemset(s.d_tile_state, 0xff, BandTiles(c) * sizeof(uint32_t)));
-        PM_TRY(hipMemset(s.d_striprow, 0, std::max<size_t>(need.size(), 1) * sizeof(uint32_t)));
     }
     // the items whose bbox reaches the band (rows: bw >= y0 && by < y1, PietRender.metal:198/:214)
     {
@@ -554,12 +548,11 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->sr_desc = c->d_sr_desc;
     p->n_sr_active = c->n_sr_active;
     p->sr_empty_dwords = c->sr_empty_dwords;
-    p->striprow_head = s->d_striprow;
     p->queue = s->d_queue;
     p->queue_cap = static_cast<uint32_t>(BandTiles(c));
     p->tile_state = s->d_tile_state;
-    p->ptcl = s->d_ptcl;
-    p->ptcl_cap = s->ptcl_cap;
+    p->tarena = s->d_ptcl;
+    p->tarena_cap = s->ptcl_cap;
     p->tile_ptcl = s->d_tile_ptcl;
     p->tile_ncmd = s->d_tile_ncmd;
     p->ctr_cur = s->d_ctr + s->parity;
@@ -1244,7 +1237,7 @@ int pm_sync(pm_ctx *c) {
             if (r != PM_OK) return r;
         }
     }
-    SetError("command-list arena overflow (frame needs more than 2^31 commands)");
+    SetError("tile arena overflow (frame needs more than 32 GiB of pieces and command lists)");
     return PM_ERR_CAPACITY;
 }
 
@@ -1632,8 +1625,8 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
     if (n_rows) *n_rows = rows;
     if (rows > max_rows) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;
-    PM_TRY(hipMalloc(&d, std::max<size_t>(rows, 1) * 12 * sizeof(unsigned long long)));
-    PM_TRY(hipMemset(d, 0, std::max<size_t>(rows, 1) * 12 * sizeof(unsigned long long)));
+    PM_TRY(hipMalloc(&d, std::max<size_t>(rows, 1) * 16 * sizeof(unsigned long long)));
+    PM_TRY(hipMemset(d, 0, std::max<size_t>(rows, 1) * 16 * sizeof(unsigned long long)));
     const int si = static_cast<int>(c->frame % c->slot.size());
     FrameSlot *s = &c->slot[si];
     pm::FrameParams p;
@@ -1648,7 +1641,7 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
         p.dbg_bin = nullptr;
         Submitted(c, si, p, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess) e = hipMemcpy(out, d, rows * 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(out, d, rows * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         if (e != hipSuccess) r = HipFail(e, "bin timeline");
     }
     (void)hipFree(d);

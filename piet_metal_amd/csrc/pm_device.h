@@ -24,7 +24,7 @@ struct Counters {
     // Every strip row of a frame adds to these with returning atomics.  The L2 executes
     // same-cache-line atomics one after the other (~90 per us measured), so each hot counter
     // lives on its own 128-byte line.
-    uint32_t ptcl_top;  // bump pointer into the command-list arena, in commands
+    uint32_t ptcl_top;  // bump pointer into the tile arena, in quads
     uint32_t pad0[31];
     struct {
         uint32_t count;  // tiles queued in this class
@@ -39,30 +39,38 @@ struct Counters {
     } ticket[kTicketParts];
 };
 
-// Arena record written by pm_bin_kernel for one (strip row, batch of <=256 items):
-//   [0] next record offset (0 = end)   [1] ncand   [2] chunks streamed (sizes segs/meta)
-//   [3] segment slots in use (= surviving chunks x kChunkSegs)
-//   mask table: ncand dwords { tag | hitmask16 << 16 }, padded to a multiple of 4
-//       (one 16-byte load per lane of the coarse kernel covers 256 candidates); a hit
-//       bit survives only where the candidate can emit a command
-//   ncand x 8 dwords: { tag | hitmask16 << 16, rgba, aux0, aux1, item index, 0, rg, ba }
-//       aux0/aux1 = bbox words (circle), width bits (line, polyline) or PietFill.flags (fill)
-//       rg/ba = the colour already through unpack_unorm4x8_srgb_to_half (4 x binary16)
-//   ncand x 16 dwords: per tile of the strip { backdrop << 20 | relevant segments }
-//       backdrop = the reference's per-tile left-ray winding sum (PietRender.metal
-//       :326-333) over all voted segments of the item, done once here
-//   segs: 16 B slots (start.xy, end.xy); surviving chunk s owns slots [s*kChunkSegs, (s+1)*kChunkSegs),
-//       one per segment of the chunk, paint order; slots of segments that lost the vote stay unused
-//   meta: one word per slot { tiles of the strip where the segment can emit | candidate << 16 |
-//       voted << 31 }, 0 for an unused slot
+// Binning works in two address spaces of HBM (per frame slot):
 //
-// Every strip row owns a private arena region [sr_base[i], sr_base[i+1]) sized by the host for
-// the worst case, so the binning kernel allocates with plain arithmetic: no atomics, no
-// counting pass.
+// * the BINNING ARENA: every strip row owns a private region [sr_desc.y, sr_desc.z) sized by the
+//   host for the worst case, so pm_bin_kernel allocates with plain arithmetic (no atomics, no
+//   counting pass).  A record of one (strip row, batch of <= 256 candidate items) is the
+//   intermediate of the vote pass, read back by the same workgroup and by nobody else:
+//     segs: 16 B slots (start.xy, end.xy); surviving chunk s owns slots [s*kChunkSegs, (s+1)*kChunkSegs),
+//         one per segment of the chunk, paint order; slots of segments that lost the vote stay unused
+//     meta: one word per slot { tiles of the strip where the segment can emit | candidate << 16 |
+//         voted << 31 }, 0 for an unused slot
 //
-// Tile queues: kClasses class queues of 16-byte entries {tile, first command slot, first binning
-// record of the strip row, commands written}; the tile kernels walk them statically, longest
-// first, so the expensive tiles start first and the cheap ones fill the tail.
+// * the TILE ARENA (16-byte "quads", bump-allocated with one atomic per record and one per strip
+//   row; grown by pm_sync when it runs out): what the tile kernel reads and writes.
+//     piece -- everything ONE tile needs from ONE record, contiguous, paint order:
+//         quad 0            { next piece of the tile (quad index, 0 = none), its candidates | segments << 9, 0, 0 }
+//         1 quad per relevant segment (start.xy, end.xy), the candidates' segments back to back
+//         2 quads per candidate that can emit a command in this tile:
+//                           { tag, rgba, aux0, aux1 } { backdrop << 20 | relevant segments, item index, rg, ba }
+//             aux0/aux1 = bbox words (circle), width bits (line, polyline) or PietFill.flags (fill);
+//             rg/ba = the colour already through unpack_unorm4x8_srgb_to_half (4 x binary16);
+//             backdrop = the reference's per-tile left-ray winding sum (PietRender.metal:326-333)
+//             over all voted segments of the item, done once in pm_bin_kernel
+//         (the candidates come last: the piece is reserved from the bbox count of candidates before
+//          binning knows how many of them really emit here; the slack stays unused behind them)
+//       One load of the queue entry, then one batch of loads (candidates + segments) starts a tile:
+//       list building is a compute pass over a contiguous run, not a scan of the strip row's record.
+//     command list -- the tile's 24-byte Cmd records (TestApp/GenTypes.h:430-495), space claimed from
+//       the estimate (3 x stream elements + 1).
+//
+// Tile queues: kClasses class queues of 16-byte entries {tile, first quad of the command list,
+// first piece, candidates | segments << kPieceHitBits of that piece}; the tile kernels walk them
+// statically, longest first, so the expensive tiles start first and the cheap ones fill the tail.
 //
 // Scene index (built once per scene upload by pm_index_kernel, like the ShortBbox
 // array the encoder builds at encode time): segments are grouped in chunks of kChunkSegs
@@ -73,11 +81,12 @@ struct Counters {
 constexpr uint32_t kChunkSegs = 8;
 constexpr uint32_t kArenaBase = 4;     // offset 0 means "none"
 constexpr int kBinWaves = 4;           // waves of one binning workgroup
-constexpr uint32_t kRecHdrDwords = 4;
-constexpr uint32_t kCandDwords = 8;
-constexpr uint32_t kCtDwords = 16;           // per candidate: one word per tile of the strip
-constexpr uint32_t kCtShift = 20;            // word = backdrop << 20 | relevant-segment count
+constexpr uint32_t kCtShift = 20;            // per (candidate, tile): backdrop << 20 | relevant-segment count
 constexpr uint32_t kCtCountMask = (1u << kCtShift) - 1u;
+constexpr uint32_t kSlotDwords = 5;          // binning arena: 16 B segment + 4 B meta word per slot
+constexpr uint32_t kPieceHitBits = 9;        // queue entry / piece header: candidates (<= 256 per record) | segments << 9
+constexpr uint32_t kPieceHitMask = (1u << kPieceHitBits) - 1u;
+constexpr uint32_t kCmdQuadsNum = 3, kCmdQuadsDen = 2;  // a 24-byte Cmd = 1.5 quads
 
 struct FrameParams {
     const uint8_t *scene;
@@ -97,13 +106,12 @@ struct FrameParams {
     const uint4 *sr_desc;     // [n_sr_active] {strip row, its private arena region begin, end, 0}
     uint32_t n_sr_active;     // strip rows some item reaches = workgroups of pm_bin_kernel
     uint32_t sr_empty_dwords; // size of a region no item's bbox reaches
-    uint32_t *striprow_head;
-    uint4 *queue;             // kClasses class queues of {tile, first command slot, first record, commands}, queue_cap entries each
+    uint4 *queue;             // kClasses class queues of {tile, command-list quad, first piece, its candidates | segments << 9}, queue_cap entries each
     uint32_t queue_cap;
     uint32_t *tile_state;     // [tiles of the band] 0 = queued for the tile kernels, else resolved colour
-    Cmd *ptcl;                // per-tile command lists (24-byte records, TestApp/GenTypes.h:430-495)
-    uint32_t ptcl_cap;        // in commands
-    uint32_t *tile_ptcl;      // [tiles] first command slot of the tile's list
+    uint4 *tarena;            // tile arena: pieces + per-tile command lists (24-byte records, TestApp/GenTypes.h:430-495)
+    uint32_t tarena_cap;      // in quads (16 B)
+    uint32_t *tile_ptcl;      // [tiles] first quad of the tile's command list
     uint32_t *tile_ncmd;      // [tiles] commands in the list (0: resolved to one colour)
     Counters *ctr_cur;
     Counters *ctr_next;

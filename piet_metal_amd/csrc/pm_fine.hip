@@ -688,7 +688,6 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     for (uint32_t pass = 0; have; ++pass) {
         const uint32_t cur_slot = slot;
         const uint4 cur = Scalar4(qe);
-        uint4 *const qentry = P.queue + qix;
         const bool draws = pass + 1u >= static_passes;  // the next tile is a drawn one
         if (!draws) {
             slot = pass_slot(pass + 1u);
@@ -720,12 +719,13 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
         PhaseTicks prof;
         CoarseTicks ct;
         if (kProf) t_begin = wall_clock64();
-        uint32_t n_cmd = cur.w;
+        uint32_t n_cmd = 0;
+        if (!kFused) n_cmd = __builtin_amdgcn_readfirstlane(P.tile_ncmd[tile]);  // pm_coarse_kernel's launch left the list's length there
         if (kFused) {
             // (wave 0 of a workgroup-mode tile has wave == 0: its region is S.w[0] either way)
             // (a workgroup tile: chunks 0..2 of the list also go to the staged-command areas of waves 1..3)
             if (!wg_mode || wave == 0)
-                n_cmd = CoarseTile<kCapture, kProf>(P, S.w[wave].c, qentry, cur, lane, lanes_below, &ct,
+                n_cmd = CoarseTile<kCapture, kProf>(P, S.w[wave].c, cur, lane, lanes_below, &ct,
                                                  wg_mode ? reinterpret_cast<uint8_t *>(S.w[1].f.cmds) : nullptr, static_cast<uint32_t>(sizeof(WaveLds)));
             if (wg_mode) {
                 if (wave == 0 && lane == 0) S.wg_ncmd[pass & 1u] = n_cmd;
@@ -739,7 +739,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
         }
         if (n_cmd == 0) next_card();
         if (n_cmd != 0) {  // 0: the coarse kernel found one opaque colour and wrote it
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(P.ptcl + cur.y);
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(P.tarena + cur.y);
             const uint32_t tx = tile % P.tiles_x;
             const uint32_t ty_rel = tile / P.tiles_x;
             const uint32_t x0 = tx * kTileW;
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(kThreads) void pm_coverage_kernel(FrameParams P, co
         if (solid != 0) {
             cov = solid != 0xffffffffu ? 1.0f : 0.0f;
         } else {
-            const Cmd *cmds = P.ptcl + P.tile_ptcl[tile];
+            const Cmd *cmds = reinterpret_cast<const Cmd *>(P.tarena + P.tile_ptcl[tile]);
             const uint32_t n = P.tile_ncmd[tile];
             float sa = 0.0f;
             for (uint32_t i = 0; i < n; ++i) {

@@ -49,6 +49,7 @@
 #include <hip/hip_ext.h>
 
 #include <cstddef>
+#include <utility>
 
 #include "pm_device.h"
 #include <pm_pin.h>  // gfx950/pm_pin.h: register pins (GCN asm constraints)
@@ -131,6 +132,16 @@ __device__ __forceinline__ uint32_t WaveLast(uint32_t v) {
 // Compiler-level ordering of LDS traffic inside one wave (the LDS itself executes a
 // wave's instructions in order); no instruction is emitted.
 __device__ __forceinline__ void WaveSync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+// Workgroup barrier that orders LDS traffic ONLY: __syncthreads() also waits for every global store
+// the wave has in flight (s_waitcnt vmcnt(0): their acknowledgements take microseconds), which a
+// barrier between phases that hand each other LDS data does not need.  Global data written before it
+// must not be read by ANOTHER wave after it.
+__device__ __forceinline__ void LdsBarrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 __device__ __forceinline__ float Sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 __device__ __forceinline__ float Sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
@@ -224,13 +235,13 @@ __device__ __forceinline__ bool VotePoly(float4 s, float hw, int y_test, int sx0
 }
 
 // Block-wide ordered rank of a predicate (NW waves).  s_part must hold NW words.
-// Contains two barriers.
+// Contains two barriers (LDS-only).
 template <int NW>
 __device__ __forceinline__ uint32_t BlockRank(bool pred, uint32_t *s_part, uint32_t *total) {
     const uint64_t m = __ballot(pred);
     const uint32_t wave = threadIdx.x >> 6;
     if (LaneId() == 0) s_part[wave] = static_cast<uint32_t>(__popcll(m));
-    __syncthreads();
+    LdsBarrier();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -238,7 +249,7 @@ __device__ __forceinline__ uint32_t BlockRank(bool pred, uint32_t *s_part, uint3
         if (w < static_cast<int>(wave)) base += v;
         tot += v;
     }
-    __syncthreads();
+    LdsBarrier();
     *total = tot;
     return base + RankBelow(m);
 }
@@ -249,7 +260,7 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_p
     const uint32_t incl = WaveInclusiveScan(v);
     const uint32_t wave = threadIdx.x >> 6;
     if (LaneId() == 63) s_part[wave] = incl;
-    __syncthreads();
+    LdsBarrier();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -257,7 +268,7 @@ __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_p
         if (w < static_cast<int>(wave)) base += x;
         tot += x;
     }
-    __syncthreads();
+    LdsBarrier();
     *total = tot;
     return base + incl - v;
 }
@@ -278,6 +289,21 @@ __device__ __forceinline__ uint32_t DppQuadXor2(uint32_t v) {  // quad_perm [2,3
 }
 __device__ __forceinline__ uint32_t DppHalfMirror(uint32_t v) {  // row_half_mirror: lane i <-> 7 - i of each 8
     return static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0x141, 0xf, 0xf, true));
+}
+
+// f(std::integral_constant<uint32_t, t>) for t = 0 .. 15: a loop over the tiles of a strip whose index is
+// a compile-time constant in every iteration (lane selects of v_writelane / v_readlane are immediates).
+template <typename F, uint32_t... kT>
+__device__ __forceinline__ void ForStripTilesImpl(F &&f, std::integer_sequence<uint32_t, kT...>) {
+    (f(std::integral_constant<uint32_t, kT>{}), ...);
+}
+template <typename F>
+__device__ __forceinline__ void ForStripTiles(F &&f) {
+    ForStripTilesImpl(f, std::make_integer_sequence<uint32_t, kStripTiles>{});
+}
+template <typename F>
+__device__ __forceinline__ void ForClasses(F &&f) {  // ... and k = 0 .. kClasses - 1
+    ForStripTilesImpl(f, std::make_integer_sequence<uint32_t, kClasses>{});
 }
 
 // Largest c in [0, n) with off[c] <= e (off ascending, off[0] == 0, n >= 1).

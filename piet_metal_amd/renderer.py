@@ -258,7 +258,7 @@ Renderer.time_tiles = _time_tiles
 
 
 def _time_bins(self, max_rows: int = 1 << 20) -> np.ndarray:
-    out = np.zeros((max_rows, 12), np.uint64)
+    out = np.zeros((max_rows, 16), np.uint64)
     n = C.c_size_t(0)
     _lib.check(self._lib.pm_debug_time_bins(self._h, out.ctypes.data, max_rows, C.byref(n)), "pm_debug_time_bins")
     return out[: n.value]

@@ -96,6 +96,7 @@ __attribute__((noinline)) static uint32_t __shfl_up(uint32_t v, unsigned delta, 
 }
 __attribute__((noinline)) static void __builtin_amdgcn_wave_barrier() { (void)pm_emu::Collective(pm_emu::kWaveBarrier, 0, 0, 0, PM_EMU_SITE()); }
 __attribute__((noinline)) static void __syncthreads() { pm_emu::BlockBarrier(PM_EMU_SITE()); }
+__attribute__((noinline)) static void __builtin_amdgcn_s_barrier() { pm_emu::BlockBarrier(PM_EMU_SITE()); }
 
 static inline uint32_t __lane_id() { return pm_emu::LaneId(); }
 static inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t mask, uint32_t add) {
@@ -106,7 +107,7 @@ static inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t add) {
     const uint32_t l = pm_emu::LaneId();
     return add + (l > 32 ? static_cast<uint32_t>(__builtin_popcount(mask & ((1u << (l - 32)) - 1u))) : 0u);
 }
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_fence(...) ((void)0)
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __threadfence_block() {}
 static inline void __threadfence() {}

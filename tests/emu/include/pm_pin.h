@@ -21,5 +21,10 @@ inline float OpaqueInfinity() {
 }
 inline void PinLoaded8(uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &) {}
 
+template <uint32_t kLane>
+inline void WriteLane(uint32_t &v, uint32_t uniform_value) {
+    if (__lane_id() == kLane) v = uniform_value;
+}
+
 }  // namespace
 }  // namespace pm

@@ -3,7 +3,9 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import piet_metal_amd as pm
-wl = pm.workloads.tiger(3840, 2160)
+wl = {"config2": lambda: pm.workloads.tiger(1920, 1080, fills_only=True), "config3": lambda: pm.workloads.tiger(3840, 2160),
+      "config4": pm.workloads.config4_blobs, "config5": pm.workloads.config5_tiger_grid}[os.environ.get("PM_TL_WORKLOAD", "config3")]()
+print("workload", wl.name, wl.width, wl.height)
 r = pm.Renderer(0)
 r.resize(wl.width, wl.height)
 r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
@@ -13,8 +15,9 @@ t = r.time_bins().astype(np.int64)
 t = t[t[:, 0] > 0]  # strip rows no item reaches never get a workgroup
 us = 1e-2
 t0 = t[:, 0].min()
-dur = (t[:, 7] - t[:, 0]) * us
-print(f"WGs {len(t)} kernel span {(t[:,7].max()-t0)*us:.1f} us; WG duration mean {dur.mean():.2f} p50 {np.median(dur):.2f} p90 {np.percentile(dur,90):.2f} max {dur.max():.2f}")
+end = np.maximum(t[:, 7], t[:, 14]) if t.shape[1] >= 16 else t[:, 7]  # (the tail wave may outlive wave 0)
+dur = (end - t[:, 0]) * us
+print(f"WGs {len(t)} kernel span {(end.max()-t0)*us:.1f} us; WG duration mean {dur.mean():.2f} p50 {np.median(dur):.2f} p90 {np.percentile(dur,90):.2f} max {dur.max():.2f}")
 print(f"start spread: last WG starts at {(t[:,0].max()-t0)*us:.1f} us")
 has = t[:, 1] > 0
 print(f"WGs with a record: {has.sum()}")
@@ -26,8 +29,13 @@ print("item scan      :", ph(0, 1, m))
 print("headers+scan   :", ph(1, 2, m))
 print("segment stream :", ph(2, 3, m), "(last record)")
 print("finalise       :", ph(3, 4, m))
-print("queues         :", ph(4, 5, m))
-print("clear+exit     :", ph(5, 7, m))
+if t.shape[1] >= 16 and (t[:, 12] > 0).any():
+    print("   candidates pass (backdrops, hit bits, ballots) :", ph(3, 12, m))
+    print("   entries + scatter (wave 0)                     :", ph(12, 4, m))
+print("wave 0 exit     :", ph(4, 7, m))
+if t.shape[1] >= 16 and (t[:, 14] > 0).any():
+    print("tail wave ends after wave 0's scatter by:", ph(4, 14, m))
+    pass
 e = ~has
 d = (t[e, 7] - t[e, 0]) * us
 if e.any(): print(f"WGs without candidates: {e.sum()}, duration mean {d.mean():.2f} max {d.max():.2f}")
@@ -40,16 +48,10 @@ for lo, hi in [(0, 8), (8, 12), (12, 20), (20, 30), (30, 45), (45, 1000)]:
     m2 = (dur >= lo) & (dur < hi)
     print(f"  WGs with {lo}-{hi} us: {m2.sum()} -> {dur[m2].sum():.0f} us total")
 print("round 0 of the segment stream (WGs with >= 512 elements in it):")
-big = (t[:, 6] >= 512) & (t[:, 11] > 0)
-for nm, a, b in [("headers done -> round start", 2, 8), ("chunk tests + scan", 8, 9), ("survivor list + barrier", 9, 10), ("expansion (wave 0)", 10, 11)]:
+big = (t[:, 6] >= 512) & (t[:, 10] > 0)
+for nm, a, b in [("headers done -> round start", 2, 8), ("chunk tests + scan (round 0)", 8, 9), ("other rounds + survivor list + barrier", 9, 10), ("votes (all rounds)", 10, 3)]:
     d = (t[big, b] - t[big, a]) * us
     print(f"   {nm:28s} mean {d.mean():.2f} p90 {np.percentile(d, 90):.2f} max {d.max():.2f}")
 el = t[big, 6]
-d = (t[big, 11] - t[big, 10]) * us
+d = (t[big, 3] - t[big, 10]) * us
 print(f"   {big.sum()} WGs, elements mean {el.mean():.0f}; expansion per 256-element step: {(d / np.ceil(el / 256)).mean():.2f} us")
-e = (t[:, 1] == 0) & (t[:, 11] > 0)
-if e.any():
-    print("strip rows without candidates, tail:")
-    for nm, a, b in [("entry -> tail", 0, 8), ("barrier", 8, 9), ("masks + clear stores issued", 9, 10), ("barrier", 10, 11), ("queue writes -> exit", 11, 7)]:
-        d = (t[e, b] - t[e, a]) * us
-        print(f"   {nm:30s} mean {d.mean():.2f} p90 {np.percentile(d, 90):.2f} max {d.max():.2f}")

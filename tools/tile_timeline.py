@@ -3,7 +3,9 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import piet_metal_amd as pm
-wl = pm.workloads.tiger(3840, 2160)
+wl = {"config2": lambda: pm.workloads.tiger(1920, 1080, fills_only=True), "config3": lambda: pm.workloads.tiger(3840, 2160),
+      "config4": pm.workloads.config4_blobs, "config5": pm.workloads.config5_tiger_grid}[os.environ.get("PM_TL_WORKLOAD", "config3")]()
+print("workload", wl.name, wl.width, wl.height)
 r = pm.Renderer(0)
 r.resize(wl.width, wl.height)
 r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
