@@ -103,7 +103,11 @@ namespace {
 // and an access costs `tid * 4` plus an immediate (as separate __shared__ arrays each one gets its own
 // hoisted base + index register, and a dozen of them end up in scratch).
 constexpr uint32_t kCtStride = kStripTiles + 1;  // row stride 17: a thread per candidate walking its row, and 16 lanes adding to one row, are both free of bank conflicts
-constexpr uint32_t kSurvLds = 1024;
+// (overridable at build time so that the test builds of tests/emu reach the spill path with small scenes)
+#ifndef PM_BIN_SURV_LDS
+#define PM_BIN_SURV_LDS 1024
+#endif
+constexpr uint32_t kSurvLds = PM_BIN_SURV_LDS;
 struct BinLds {
     uint32_t s_part[kBinWaves];
     uint32_t s_cidx[kThreads];   // candidate item index
@@ -151,10 +155,27 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = LaneId();
     const uint32_t wave = tid >> 6;
-    // Workgroup -> strip row: the host lists the strip rows some item's bbox reaches (it sized
+    if (blockIdx.x == 0 && tid < kTicketParts) PM_PP(ctr_next)->ticket[tid].count = 0;
+    if (blockIdx.x == 0 && tid == 0) {
+        // The counters of the NEXT frame (the other parity) are idle now: reset them
+        // here so that no separate memset launch is needed.
+        PM_PP(ctr_next)->arena_top = 0;
+        PM_PP(ctr_next)->ptcl_top = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kClasses; ++k) PM_PP(ctr_next)->cls[k].count = 0;
+        PM_PP(ctr_next)->overflow = 0;
+    }
+    // Workgroup -> strip rows: the host lists the strip rows some item's bbox reaches (it sized
     // their arena regions from the same predicate); the others are background for the whole
-    // life of the scene and never get a workgroup.  One 16-byte load: {strip row, region, end}.
-    const uint4 srd = PM_PP(sr_desc)[blockIdx.x];
+    // life of the scene and never get a workgroup.  The grid is no larger than what the chip holds
+    // at once (a workgroup that has to wait for a slot starts when the first ones END, 20 us into
+    // the launch, and then sets its span): with more strip rows than that, a workgroup takes the rows
+    // blockIdx.x, blockIdx.x + gridDim.x, ... one after the other -- in natural order that pairs the
+    // top rows of the picture with the bottom ones, the lightest with the lightest.
+    for (uint32_t rix = blockIdx.x; rix < PM_PU(n_sr_active); rix += gridDim.x) {
+    if (rix != blockIdx.x) LdsBarrier();  // the previous strip row's LDS is done with
+    // One 16-byte load: {strip row, region, end}.
+    const uint4 srd = PM_PP(sr_desc)[rix];
     const uint32_t sr = __builtin_amdgcn_readfirstlane(srd.x);
     const uint32_t strip = sr % PM_PU(strips_x);
     const uint32_t row_rel = sr / PM_PU(strips_x);
@@ -169,16 +190,6 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     const float fy0 = uniform_f(y0), fy1 = uniform_f(y0 + static_cast<int>(kTileH));
     const float fsy0 = uniform_f(sy0), fsy1 = uniform_f(sy0 + static_cast<int>(kGroupH));
 
-    if (blockIdx.x == 0 && tid < kTicketParts) PM_PP(ctr_next)->ticket[tid].count = 0;
-    if (blockIdx.x == 0 && tid == 0) {
-        // The counters of the NEXT frame (the other parity) are idle now: reset them
-        // here so that no separate memset launch is needed.
-        PM_PP(ctr_next)->arena_top = 0;
-        PM_PP(ctr_next)->ptcl_top = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < kClasses; ++k) PM_PP(ctr_next)->cls[k].count = 0;
-        PM_PP(ctr_next)->overflow = 0;
-    }
     // Developer timeline (kProfile builds only): thread 0 stores the clock straight to memory, so
     // that the profiled kernel keeps the register allocation of the production one.
     // slots: 0 entry, 1 item scan done, 2 first record's headers done, 3 last segment stream done,
@@ -220,9 +231,18 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
 
     // ---- the strip row's tail (one wave): queue the tiles with something to draw, mark the others ----
     // Lane t owns tile t of the strip row; the class masks are ballots, the command-list offsets a
-    // wave scan, and the atomics' results travel by v_readlane.
+    // wave scan, and the atomics' results travel by v_readlane.  In two halves: RowTailIssue sends the
+    // atomics off (tile-arena space for the lists, class queue positions), RowTailFinish looks at what
+    // they returned and writes the queue entries -- the wave places its share of candidates and
+    // segments in between, under the atomics' round trip.
     bool tail_done = false;
-    auto RowTail = [&]() {
+    struct TailState {
+        uint32_t qres;      // what this lane's atomic returned (lane c < kClasses: class c's queue; lane kClasses: tile arena)
+        uint32_t list_off;  // the tile's command list inside the strip row's allocation, in quads
+        uint32_t packed;    // is_queued | class << 1 | rank of the tile among the row's tiles of its class << 4
+        uint32_t qtotal;    // (uniform) quads of the strip row's lists; 0: nothing to queue
+    };
+    auto RowTailIssue = [&]() -> TailState {
         const uint32_t tiles_here = min(kStripTiles, PM_PU(tiles_x) - strip * kStripTiles);
         const bool tile_lane = lane < tiles_here;
         const uint32_t est = tile_lane ? L.s_est[lane & (kStripTiles - 1u)] : 0u;
@@ -246,12 +266,15 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         // item's closing command, plus End; 24 bytes each
         const uint32_t slots = is_queued ? ((3u * est + 1u) * kCmdQuadsNum + kCmdQuadsDen - 1u) / kCmdQuadsDen : 0u;
         const uint32_t slots_incl = WaveInclusiveScan(slots);
-        const uint32_t qtotal = WaveLast(slots_incl);
+        TailState ts;
+        ts.qtotal = WaveLast(slots_incl);
+        ts.list_off = slots_incl - slots;
+        ts.packed = (is_queued ? 1u : 0u) | (cls << 1) | (static_cast<uint32_t>(__popc(my_mask & ((1u << lane) - 1u))) << 4);
         // tile-arena space and the class queue positions: ONE atomic instruction, a lane per counter
-        uint32_t qres = 0;
-        if (qtotal) {  // uniform
-            if (lane < kClasses && lane_cnt) qres = atomicAdd(&PM_PP(ctr_cur)->cls[lane].count, lane_cnt);
-            if (lane == kClasses) qres = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, qtotal);
+        ts.qres = 0;
+        if (ts.qtotal) {  // uniform
+            if (lane < kClasses && lane_cnt) ts.qres = atomicAdd(&PM_PP(ctr_cur)->cls[lane].count, lane_cnt);
+            if (lane == kClasses) ts.qres = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, ts.qtotal);
         }
         // tiles with nothing to draw are background: no item touches them, or every touching
         // item lost all its segments in phase 1 (the reference writes Bail/white for them).  Their
@@ -260,22 +283,26 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + lane;
         if (tile_lane)  // what this kernel decided per tile: 0 = queued, else the tile's colour
             PM_PP(tile_state)[tile] = is_queued ? 0u : (is_solid ? L.s_solid_rgba[lane] : 0xffffffffu);
-        if (!qtotal) return;
-        const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(qres), kClasses)) + 1u;  // (quad 0 stays unused: 0 = "no piece")
-        const uint32_t q_base = static_cast<uint32_t>(__shfl(static_cast<int>(qres), static_cast<int>(cls)));  // my class's queue position
-        // (L.s_alloc[1]: an earlier record of this strip row found the tile arena full -- its pieces do not exist)
-        const bool fits = base + qtotal <= PM_PU(tarena_cap) && base + qtotal >= base && L.s_alloc[1] == 0u;
+        return ts;
+    };
+    auto RowTailFinish = [&](const TailState &ts) {
+        if (!ts.qtotal) return;
+        const uint32_t cls = (ts.packed >> 1) & 7u;
+        const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ts.qres), kClasses)) + 1u;  // (quad 0 stays unused: 0 = "no piece")
+        const uint32_t q_base = static_cast<uint32_t>(__shfl(static_cast<int>(ts.qres), static_cast<int>(cls)));  // my class's queue position
+        // (L.s_alloc[1]: a record of this strip row found the tile arena full -- its pieces do not exist)
+        const bool fits = base + ts.qtotal <= PM_PU(tarena_cap) && base + ts.qtotal >= base && L.s_alloc[1] == 0u;
         // (on overflow the tiles are still queued but marked "no list": the tile kernels skip
         //  them, the frame has holes, and pm_sync re-renders it with a larger arena)
         if (!fits && lane == 0) PM_PP(ctr_cur)->overflow = 1;
-        if (is_queued) {
-            const uint32_t list_slot = fits ? base + (slots_incl - slots) : 0xffffffffu;
+        if (ts.packed & 1u) {
+            const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + lane;
+            const uint32_t list_slot = fits ? base + ts.list_off : 0xffffffffu;
             PM_PP(tile_ptcl)[tile] = list_slot;
             // A queue entry is everything the tile kernels need to start: {tile, first quad of its
             // command list, its first piece, that piece's candidates | segments << 9}
             const uint4 entry = make_uint4(tile, list_slot, L.s_head_q[lane], L.s_head_n[lane]);
-            const uint32_t below = (1u << lane) - 1u;
-            PM_PP(queue)[cls * PM_PU(queue_cap) + q_base + __popc(my_mask & below)] = entry;
+            PM_PP(queue)[cls * PM_PU(queue_cap) + q_base + (ts.packed >> 4)] = entry;
         }
     };
 
@@ -509,6 +536,9 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             sbase += ns;
         }
         const uint32_t n_slots = sbase * kChunkSegs;  // slots of the record in use
+        // the heaviest strip rows set the span of the launch: their waves win the issue arbitration
+        if (n_slots >= PM_PU(bin_prio_slots)) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
         if (sbase > kSurvLds) __syncthreads();  // (survivors beyond the LDS list sit in global memory, written by any wave)
         else LdsBarrier();        // the survivor list is complete
         if (kProfile && prof_first) {
@@ -554,11 +584,16 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             uint32_t vc_n, k_n, ctag_n;
             float2 a_n, b_n;
             fetch(w_lo + lane, vc_n, k_n, ctag_n, a_n, b_n);
+            WaveSync();
             for (uint32_t f0 = w_lo; f0 < w_hi; f0 += 64u) {
                 const uint32_t f = f0 + lane;
                 const uint32_t vc = vc_n, k = k_n, ctag_f = ctag_n;
                 float2 a = a_n, b = b_n;
                 fetch(f + 64u, vc_n, k_n, ctag_n, a_n, b_n);
+                // (survivors beyond the LDS list are read from the first meta word of their chunk: every lane
+                //  has done so before the chunk's first lane overwrites it below -- in lockstep on the GPU
+                //  anyway; the statement keeps a lane-by-lane execution of this source honest)
+                WaveSync();
                 bool vote = false;
                 float4 seg = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ctag_f == kItemFill) {
@@ -785,6 +820,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         if (kProfile) stamp(12);
         const uint32_t base_q = L.s_alloc[0];
         const bool last_record = !more;  // uniform
+        TailState tail_state{0u, 0u, 0u, 0u};
         // ---- the tail wave: piece headers, the strip row's running estimates; after the strip row's
         //      LAST record also the row's tail -- classes, command-list space, queue entries -- while
         //      the other waves already place candidates and segments --------------------------------------
@@ -820,7 +856,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                     L.s_prev_q[lane] = pq;
                 }
             }
-            if (last_record) RowTail();
+            if (last_record) tail_state = RowTailIssue();
             if (hdr_q) {
                 PM_PP(tarena)[hdr_q] = make_uint4(0u, 0u, 0u, 0u);
                 if (hdr_prev) *reinterpret_cast<uint2 *>(PM_PP(tarena) + hdr_prev) = make_uint2(hdr_q, hdr_n);
@@ -913,6 +949,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             }
         }
         if (!more) {  // the strip row's last record: nothing left to wait for (its stores drain on their own)
+            if (wave == kTailWave) RowTailFinish(tail_state);
             tail_done = true;
             stamp(4);  // record finalised
             break;
@@ -931,7 +968,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     // the strip row's tail, unless its last record took care of it
     if (!tail_done) {  // uniform
         LdsBarrier();  // L.s_est, s_last_*, s_head_* of the last record are in
-        if (wave == kBinWaves - 1) RowTail();
+        if (wave == kBinWaves - 1) RowTailFinish(RowTailIssue());
     }
     (void)prof_chunks;
     if (kProfile) {
@@ -942,6 +979,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
         if (tid < 14) PM_PP(dbg_bin)[16ull * sr + tid] = L.s_stamp[tid];
         if (wave == kBinWaves - 1 && lane == 0) PM_PP(dbg_bin)[16ull * sr + 14] = wall_clock64();
     }
+    }  // strip rows of this workgroup
 }
 
 // =====================================================================================
@@ -955,7 +993,7 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, cons
 }
 
 void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
-    const uint32_t n_striprows = p.n_sr_active;
+    const uint32_t n_striprows = p.bin_grid ? min(p.n_sr_active, p.bin_grid) : p.n_sr_active;
     if (p.use_row_lists) hipLaunchKernelGGL(pm_rowcull_kernel, dim3(p.row1 - p.row0), dim3(kBinThreads), 0, stream, p);
     if (p.dbg_bin)
         PM_LAUNCH(pm_bin_kernel<true>, dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);

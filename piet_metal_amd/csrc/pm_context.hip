@@ -177,6 +177,7 @@ struct pm_ctx {
     int target_fmt = PM_FMT_RGBA8;  // byte order the kernels store pixels in (pm_set_target_format)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
     uint32_t heavy_stream = 32, heavy_stream_lone = 24, vheavy_stream = 96;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
+    uint32_t bin_wg_per_cu = 0xff;  // pm_bin_kernel's workgroups per CU (PM_BIN_WG_PER_CU; 0 = one per strip row, default: by the number of strip rows)
     uint32_t coarse_wg_per_cu = 5, fine_wg_per_cu = 5;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
@@ -420,6 +421,14 @@ int EnsureArena(pm_ctx *c) {
     // (strip rows stay in their natural order: heaviest-first was measured 2.5 us slower -- the heavy
     //  ones then share CUs -- and so was a snake order over CU periods; neighbouring strip rows share
     //  data and belong together)
+    if (const int stride = EnvInt("PM_BIN_STRIDE", 0, 0, 1 << 20); stride > 1 && desc.size() > 2) {
+        // (experiment: neighbours in the work list are `stride` strip rows apart in the picture)
+        std::vector<uint4> perm;
+        perm.reserve(desc.size());
+        for (size_t r = 0; r < static_cast<size_t>(stride); ++r)
+            for (size_t k = r; k < desc.size(); k += static_cast<size_t>(stride)) perm.push_back(desc[k]);
+        desc.swap(perm);
+    }
     if (desc.empty()) desc.push_back(make_uint4(0u, base[0], need.empty() ? base[0] : base[1], 0u));
     c->n_sr_active = static_cast<uint32_t>(desc.size());
     if (desc.size() > c->sr_desc_cap) {  // (grow only: an animation re-sizes every frame)
@@ -547,6 +556,16 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->arena_cap = s->arena_cap;
     p->sr_desc = c->d_sr_desc;
     p->n_sr_active = c->n_sr_active;
+    p->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 1024, 0, 1 << 30));
+    {
+        // pm_bin_kernel's grid: what the chip holds at once (four workgroups per CU) when strip rows are
+        // plenty -- a throughput problem (config 4: 4 096 rows, 200 -> 224 us with three) --, one less
+        // when every workgroup gets one or two rows and the launch ends with its heaviest ones: their
+        // waves then share the SIMDs with fewer others (Tiger 4K: 39.5 -> 37.4 us)
+        uint32_t per_cu = c->bin_wg_per_cu;
+        if (per_cu == 0xffu) per_cu = c->n_sr_active <= 6u * static_cast<uint32_t>(c->n_cus) ? 3u : 4u;
+        p->bin_grid = static_cast<uint32_t>(c->n_cus) * per_cu;
+    }
     p->sr_empty_dwords = c->sr_empty_dwords;
     p->queue = s->d_queue;
     p->queue_cap = static_cast<uint32_t>(BandTiles(c));
@@ -982,6 +1001,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->fused = EnvInt("PM_FUSED", 1, 0, 1) != 0;
     c->handout = EnvInt("PM_HANDOUT", 0, 0, 2);
     c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 5, 1, 16));
+    c->bin_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_BIN_WG_PER_CU", 0xff, 0, 0xff));
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
     for (auto &s : c->slot) {

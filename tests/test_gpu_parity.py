@@ -105,6 +105,24 @@ def test_many_items_multiple_batches_and_long_lists(pm, pmo, renderer):
     assert_ptcl_equal(renderer, pmo, scene, 256, 256, maxc=4096)
 
 
+def test_one_strip_row_with_thousands_of_surviving_chunks(pm, pmo, renderer):
+    """Three fills and a polyline of 7 000 points each zigzag inside a single strip row: every chunk of 8
+    segments survives binning's box test there -- 3 500 chunks, far more than the LDS survivor list
+    (1 024) holds: the spill path of pm_bin_kernel, and dozens of vote / scatter rounds per wave.
+    (7 000 points keep an item's winding inside the packed per-tile counter)"""
+    n = 7000
+    xs = 3.0 + 245.0 * (np.arange(n) % 2) + 0.01 * np.arange(n)
+    ys = 99.5 + 12.0 * ((np.arange(n) // 2) % 2) + 0.0003 * np.arange(n)
+    pts = np.stack([xs, ys], axis=1)
+    ops = [("fill", pts, 0x3060A0C0), ("fill", pts + np.array([0.5, -1.25]), 0xA0303080), ("circle", 120.0, 104.0, 40.0),
+           ("poly", pts[::-1] + np.array([1.5, 2.25]), 0x20C040FF, 1.5), ("fill", pts * np.array([1.0, 1.01]), 0x10F01060)]
+    scene = encode_ops(pm, ops, cap=1 << 20)
+    w, h = 340, 160
+    got = gpu_render(renderer, scene, w, h)
+    assert np.array_equal(got, pmo.render(scene, w, h))
+    assert_ptcl_equal(renderer, pmo, scene, w, h, maxc=1 << 16)
+
+
 def test_list_longer_than_the_lds_command_buffer(pm, pmo, renderer):
     # 900 translucent polylines through one tile: > 2000 commands, so the per-tile kernel
     # must flush its 768-slot LDS list mid-stream (pixel state carried in registers); an
