@@ -169,13 +169,14 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     // their arena regions from the same predicate); the others are background for the whole
     // life of the scene and never get a workgroup.  The grid is no larger than what the chip holds
     // at once (a workgroup that has to wait for a slot starts when the first ones END, 20 us into
-    // the launch, and then sets its span): with more strip rows than that, a workgroup takes the rows
-    // blockIdx.x, blockIdx.x + gridDim.x, ... one after the other -- in natural order that pairs the
-    // top rows of the picture with the bottom ones, the lightest with the lightest.
-    for (uint32_t rix = blockIdx.x; rix < PM_PU(n_sr_active); rix += gridDim.x) {
+    // the launch, and then sets its span): with more strip rows than that, a workgroup walks a chain
+    // of rows the host linked (the lightest rows share workgroups: pm_context.hip, EnsureArena).
+    for (uint32_t rix = blockIdx.x, rix_next = 0; rix < PM_PU(n_sr_active); rix = rix_next) {
     if (rix != blockIdx.x) LdsBarrier();  // the previous strip row's LDS is done with
-    // One 16-byte load: {strip row, region, end}.
+    // One 16-byte load: {strip row, region, end, next strip row of this workgroup (0: none)}.
     const uint4 srd = PM_PP(sr_desc)[rix];
+    rix_next = __builtin_amdgcn_readfirstlane(srd.w);
+    if (rix_next == 0) rix_next = 0xffffffffu;
     const uint32_t sr = __builtin_amdgcn_readfirstlane(srd.x);
     const uint32_t strip = sr % PM_PU(strips_x);
     const uint32_t row_rel = sr / PM_PU(strips_x);
@@ -739,65 +740,74 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             if (alloc_total && lane == 0) alloc_q = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, alloc_total);  // (looked at after the pass below)
         }
 
-        // ---- candidates pass, thread = candidate.  Per tile of the strip: the backdrop (prefix of the
-        //      recorded steps), whether the candidate can emit anything there (its hit bit), whether it
-        //      is nothing but an opaque Solid; ballots over the wave's candidates give, per tile, the
-        //      candidates of its piece, the pseudo elements (candidates without segments), the last
-        //      candidate that can emit and the last opaque Solid ---------------------------------------------
-        uint32_t hm = 0;  // this candidate's hit bits
+        // ---- candidates pass.  Lane = candidate (64 at a time), and every wave takes a QUARTER of the
+        //      strip's tiles for ALL candidates: per tile the backdrop (prefix of the recorded steps),
+        //      whether the candidate can emit anything there (its hit bit), whether it is nothing but an
+        //      opaque Solid; ballots over the candidates give, per tile, the candidates of its piece, the
+        //      pseudo elements (candidates without segments), the last candidate that can emit and the
+        //      last opaque Solid.  (Most strip rows have well under 64 candidates: split by candidates,
+        //      one wave would walk all 16 tiles while three wait.)
+        constexpr uint32_t kGroups = kBatch / 64u;
+        static_assert(kGroups * 4u <= 32u, "hit bits of a lane's candidates: four per group in one register");
+        const uint32_t wq = WaveId();   // this wave's tiles: 4 * wq .. 4 * wq + 3
+        const uint32_t t0 = 4u * wq;
+        const uint32_t n_groups = (ncand + 63u) / 64u;  // (uniform)
+        uint32_t hq = 0;                // this lane's candidates (one per group): hit bits in the wave's tiles, 4 bits per group
+        // per candidate: what both passes need
+        auto cand_flags = [&](uint32_t c, uint32_t &cm, uint32_t &fill_bit, uint32_t &circle_bit, uint32_t &opaque_bit, uint32_t &rule) {
+            // (threads beyond the candidates read stale rows: with an empty bbox mask nothing of it counts)
+            cm = c < ncand ? L.s_cmask[c] : 0u;
+            const uint32_t tag = L.s_ctag[c], rgba = L.s_crgba[c];
+            fill_bit = tag == kItemFill ? 1u : 0u;
+            circle_bit = tag == kItemCircle ? 1u : 0u;
+            opaque_bit = (rgba & 0xff000000u) == 0xff000000u ? fill_bit : 0u;
+            // a tile wholly inside a fill is covered if its winding is non-zero (all bits) / odd (bit 0)
+            rule = (L.s_caux0[c] & kFillEvenOdd) ? 1u : 0xffffffffu;
+        };
         {
-            uint32_t wh = 0, we = 0, wlk = 0, wls = 0;  // lane t < 16: this wave's totals for tile t
-            if (wave * 64u < ncand) {  // uniform: the wave holds candidates
-                // (Opaque: LDS addresses derived from it are made here, not at kernel entry and spilled)
-                const uint32_t tid = Opaque(threadIdx.x);
-                // (threads beyond the candidates read stale rows: with an empty bbox mask nothing of it counts)
-                const uint32_t cm = tid < ncand ? L.s_cmask[tid] : 0u;
-                const uint32_t tag = L.s_ctag[tid], rgba = L.s_crgba[tid];
-                const uint32_t fill_bit = tag == kItemFill ? 1u : 0u;
-                const uint32_t circle_bit = tag == kItemCircle ? 1u : 0u;
-                const uint32_t opaque_bit = (rgba & 0xff000000u) == 0xff000000u ? fill_bit : 0u;
-                // a tile wholly inside a fill is covered if its winding is non-zero (all bits) / odd (bit 0)
-                const uint32_t rule = (L.s_caux0[tid] & kFillEvenOdd) ? 1u : 0xffffffffu;
-                uint32_t *const ct_row = &L.s_ct[tid * kCtStride];
-                uint32_t sm = 0, zm = 0;  // nothing but an opaque Solid / hit without segments
-                int run = 0;  // backdrop steps were recorded at the first tile they apply to
-                ForStripTiles([&](auto tc) {
-                    constexpr uint32_t t = decltype(tc)::value;
+            uint32_t nh_q[4] = {0u, 0u, 0u, 0u}, ne_q[4] = {0u, 0u, 0u, 0u}, lk_q[4] = {0u, 0u, 0u, 0u}, ls_q[4] = {0u, 0u, 0u, 0u};  // (uniform)
+#pragma unroll 1
+            for (uint32_t g = 0; g < n_groups; ++g) {
+                const uint32_t c = g * 64u + Opaque(lane);
+                uint32_t cm, fill_bit, circle_bit, opaque_bit, rule;
+                cand_flags(c, cm, fill_bit, circle_bit, opaque_bit, rule);
+                const uint32_t *const ct_row = &L.s_ct[c * kCtStride];
+                int run = 0;  // backdrop steps were recorded at the first tile they apply to: the tiles before this wave's
+#pragma unroll 1
+                for (uint32_t t = 0; t < t0; ++t) run += static_cast<int>(ct_row[t]) >> kCtShift;
+                uint32_t hb = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    const uint32_t t = t0 + j;
                     const uint32_t raw = ct_row[t];
-                    const uint32_t cnt = raw & kCtCountMask;
                     run += static_cast<int>(raw) >> kCtShift;
-                    ct_row[t] = (static_cast<uint32_t>(run) << kCtShift) | cnt;
+                    const uint32_t cnt = raw & kCtCountMask;
                     const uint32_t inside = (static_cast<uint32_t>(run) & rule) != 0u ? fill_bit : 0u;
                     // a hit bit only where the candidate can emit something: a relevant segment, a
                     // non-zero backdrop (Solid / DrawFill), or a circle
                     const uint32_t some = (cnt != 0u ? 1u : 0u) | inside | circle_bit;
                     const uint32_t hit = some & (cm >> t) & 1u;
                     const uint32_t nos = cnt == 0u ? hit : 0u;
-                    hm |= hit << t;
-                    zm |= nos << t;
-                    sm |= (nos & opaque_bit) << t;
-                });
-                const uint32_t wbase = WaveId() * 64u + 64u;
-                ForStripTiles([&](auto tc) {
-                    constexpr uint32_t t = decltype(tc)::value;
-                    const uint64_t bh = __ballot((hm >> t) & 1u), bz = __ballot((zm >> t) & 1u), bs = __ballot((sm >> t) & 1u);
-                    WriteLane<t>(wh, static_cast<uint32_t>(__popcll(bh)));
-                    WriteLane<t>(we, static_cast<uint32_t>(__popcll(bz)));
-                    WriteLane<t>(wlk, bh ? wbase - static_cast<uint32_t>(__builtin_clzll(bh)) : 0u);  // candidate index + 1
-                    WriteLane<t>(wls, bs ? wbase - static_cast<uint32_t>(__builtin_clzll(bs)) : 0u);
-                });
-                if (tid < ncand) {
-                    L.s_cmask[tid] = hm | (sm << 16);
-                    // the colour already through unpack_unorm4x8_srgb_to_half
-                    L.s_cpts[tid] = (L.s_lut[rgba & 0xffu] & 0xffffu) | (L.s_lut[(rgba >> 8) & 0xffu] << 16);         // rg
-                    L.s_cnpt[tid] = (L.s_lut[(rgba >> 16) & 0xffu] & 0xffffu) | (L.s_lut[rgba >> 24] & 0xffff0000u);  // ba
+                    hb |= hit << j;
+                    const uint64_t bh = __ballot(hit), bz = __ballot(nos), bs = __ballot(nos & opaque_bit);
+                    nh_q[j] += static_cast<uint32_t>(__popcll(bh));
+                    ne_q[j] += static_cast<uint32_t>(__popcll(bz));
+                    if (bh) lk_q[j] = g * 64u + 64u - static_cast<uint32_t>(__builtin_clzll(bh));  // candidate index + 1
+                    if (bs) ls_q[j] = g * 64u + 64u - static_cast<uint32_t>(__builtin_clzll(bs));
+                }
+                hq |= hb << (4u * g);
+                if (wq == (g & 3u) && c < ncand) {  // (one wave per group) the colour already through unpack_unorm4x8_srgb_to_half
+                    const uint32_t rgba = L.s_crgba[c];
+                    L.s_cpts[c] = (L.s_lut[rgba & 0xffu] & 0xffffu) | (L.s_lut[(rgba >> 8) & 0xffu] << 16);         // rg
+                    L.s_cnpt[c] = (L.s_lut[(rgba >> 16) & 0xffu] & 0xffffu) | (L.s_lut[rgba >> 24] & 0xffff0000u);  // ba
                 }
             }
-            if (lane < kStripTiles) {
-                L.s_wh[wave][lane] = wh;
-                L.s_we[wave][lane] = we;
-                L.s_wlk[wave][lane] = wlk;
-                L.s_wls[wave][lane] = wls;
+            if (lane < 4u) {
+                const uint32_t j = lane, t = t0 + lane;
+                L.s_wh[0][t] = j == 0 ? nh_q[0] : (j == 1 ? nh_q[1] : (j == 2 ? nh_q[2] : nh_q[3]));
+                L.s_we[0][t] = j == 0 ? ne_q[0] : (j == 1 ? ne_q[1] : (j == 2 ? ne_q[2] : ne_q[3]));
+                L.s_wlk[0][t] = j == 0 ? lk_q[0] : (j == 1 ? lk_q[1] : (j == 2 ? lk_q[2] : lk_q[3]));
+                L.s_wls[0][t] = j == 0 ? ls_q[0] : (j == 1 ? ls_q[1] : (j == 2 ? ls_q[2] : ls_q[3]));
             }
         }
         // the tail wave: where the pieces went
@@ -828,13 +838,10 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
             uint32_t nh = 0, ne = 0, lkm = 0, lsm = 0;
             uint32_t hdr_q = 0, hdr_prev = 0, hdr_n = 0;
             if (lane < kStripTiles) {
-#pragma unroll
-                for (uint32_t w = 0; w < static_cast<uint32_t>(kBinWaves); ++w) {
-                    nh += L.s_wh[w][lane];
-                    ne += L.s_we[w][lane];
-                    lkm = max(lkm, L.s_wlk[w][lane]);
-                    lsm = max(lsm, L.s_wls[w][lane]);
-                }
+                nh = L.s_wh[0][lane];
+                ne = L.s_we[0][lane];
+                lkm = L.s_wlk[0][lane];
+                lsm = L.s_wls[0][lane];
                 L.s_est[lane] += nrel_t + ne;
                 if (lkm) L.s_last_kept[lane] = L.s_cidx[lkm - 1u] + 1u;  // records come in paint order
                 if (lsm) {
@@ -871,38 +878,41 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
                 mw_n = meta[w_lo + lane];  // (this wave wrote it)
                 seg_n = segs[w_lo + lane];
             }
-            // ---- candidate entries, thread = candidate: its rank among the tile's candidates is a
-            //      ballot away; two quads per (candidate, tile) behind the piece's segments ------------------
-            if (wave * 64u < ncand) {  // uniform
-                const uint32_t tid = Opaque(threadIdx.x);
-                const bool is_c = tid < ncand;
-                uint4 e0 = make_uint4(0u, 0u, 0u, 0u);
-                uint32_t e1y = 0, e1z = 0, e1w = 0;
-                if (is_c) {
-                    e0 = make_uint4(L.s_ctag[tid], L.s_crgba[tid], L.s_caux0[tid], L.s_caux1[tid]);
-                    e1y = L.s_cidx[tid];
-                    e1z = L.s_cpts[tid];
-                    e1w = L.s_cnpt[tid];
-                }
-                // lane t < 16: quad of the first candidate entry this wave writes for tile t
+            // ---- candidate entries, the same way: lane = candidate, the wave's quarter of the tiles for every
+            //      group of 64 candidates; a candidate's rank in a tile's piece is the hits of the earlier
+            //      groups plus a ballot; two quads per (candidate, tile) behind the piece's segments --------
+            {
+                // lane t < 16: quad of the tile's first candidate entry
                 uint32_t cq = 0;
-                if (lane < kStripTiles) {
-                    uint32_t before = 0;
-                    for (uint32_t w = 0; w < wave; ++w) before += L.s_wh[w][lane];
-                    cq = L.s_piece_q[lane] + 1u + L.s_piece_n[lane] + 2u * before;
-                }
-                const uint32_t *const ct_row = &L.s_ct[(is_c ? tid : 0u) * kCtStride];
-                ForStripTiles([&](auto tc) {
-                    constexpr uint32_t t = decltype(tc)::value;
-                    const bool hit = (hm >> t) & 1u;
-                    const uint64_t bh = __ballot(hit);
-                    const uint32_t q0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cq), static_cast<int>(t)));
-                    if (hit) {
-                        uint4 *e = PM_PP(tarena) + q0 + 2u * RankBelow(bh);
-                        e[0] = e0;
-                        e[1] = make_uint4(ct_row[t], e1y, e1z, e1w);
+                if (lane < kStripTiles) cq = L.s_piece_q[lane] + 1u + L.s_piece_n[lane];
+                uint32_t rank_q[4] = {0u, 0u, 0u, 0u};  // (uniform) entries written so far in the wave's tiles
+#pragma unroll 1
+                for (uint32_t g = 0; g < n_groups; ++g) {
+                    const uint32_t hb = (hq >> (4u * g)) & 15u;
+                    if (__ballot(hb != 0u) == 0ull) continue;  // uniform: nothing of this group in the wave's tiles
+                    const uint32_t c = min(g * 64u + Opaque(lane), ncand - 1u);
+                    const uint4 e0 = make_uint4(L.s_ctag[c], L.s_crgba[c], L.s_caux0[c], L.s_caux1[c]);
+                    const uint32_t e1y = L.s_cidx[c], e1z = L.s_cpts[c], e1w = L.s_cnpt[c];
+                    const uint32_t *const ct_row = &L.s_ct[c * kCtStride];
+                    int run = 0;
+#pragma unroll 1
+                    for (uint32_t t = 0; t < t0; ++t) run += static_cast<int>(ct_row[t]) >> kCtShift;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const uint32_t t = t0 + j;
+                        const uint32_t raw = ct_row[t];
+                        run += static_cast<int>(raw) >> kCtShift;
+                        const bool hit = (hb >> j) & 1u;
+                        const uint64_t bh = __ballot(hit);
+                        const uint32_t q0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cq), static_cast<int>(t)));
+                        if (hit) {
+                            uint4 *e = PM_PP(tarena) + q0 + 2u * (rank_q[j] + RankBelow(bh));
+                            e[0] = e0;
+                            e[1] = make_uint4((static_cast<uint32_t>(run) << kCtShift) | (raw & kCtCountMask), e1y, e1z, e1w);
+                        }
+                        rank_q[j] += static_cast<uint32_t>(__popcll(bh));
                     }
-                });
+                }
             }
             // ---- scatter: every relevant (segment, tile) pair to its place in the tile's piece; lane
             //      t < 16 keeps the quad of the next segment of tile t written by this wave.  The next
@@ -993,7 +1003,7 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, cons
 }
 
 void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
-    const uint32_t n_striprows = p.bin_grid ? min(p.n_sr_active, p.bin_grid) : p.n_sr_active;
+    const uint32_t n_striprows = p.bin_grid;
     if (p.use_row_lists) hipLaunchKernelGGL(pm_rowcull_kernel, dim3(p.row1 - p.row0), dim3(kBinThreads), 0, stream, p);
     if (p.dbg_bin)
         PM_LAUNCH(pm_bin_kernel<true>, dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);

@@ -207,6 +207,7 @@ struct pm_ctx {
     size_t sr_desc_cap = 0, band_cap = 0;
     uint4 *d_sr_desc = nullptr;     // strip rows some item reaches: {strip row, arena region begin, end, 0}
     uint32_t n_sr_active = 0;
+    uint32_t bin_grid = 1;          // workgroups of pm_bin_kernel (each walks a chain of strip rows)
     uint32_t sr_empty_dwords = 0;   // size of a region no item reaches
     uint2 *d_band_bbox = nullptr;   // items that reach the band (bbox, scene index), paint order
     uint32_t *d_band_item = nullptr;
@@ -421,16 +422,27 @@ int EnsureArena(pm_ctx *c) {
     // (strip rows stay in their natural order: heaviest-first was measured 2.5 us slower -- the heavy
     //  ones then share CUs -- and so was a snake order over CU periods; neighbouring strip rows share
     //  data and belong together)
-    if (const int stride = EnvInt("PM_BIN_STRIDE", 0, 0, 1 << 20); stride > 1 && desc.size() > 2) {
-        // (experiment: neighbours in the work list are `stride` strip rows apart in the picture)
-        std::vector<uint4> perm;
-        perm.reserve(desc.size());
-        for (size_t r = 0; r < static_cast<size_t>(stride); ++r)
-            for (size_t k = r; k < desc.size(); k += static_cast<size_t>(stride)) perm.push_back(desc[k]);
-        desc.swap(perm);
-    }
     if (desc.empty()) desc.push_back(make_uint4(0u, base[0], need.empty() ? base[0] : base[1], 0u));
     c->n_sr_active = static_cast<uint32_t>(desc.size());
+    {
+        // pm_bin_kernel's grid is no larger than what the chip holds at once: four workgroups per CU when
+        // strip rows are plenty -- a throughput problem (config 4: 4 096 rows, 200 -> 224 us with three) --,
+        // one less when a workgroup gets one or two rows and the launch ends with its heaviest ones: their
+        // waves then share the SIMDs with fewer others (Tiger 4K: 39.5 -> 37.4 us).  A workgroup walks a
+        // chain of strip rows (desc.w = index of the next one, 0 = none): row b, b + grid, b + 2 grid ... in
+        // natural order -- at Tiger 4K that pairs the top of the picture with its bottom, light rows with
+        // light rows.  (Measured and not kept: any permutation of ALL rows, +25 % -- neighbouring strip
+        // rows share data; pairing the lightest rows by their arena need, +9 % -- the need is the worst
+        // case of the chunk test, not the work.)
+        uint32_t per_cu = c->bin_wg_per_cu;
+        if (per_cu == 0xffu) per_cu = c->n_sr_active <= 6u * static_cast<uint32_t>(c->n_cus) ? 3u : 4u;
+        const size_t n = desc.size();
+        const size_t grid = per_cu == 0 ? n : std::min<size_t>(n, static_cast<size_t>(c->n_cus) * per_cu);
+        if (n > grid) {
+            for (size_t i = 0; i + grid < n; ++i) desc[i].w = static_cast<uint32_t>(i + grid);
+        }
+        c->bin_grid = static_cast<uint32_t>(grid);
+    }
     if (desc.size() > c->sr_desc_cap) {  // (grow only: an animation re-sizes every frame)
         if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
         c->d_sr_desc = nullptr;
@@ -556,6 +568,8 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->arena_cap = s->arena_cap;
     p->sr_desc = c->d_sr_desc;
     p->n_sr_active = c->n_sr_active;
+    p->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 1024, 0, 1 << 30));
+    p->bin_grid = c->bin_grid;
     p->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 1024, 0, 1 << 30));
     {
         // pm_bin_kernel's grid: what the chip holds at once (four workgroups per CU) when strip rows are
