@@ -157,6 +157,8 @@ struct FrameSlot {
     uint32_t ptcl_cap = 0;    // quads (16 B)
     uint2 *d_row_bbox = nullptr;  // per-tile-row item lists of this slot's frame (large scenes)
     uint32_t *d_row_item = nullptr;
+    uint64_t row_cap = 0;         // entries allocated for them
+    uint32_t state_epoch = 0;     // arena_epoch its tile_state was last reset for (0: never)
     pm::Counters *d_ctr = nullptr;  // two: a frame's binning kernel zeroes the one the slot's next frame uses
     uint32_t parity = 0;
     hipEvent_t ev_done = nullptr;  // end of the slot's last frame
@@ -192,6 +194,11 @@ struct pm_ctx {
     uint32_t dev_bbox_ix = 8, dev_items_ix = 0;  // the drawn group's ShortBbox / item arrays in d_scene
     uint32_t n_items = 0;
     std::vector<uint8_t> item_meta;  // copy of header + bboxes + items (arena sizing)
+    std::vector<uint32_t> chunk_base_host;  // source of the asynchronous upload of the chunk table
+    std::vector<uint4> stage_desc;          // ... of the strip-row work list,
+    std::vector<uint2> stage_bbs;           // ... the band's item boxes
+    std::vector<uint32_t> stage_ids, stage_rb;  // ... and indices, the per-row list offsets
+    size_t row_base_cap = 0;
     uint32_t *d_chunk_base = nullptr;  // scene index: first chunk of every item (+ total)
     float4 *d_chunk_bbox = nullptr;    // scene index: bounding box of every chunk of segments
     size_t chunk_base_cap = 0, chunk_bbox_cap = 0;
@@ -218,6 +225,7 @@ struct pm_ctx {
     uint32_t arena_cap = 0;         // dwords per slot
     uint64_t ptcl_want = 0;         // commands a slot's list arena starts with / was grown to
     bool arena_dirty = true;
+    uint32_t arena_epoch = 0;       // bumped whenever the set of strip rows without a workgroup changes (EnsureArena)
 
     std::vector<FrameSlot> slot;
     uint32_t frame = 0;
@@ -268,8 +276,21 @@ void FreeViewport(pm_ctx *c) {
         s.d_tile_state = s.d_tile_ptcl = s.d_tile_ncmd = nullptr;
         s.in_flight = false;
         s.needs_check = false;
+        s.state_epoch = 0;
     }
     c->last_slot = -1;
+}
+
+int AllocSlotViewport(pm_ctx *c, FrameSlot *s) {
+    if (s->d_fb) return PM_OK;
+    const size_t tiles = BandTiles(c);
+    PM_TRY(hipMalloc(&s->d_fb, std::max<size_t>(c->fb_bytes, 16)));
+    PM_TRY(hipMalloc(&s->d_queue, pm::kClasses * tiles * sizeof(uint4)));  // one queue per cost class
+    PM_TRY(hipMalloc(&s->d_tile_state, tiles * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&s->d_tile_ptcl, tiles * sizeof(uint32_t)));
+    PM_TRY(hipMalloc(&s->d_tile_ncmd, tiles * sizeof(uint32_t)));
+    s->state_epoch = 0;  // (never initialised)
+    return PM_OK;
 }
 
 int AllocViewport(pm_ctx *c) {
@@ -277,14 +298,10 @@ int AllocViewport(pm_ctx *c) {
     const uint32_t rows = BandRows(c);
     c->fb_stride = static_cast<size_t>(c->width) * 4;
     c->fb_bytes = c->fb_stride * static_cast<size_t>(rows) * pm::kTileH;
-    const size_t tiles = BandTiles(c);
-    for (auto &s : c->slot) {
-        PM_TRY(hipMalloc(&s.d_fb, std::max<size_t>(c->fb_bytes, 16)));
-        PM_TRY(hipMalloc(&s.d_queue, pm::kClasses * tiles * sizeof(uint4)));  // one queue per cost class
-        PM_TRY(hipMalloc(&s.d_tile_state, tiles * sizeof(uint32_t)));
-        PM_TRY(hipMalloc(&s.d_tile_ptcl, tiles * sizeof(uint32_t)));
-        PM_TRY(hipMalloc(&s.d_tile_ncmd, tiles * sizeof(uint32_t)));
-    }
+    // (slot 0 now -- pm_framebuffer_device_ptr names its framebuffer before the first frame --, the
+    //  others when they are first used: a resize followed by one frame pays for one set of buffers)
+    const int r0 = AllocSlotViewport(c, &c->slot[0]);
+    if (r0 != PM_OK) return r0;
     c->arena_dirty = true;
     return PM_OK;
 }
@@ -327,6 +344,8 @@ void SetClassThresholds(const pm_ctx *c, pm::FrameParams *p, uint32_t heavy) {
 // A slot's binning arena and command-list arena, allocated (or grown to what EnsureArena asked for)
 // when the slot is about to be used.
 int EnsureSlotBuffers(pm_ctx *c, FrameSlot *s) {
+    const int rv = AllocSlotViewport(c, s);
+    if (rv != PM_OK) return rv;
     if (!s->d_arena || s->arena_cap < c->arena_cap) {
         if (s->d_arena) (void)hipFree(s->d_arena);  // (hipFree waits for the device: nothing is using it any more)
         s->d_arena = nullptr;
@@ -382,7 +401,7 @@ int EnsureArena(pm_ctx *c) {
     if (!c->arena_dirty && c->arena_cap != 0) return PM_OK;
     if (c->item_meta.empty() || c->tiles_x == 0) return PM_OK;  // nothing to size against yet
     const WallTimer timer;
-    PM_TRY(SyncAll(c) == PM_OK ? hipSuccess : hipErrorUnknown);
+    // (host work first: the scene-index kernel of a scene replacement is still running on the device)
     std::vector<uint64_t> need;
     StripRowBounds(c, &need);
     std::vector<uint32_t> base(need.size() + 1);
@@ -416,7 +435,8 @@ int EnsureArena(pm_ctx *c) {
     // The strip rows some item's bbox reaches get a workgroup of pm_bin_kernel each; the others are
     // background for as long as this scene and viewport last: their tile_state is set to white
     // once, here.  (An empty list still launches one workgroup: it resets the frame counters.)
-    std::vector<uint4> desc;
+    std::vector<uint4> &desc = c->stage_desc;  // (sources of asynchronous uploads live in the context)
+    desc.clear();
     for (size_t i = 0; i < need.size(); ++i)
         if (((need[i] + 3u) & ~3ull) != c->sr_empty_dwords) desc.push_back(make_uint4(static_cast<uint32_t>(i), base[i], base[i + 1], 0u));
     // (strip rows stay in their natural order: heaviest-first was measured 2.5 us slower -- the heavy
@@ -443,6 +463,7 @@ int EnsureArena(pm_ctx *c) {
         }
         c->bin_grid = static_cast<uint32_t>(grid);
     }
+    PM_TRY(SyncAll(c) == PM_OK ? hipSuccess : hipErrorUnknown);  // frames in flight still read the lists replaced below
     if (desc.size() > c->sr_desc_cap) {  // (grow only: an animation re-sizes every frame)
         if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
         c->d_sr_desc = nullptr;
@@ -450,15 +471,15 @@ int EnsureArena(pm_ctx *c) {
         PM_TRY(hipMalloc(&c->d_sr_desc, (desc.size() + desc.size() / 4 + 16) * sizeof(uint4)));
         c->sr_desc_cap = desc.size() + desc.size() / 4 + 16;
     }
-    PM_TRY(hipMemcpy(c->d_sr_desc, desc.data(), desc.size() * sizeof(uint4), hipMemcpyHostToDevice));
-    for (auto &s : c->slot) {
-        PM_TRY(hipMemset(s.d_tile_state, 0xff, BandTiles(c) * sizeof(uint32_t)));
-    }
+    PM_TRY(hipMemcpyAsync(c->d_sr_desc, desc.data(), desc.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    c->arena_epoch += 1;  // (a slot's tile_state is reset to "background" on the frame's own stream when the slot is next used)
     // the items whose bbox reaches the band (rows: bw >= y0 && by < y1, PietRender.metal:198/:214)
     {
         const uint8_t *meta = c->item_meta.data();
-        std::vector<uint2> bbs;
-        std::vector<uint32_t> ids;
+        std::vector<uint2> &bbs = c->stage_bbs;
+        std::vector<uint32_t> &ids = c->stage_ids;
+        bbs.clear();
+        ids.clear();
         const uint32_t y0 = c->row0 * pm::kTileH, y1 = c->row1 * pm::kTileH;
         for (uint32_t i = 0; i < c->n_items; ++i) {
             uint32_t w[2];
@@ -482,24 +503,17 @@ int EnsureArena(pm_ctx *c) {
             c->band_cap = want;
         }
         if (!ids.empty()) {
-            PM_TRY(hipMemcpy(c->d_band_bbox, bbs.data(), ids.size() * sizeof(uint2), hipMemcpyHostToDevice));
-            PM_TRY(hipMemcpy(c->d_band_item, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            PM_TRY(hipMemcpyAsync(c->d_band_bbox, bbs.data(), ids.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
+            PM_TRY(hipMemcpyAsync(c->d_band_item, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         }
         // Large scenes: every tile row gets its own item list each frame (pm_rowcull_kernel); the
         // host only sizes the lists, with the kernel's predicate.
         const int min_items = EnvInt("PM_ROW_LIST_MIN_ITEMS", 2048, 0, 1 << 30);
         c->use_row_lists = static_cast<int>(ids.size()) >= min_items && !ids.empty();
-        for (auto &s : c->slot) {
-            if (s.d_row_bbox) (void)hipFree(s.d_row_bbox);
-            if (s.d_row_item) (void)hipFree(s.d_row_item);
-            s.d_row_bbox = nullptr;
-            s.d_row_item = nullptr;
-        }
-        if (c->d_row_base) (void)hipFree(c->d_row_base);
-        c->d_row_base = nullptr;
         if (c->use_row_lists) {
             const uint32_t rows = BandRows(c);
-            std::vector<uint32_t> rb(rows + 1, 0u);
+            std::vector<uint32_t> &rb = c->stage_rb;
+            rb.assign(rows + 1, 0u);
             for (const uint2 &b : bbs) {
                 const uint32_t by = b.x >> 16, bw = b.y >> 16;
                 const uint32_t r_lo = std::max(by / pm::kTileH, c->row0), r_hi = std::min(bw / pm::kTileH, c->row1 - 1);
@@ -517,14 +531,29 @@ int EnsureArena(pm_ctx *c) {
             }
             rb[rows] = static_cast<uint32_t>(run);
             c->row_total = static_cast<uint32_t>(run);
-            PM_TRY(hipMalloc(&c->d_row_base, rb.size() * sizeof(uint32_t)));
-            PM_TRY(hipMemcpy(c->d_row_base, rb.data(), rb.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            if (rb.size() > c->row_base_cap || !c->d_row_base) {  // (grow only)
+                if (c->d_row_base) (void)hipFree(c->d_row_base);
+                c->d_row_base = nullptr;
+                c->row_base_cap = 0;
+                PM_TRY(hipMalloc(&c->d_row_base, (rb.size() + 64) * sizeof(uint32_t)));
+                c->row_base_cap = rb.size() + 64;
+            }
+            PM_TRY(hipMemcpyAsync(c->d_row_base, rb.data(), rb.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            const uint64_t want = std::max<uint64_t>(run, 1);
             for (auto &s : c->slot) {
-                PM_TRY(hipMalloc(&s.d_row_bbox, std::max<uint64_t>(run, 1) * sizeof(uint2)));
-                PM_TRY(hipMalloc(&s.d_row_item, std::max<uint64_t>(run, 1) * sizeof(uint32_t)));
+                if (s.row_cap >= want && s.d_row_bbox) continue;
+                if (s.d_row_bbox) (void)hipFree(s.d_row_bbox);
+                if (s.d_row_item) (void)hipFree(s.d_row_item);
+                s.d_row_bbox = nullptr;
+                s.d_row_item = nullptr;
+                s.row_cap = 0;
+                PM_TRY(hipMalloc(&s.d_row_bbox, (want + want / 4) * sizeof(uint2)));
+                PM_TRY(hipMalloc(&s.d_row_item, (want + want / 4) * sizeof(uint32_t)));
+                s.row_cap = want + want / 4;
             }
         }
     }
+    PM_TRY(hipStreamSynchronize(c->stream));  // ONE wait: the lists are in place before a frame on any stream reads them
     c->arena_dirty = false;
     c->t_arena_ms = timer.ms();
     return PM_OK;
@@ -543,6 +572,9 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     }
     int r = EnsureArena(c);
     if (r != PM_OK) return r;
+    r = EnsureSlotBuffers(c, s);  // (the slot's buffers come into being when it is first used)
+    if (r != PM_OK) return r;
+    if (!fb) fb = s->d_fb;
     std::memset(p, 0, sizeof(*p));
     p->scene = c->d_scene;
     p->scene_bytes = static_cast<uint32_t>(c->scene_bytes);
@@ -560,10 +592,6 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->fb_stride = static_cast<uint32_t>(stride);
     p->fb_vec16 = ((reinterpret_cast<uintptr_t>(fb) & 15u) == 0 && (stride & 15u) == 0) ? 1u : 0u;
     p->fb_bgra = c->target_fmt == PM_FMT_BGRA8 ? 1u : 0u;
-    {
-        const int rb = EnsureSlotBuffers(c, s);
-        if (rb != PM_OK) return rb;
-    }
     p->arena = s->d_arena;
     p->arena_cap = s->arena_cap;
     p->sr_desc = c->d_sr_desc;
@@ -626,6 +654,14 @@ uint32_t FineGrid(const pm_ctx *c) {
     return std::max(1u, std::min(tiles, static_cast<uint32_t>(c->n_cus) * c->fine_wg_per_cu));
 }
 
+// Strip rows no item reaches get no workgroup: their tiles are background for as long as this scene
+// and viewport last -- set once per slot and arena epoch, in stream order before the frame.
+hipError_t ResetTileState(pm_ctx *c, FrameSlot *s, hipStream_t q) {
+    if (s->state_epoch == c->arena_epoch) return hipSuccess;
+    s->state_epoch = c->arena_epoch;
+    return hipMemsetAsync(s->d_tile_state, 0xff, BandTiles(c) * sizeof(uint32_t), q);
+}
+
 void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t frame_stream) {
     FrameSlot *s = &c->slot[si];
     s->in_flight = true;
@@ -645,6 +681,10 @@ void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t frame_st
 int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipEvent_t *tev = nullptr) {
     const int si = static_cast<int>(c->frame % c->slot.size());
     FrameSlot *s = &c->slot[si];
+    if (c->tiles_x != 0) {  // (a slot's viewport buffers come into being when the slot is first used)
+        const int ra = AllocSlotViewport(c, s);
+        if (ra != PM_OK) return ra;
+    }
     if (!fb) fb = s->d_fb;
     pm::FrameParams p;
     int r = BuildParams(c, s, fb, stride, &p);
@@ -685,6 +725,7 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     // span, wasteful when neighbours could use the SIMDs): lone frame -1.4 us, sustained +2.6 %
     if (p.handout_static) SetClassThresholds(c, &p, c->heavy_stream);
     const uint32_t n_striprows = BandRows(c) * c->strips_x;
+    PM_TRY(ResetTileState(c, s, q));
     pm::LaunchBin(p, q, t[0], t[1]);
     if (!c->fold_clear) pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // the resolved tiles' pixels (needs tile_state)
     if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, q, t[4], t[5]);
@@ -704,7 +745,8 @@ int BuildSceneIndex(pm_ctx *c) {
     uint32_t n, items_ix;
     std::memcpy(&n, meta, 4);
     std::memcpy(&items_ix, meta + 4, 4);
-    std::vector<uint32_t> base(static_cast<size_t>(n) + 1);
+    std::vector<uint32_t> &base = c->chunk_base_host;  // (the source of an asynchronous copy: it lives in the context)
+    base.resize(static_cast<size_t>(n) + 1);
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; ++i) {
         base[i] = static_cast<uint32_t>(total);
@@ -739,7 +781,8 @@ int BuildSceneIndex(pm_ctx *c) {
     PM_TRY(hipMemcpyAsync(c->d_chunk_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     pm::LaunchIndex(c->d_scene, n, c->dev_items_ix, c->d_chunk_base, c->n_chunks, c->d_chunk_bbox, c->stream);
     PM_TRY(hipGetLastError());
-    PM_TRY(hipStreamSynchronize(c->stream));  // `base` is a stack-owned source buffer
+    // (no wait: frames run on streams that are ordered behind c->stream where it matters -- Enqueue below --
+    //  and the next scene replacement starts with SyncAll before `base` is touched again)
     return PM_OK;
 }
 
@@ -802,9 +845,14 @@ int SetScene(pm_ctx *c, size_t bytes, const uint8_t *host) {
         InvalidateScene(c);
         return PM_ERR_SCENE;
     };
+    // (a scene the flatten kernels wrote: its head -- header, boxes, items -- came back with the totals)
+    const uint8_t *head = c->flatten_cache.meta_bytes >= 8 && !host ? c->flatten_cache.h_meta + 32 : nullptr;
+    const size_t head_bytes = head ? c->flatten_cache.meta_bytes : 0;
     uint32_t hdr[2];
     if (host) {
         std::memcpy(hdr, host, 8);
+    } else if (head) {
+        std::memcpy(hdr, head, 8);
     } else {
         PM_TRY(hipMemcpyAsync(hdr, c->d_scene, 8, hipMemcpyDeviceToHost, c->stream));
         PM_TRY(hipStreamSynchronize(c->stream));
@@ -852,6 +900,9 @@ int SetScene(pm_ctx *c, size_t bytes, const uint8_t *host) {
     } else if (host) {
         std::memcpy(meta.data() + 8, host + 8, 8 * n0);
         std::memcpy(meta.data() + 8 + 8 * n0, host + items0, 32 * n0);
+    } else if (head && items0 + 32 * n0 <= head_bytes) {
+        std::memcpy(meta.data() + 8, head + 8, 8 * n0);
+        std::memcpy(meta.data() + 8 + 8 * n0, head + items0, 32 * n0);
     } else if (n0) {
         PM_TRY(hipMemcpyAsync(meta.data() + 8, c->d_scene + 8, 8 * n0, hipMemcpyDeviceToHost, c->stream));
         PM_TRY(hipMemcpyAsync(meta.data() + 8 + 8 * n0, c->d_scene + items0, 32 * n0, hipMemcpyDeviceToHost, c->stream));
@@ -1038,10 +1089,62 @@ pm_ctx *pm_create(int device, int *err) {
     if (e == hipSuccess) e = hipMemcpy(c->d_lut_lin2srgb, l->lin2srgb, sizeof(l->lin2srgb), hipMemcpyHostToDevice);
     delete l;
     if (e != hipSuccess) return fail(e, "lookup tables");
+    // The working set of an ordinary scene is reserved now (HBM is 288 GB; a context is created once):
+    // flatten scratch, scene index, binning lists and frame slot 0's arenas.  The first scene and the
+    // first frame then allocate nothing; larger scenes grow the buffers as before.
+    if (EnvInt("PM_PREALLOC", 1, 0, 1)) {
+        e = c->flatten_cache.Reserve(4096, 65536);
+        if (e == hipSuccess) e = hipMalloc(&c->d_chunk_base, (65536 + 1) * sizeof(uint32_t));
+        if (e == hipSuccess) c->chunk_base_cap = 65536 + 1;
+        if (e == hipSuccess) e = hipMalloc(&c->d_chunk_bbox, (1u << 18) * sizeof(float4));
+        if (e == hipSuccess) c->chunk_bbox_cap = 1u << 18;
+        if (e == hipSuccess) e = hipMalloc(&c->d_sr_desc, 65536 * sizeof(uint4));
+        if (e == hipSuccess) c->sr_desc_cap = 65536;
+        if (e == hipSuccess) e = hipMalloc(&c->d_band_bbox, 65536 * sizeof(uint2));
+        if (e == hipSuccess) e = hipMalloc(&c->d_band_item, 65536 * sizeof(uint32_t));
+        if (e == hipSuccess) c->band_cap = 65536;
+        const uint32_t arena0 = 48u << 20;  // dwords (192 MB)
+        const uint32_t tile0 = ((1u << 22) * pm::kCmdQuadsNum) / pm::kCmdQuadsDen;  // quads: what EnsureArena asks for at least
+        if (e == hipSuccess) e = hipMalloc(&c->slot[0].d_arena, static_cast<size_t>(arena0) * sizeof(uint32_t));
+        if (e == hipSuccess) c->slot[0].arena_cap = arena0;
+        if (e == hipSuccess && !std::getenv("PM_PTCL_INITIAL_CMDS")) {
+            e = hipMalloc(&c->slot[0].d_ptcl, static_cast<size_t>(tile0) * sizeof(uint4));
+            if (e == hipSuccess) c->slot[0].ptcl_cap = tile0;
+        }
+        if (e != hipSuccess) return fail(e, "working-set reservation");
+    }
     if (ReserveScene(c, 16u << 20) != PM_OK) {  // 16 MiB like PietRenderer.m:53
         *err = PM_ERR_HIP;
         pm_destroy(c);
         return nullptr;
+    }
+    // -initWithMetalKitView: builds its pipeline states up front (PietRenderer.m:33-47); here every
+    // kernel of the path runs once on a three-point scene, so that the first real scene and frame do
+    // not pay for code-object loading (about 1.5 ms spread over a dozen first launches).
+    if (EnvInt("PM_WARMUP", 1, 0, 1)) {
+        const pm_path wp = {0u, 3u, PM_PATH_FILL | PM_PATH_STROKE, 0x000000ffu, 0x000000ffu, 1.0f};
+        pm_path_el we[3] = {};
+        we[0].tag = PM_EL_MOVE; we[0].p[0] = 2.0; we[0].p[1] = 2.0;
+        we[1].tag = PM_EL_LINE; we[1].p[0] = 12.0; we[1].p[1] = 3.0;
+        we[2].tag = PM_EL_CURVE; we[2].p[0] = 12.0; we[2].p[1] = 8.0; we[2].p[2] = 8.0; we[2].p[3] = 12.0; we[2].p[4] = 3.0; we[2].p[5] = 12.0;
+        const double ident[6] = {1.0, 0.0, 0.0, 1.0, 0.0, 0.0};
+        int rw = pm_resize(c, 40, 24);
+        if (rw == PM_OK) rw = pm_flatten_and_encode(c, &wp, 1, we, 3, ident, 1.0f, nullptr, nullptr);
+        if (rw == PM_OK) rw = pm_render(c);
+        if (rw == PM_OK) rw = pm_sync(c);
+        if (rw != PM_OK) {
+            *err = rw;
+            pm_destroy(c);
+            return nullptr;
+        }
+        // back to a context without scene and viewport
+        InvalidateScene(c);
+        FreeViewport(c);
+        c->flatten_cache.resident = false;
+        c->flatten_cache.meta_bytes = 0;
+        c->width = c->height = c->tiles_x = c->tiles_y = c->strips_x = c->row0 = c->row1 = 0;
+        c->frame = 0;
+        c->t_flatten_ms = c->t_index_ms = c->t_arena_ms = 0;
     }
     *err = PM_OK;
     return c;
@@ -1333,6 +1436,7 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             pm::FrameParams p;
             if ((r = BuildParams(c, s, s->d_fb, c->fb_stride, &p)) != PM_OK) return r;
             // each dispatch carries its own begin / end events: pure kernel durations
+            PM_TRY(ResetTileState(c, s, c->stream));
             pm::LaunchBin(p, c->stream, c->ev[0], c->ev[1]);
             if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream, c->ev[2], c->ev[3]);
             pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->fused, c->stream, c->ev[4], c->ev[5]);
@@ -1564,6 +1668,7 @@ int pm_fill_coverage(pm_ctx *c, uint32_t item_ix, float *dst, size_t dst_stride_
             p.dbg_solid = d_solid;
             p.dbg_cmds = nullptr;
             p.dbg_max = 0;
+            (void)ResetTileState(c, s, c->stream);
             pm::LaunchBin(p, c->stream);
             pm::LaunchCoarse(p, CoarseGrid(c), true, c->stream);
             pm::LaunchCoverage(p, static_cast<uint32_t>(tiles), d_solid, d_out, c->width, c->stream);
@@ -1667,7 +1772,7 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
     r = BuildParams(c, s, s->d_fb, c->fb_stride, &p);
     if (r == PM_OK) {
         p.dbg_bin = d;
-        hipError_t e = hipSuccess;
+        hipError_t e = ResetTileState(c, s, c->stream);
         pm::LaunchBin(p, c->stream);
         if (!c->fold_clear) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
         if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);

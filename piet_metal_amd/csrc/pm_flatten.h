@@ -20,11 +20,17 @@ struct FlattenCache {
     double *d_bbox = nullptr;
     size_t cap_paths = 0, cap_els = 0, cap_u32 = 0, cap_bbox = 0;
     size_t n_paths = 0, n_els = 0;  // what is resident in d_paths / d_els
+    size_t max_items = 0;           // ... and an upper bound of the items they encode to
+    // pinned: {totals[4], error flag, pad} then, at +32, the head of the scene the kernels just wrote
+    // (SimpleGroup, boxes, items) -- fetched in the same wait as the totals, for validation and arena sizing
+    uint8_t *h_meta = nullptr;
+    size_t cap_meta = 0, meta_bytes = 0;  // meta_bytes: valid bytes at h_meta + 32 (0: not fetched)
     bool resident = false;
     void Free();
+    hipError_t Reserve(size_t n_paths, size_t n_els);  // room for this many paths / elements (pm_create)
 };
 
-// Flatten + encode on the device (see pm_flatten.hip).  Synchronises `stream`.
+// Flatten + encode on the device (see pm_flatten.hip).  Synchronises `stream` (once, at the end).
 // use_resident: ignore h_paths / h_els and flatten the paths resident in `cache` again.
 // On PM_ERR_CAPACITY *scene_bytes holds the size that would have been needed.
 int FlattenEncodeOnDevice(hipStream_t stream, FlattenCache *cache, bool use_resident, const pm_path *h_paths, size_t n_paths, const pm_path_el *h_els,

@@ -94,6 +94,16 @@ __attribute__((noinline)) static uint32_t __shfl_up(uint32_t v, unsigned delta, 
     (void)width;
     return static_cast<uint32_t>(pm_emu::Collective(pm_emu::kShflUp, v, delta, 0, PM_EMU_SITE()));
 }
+__attribute__((noinline)) static double __shfl_xor(double v, int lane_mask, int width = 64) {
+    (void)width;
+    uint64_t bits;
+    std::memcpy(&bits, &v, 8);
+    const uint64_t r = pm_emu::Collective(pm_emu::kShfl, bits, (pm_emu::LaneId() ^ static_cast<uint32_t>(lane_mask)) & 63u, 0, PM_EMU_SITE());
+    double out;
+    std::memcpy(&out, &r, 8);
+    return out;
+}
+static inline double __longlong_as_double(long long v) { double d; std::memcpy(&d, &v, 8); return d; }
 __attribute__((noinline)) static void __builtin_amdgcn_wave_barrier() { (void)pm_emu::Collective(pm_emu::kWaveBarrier, 0, 0, 0, PM_EMU_SITE()); }
 __attribute__((noinline)) static void __syncthreads() { pm_emu::BlockBarrier(PM_EMU_SITE()); }
 __attribute__((noinline)) static void __builtin_amdgcn_s_barrier() { pm_emu::BlockBarrier(PM_EMU_SITE()); }
