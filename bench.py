@@ -108,6 +108,7 @@ class Job:
         self.band = self.full = self.pad = self.scratch = None
         self.stream = torch.cuda.current_stream()
         self.balance_log = []
+        self.comm, self.gather_impl = None, args.gather_impl
         if world > 1:
             self._set_cuts([b[0] for b in self.layout] + [self.layout[-1][1]])
             if not args.equal_bands:
@@ -119,6 +120,33 @@ class Job:
                         break
                     self._set_cuts(new)
             self._alloc()
+            self._setup_cabi()
+
+    # ---- the product's own collective (pm_comm_* / pm_gather): id from rank 0 through the torch store ----
+    def _setup_cabi(self):
+        self.comm, self.gather_impl = None, self.args.gather_impl
+        if self.gather_impl not in ("auto", "cabi"):
+            return
+        ok, why = 1, ""
+        try:
+            box = [self.pm.Comm.unique_id() if self.rank == 0 else None]
+            self.dist.broadcast_object_list(box, src=0)
+            self.comm = self.pm.Comm(self.r, box[0], self.rank, self.world)
+            self.r.render_to(self.band, self.stream)
+            self.comm.gather(self.layout, root=0, full=self.full, band=self.band, stream=self.stream)  # one exchange: it works or it does not
+            self.torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- any failure means: not on this stack
+            ok, why = 0, repr(e)
+        t = self.torch.tensor([ok], dtype=self.torch.int32, device=self.band.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        if int(t.item()) == 1:
+            self.gather_impl = "cabi"
+            return
+        if self.args.gather_impl == "cabi":
+            raise RuntimeError(f"--gather-impl cabi: pm_comm_create / pm_gather failed on some rank ({why or 'another rank'})")
+        if self.rank == 0:
+            print(f"bench.py: pm_gather not usable here ({why or 'another rank failed'}): falling back to torch.distributed send/recv", file=sys.stderr)
+        self.comm, self.gather_impl = None, "sendrecv"
 
     # ---- bands -------------------------------------------------------------------------
     def _set_cuts(self, cuts):
@@ -155,7 +183,9 @@ class Job:
         self.gather()
 
     def gather(self):
-        if self.args.gather_impl == "allgather":
+        if self.gather_impl == "cabi":
+            self.comm.gather(self.layout, root=0, full=self.full, band=self.band, stream=self.stream)
+        elif self.gather_impl == "allgather":
             if self.pad is None:
                 rows = self.pmd.padded_band_rows(self.wl.height, self.world, self.cuts)
                 self.pad = self.torch.zeros((rows, self.wl.width, 4), dtype=self.torch.uint8, device=self.band.device)
@@ -228,8 +258,10 @@ def main() -> int:
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--equal-bands", action="store_true", help="N>1: near-equal tile-row split instead of cost-balanced cuts")
-    ap.add_argument("--gather-impl", choices=["sendrecv", "allgather"], default="sendrecv",
-                    help="N>1: grouped send/recv into the final image (default) or padded all-gather")
+    ap.add_argument("--gather-impl", choices=["auto", "cabi", "sendrecv", "allgather"], default="auto",
+                    help="N>1: cabi = the product's own collective behind the C ABI (pm_comm_create / pm_gather: grouped RCCL send/recv "
+                         "into the final image); sendrecv = the same exchange through torch.distributed; allgather = padded all-gather; "
+                         "auto (default) = cabi, falling back to sendrecv on every rank if any rank cannot set it up")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 block")
     ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config3",
                     help="the main line's workload (default: BASELINE config 3, the one the metric is quoted on; the others are for profiles/)")
@@ -267,6 +299,8 @@ def main() -> int:
     staged = backend != "nccl" and world > 1  # gloo rehearsal: bands travel through host tensors
     if staged:
         _patch_for_host_transport(pmd, torch)
+        if args.gather_impl in ("auto", "cabi"):
+            args.gather_impl = "sendrecv"  # (the rehearsal's ranks share one GPU: no RCCL communicator between them)
 
     r = pm.Renderer(local)
     wl = {"config2": lambda: pm.workloads.tiger(1920, 1080, fills_only=True), "config3": lambda: pm.workloads.tiger(3840, 2160),
@@ -372,7 +406,9 @@ def main() -> int:
                 "workload": workload_name,
                 "viewport": [W, H], "items": job.n_items, "scene_bytes": job.scene_bytes,
                 "parallelism": "1 GPU" if world == 1 else f"tile-row bands x{world} ({'near-equal' if args.equal_bands else 'cost-balanced'} cuts), scene replicated, "
-                               f"{'grouped send/recv' if args.gather_impl == 'sendrecv' else 'padded all-gather'} of the bands into the final image on rank 0 in every step",
+                               f"{ {'cabi': 'pm_gather (C ABI: grouped RCCL send/recv)', 'sendrecv': 'grouped send/recv (torch.distributed)', 'allgather': 'padded all-gather'}.get(job.gather_impl, job.gather_impl) } "
+                               "of the bands into the final image on rank 0 in every step",
+                "gather_impl": None if world == 1 else job.gather_impl,
                 "band_cuts": job.cuts, "balance": job.balance_log or None,
                 "t_render_ms": round(t_render, 5), "t_gather_ms": round(t_gather, 5), "t_frame_e2e_ms": round(t_frame_host, 5),
                 "queued_tiles_rank0": st["queued_tiles"], "precondition_steps": precondition,

@@ -187,14 +187,28 @@ int pm_gather(pm_ctx *c, pm_comm *m, const void *src_band, size_t src_stride, co
         *offset = static_cast<size_t>(y0 * tight);
         return y1 > y0 ? static_cast<size_t>((y1 - y0) * tight) : 0;
     };
-    // one group: the root's receives all progress concurrently, one xGMI link per peer
-    ncclResult_t e = r->GroupStart();
-    if (e != ncclSuccess) return RcclFail(r, e, "ncclGroupStart");
+    // one group: the root's receives all progress concurrently, one xGMI link per peer.  The root's OWN
+    // band never goes through RCCL: a frame rendered straight into its rows of dst_image (pm_render_to)
+    // is already where it belongs, any other source is one device copy on the same stream.
     size_t off = 0;
     const size_t mine = band_bytes(m->rank, &off);
-    if (mine && e == ncclSuccess) e = r->Send(src_band, mine, ncclUint8, root, m->comm, q);
+    if (m->rank == root && mine) {
+        uint8_t *place = static_cast<uint8_t *>(dst_image) + off;
+        if (place != static_cast<const uint8_t *>(src_band)) {
+            const uint8_t *sb = static_cast<const uint8_t *>(src_band);
+            if (sb < place + mine && place < sb + mine) {
+                pm::SetLastError("pm_gather: the root's band overlaps its rows of dst_image without being them");
+                return PM_ERR_INVALID;
+            }
+            if (hipMemcpyAsync(place, src_band, mine, hipMemcpyDeviceToDevice, q) != hipSuccess) return PM_ERR_HIP;
+        }
+    }
+    ncclResult_t e = r->GroupStart();
+    if (e != ncclSuccess) return RcclFail(r, e, "ncclGroupStart");
+    if (m->rank != root && mine && e == ncclSuccess) e = r->Send(src_band, mine, ncclUint8, root, m->comm, q);
     if (m->rank == root) {
         for (int k = 0; k < m->world && e == ncclSuccess; ++k) {
+            if (k == root) continue;
             const size_t n = band_bytes(k, &off);
             if (n) e = r->Recv(static_cast<uint8_t *>(dst_image) + off, n, ncclUint8, k, m->comm, q);
         }

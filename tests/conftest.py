@@ -30,31 +30,10 @@ def _swap_in_the_emulated_library():
     compiled as plain C++ and run lane by lane on the CPU with wave64 semantics (tests/emu/).  It
     checks kernel LOGIC against the oracle before a GPU is spent on it; the product never loads it,
     and with a GPU present this switch is refused."""
-    import ctypes
-    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from emu_swap import swap_in_emulated_library
 
-    import torch
-
-    if torch.cuda.is_available():
-        raise RuntimeError("PM_TEST_EMU=1 on a box with a GPU: run the real library")
-    # PM_EMU_SUFFIX=_O0 (+ PM_EMU_STRICT=1): the unoptimized build, where every source-level
-    # cross-lane operation is one call site and a divergent one can be told from a duplicated one
-    # PM_EMU_SUFFIX=_small: tiny LDS survivor list / block table, so that small scenes reach the
-    # spill paths of pm_bin_kernel
-    suffix = os.environ.get("PM_EMU_SUFFIX", "")
-    opt = ["OPT=-O0", "SUFFIX=_O0"] if suffix == "_O0" else []
-    if suffix == "_small":
-        opt = ["SUFFIX=_small", "DEFS=-DPM_BIN_SURV_LDS=24"]
-    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "tests", "emu")] + opt)
-    from piet_metal_amd import _lib
-
-    emu = ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "_build" + suffix, "libpiet_metal_amd_emu.so"))
-    for name, (restype, argtypes) in _lib.SIGNATURES.items():
-        fn = getattr(emu, name)
-        fn.restype = restype
-        fn.argtypes = argtypes
-    _lib._lib = emu
-    return emu
+    return swap_in_emulated_library()
 
 
 @pytest.fixture(scope="session")

@@ -101,3 +101,37 @@ def test_balanced_cuts_converge_and_stay_valid():
     # degenerate: more ranks than rows keeps the split untouched; zero times do not divide by zero
     assert pmd.balanced_cuts([0, 1, 2], [0.0, 0.0]) == [0, 1, 2]
     assert pmd.balanced_cuts([0, 2, 4, 6], [0.0, 0.0, 0.0])[-1] == 6
+
+
+@pytest.mark.parametrize("world,root", [(2, 0), (3, 1)])
+def test_c_abi_gather_across_processes_with_a_mock_rccl(built, tmp_path, world, root):
+    """pm_comm_create / pm_gather -- the C-ABI collective SCALE runs would time -- across real processes on
+    a GPU-less box: the library is the CPU emulation of tests/emu ("device" pointers are host pointers),
+    RCCL is tests/mock_rccl bound through PM_RCCL_LIB (messages travel as files).  Uneven bands; the
+    root's band copied into place (last frame) and already in place (pm_render_to into its rows of the
+    image); a band table that does not match is refused.  What it cannot show is RCCL itself: the first
+    real N > 1 run is the driver's."""
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: test_c_abi_gather_single_rank runs the real library against the real RCCL")
+    from oracle import pmo
+
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "tests", "emu")])
+    shim = str(tmp_path / "libmock_rccl.so")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-shared", "-fPIC", "-Wall", "-Wextra", "-o", shim, os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.c")])
+    box = tmp_path / "box"
+    box.mkdir()
+    width, height = 400, 300
+    env = dict(os.environ, PM_RCCL_LIB=shim, PM_MOCK_RCCL_DIR=str(box), PM_WARMUP="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "cabi_gather_worker.py"), str(k), str(world), str(width), str(height), str(box), str(root)],
+                              env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for k in range(world)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for k, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {k}: {outs[k][-2000:]}"
+    want = pmo.render(pmo.scene_cardioid(), width, height)
+    assert np.array_equal(np.load(box / "full_a.npy"), want)
+    assert np.array_equal(np.load(box / "full_b.npy"), want)
+    assert not [f for f in os.listdir(box) if f.startswith("msg_")], "every message was consumed"
