@@ -360,15 +360,31 @@ def main() -> int:
         if kernels["pm_coarse_kernel"] == 0:  # fused: pm_fine_kernel<true> builds each tile's list itself
             kernels.pop("pm_coarse_kernel")
             alone_ms.pop("pm_coarse_kernel")
-        dom = max(kernels, key=kernels.get)
-        dom_ms = kernels[dom]
+        # the dominant kernel and its duration: kernels serialized on one stream, every launch alone on the
+        # GPU (a duration that fits inside a step; with four frames in flight the launches stretch each
+        # other and their in-flight durations exceed ms_per_step: kept below as *_inflight)
+        dom = max(alone_ms, key=alone_ms.get)
+        dom_ms = alone_ms[dom]
         achieved = b_alg / (dom_ms * 1e-3) / 1e9
+        dom_inflight_ms = kernels[dom]
         pipelined_ms = tm["total_ms"] / tm["iters"]
-        traffic, traffic_frame, issue = None, None, None
+        traffic, traffic_frame, issue, traffic_meta = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and world == 1 and args.workload == "config3":
             try:
                 prof = json.load(open(tpath))
+                # the PMC figures are copied from a committed profile, not measured in this run: say which
+                # kernels they were taken on, and whether those are the kernels running now
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from make_traffic import kernel_sources_sha16
+
+                now = kernel_sources_sha16()
+                traffic_meta = {"source": prof.get("_source"), "measured_at_commit": prof.get("_commit"),
+                                "kernel_sources_sha16": prof.get("_kernel_sources_sha16"), "kernel_sources_sha16_now": now,
+                                "stale": prof.get("_kernel_sources_sha16") != now}
+                if traffic_meta["stale"]:
+                    print(f"bench.py: profiles/hbm_traffic.json was measured on other kernel sources ({prof.get('_kernel_sources_sha16')} at commit "
+                          f"{prof.get('_commit')}, now {now}): roofline.traffic / issue_roofline are from that profile", file=sys.stderr)
                 traffic = prof.get(dom, {}).get("hbm_bytes_per_launch")
                 per_kernel = [prof[k]["hbm_bytes_per_launch"] for k in kernels if "hbm_bytes_per_launch" in prof.get(k, {})]
                 if len(per_kernel) == len(kernels):
@@ -392,8 +408,8 @@ def main() -> int:
             "metric": "Mpixels/s, Ghostscript Tiger 3840x2160 (fills+strokes): W*H / t_frame" if args.workload == "config3" else f"Mpixels/s, {workload_name}: W*H / t_frame",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "t_frame_ms": round(t_frame, 5),
-            "value_definition": ("W*H / t_frame; t_frame = one frame alone, first kernel begin to last kernel end, dispatch timestamps, median of "
-                                 f"{lat['iters']} (SURVEY.md 8d)") if world == 1 else
+            "value_definition": ("W*H / t_frame; t_frame = one frame alone, first kernel begin to last kernel end: two HIP events on the frame's stream "
+                                 f"around the plain launches pm_render makes (pm_frame_latency), median of {lat['iters']} (SURVEY.md 8d)") if world == 1 else
                                 ("W*H / t_frame_e2e; one step alone = band render + gather into the final image on rank 0 + device sync, host-timed, "
                                  "median, MAX over ranks (includes launch and RCCL latency; compare with t_frame_host_ms at N=1)"),
             "sustained_mpix_s": round(sustained, 1), "ms_per_step": round(ms_per_step, 5),
@@ -422,20 +438,23 @@ def main() -> int:
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_frame": traffic_frame,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_frame": traffic_frame, "traffic_profile": traffic_meta,
                 "algorithmic_bytes_per_launch": b_alg, "kernel_ms": round(dom_ms, 5),
-                "kernels_ms": {k: round(v, 5) for k, v in kernels.items()},
                 "kernels_alone_ms": {k: round(v, 5) for k, v in alone_ms.items()},
+                "kernels_inflight_ms": {k: round(v, 5) for k, v in kernels.items()},
+                "frac_inflight": round(b_alg / (dom_inflight_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "trace_average_ms": {k: round((n_overlapped * kernels[k] + n_serial * alone_ms[k]) / (n_overlapped + n_serial), 5) for k in kernels},
-                "frac_alone": round(b_alg / (max(alone_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "trace_average_note": "what the AverageNs column of a kernel trace of THIS command shows: the mix of in-flight and serialized launches it makes",
                 "frame_latency_ms": round(t_render, 5),
                 "frac_frame": round(b_alg_frame / world / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "frame_pipelined_ms": round(pipelined_ms, 5),
                 "frac_frame_pipelined": round(b_alg / (pipelined_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "achieved/frac: algorithmic bytes of one launch / the dominant kernel's average launch duration INSIDE the overlapping batch "
-                        "(frames in flight on four streams, as in the timed steps; events carried by the dispatches = what rocprofv3 --kernel-trace shows); "
-                        "frac_alone: the same kernels serialized on one stream (non-overlapped denominator); frac_frame: B_alg(N)/N / the slowest rank's "
-                        "lone-frame time (SURVEY 8d multi-GPU roofline); the path is latency/VALU bound, not HBM bound (DESIGN.md)",
+                "note": "achieved/frac: algorithmic bytes of one launch / the dominant kernel's average launch duration with the kernels serialized on one "
+                        "stream, events carried by the dispatches (what a rocprofv3 --kernel-trace of PM_FRAME_STREAMS=1 PM_SLOTS=1 shows: "
+                        "profiles/*_serial_kernel_stats.csv); frac_inflight / kernels_inflight_ms: the same launches inside the overlapping batch of the "
+                        "timed steps (four frames in flight: the durations stretch each other and exceed ms_per_step; what the default kernel trace "
+                        "shows); frac_frame: B_alg(N)/N / the slowest rank's lone-frame time (SURVEY 8d multi-GPU roofline); frac_frame_pipelined: "
+                        "B_alg / ms_per_step; the path is latency bound, not HBM bound (DESIGN.md)",
             },
         }
         if issue is not None:

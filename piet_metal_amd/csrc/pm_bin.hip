@@ -1,6 +1,7 @@
 // pm_index_kernel, pm_rowcull_kernel, pm_bin_kernel: scene index and the strip-level half of tileKernel
 // (see pm_kernels_common.h for the decomposition and the rules shared by the three files)
 #include "pm_kernels_common.h"
+#include <type_traits>
 #include <pm_params.h>  // gfx950/pm_params.h: kernel arguments held in a VGPR, read with v_readlane
 
 namespace pm {
@@ -148,10 +149,22 @@ struct BinLds {
 
 };
 
-template <bool kProfile>
-__global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
+// The same storage plus dead weight: 46 KB instead of 37 let THREE workgroups share a CU, not four.
+// A frame with the chip to itself and few strip rows is bounded by its heaviest rows, and those run
+// faster with fewer neighbours on their SIMDs; with one workgroup per row (no chains) the dispatcher
+// then refills a CU as soon as a row ends (Tiger 4K alone: 37.5 -> 35.0 us; pipelined frames lose
+// 8 % of their throughput to it, so they keep the dense variant -- pm_context.hip, BuildParams).
+struct BinLdsSparse : BinLds {
+    uint32_t s_dead_weight[2200];
+};
+
+#ifndef PM_BIN_SPARSE_WAVES
+#define PM_BIN_SPARSE_WAVES 4
+#endif
+template <bool kProfile, bool kSparse>
+__global__ __launch_bounds__(kBinThreads, PM_BIN_SPARSE_WAVES) void pm_bin_kernel(FrameParams P) {
     const ParamRegs PR = LoadParams(P);
-    __shared__ BinLds L;
+    __shared__ std::conditional_t<kSparse, BinLdsSparse, BinLds> L;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = LaneId();
     const uint32_t wave = tid >> 6;
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(kBinThreads, 4) void pm_bin_kernel(FrameParams P) {
     if (rix != blockIdx.x) LdsBarrier();  // the previous strip row's LDS is done with
     // One 16-byte load: {strip row, region, end, next strip row of this workgroup (0: none)}.
     const uint4 srd = PM_PP(sr_desc)[rix];
-    rix_next = __builtin_amdgcn_readfirstlane(srd.w);
+    rix_next = kSparse ? 0u : __builtin_amdgcn_readfirstlane(srd.w);  // (the sparse launch has a workgroup per row)
     if (rix_next == 0) rix_next = 0xffffffffu;
     const uint32_t sr = __builtin_amdgcn_readfirstlane(srd.x);
     const uint32_t strip = sr % PM_PU(strips_x);
@@ -1005,10 +1018,14 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, cons
 void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
     const uint32_t n_striprows = p.bin_grid;
     if (p.use_row_lists) hipLaunchKernelGGL(pm_rowcull_kernel, dim3(p.row1 - p.row0), dim3(kBinThreads), 0, stream, p);
-    if (p.dbg_bin)
-        PM_LAUNCH(pm_bin_kernel<true>, dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
+    if (p.dbg_bin && p.bin_sparse)
+        PM_LAUNCH((pm_bin_kernel<true, true>), dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
+    else if (p.dbg_bin)
+        PM_LAUNCH((pm_bin_kernel<true, false>), dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
+    else if (p.bin_sparse)
+        PM_LAUNCH((pm_bin_kernel<false, true>), dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
     else
-        PM_LAUNCH(pm_bin_kernel<false>, dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
+        PM_LAUNCH((pm_bin_kernel<false, false>), dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
 }
 
 }  // namespace pm

@@ -215,6 +215,8 @@ struct pm_ctx {
     uint4 *d_sr_desc = nullptr;     // strip rows some item reaches: {strip row, arena region begin, end, 0}
     uint32_t n_sr_active = 0;
     uint32_t bin_grid = 1;          // workgroups of pm_bin_kernel (each walks a chain of strip rows)
+    uint32_t bin_prio_slots = 1024; // PM_BIN_PRIO_SLOTS
+    int bin_sparse_mode = 2;        // PM_BIN_SPARSE: 0 never, 1 always, 2 (default) for a frame with nothing else in flight
     uint32_t sr_empty_dwords = 0;   // size of a region no item reaches
     uint2 *d_band_bbox = nullptr;   // items that reach the band (bbox, scene index), paint order
     uint32_t *d_band_item = nullptr;
@@ -596,17 +598,20 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->arena_cap = s->arena_cap;
     p->sr_desc = c->d_sr_desc;
     p->n_sr_active = c->n_sr_active;
-    p->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 1024, 0, 1 << 30));
+    p->bin_prio_slots = c->bin_prio_slots;
     p->bin_grid = c->bin_grid;
-    p->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 1024, 0, 1 << 30));
+    p->bin_sparse = 0;
     {
-        // pm_bin_kernel's grid: what the chip holds at once (four workgroups per CU) when strip rows are
-        // plenty -- a throughput problem (config 4: 4 096 rows, 200 -> 224 us with three) --, one less
-        // when every workgroup gets one or two rows and the launch ends with its heaviest ones: their
-        // waves then share the SIMDs with fewer others (Tiger 4K: 39.5 -> 37.4 us)
-        uint32_t per_cu = c->bin_wg_per_cu;
-        if (per_cu == 0xffu) per_cu = c->n_sr_active <= 6u * static_cast<uint32_t>(c->n_cus) ? 3u : 4u;
-        p->bin_grid = static_cast<uint32_t>(c->n_cus) * per_cu;
+        // Nothing else in flight (every earlier frame was waited for) and few strip rows: the frame is
+        // bounded by its heaviest rows -- three workgroups per CU, one per row (pm_bin.hip, BinLdsSparse).
+        // Frames submitted behind one another keep the dense variant and its chains.
+        bool lone = true;
+        for (const FrameSlot &o : c->slot) lone = lone && !o.in_flight;
+        const bool few_rows = c->n_sr_active <= 6u * static_cast<uint32_t>(c->n_cus);
+        if (c->bin_sparse_mode == 1 || (c->bin_sparse_mode == 2 && lone && few_rows && c->bin_wg_per_cu == 0xffu)) {
+            p->bin_sparse = 1;
+            p->bin_grid = c->n_sr_active;
+        }
     }
     p->sr_empty_dwords = c->sr_empty_dwords;
     p->queue = s->d_queue;
@@ -1067,6 +1072,8 @@ pm_ctx *pm_create(int device, int *err) {
     c->handout = EnvInt("PM_HANDOUT", 0, 0, 2);
     c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 5, 1, 16));
     c->bin_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_BIN_WG_PER_CU", 0xff, 0, 0xff));
+    c->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 1024, 0, 1 << 30));
+    c->bin_sparse_mode = EnvInt("PM_BIN_SPARSE", 2, 0, 2);
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
     for (auto &s : c->slot) {

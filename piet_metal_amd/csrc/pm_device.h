@@ -105,7 +105,8 @@ struct FrameParams {
     uint32_t arena_cap;   // dwords
     const uint4 *sr_desc;     // [n_sr_active] {strip row, its private arena region begin, end, 0}
     uint32_t n_sr_active;     // strip rows some item reaches: pm_bin_kernel's work list
-    uint32_t bin_grid;        // its grid: what the chip holds at once (0: a workgroup per strip row)
+    uint32_t bin_grid;        // its grid: what the chip holds at once, or a workgroup per strip row (bin_sparse)
+    uint32_t bin_sparse;      // host only: launch the three-per-CU variant (a frame with the chip to itself)
     uint32_t bin_prio_slots;  // strip rows with at least this many segment slots raise their waves' issue priority
     uint32_t sr_empty_dwords; // size of a region no item's bbox reaches
     uint4 *queue;             // kClasses class queues of {tile, command-list quad, first piece, its candidates | segments << 9}, queue_cap entries each

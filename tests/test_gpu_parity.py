@@ -637,6 +637,34 @@ def test_every_frame_path_switch_agrees_with_the_oracle(pm, pmo, monkeypatch, fu
         r.close()
 
 
+@pytest.mark.parametrize("sparse,wg_per_cu", [("0", None), ("1", None), ("2", None), ("0", "1"), ("0", "0"), ("1", "2")])
+def test_binning_launch_variants(pm, pmo, monkeypatch, sparse, wg_per_cu):
+    """pm_bin_kernel runs as chains of strip rows over a grid the chip holds at once (PM_BIN_WG_PER_CU
+    per CU; 0: a workgroup per row) or, for a frame with nothing else in flight, as the three-per-CU
+    variant with a workgroup per row (PM_BIN_SPARSE: 0 never, 1 always, 2 decided per frame).  Same
+    bytes either way, for frames submitted behind one another and for frames waited for one by one."""
+    monkeypatch.setenv("PM_BIN_SPARSE", sparse)
+    if wg_per_cu is not None:
+        monkeypatch.setenv("PM_BIN_WG_PER_CU", wg_per_cu)
+    r = pm.Renderer(0)
+    try:
+        wl = pm.workloads.tiger(960, 540)
+        r.resize(wl.width, wl.height)
+        r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        scene = r.download_scene()
+        want = pmo.render(scene, wl.width, wl.height)
+        for _ in range(3):  # behind one another: the per-frame decision sees frames in flight
+            r.render()
+        assert np.array_equal(r.read_pixels(), want)
+        for _ in range(2):  # one by one: nothing in flight
+            r.render()
+            r.sync()
+        assert np.array_equal(r.read_pixels(), want)
+        assert_ptcl_equal(r, pmo, scene, wl.width, wl.height)
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("coarse_wg,fine_wg,fused", [("1", "1", "1"), ("7", "3", "0"), ("2", "9", "1")])
 def test_persistent_grid_sizes(pm, pmo, monkeypatch, coarse_wg, fine_wg, fused):
     """PM_COARSE_WG_PER_CU / PM_FINE_WG_PER_CU size the persistent grids; the hand-out must cover

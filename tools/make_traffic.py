@@ -5,19 +5,46 @@ and on gfx950 FETCH_SIZE counts 128-B read requests at 64 B (MI355X_MICROARCH.md
 section), so the read side is doubled -- an upper bound for this path, whose reads are a
 mix of 4..16 B per lane.  bench.py copies the dominant kernel's figure into
 roofline.traffic."""
+import hashlib
 import json
+import os
+import subprocess
 import sys
 
-src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-summ = json.load(open(src))
-out = {"_source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes)",
-       "_formula": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024"}
-for k, d in summ.items():
-    name = k.split("::")[-1]
-    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
-        out[name] = {"hbm_bytes_per_launch": int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024),
-                     "fetch_size_kib": round(d["FETCH_SIZE"], 1), "write_size_kib": round(d["WRITE_SIZE"], 1)}
-        if "SQ_INSTS_VALU" in d:  # wave-instructions per launch (SQ counters of the same summary)
-            out[name]["valu_insts_per_launch"] = int(d["SQ_INSTS_VALU"])
-json.dump(out, open(dst, "w"), indent=1)
-print(json.dumps(out, indent=1))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ["pm_bin.hip", "pm_fine.hip", "pm_coarse.hip", "pm_coarse_tile.h", "pm_kernels_common.h", "pm_device.h", "gfx950/pm_pin.h", "gfx950/pm_params.h"]
+
+
+def kernel_sources_sha16(root=ROOT):
+    """What the PMC figures were measured on: a digest of the kernel sources (bench.py recomputes it and
+    says so when the committed figures are older than the kernels it runs)."""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(root, "piet_metal_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def main():
+    src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    summ = json.load(open(src))
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:
+        commit = None
+    out = {"_source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes)",
+           "_formula": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
+           "_kernel_sources_sha16": kernel_sources_sha16(), "_commit": commit}
+    for k, d in summ.items():
+        name = k.split("::")[-1]
+        if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            out[name] = {"hbm_bytes_per_launch": int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024),
+                         "fetch_size_kib": round(d["FETCH_SIZE"], 1), "write_size_kib": round(d["WRITE_SIZE"], 1)}
+            if "SQ_INSTS_VALU" in d:  # wave-instructions per launch (SQ counters of the same summary)
+                out[name]["valu_insts_per_launch"] = int(d["SQ_INSTS_VALU"])
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

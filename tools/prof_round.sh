@@ -2,7 +2,8 @@
 # Round profile (run on the GPU box through gpurun):  tools/prof_round.sh <tag>
 #   1. bench.py (default flags) -> gpurun_out/<tag>/bench.json
 #   2. rocprofv3 --kernel-trace --stats of the same command -> kernel_stats.csv (+ that run's own
-#      JSON line -> bench_traced.json)
+#      JSON line -> bench_traced.json); again with PM_FRAME_STREAMS=1 PM_SLOTS=1 -> serial_kernel_stats.csv
+#      (+ bench_serial_traced.json): launches that do not overlap
 #   3. PMC passes (FETCH_SIZE, WRITE_SIZE, then SQ counters), each in its own run with
 #      --kernel-trace only, -> pmc_passN.csv + pmc_summary.json
 set -u
@@ -19,6 +20,12 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -
 grep '^{"metric"' $OUT/trace.log | tail -1 > $OUT/bench_traced.json
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -8 $OUT/kernel_stats.csv
 find $OUT/trace -name "*kernel_trace.csv" -size +30M -delete
+# the same command with frames SERIALIZED (one stream, one frame slot): every launch alone on the GPU, so the
+# stats' AverageNs is a duration that fits inside a step (with four frames in flight the launches stretch each
+# other); this is the trace roofline.frac / kernel_ms of the bench line agree with
+PM_FRAME_STREAMS=1 PM_SLOTS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -- $BENCH --no-cpu-baseline $WL > $OUT/trace_serial.log 2>&1
+grep '^{"metric"' $OUT/trace_serial.log | tail -1 > $OUT/bench_serial_traced.json
+f=$(find $OUT/trace_serial -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/serial_kernel_stats.csv && head -5 $OUT/serial_kernel_stats.csv
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
   i=$((i+1))
@@ -38,5 +45,5 @@ summ = {k: {c: sum(v) / len(v) for c, v in d.items()} | {"launches": len(next(it
 json.dump(summ, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summ, indent=1))
 PY
-rm -rf $OUT/trace $OUT/pmc[0-9]
+rm -rf $OUT/trace $OUT/trace_serial $OUT/pmc[0-9]
 ls -la $OUT
