@@ -158,11 +158,8 @@ struct BinLdsSparse : BinLds {
     uint32_t s_dead_weight[2200];
 };
 
-#ifndef PM_BIN_SPARSE_WAVES
-#define PM_BIN_SPARSE_WAVES 4
-#endif
 template <bool kProfile, bool kSparse>
-__global__ __launch_bounds__(kBinThreads, PM_BIN_SPARSE_WAVES) void pm_bin_kernel(FrameParams P) {
+__global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(FrameParams P) {
     const ParamRegs PR = LoadParams(P);
     __shared__ std::conditional_t<kSparse, BinLdsSparse, BinLds> L;
     const uint32_t tid = threadIdx.x;

@@ -1450,6 +1450,7 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             if (!c->fold_clear) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream, c->ev[6], c->ev[7]);
             PM_TRY(hipStreamSynchronize(c->stream));
             Submitted(c, si, p, c->stream);
+            s->in_flight = false;  // (waited for just above: the next frame is alone too, and is launched as such)
             float t1 = 0, t2 = 0, t3 = 0, t4 = 0;
             PM_TRY(hipEventElapsedTime(&t1, c->ev[0], c->ev[1]));
             if (!c->fused) PM_TRY(hipEventElapsedTime(&t2, c->ev[2], c->ev[3]));
