@@ -12,8 +12,9 @@ per resize, PietRenderer.m:145; its cost is reported as scene.*).
 
 Two figures, both top level and both named:
   value               W*H / t_frame, t_frame = ONE frame alone, first kernel begin to last
-                      kernel end, from the dispatches' own timestamps, median over the K timed
-                      steps' worth of frames (>= 100).  The contract metric.
+                      kernel end: two HIP events on the frame's stream around the plain launches
+                      pm_render makes (pm_frame_latency), median over the K timed steps' worth of
+                      frames (>= 100).  The contract metric.
   sustained_mpix_s    W*H / (wall time of the K timed steps / K): frames submitted back to
                       back without waiting, as the reference commits command buffers
                       (PietRenderer.m:102); up to four frames overlap on four in-order streams.

@@ -248,14 +248,16 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
                              float *clear_ms);
 
 /* Latency of ONE frame with nothing else in flight: begin of its first kernel to end of its
- * last one, two HIP events on the frame's stream around the three launches pm_render makes;
+ * last one, two HIP events on the frame's stream around the plain launches pm_render makes (two
+ * by default: pm_bin_kernel, pm_fine_kernel);
  * median and minimum over `iters` frames (SURVEY.md 8d's t_frame; PietRenderer.m has no timing
  * at all). */
 int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms);
 
 /* Developer hook: the lone frame taken apart -- medians over `iters` frames of {pm_bin_kernel,
- * gap, pm_coarse_kernel, gap, pm_fine_kernel, first begin -> last end}, ms, dispatch timestamps
- * (needs the default PM_FOLD_CLEAR=1: three launches per frame). */
+ * gap, pm_coarse_kernel, gap, pm_fine_kernel, first begin -> last end}, ms, from events attached to
+ * the dispatches (which stretch the gaps: a breakdown, not t_frame -- that is pm_frame_latency;
+ * needs the default PM_FOLD_CLEAR=1; the coarse entries are 0 in the default fused path). */
 int pm_debug_frame_timeline(pm_ctx *c, int iters, float *out6);
 
 typedef struct {
