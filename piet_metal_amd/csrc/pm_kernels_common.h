@@ -21,16 +21,18 @@
 //         and each lane evaluates the reference's "phase 1" segment vote for one slot
 //         (PietRender.metal:258-295 fills, :374-399 polylines), the 16-bit mask of tiles the
 //         segment can matter to, and for fills the backdrop step;
-//       - per (item, tile) counts and backdrops, the TileEncoder solid rule per tile, the
-//         command-list space of every tile and its place in one of eight cost-class queues.
+//       - per (item, tile) counts and backdrops; then, per tile, ONE contiguous PIECE in the tile
+//         arena: the tile's relevant segments and the candidates that can emit there, both in
+//         paint order (pm_device.h) -- all a tile needs from the record, nothing it does not;
+//       - the TileEncoder solid rule per tile, the command-list space of every tile and its place
+//         in one of eight cost-class queues.
 //   pm_fine_kernel<fused>   persistent; per queued tile, by the wave(s) that will render it:
-//       - CoarseTile (pm_coarse_tile.h; ONE WAVE, no workgroup barriers): candidates are filtered
-//         by a per-tile hit bit; the record's slots carrying the tile's bit are gathered in paint
-//         order; each lane runs the reference's "phase 2" test for (tile, segment) (:302-357,
-//         :406-440) and emits 0..3 commands; ballots / mbcnt prefix ranks give every command its
-//         slot in the tile's command list in HBM (the reference's 24-byte Cmd records);
-//         opaque-solid detection (TileEncoder::encodeSolid/end) restarts the list; Bail tiles are
-//         written as one constant there;
+//       - CoarseTile (pm_coarse_tile.h; ONE WAVE, no workgroup barriers): walks the tile's pieces
+//         -- one batch of loads each --; each lane runs the reference's "phase 2" test for (tile,
+//         segment) (:302-357, :406-440) and emits 0..3 commands; ballots / mbcnt prefix ranks give
+//         every command its slot in the tile's command list in HBM (the reference's 24-byte Cmd
+//         records); opaque-solid detection (TileEncoder::encodeSolid/end) restarts the list; Bail
+//         tiles are written as one constant there;
 //       - renderKernel over the list for the tile's 256 pixels: one wave (4 px per lane, row-sparse
 //         Fill evaluation), or the workgroup's four waves for a long list (items evaluated in
 //         parallel into binary16 alpha images, blended in list order).  Accumulators are binary16
@@ -38,8 +40,9 @@
 //         accumulation is order dependent);
 //       - extra workgroups of the same launch write the pixels of the tiles binning resolved
 //         (background / one opaque colour): the composite for tiles that never get a list.
-//   pm_coarse_kernel  CoarseTile as a launch of its own (PM_FUSED=0, and the list-capture hooks
-//       behind pm_debug_capture_ptcl / pm_fill_coverage); pm_clear_kernel likewise (PM_FOLD_CLEAR=0).
+//   pm_coarse_kernel  CoarseTile as a launch of its own (PM_FUSED=0, pm_fill_coverage);
+//       pm_clear_kernel likewise (PM_FOLD_CLEAR=0).  pm_debug_capture_ptcl captures the lists from
+//       whichever kernel built them (the fused tile kernel's kCapture instantiation by default).
 //
 // Compile with -ffp-contract=off: every source-level f32/f16 operation is one
 // IEEE rounding, as in the oracle.
