@@ -106,10 +106,15 @@ __global__ void KCount(const pm_path *paths, uint32_t n_paths, const pm_path_el 
         } else if (tag == PM_EL_LINE || tag == PM_EL_CURVE) {
             double lx, ly;
             // a sub-path must have been opened (cur_path.as_mut().unwrap(), flatten.rs:24,:36)
-            bool opened = false;
-            for (uint32_t j = i; j > paths[p].el_begin;) {
-                --j;
-                if (els[j].tag == PM_EL_MOVE) { opened = true; break; }
+            // (a path that starts with a MoveTo -- every well-formed one -- answers with one load; walking back
+            //  to the sub-path's MoveTo is a chain of dependent loads as long as the sub-path: 32 us for the
+            //  Tiger's longest, the whole kernel's duration)
+            bool opened = i > paths[p].el_begin && els[paths[p].el_begin].tag == PM_EL_MOVE;
+            if (!opened) {
+                for (uint32_t j = i; j > paths[p].el_begin;) {
+                    --j;
+                    if (els[j].tag == PM_EL_MOVE) { opened = true; break; }
+                }
             }
             if (!opened) {
                 atomicExch(err, 1u);
