@@ -783,8 +783,13 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
                 cand_flags(c, cm, fill_bit, circle_bit, opaque_bit, rule);
                 const uint32_t *const ct_row = &L.s_ct[c * kCtStride];
                 int run = 0;  // backdrop steps were recorded at the first tile they apply to: the tiles before this wave's
-#pragma unroll 1
-                for (uint32_t t = 0; t < t0; ++t) run += static_cast<int>(ct_row[t]) >> kCtShift;
+                // (all twelve words requested at once, whatever the wave's quarter: one LDS round trip instead of
+                //  up to twelve dependent ones on the wave the others then wait for)
+#pragma unroll
+                for (uint32_t t = 0; t < 12u; ++t) {
+                    const int v = static_cast<int>(ct_row[t]) >> kCtShift;
+                    run += t < t0 ? v : 0;
+                }
                 uint32_t hb = 0;
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; ++j) {
@@ -905,8 +910,11 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
                     const uint32_t e1y = L.s_cidx[c], e1z = L.s_cpts[c], e1w = L.s_cnpt[c];
                     const uint32_t *const ct_row = &L.s_ct[c * kCtStride];
                     int run = 0;
-#pragma unroll 1
-                    for (uint32_t t = 0; t < t0; ++t) run += static_cast<int>(ct_row[t]) >> kCtShift;
+#pragma unroll
+                    for (uint32_t t = 0; t < 12u; ++t) {
+                        const int v = static_cast<int>(ct_row[t]) >> kCtShift;
+                        run += t < t0 ? v : 0;
+                    }
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j) {
                         const uint32_t t = t0 + j;
