@@ -357,6 +357,7 @@ def main() -> int:
         alone_ms = {"pm_bin_kernel": alone["bin_ms"], "pm_coarse_kernel": alone["coarse_ms"], "pm_fine_kernel": alone["fine_ms"], "pm_clear_kernel": alone["clear_ms"]}
         if kernels["pm_clear_kernel"] == 0:  # folded into pm_fine_kernel's launch
             kernels.pop("pm_clear_kernel")
+        if alone_ms["pm_clear_kernel"] == 0:  # (a frame alone folds it by default, frames behind others do not)
             alone_ms.pop("pm_clear_kernel")
         if kernels["pm_coarse_kernel"] == 0:  # fused: pm_fine_kernel<true> builds each tile's list itself
             kernels.pop("pm_coarse_kernel")
@@ -387,10 +388,13 @@ def main() -> int:
                     print(f"bench.py: profiles/hbm_traffic.json was measured on other kernel sources ({prof.get('_kernel_sources_sha16')} at commit "
                           f"{prof.get('_commit')}, now {now}): roofline.traffic / issue_roofline are from that profile", file=sys.stderr)
                 traffic = prof.get(dom, {}).get("hbm_bytes_per_launch")
-                per_kernel = [prof[k]["hbm_bytes_per_launch"] for k in kernels if "hbm_bytes_per_launch" in prof.get(k, {})]
-                if len(per_kernel) == len(kernels):
+                # (the counted runs pin PM_FOLD_CLEAR=1, tools/prof_round.sh: a frame is the launches a frame ALONE
+                #  makes, clearing inside the tile kernel's -- a separate pm_clear_kernel moves the same bytes)
+                counted = [k for k in alone_ms if k != "pm_clear_kernel"]
+                per_kernel = [prof[k]["hbm_bytes_per_launch"] for k in counted if "hbm_bytes_per_launch" in prof.get(k, {})]
+                if len(per_kernel) == len(counted):
                     traffic_frame = {"hbm_bytes_per_frame": int(sum(per_kernel)), "ratio_to_algorithmic": round(sum(per_kernel) / b_alg, 3)}
-                insts = sum(prof[k]["valu_insts_per_launch"] for k in kernels if "valu_insts_per_launch" in prof.get(k, {}))
+                insts = sum(prof[k]["valu_insts_per_launch"] for k in counted if "valu_insts_per_launch" in prof.get(k, {}))
                 props = torch.cuda.get_device_properties(local)
                 n_simd = props.multi_processor_count * 4
                 clock_ghz = getattr(props, "clock_rate", 2400000) / 1e6
@@ -444,7 +448,7 @@ def main() -> int:
                 "kernels_alone_ms": {k: round(v, 5) for k, v in alone_ms.items()},
                 "kernels_inflight_ms": {k: round(v, 5) for k, v in kernels.items()},
                 "frac_inflight": round(b_alg / (dom_inflight_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "trace_average_ms": {k: round((n_overlapped * kernels[k] + n_serial * alone_ms[k]) / (n_overlapped + n_serial), 5) for k in kernels},
+                "trace_average_ms": {k: round((n_overlapped * kernels[k] + n_serial * alone_ms.get(k, 0.0)) / (n_overlapped + (n_serial if k in alone_ms else 0)), 5) for k in kernels},
                 "trace_average_note": "what the AverageNs column of a kernel trace of THIS command shows: the mix of in-flight and serialized launches it makes",
                 "frame_latency_ms": round(t_render, 5),
                 "frac_frame": round(b_alg_frame / world / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

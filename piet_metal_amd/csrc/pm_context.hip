@@ -173,7 +173,8 @@ struct pm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // == streams[0]: scene upload, flatten, index, debug replays
     std::vector<hipStream_t> streams;  // frame N runs on streams[N % n]; stream == streams[0]
-    bool fold_clear = true;  // pm_fine_kernel's launch also writes the resolved tiles (no pm_clear_kernel launch)
+    bool fold_clear = true;  // a frame alone: pm_fine_kernel's launch also writes the resolved tiles (no pm_clear_kernel launch)
+    int fold_clear_mode = 2;  // PM_FOLD_CLEAR: 0 never, 1 always, 2 (default) per frame -- folded when the frame is alone
     bool fused = true;       // pm_fine_kernel<true>: each tile's list is built and interpreted by the same wave(s)
     int handout = 0;         // tile hand-out: 0 = drawn for a lone frame, static when frames overlap; 1 = static; 2 = drawn
     int target_fmt = PM_FMT_RGBA8;  // byte order the kernels store pixels in (pm_set_target_format)
@@ -731,10 +732,17 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     if (p.handout_static) SetClassThresholds(c, &p, c->heavy_stream);
     const uint32_t n_striprows = BandRows(c) * c->strips_x;
     PM_TRY(ResetTileState(c, s, q));
+    // The resolved tiles' pixels (26 MB of stores at Tiger 4K): extra workgroups of the tile kernel's
+    // launch for a frame alone (one launch less: -7 us), a launch of its own between the two kernels
+    // when other frames are in flight -- there it fills the SIMDs binning's tail leaves idle instead of
+    // queueing behind the persistent tile workgroups (sustained +3 %).
+    // (Small frames keep the fold: at 1080p a pipelined frame is 17 us, about what submitting two launches
+    //  costs the host, and a third one took the sustained rate from 122 k to 100 k Mpix/s.)
+    const bool fold = c->fold_clear_mode == 1 || (c->fold_clear_mode == 2 && (!p.handout_static || BandTiles(c) < 16384u));
     pm::LaunchBin(p, q, t[0], t[1]);
-    if (!c->fold_clear) pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // the resolved tiles' pixels (needs tile_state)
+    if (!fold) pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // (needs tile_state)
     if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, q, t[4], t[5]);
-    pm::LaunchFine(p, c->fold_clear ? n_striprows : 0u, c->fused, q, t[6], t[7]);  // (+ the resolved tiles' pixels)
+    pm::LaunchFine(p, fold ? n_striprows : 0u, c->fused, q, t[6], t[7]);
     PM_TRY(hipGetLastError());
     Submitted(c, si, p, q);
     s->user_stream = user_stream != nullptr && std::find(c->streams.begin(), c->streams.end(), q) == c->streams.end();
@@ -1067,7 +1075,8 @@ pm_ctx *pm_create(int device, int *err) {
     c->heavy_stream = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM", 32, 1, 1 << 20));
     c->heavy_stream_lone = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM_LONE", std::min<int>(24, static_cast<int>(c->heavy_stream)), 1, 1 << 20));
     c->vheavy_stream = static_cast<uint32_t>(EnvInt("PM_VHEAVY_STREAM", 96, 1, 1 << 20));
-    c->fold_clear = EnvInt("PM_FOLD_CLEAR", 1, 0, 1) != 0;
+    c->fold_clear_mode = EnvInt("PM_FOLD_CLEAR", 2, 0, 2);
+    c->fold_clear = c->fold_clear_mode != 0;
     c->fused = EnvInt("PM_FUSED", 1, 0, 1) != 0;
     c->handout = EnvInt("PM_HANDOUT", 0, 0, 2);
     c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 5, 1, 16));
@@ -1482,7 +1491,13 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
     r = PM_OK;
     if (e != hipSuccess) r = HipFail(e, "hipEventCreate");
     if (r == PM_OK) e = hipEventRecord(c->ev[0], c->stream);
+    // (every frame of the batch as a frame among others is launched: the per-frame decision would fold the
+    //  first one's clearing into its tile kernel and leave that frame's clear events unrecorded)
+    const int fold_mode = c->fold_clear_mode;
+    if (fold_mode == 2) c->fold_clear_mode = 0;
+    const bool folded = c->fold_clear_mode == 1;
     for (int i = 0; i < iters && r == PM_OK; ++i) r = Enqueue(c, nullptr, c->fb_stride, nullptr, &tev[static_cast<size_t>(i) * 8]);
+    c->fold_clear_mode = fold_mode;
     if (r == PM_OK) {
         for (auto &s : c->slot) {
             if (!s.in_flight || s.frame_stream == c->stream) continue;
@@ -1495,7 +1510,7 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
         double acc[4] = {0, 0, 0, 0};  // bin, clear, coarse, fine
         for (int i = 0; i < iters && e == hipSuccess && r == PM_OK; ++i)
             for (int k = 0; k < 4 && e == hipSuccess; ++k) {
-                if (k == 1 && c->fold_clear) continue;  // no separate clear launch
+                if (k == 1 && folded) continue;  // no separate clear launch
                 if (k == 2 && c->fused) continue;       // no separate coarse launch
                 float t = 0;
                 e = hipEventElapsedTime(&t, tev[static_cast<size_t>(i) * 8 + 2 * k], tev[static_cast<size_t>(i) * 8 + 2 * k + 1]);

@@ -29,7 +29,9 @@ f=$(find $OUT/trace_serial -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && 
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- $BENCH --steps 20 --warmup 5 --no-cpu-baseline $WL > $OUT/pmc$i.log 2>&1
+  # (PM_FOLD_CLEAR=1: every frame of the counted runs is two launches, clearing inside the tile kernel's -- the
+  #  per-launch averages then add up to one frame; by default frames behind other frames clear in a launch of their own)
+  PM_FOLD_CLEAR=1 timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc$i -- $BENCH --steps 20 --warmup 5 --no-cpu-baseline $WL > $OUT/pmc$i.log 2>&1
   f=$(find $OUT/pmc$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && cp $f $OUT/pmc_pass$i.csv || tail -5 $OUT/pmc$i.log
 done
