@@ -564,7 +564,8 @@ int EnsureArena(pm_ctx *c) {
 
 uint32_t FineGrid(const pm_ctx *c);
 
-int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FrameParams *p) {
+// q: the stream the frame will run on (frames in flight on that very stream cannot overlap it)
+int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FrameParams *p, hipStream_t q = nullptr) {
     if (!c->d_scene || c->scene_bytes < 8) {
         SetError("no scene resident (pm_upload_scene / pm_flatten_and_encode first)");
         return PM_ERR_INVALID;
@@ -607,7 +608,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
         // bounded by its heaviest rows -- three workgroups per CU, one per row (pm_bin.hip, BinLdsSparse).
         // Frames submitted behind one another keep the dense variant and its chains.
         bool lone = true;
-        for (const FrameSlot &o : c->slot) lone = lone && !o.in_flight;
+        for (const FrameSlot &o : c->slot) lone = lone && (!o.in_flight || (q != nullptr && o.frame_stream == q));
         const bool few_rows = c->n_sr_active <= 6u * static_cast<uint32_t>(c->n_cus);
         if (c->bin_sparse_mode == 1 || (c->bin_sparse_mode == 2 && lone && few_rows && c->bin_wg_per_cu == 0xffu)) {
             p->bin_sparse = 1;
@@ -693,9 +694,9 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     }
     if (!fb) fb = s->d_fb;
     pm::FrameParams p;
-    int r = BuildParams(c, s, fb, stride, &p);
-    if (r != PM_OK) return r;
     hipStream_t q = user_stream ? user_stream : c->streams[c->frame % c->streams.size()];
+    int r = BuildParams(c, s, fb, stride, &p, q);
+    if (r != PM_OK) return r;
     hipEvent_t none[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t *t = tev ? tev : none;
     // the slot's previous frame (same stream unless the caller's streams are involved or the
@@ -722,7 +723,7 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
         const FrameSlot &l = c->slot[c->last_slot];
         if (l.in_flight) {
             const hipError_t st = l.user_stream ? hipEventQuery(l.ev_done) : hipStreamQuery(l.frame_stream);
-            p.handout_static = st == hipErrorNotReady ? 1u : 0u;
+            p.handout_static = st == hipErrorNotReady && l.frame_stream != q ? 1u : 0u;  // (behind it on the same stream: alone all the same)
             (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure)
         }
     }
