@@ -106,16 +106,14 @@ namespace {
 constexpr uint32_t kCtStride = kStripTiles + 1;  // row stride 17: a thread per candidate walking its row, and 16 lanes adding to one row, are both free of bank conflicts
 // (overridable at build time so that the test builds of tests/emu reach the spill path with small scenes)
 #ifndef PM_BIN_SURV_LDS
-#define PM_BIN_SURV_LDS 1024
+#define PM_BIN_SURV_LDS 512
 #endif
 constexpr uint32_t kSurvLds = PM_BIN_SURV_LDS;
 struct BinLds {
     uint32_t s_part[kBinWaves];
     uint32_t s_cidx[kThreads];   // candidate item index
-    uint32_t s_cmask[kThreads];  // candidate per-tile hit mask (16 bits)
-    uint32_t s_ctag[kThreads];
+    uint32_t s_cmask[kThreads];  // candidate per-tile hit mask (16 bits) | item tag << 16
     uint32_t s_cpts[kThreads];   // points_ix (or byte offset of start/end for lines)
-    uint32_t s_cnseg[kThreads];  // segments of the item
     uint32_t s_cnpt[kThreads];
     float s_chw[kThreads];       // 0.5*width + 0.5 for polylines
     uint32_t s_cchunk[kThreads]; // first chunk-table entry of the item
@@ -141,25 +139,32 @@ struct BinLds {
     uint32_t s_wcnt[kBinWaves][kStripTiles];  // relevant segments per tile in each wave's share of the slots
     // finalisation, per wave of candidates and tile: candidates that can emit, their relevant segments,
     // pseudo elements (candidates without segments), last candidate that can emit / last opaque Solid (index + 1)
-    uint32_t s_wh[kBinWaves][kStripTiles], s_we[kBinWaves][kStripTiles];
-    uint32_t s_wlk[kBinWaves][kStripTiles], s_wls[kBinWaves][kStripTiles];
+    uint32_t s_wh[kStripTiles], s_we[kStripTiles];
+    uint32_t s_wlk[kStripTiles], s_wls[kStripTiles];
     uint32_t s_whub[kBinWaves][kStripTiles];  // per wave of candidates and tile: candidates whose bbox reaches the tile
     uint32_t s_alloc[2];  // {first quad of this record's pieces (0xffffffff: the tile arena ran out), overflow seen}
     unsigned long long s_stamp[14];  // developer timeline (kProfile builds)
 
 };
 
-// The same storage plus dead weight: 46 KB instead of 37 let THREE workgroups share a CU, not four.
+// BinLds is kept under 32 KB (tag and bbox mask share a word, the segment count is derived, 512
+// survivors in LDS): with FIVE of them fitting a CU's 160 KB, binning workgroups of one frame share
+// CUs with the tile kernel's (30.6 KB each) of its neighbours -- sustained throughput +4 % in every
+// configuration (Tiger 4K 212 -> 221 k Mpix/s); its own grid stays at three or four per CU (five
+// co-resident binning workgroups slow each other down: config 5 alone 0.40 -> 0.49 ms).
+// The same storage plus dead weight: 46 KB let THREE workgroups share a CU.
 // A frame with the chip to itself and few strip rows is bounded by its heaviest rows, and those run
 // faster with fewer neighbours on their SIMDs; with one workgroup per row (no chains) the dispatcher
 // then refills a CU as soon as a row ends (Tiger 4K alone: 37.5 -> 35.0 us; pipelined frames lose
 // 8 % of their throughput to it, so they keep the dense variant -- pm_context.hip, BuildParams).
 struct BinLdsSparse : BinLds {
-    uint32_t s_dead_weight[2200];
+    uint32_t s_dead_weight[3400];
 };
+static_assert(sizeof(BinLds) <= 32768 || kSurvLds != 512, "five per CU next to the tile kernel's workgroups");
+static_assert(sizeof(BinLdsSparse) > 40960 && sizeof(BinLdsSparse) <= 54528, "exactly three per CU");
 
 template <bool kProfile, bool kSparse>
-__global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(FrameParams P) {
+__global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(FrameParams P) {
     const ParamRegs PR = LoadParams(P);
     __shared__ std::conditional_t<kSparse, BinLdsSparse, BinLds> L;
     const uint32_t tid = threadIdx.x;
@@ -445,13 +450,12 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
             } else {
                 tag = 0;
             }
-            L.s_ctag[tid] = tag;
+            L.s_cmask[tid] = (L.s_cmask[tid] & 0xffffu) | (tag << 16);  // (this thread's own candidate)
             L.s_crgba[tid] = rgba;
             L.s_caux0[tid] = aux0;
             L.s_caux1[tid] = aux1;
             L.s_cpts[tid] = pts;
             L.s_cnpt[tid] = npt;
-            L.s_cnseg[tid] = nseg;
             L.s_chw[tid] = hw;
             L.s_cchunk[tid] = cbase;
 #pragma unroll
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
         }
         {   // per tile: how many of the wave's candidates reach it with their bbox (an upper bound of the
             // candidates of the tile's piece); the per-share segment counters start at zero
-            const uint32_t cm = tid < ncand ? L.s_cmask[tid] : 0u;
+            const uint32_t cm = tid < ncand ? (L.s_cmask[tid] & 0xffffu) : 0u;
             uint32_t hub = 0;
             ForStripTiles([&](auto tc) {
                 constexpr uint32_t t = decltype(tc)::value;
@@ -515,12 +519,12 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
                     const uint32_t j = e - L.s_choff[c];
                     pk[u] = (c << 24) | j;
                     bb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < total_ch && L.s_ctag[c] != kItemLine) bb[u] = PM_PP(chunk_bbox)[L.s_cchunk[c] + j];
+                    if (e < total_ch && (L.s_cmask[c] >> 16) != kItemLine) bb[u] = PM_PP(chunk_bbox)[L.s_cchunk[c] + j];
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < kCPL; ++u) {
                     if (eb + u >= total_ch) continue;
-                    const uint32_t ctag = L.s_ctag[cc[u]];
+                    const uint32_t ctag = L.s_cmask[cc[u]] >> 16;
                     bool sv;
                     if (ctag == kItemLine) {
                         sv = true;
@@ -579,8 +583,9 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
                     const uint32_t spk = six < kSurvLds ? L.s_surv[six] : meta[six * kChunkSegs];
                     vc = spk >> 24;
                     k = (spk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
-                    if (k < L.s_cnseg[vc]) {
-                        ctag = L.s_ctag[vc];
+                    const uint32_t vtag = L.s_cmask[vc] >> 16;
+                    if (k < SegsOf(vtag, L.s_cnpt[vc])) {
+                        ctag = vtag;
                         const uint8_t *pts = scene + L.s_cpts[vc];
                         // Fill: point k to point k + 1, the last one back to point 0 (:262-263); polyline:
                         // k to k + 1 (:376-377); line: its start and end sit in the item itself
@@ -635,8 +640,8 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
                         // x/box pre-conditions of phase 2 (:334, :349-350, :416-417); (b) for fills,
                         // the backdrop term of :326-333, which the reference accumulates per tile over
                         // EVERY voted segment of the row, is summed once per (item, tile) here.
-                        const uint32_t ctag = L.s_ctag[vc];
-                        const uint32_t hm = L.s_cmask[vc];
+                        const uint32_t tm = L.s_cmask[vc];
+                        const uint32_t ctag = tm >> 16, hm = tm & 0xffffu;
                         uint32_t M = 0;
                         const float xmin = fminf(seg.x, seg.z), ymin = fminf(seg.y, seg.w);
                         const float xmax = fmaxf(seg.x, seg.z), ymax = fmaxf(seg.y, seg.w);
@@ -766,8 +771,9 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
         // per candidate: what both passes need
         auto cand_flags = [&](uint32_t c, uint32_t &cm, uint32_t &fill_bit, uint32_t &circle_bit, uint32_t &opaque_bit, uint32_t &rule) {
             // (threads beyond the candidates read stale rows: with an empty bbox mask nothing of it counts)
-            cm = c < ncand ? L.s_cmask[c] : 0u;
-            const uint32_t tag = L.s_ctag[c], rgba = L.s_crgba[c];
+            const uint32_t tm = L.s_cmask[c];
+            cm = c < ncand ? (tm & 0xffffu) : 0u;
+            const uint32_t tag = tm >> 16, rgba = L.s_crgba[c];
             fill_bit = tag == kItemFill ? 1u : 0u;
             circle_bit = tag == kItemCircle ? 1u : 0u;
             opaque_bit = (rgba & 0xff000000u) == 0xff000000u ? fill_bit : 0u;
@@ -819,10 +825,10 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
             }
             if (lane < 4u) {
                 const uint32_t j = lane, t = t0 + lane;
-                L.s_wh[0][t] = j == 0 ? nh_q[0] : (j == 1 ? nh_q[1] : (j == 2 ? nh_q[2] : nh_q[3]));
-                L.s_we[0][t] = j == 0 ? ne_q[0] : (j == 1 ? ne_q[1] : (j == 2 ? ne_q[2] : ne_q[3]));
-                L.s_wlk[0][t] = j == 0 ? lk_q[0] : (j == 1 ? lk_q[1] : (j == 2 ? lk_q[2] : lk_q[3]));
-                L.s_wls[0][t] = j == 0 ? ls_q[0] : (j == 1 ? ls_q[1] : (j == 2 ? ls_q[2] : ls_q[3]));
+                L.s_wh[t] = j == 0 ? nh_q[0] : (j == 1 ? nh_q[1] : (j == 2 ? nh_q[2] : nh_q[3]));
+                L.s_we[t] = j == 0 ? ne_q[0] : (j == 1 ? ne_q[1] : (j == 2 ? ne_q[2] : ne_q[3]));
+                L.s_wlk[t] = j == 0 ? lk_q[0] : (j == 1 ? lk_q[1] : (j == 2 ? lk_q[2] : lk_q[3]));
+                L.s_wls[t] = j == 0 ? ls_q[0] : (j == 1 ? ls_q[1] : (j == 2 ? ls_q[2] : ls_q[3]));
             }
         }
         // the tail wave: where the pieces went
@@ -853,10 +859,10 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
             uint32_t nh = 0, ne = 0, lkm = 0, lsm = 0;
             uint32_t hdr_q = 0, hdr_prev = 0, hdr_n = 0;
             if (lane < kStripTiles) {
-                nh = L.s_wh[0][lane];
-                ne = L.s_we[0][lane];
-                lkm = L.s_wlk[0][lane];
-                lsm = L.s_wls[0][lane];
+                nh = L.s_wh[lane];
+                ne = L.s_we[lane];
+                lkm = L.s_wlk[lane];
+                lsm = L.s_wls[lane];
                 L.s_est[lane] += nrel_t + ne;
                 if (lkm) L.s_last_kept[lane] = L.s_cidx[lkm - 1u] + 1u;  // records come in paint order
                 if (lsm) {
@@ -906,7 +912,7 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 4) void pm_bin_kernel(Fr
                     const uint32_t hb = (hq >> (4u * g)) & 15u;
                     if (__ballot(hb != 0u) == 0ull) continue;  // uniform: nothing of this group in the wave's tiles
                     const uint32_t c = min(g * 64u + Opaque(lane), ncand - 1u);
-                    const uint4 e0 = make_uint4(L.s_ctag[c], L.s_crgba[c], L.s_caux0[c], L.s_caux1[c]);
+                    const uint4 e0 = make_uint4(L.s_cmask[c] >> 16, L.s_crgba[c], L.s_caux0[c], L.s_caux1[c]);
                     const uint32_t e1y = L.s_cidx[c], e1z = L.s_cpts[c], e1w = L.s_cnpt[c];
                     const uint32_t *const ct_row = &L.s_ct[c * kCtStride];
                     int run = 0;

@@ -167,6 +167,9 @@ __device__ __forceinline__ float2 LoadF2(const uint8_t *p) { return *reinterpret
 // Segments of an item as the kernels count them.
 __device__ __forceinline__ uint32_t FillSegs(uint32_t npt) { return npt; }                      // implicitly closed (:262)
 __device__ __forceinline__ uint32_t PolySegs(uint32_t npt) { return npt >= 2 ? npt - 1 : 0; }  // open (:369)
+__device__ __forceinline__ uint32_t SegsOf(uint32_t tag, uint32_t npt) {  // segments of an item (a line: its one)
+    return tag == kItemFill ? FillSegs(npt) : (tag == kItemPoly ? PolySegs(npt) : (tag == kItemLine ? 1u : 0u));
+}
 
 // ---------------------------------------------------------------------------------
 // phase-1 votes (strip level)
