@@ -175,7 +175,8 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
         // The counters of the NEXT frame (the other parity) are idle now: reset them
         // here so that no separate memset launch is needed.
         PM_PP(ctr_next)->arena_top = 0;
-        PM_PP(ctr_next)->ptcl_top = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < kArenaShards; ++k) PM_PP(ctr_next)->ptcl[k].top = 0;
 #pragma unroll
         for (uint32_t k = 0; k < kClasses; ++k) PM_PP(ctr_next)->cls[k].count = 0;
         PM_PP(ctr_next)->overflow = 0;
@@ -193,6 +194,10 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
     rix_next = kSparse ? 0u : __builtin_amdgcn_readfirstlane(srd.w);  // (the sparse launch has a workgroup per row)
     if (rix_next == 0) rix_next = 0xffffffffu;
     const uint32_t sr = __builtin_amdgcn_readfirstlane(srd.x);
+    // this strip row's part of the tile arena (pm_device.h, Counters)
+    const uint32_t shard = rix % kArenaShards;
+    const uint32_t shard_quads = PM_PU(tarena_cap) / kArenaShards;
+    const uint32_t shard_base = shard * shard_quads;
     const uint32_t strip = sr % PM_PU(strips_x);
     const uint32_t row_rel = sr / PM_PU(strips_x);
     const uint32_t ty = PM_PU(row0) + row_rel;
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
         ts.qres = 0;
         if (ts.qtotal) {  // uniform
             if (lane < kClasses && lane_cnt) ts.qres = atomicAdd(&PM_PP(ctr_cur)->cls[lane].count, lane_cnt);
-            if (lane == kClasses) ts.qres = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, ts.qtotal);
+            if (lane == kClasses) ts.qres = atomicAdd(&PM_PP(ctr_cur)->ptcl[shard].top, ts.qtotal);
         }
         // tiles with nothing to draw are background: no item touches them, or every touching
         // item lost all its segments in phase 1 (the reference writes Bail/white for them).  Their
@@ -304,10 +309,11 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
     auto RowTailFinish = [&](const TailState &ts) {
         if (!ts.qtotal) return;
         const uint32_t cls = (ts.packed >> 1) & 7u;
-        const uint32_t base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ts.qres), kClasses)) + 1u;  // (quad 0 stays unused: 0 = "no piece")
+        const uint32_t used = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ts.qres), kClasses)) + 1u;  // (a part's quad 0 stays unused: 0 = "no piece")
+        const uint32_t base = shard_base + used;
         const uint32_t q_base = static_cast<uint32_t>(__shfl(static_cast<int>(ts.qres), static_cast<int>(cls)));  // my class's queue position
         // (L.s_alloc[1]: a record of this strip row found the tile arena full -- its pieces do not exist)
-        const bool fits = base + ts.qtotal <= PM_PU(tarena_cap) && base + ts.qtotal >= base && L.s_alloc[1] == 0u;
+        const bool fits = used + ts.qtotal <= shard_quads && used + ts.qtotal >= used && L.s_alloc[1] == 0u;
         // (on overflow the tiles are still queued but marked "no list": the tile kernels skip
         //  them, the frame has holes, and pm_sync re-renders it with a larger arena)
         if (!fits && lane == 0) PM_PP(ctr_cur)->overflow = 1;
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
             const uint32_t incl = WaveInclusiveScan(quads);
             alloc_total = WaveLast(incl);
             pq_rel = incl - quads;
-            if (alloc_total && lane == 0) alloc_q = atomicAdd(&PM_PP(ctr_cur)->ptcl_top, alloc_total);  // (looked at after the pass below)
+            if (alloc_total && lane == 0) alloc_q = atomicAdd(&PM_PP(ctr_cur)->ptcl[shard].top, alloc_total);  // (looked at after the pass below)
         }
 
         // ---- candidates pass.  Lane = candidate (64 at a time), and every wave takes a QUARTER of the
@@ -835,8 +841,8 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
         if (wave == kTailWave) {
             uint32_t base_q = 1u;
             if (alloc_total) {  // uniform
-                base_q = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(alloc_q))) + 1u;  // (quad 0 stays unused: 0 = "no piece")
-                if (!(base_q + alloc_total <= PM_PU(tarena_cap) && base_q + alloc_total >= base_q)) base_q = 0xffffffffu;
+                const uint32_t used = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(alloc_q))) + 1u;  // (a part's quad 0 stays unused: 0 = "no piece")
+                base_q = used + alloc_total <= shard_quads && used + alloc_total >= used ? shard_base + used : 0xffffffffu;
             }
             if (lane < kStripTiles) {
                 L.s_piece_q[lane] = base_q != 0xffffffffu ? base_q + pq_rel : 0u;

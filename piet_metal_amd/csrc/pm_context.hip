@@ -1397,10 +1397,15 @@ int pm_sync(pm_ctx *c) {
         uint64_t want = 0;
         for (int si : latest) {
             const FrameSlot &s = c->slot[si];
-            uint32_t overflow = 0, top = 0;
+            uint32_t overflow = 0;
             PM_TRY(hipMemcpy(&overflow, &s.params.ctr_cur->overflow, sizeof(overflow), hipMemcpyDeviceToHost));
             if (!overflow) continue;
-            PM_TRY(hipMemcpy(&top, &s.params.ctr_cur->ptcl_top, sizeof(top), hipMemcpyDeviceToHost));
+            // (every part of the arena has to hold what ITS strip rows asked for: size all by the fullest)
+            pm::Counters k;
+            PM_TRY(hipMemcpy(&k, s.params.ctr_cur, offsetof(pm::Counters, cls), hipMemcpyDeviceToHost));
+            uint64_t top = 0;
+            for (uint32_t i = 0; i < pm::kArenaShards; ++i) top = std::max<uint64_t>(top, k.ptcl[i].top);
+            top = (top + 2) * pm::kArenaShards;
             want = std::max<uint64_t>(want, std::max<uint64_t>(4ull * s.ptcl_cap, 2ull * top));
             redo.push_back(s.params);
         }
@@ -1638,7 +1643,8 @@ int pm_get_stats(pm_ctx *c, pm_stats *out) {
         for (uint32_t q = 0; q < pm::kClasses; ++q) out->queued_tiles += k.cls[q].count;
         for (uint32_t q = 0; q < 3; ++q) out->heavy_tiles += k.cls[q].count;  // (n_heavy_classes)
         out->arena_used_dwords = k.arena_top;
-        out->ptcl_used_cmds = k.ptcl_top;
+        out->ptcl_used_cmds = 0;
+        for (uint32_t i = 0; i < pm::kArenaShards; ++i) out->ptcl_used_cmds += k.ptcl[i].top;
         out->overflow = k.overflow;
     }
     return PM_OK;
