@@ -1,7 +1,6 @@
 // pm_index_kernel, pm_rowcull_kernel, pm_bin_kernel: scene index and the strip-level half of tileKernel
 // (see pm_kernels_common.h for the decomposition and the rules shared by the three files)
 #include "pm_kernels_common.h"
-#include <type_traits>
 #include <pm_params.h>  // gfx950/pm_params.h: kernel arguments held in a VGPR, read with v_readlane
 
 namespace pm {
@@ -109,13 +108,16 @@ constexpr uint32_t kCtStride = kStripTiles + 1;  // row stride 17: a thread per 
 #define PM_BIN_SURV_LDS 512
 #endif
 constexpr uint32_t kSurvLds = PM_BIN_SURV_LDS;
+// 0.5 * width + 0.5 of a polyline / line candidate, from the width bits its aux0 word carries (the
+// expression the header phase used to store per candidate: one LDS array less)
+__device__ __forceinline__ float HalfWidthOf(uint32_t aux0) { return 0.5f * __uint_as_float(aux0) + 0.5f; }
+
 struct BinLds {
     uint32_t s_part[kBinWaves];
     uint32_t s_cidx[kThreads];   // candidate item index
     uint32_t s_cmask[kThreads];  // candidate per-tile hit mask (16 bits) | item tag << 16
     uint32_t s_cpts[kThreads];   // points_ix (or byte offset of start/end for lines)
     uint32_t s_cnpt[kThreads];
-    float s_chw[kThreads];       // 0.5*width + 0.5 for polylines
     uint32_t s_cchunk[kThreads]; // first chunk-table entry of the item
     uint32_t s_choff[kThreads + 1];  // chunk-stream offsets
     // per (candidate, tile): backdrop steps << 20 | relevant segments.  Row stride 17: a thread per
@@ -147,26 +149,16 @@ struct BinLds {
 
 };
 
-// BinLds is kept under 32 KB (tag and bbox mask share a word, the segment count is derived, 512
-// survivors in LDS): with FIVE of them fitting a CU's 160 KB, binning workgroups of one frame share
-// CUs with the tile kernel's (30.6 KB each) of its neighbours -- sustained throughput +4 % in every
-// configuration (Tiger 4K 212 -> 221 k Mpix/s); its own grid stays at three or four per CU (five
-// co-resident binning workgroups slow each other down: config 5 alone 0.40 -> 0.49 ms).
-// The same storage plus dead weight: 46 KB let THREE workgroups share a CU.
-// A frame with the chip to itself and few strip rows is bounded by its heaviest rows, and those run
-// faster with fewer neighbours on their SIMDs; with one workgroup per row (no chains) the dispatcher
-// then refills a CU as soon as a row ends (Tiger 4K alone: 37.5 -> 35.0 us; pipelined frames lose
-// 8 % of their throughput to it, so they keep the dense variant -- pm_context.hip, BuildParams).
-struct BinLdsSparse : BinLds {
-    uint32_t s_dead_weight[3400];
-};
-static_assert(sizeof(BinLds) <= 32768 || kSurvLds != 512, "five per CU next to the tile kernel's workgroups");
-static_assert(sizeof(BinLdsSparse) > 40960 && sizeof(BinLdsSparse) <= 54528, "exactly three per CU");
+// BinLds is kept at 30.5 KB (tag and bbox mask share a word, segment counts and stroke half-widths are
+// derived, 512 survivors in LDS): FIVE workgroups then share a CU -- measured: 31 184 B does, 32 208 B does
+// not -- its own, or the tile kernel's (30.6 KB each) of the neighbouring frames.  Config 5 alone: binning
+// 0.313 -> 0.270 ms; sustained throughput +4 % in every configuration.
+static_assert(sizeof(BinLds) <= 31232 || kSurvLds != 512, "five workgroups per CU");
 
-template <bool kProfile, bool kSparse>
-__global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(FrameParams P) {
+template <bool kProfile>
+__global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
     const ParamRegs PR = LoadParams(P);
-    __shared__ std::conditional_t<kSparse, BinLdsSparse, BinLds> L;
+    __shared__ BinLds L;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = LaneId();
     const uint32_t wave = tid >> 6;
@@ -174,9 +166,11 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
     if (blockIdx.x == 0 && tid == 0) {
         // The counters of the NEXT frame (the other parity) are idle now: reset them
         // here so that no separate memset launch is needed.
-        PM_PP(ctr_next)->arena_top = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < kArenaShards; ++k) PM_PP(ctr_next)->ptcl[k].top = 0;
+        for (uint32_t k = 0; k < kArenaShards; ++k) {
+            PM_PP(ctr_next)->ptcl[k].top = 0;
+            PM_PP(ctr_next)->ptcl[k].bin_dwords = 0;
+        }
 #pragma unroll
         for (uint32_t k = 0; k < kClasses; ++k) PM_PP(ctr_next)->cls[k].count = 0;
         PM_PP(ctr_next)->overflow = 0;
@@ -191,7 +185,7 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
     if (rix != blockIdx.x) LdsBarrier();  // the previous strip row's LDS is done with
     // One 16-byte load: {strip row, region, end, next strip row of this workgroup (0: none)}.
     const uint4 srd = PM_PP(sr_desc)[rix];
-    rix_next = kSparse ? 0u : __builtin_amdgcn_readfirstlane(srd.w);  // (the sparse launch has a workgroup per row)
+    rix_next = __builtin_amdgcn_readfirstlane(srd.w);
     if (rix_next == 0) rix_next = 0xffffffffu;
     const uint32_t sr = __builtin_amdgcn_readfirstlane(srd.x);
     // this strip row's part of the tile arena (pm_device.h, Counters)
@@ -427,7 +421,6 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
             }
             tag = w01v.x & 0xffffu;
             uint32_t pts = 0, npt = 0, nseg = 0;
-            float hw = 0.0f;
             if (tag == kItemCircle) {
                 rgba = (w01v.x & kCircleEllipse) ? kCmdCircleEllipse : 0u;  // (a circle has no colour: the slot carries CmdCircle.flags)
                 aux0 = ibbv.x;
@@ -450,7 +443,6 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
                 aux0 = w23v.x;  // width bits
                 npt = w23v.y;
                 pts = w4v;
-                hw = 0.5f * __uint_as_float(aux0) + 0.5f;
                 nseg = PolySegs(npt);
                 nch = (nseg + kChunkSegs - 1) / kChunkSegs;
             } else {
@@ -462,7 +454,6 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
             L.s_caux1[tid] = aux1;
             L.s_cpts[tid] = pts;
             L.s_cnpt[tid] = npt;
-            L.s_chw[tid] = hw;
             L.s_cchunk[tid] = cbase;
 #pragma unroll
             for (uint32_t t = 0; t < kStripTiles; ++t) L.s_ct[tid * kCtStride + t] = 0;
@@ -537,7 +528,7 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
                     } else if (ctag == kItemFill) {  // necessary part of :264-265 for any segment of the chunk
                         sv = bb[u].w >= fy0 && bb[u].y < fy1 && bb[u].x < fsx1;
                     } else {  // necessary part of :378-379
-                        const float hw = L.s_chw[cc[u]];
+                        const float hw = HalfWidthOf(L.s_caux0[cc[u]]);
                         sv = bb[u].w > fsy0 - hw && bb[u].y < fsy1 + hw && bb[u].z > fsx0 - hw && bb[u].x < fsx1 + hw;
                     }
                     if (sv) svb |= 1u << u;
@@ -634,7 +625,7 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
                 } else if (ctag_f == kItemPoly) {
                     seg = make_float4(a.x, a.y, b.x, b.y);
                     const int y_test = sy0 + static_cast<int>(((k & 31u) >> 4) * kTileH);
-                    vote = VotePoly(seg, L.s_chw[vc], y_test, sx0, sy0);
+                    vote = VotePoly(seg, HalfWidthOf(L.s_caux0[vc]), y_test, sx0, sy0);
                 } else if (ctag_f == kItemLine) {
                     seg = make_float4(a.x, a.y, b.x, b.y);
                     vote = true;
@@ -678,7 +669,7 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
                                 }
                             }
                         } else if (ctag == kItemPoly) {
-                            const float hw = L.s_chw[vc];
+                            const float hw = HalfWidthOf(L.s_caux0[vc]);
                             if (ymax > fy0 - hw && ymin < fy1 + hw) {
                                 // tiles t with xmax > fx0(t) - hw && xmin < fx1(t) + hw (:416-417).  Both
                                 // bounds are monotone in t (tile edges are integers, every rounding is
@@ -1004,7 +995,7 @@ __global__ __launch_bounds__(kBinThreads, kSparse ? 3 : 5) void pm_bin_kernel(Fr
         }
         ncand = nb;
     }
-    if (tid == 0) atomicAdd(&PM_PP(ctr_cur)->arena_top, cursor - region_begin);  // dwords used (stats only)
+    if (tid == 0) atomicAdd(&PM_PP(ctr_cur)->ptcl[shard].bin_dwords, cursor - region_begin);  // dwords used (stats only)
     // the strip row's tail, unless its last record took care of it
     if (!tail_done) {  // uniform
         LdsBarrier();  // L.s_est, s_last_*, s_head_* of the last record are in
@@ -1035,14 +1026,10 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, cons
 void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
     const uint32_t n_striprows = p.bin_grid;
     if (p.use_row_lists) hipLaunchKernelGGL(pm_rowcull_kernel, dim3(p.row1 - p.row0), dim3(kBinThreads), 0, stream, p);
-    if (p.dbg_bin && p.bin_sparse)
-        PM_LAUNCH((pm_bin_kernel<true, true>), dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
-    else if (p.dbg_bin)
-        PM_LAUNCH((pm_bin_kernel<true, false>), dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
-    else if (p.bin_sparse)
-        PM_LAUNCH((pm_bin_kernel<false, true>), dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
+    if (p.dbg_bin)
+        PM_LAUNCH(pm_bin_kernel<true>, dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
     else
-        PM_LAUNCH((pm_bin_kernel<false, false>), dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
+        PM_LAUNCH(pm_bin_kernel<false>, dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
 }
 
 }  // namespace pm

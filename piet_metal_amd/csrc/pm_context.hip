@@ -219,7 +219,6 @@ struct pm_ctx {
     uint32_t n_sr_active = 0;
     uint32_t bin_grid = 1;          // workgroups of pm_bin_kernel (each walks a chain of strip rows)
     uint32_t bin_prio_slots = 1024; // PM_BIN_PRIO_SLOTS
-    int bin_sparse_mode = 2;        // PM_BIN_SPARSE: 0 never, 1 always, 2 (default) for a frame with nothing else in flight
     uint32_t sr_empty_dwords = 0;   // size of a region no item reaches
     uint2 *d_band_bbox = nullptr;   // items that reach the band (bbox, scene index), paint order
     uint32_t *d_band_item = nullptr;
@@ -466,17 +465,17 @@ int EnsureArena(pm_ctx *c) {
     if (desc.empty()) desc.push_back(make_uint4(0u, base[0], need.empty() ? base[0] : base[1], 0u));
     c->n_sr_active = static_cast<uint32_t>(desc.size());
     {
-        // pm_bin_kernel's grid is no larger than what the chip holds at once: four workgroups per CU when
-        // strip rows are plenty -- a throughput problem (config 4: 4 096 rows, 200 -> 224 us with three) --,
-        // one less when a workgroup gets one or two rows and the launch ends with its heaviest ones: their
-        // waves then share the SIMDs with fewer others (Tiger 4K: 39.5 -> 37.4 us).  A workgroup walks a
-        // chain of strip rows (desc.w = index of the next one, 0 = none): row b, b + grid, b + 2 grid ... in
-        // natural order -- at Tiger 4K that pairs the top of the picture with its bottom, light rows with
-        // light rows.  (Measured and not kept: any permutation of ALL rows, +25 % -- neighbouring strip
-        // rows share data; pairing the lightest rows by their arena need, +9 % -- the need is the worst
-        // case of the chunk test, not the work.)
+        // pm_bin_kernel's grid is no larger than what the chip holds at once: five workgroups per CU (its LDS
+        // is sized for that).  A workgroup walks a chain of strip rows (desc.w = index of the next one, 0 =
+        // none): row b, b + grid, b + 2 grid ... in natural order -- a grid larger than the residency would
+        // start its last workgroups when the first END their chains.  (While the tile arena had ONE allocation
+        // counter, fewer resident workgroups were faster -- three per CU for the Tiger, four for config 4 --:
+        // less contention on that cache line, not a property of the kernel; pm_device.h, Counters.  Measured
+        // and not kept: any permutation of ALL rows, +25 % -- neighbouring strip rows share data; pairing
+        // the lightest rows by their arena need, +9 % -- the need is the worst case of the chunk test, not
+        // the work.)
         uint32_t per_cu = c->bin_wg_per_cu;
-        if (per_cu == 0xffu) per_cu = c->n_sr_active <= 6u * static_cast<uint32_t>(c->n_cus) ? 3u : 4u;
+        if (per_cu == 0xffu) per_cu = 5u;
         const size_t n = desc.size();
         const size_t grid = per_cu == 0 ? n : std::min<size_t>(n, static_cast<size_t>(c->n_cus) * per_cu);
         if (n > grid) {
@@ -582,8 +581,7 @@ int EnsureArena(pm_ctx *c) {
 
 uint32_t FineGrid(const pm_ctx *c);
 
-// q: the stream the frame will run on (frames in flight on that very stream cannot overlap it)
-int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FrameParams *p, hipStream_t q = nullptr) {
+int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FrameParams *p) {
     if (!c->d_scene || c->scene_bytes < 8) {
         SetError("no scene resident (pm_upload_scene / pm_flatten_and_encode first)");
         return PM_ERR_INVALID;
@@ -620,19 +618,6 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->n_sr_active = c->n_sr_active;
     p->bin_prio_slots = c->bin_prio_slots;
     p->bin_grid = c->bin_grid;
-    p->bin_sparse = 0;
-    {
-        // Nothing else in flight (every earlier frame was waited for) and few strip rows: the frame is
-        // bounded by its heaviest rows -- three workgroups per CU, one per row (pm_bin.hip, BinLdsSparse).
-        // Frames submitted behind one another keep the dense variant and its chains.
-        bool lone = true;
-        for (const FrameSlot &o : c->slot) lone = lone && (!o.in_flight || (q != nullptr && o.frame_stream == q));
-        const bool few_rows = c->n_sr_active <= 6u * static_cast<uint32_t>(c->n_cus);
-        if (c->bin_sparse_mode == 1 || (c->bin_sparse_mode == 2 && lone && few_rows && c->bin_wg_per_cu == 0xffu)) {
-            p->bin_sparse = 1;
-            p->bin_grid = c->n_sr_active;
-        }
-    }
     p->sr_empty_dwords = c->sr_empty_dwords;
     p->queue = s->d_queue;
     p->queue_cap = static_cast<uint32_t>(BandTiles(c));
@@ -713,7 +698,7 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     if (!fb) fb = s->d_fb;
     pm::FrameParams p;
     hipStream_t q = user_stream ? user_stream : c->streams[c->frame % c->streams.size()];
-    int r = BuildParams(c, s, fb, stride, &p, q);
+    int r = BuildParams(c, s, fb, stride, &p);
     if (r != PM_OK) return r;
     hipEvent_t none[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t *t = tev ? tev : none;
@@ -1107,7 +1092,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->fine_wg_per_cu_inflight = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU_INFLIGHT", 3, 1, 16));
     c->bin_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_BIN_WG_PER_CU", 0xff, 0, 0xff));
     c->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 1024, 0, 1 << 30));
-    c->bin_sparse_mode = EnvInt("PM_BIN_SPARSE", 2, 0, 2);
+
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
     for (auto &s : c->slot) {
@@ -1642,7 +1627,8 @@ int pm_get_stats(pm_ctx *c, pm_stats *out) {
         PM_TRY(hipMemcpy(&k, c->slot[c->last_slot].params.ctr_cur, sizeof(k), hipMemcpyDeviceToHost));
         for (uint32_t q = 0; q < pm::kClasses; ++q) out->queued_tiles += k.cls[q].count;
         for (uint32_t q = 0; q < 3; ++q) out->heavy_tiles += k.cls[q].count;  // (n_heavy_classes)
-        out->arena_used_dwords = k.arena_top;
+        out->arena_used_dwords = 0;
+        for (uint32_t i = 0; i < pm::kArenaShards; ++i) out->arena_used_dwords += k.ptcl[i].bin_dwords;
         out->ptcl_used_cmds = 0;
         for (uint32_t i = 0; i < pm::kArenaShards; ++i) out->ptcl_used_cmds += k.ptcl[i].top;
         out->overflow = k.overflow;

@@ -32,15 +32,15 @@ struct Counters {
     // binning bound by exactly that: 35 -> 30 us).
     struct {
         uint32_t top;
-        uint32_t pad[31];
+        uint32_t bin_dwords;  // dwords of binning records written by the part's strip rows (statistics)
+        uint32_t pad[30];
     } ptcl[kArenaShards];
     struct {
         uint32_t count;  // tiles queued in this class
         uint32_t pad[31];
     } cls[kClasses];
-    uint32_t arena_top;  // dwords of binning records written (statistics)
     uint32_t overflow;   // set if the command-list arena ran out
-    uint32_t pad4[30];
+    uint32_t pad4[31];
     struct {
         uint32_t count;  // cards drawn from this deck of tiles (pm_fine_kernel's hand-out)
         uint32_t pad[31];
@@ -113,8 +113,7 @@ struct FrameParams {
     uint32_t arena_cap;   // dwords
     const uint4 *sr_desc;     // [n_sr_active] {strip row, its private arena region begin, end, 0}
     uint32_t n_sr_active;     // strip rows some item reaches: pm_bin_kernel's work list
-    uint32_t bin_grid;        // its grid: what the chip holds at once, or a workgroup per strip row (bin_sparse)
-    uint32_t bin_sparse;      // host only: launch the three-per-CU variant (a frame with the chip to itself)
+    uint32_t bin_grid;        // its grid: what the chip holds at once (five workgroups per CU), or a workgroup per strip row
     uint32_t bin_prio_slots;  // strip rows with at least this many segment slots raise their waves' issue priority
     uint32_t sr_empty_dwords; // size of a region no item's bbox reaches
     uint4 *queue;             // kClasses class queues of {tile, command-list quad, first piece, its candidates | segments << 9}, queue_cap entries each

@@ -637,13 +637,11 @@ def test_every_frame_path_switch_agrees_with_the_oracle(pm, pmo, monkeypatch, fu
         r.close()
 
 
-@pytest.mark.parametrize("sparse,wg_per_cu", [("0", None), ("1", None), ("2", None), ("0", "1"), ("0", "0"), ("1", "2")])
-def test_binning_launch_variants(pm, pmo, monkeypatch, sparse, wg_per_cu):
+@pytest.mark.parametrize("wg_per_cu", [None, "1", "2", "7", "0"])
+def test_binning_launch_variants(pm, pmo, monkeypatch, wg_per_cu):
     """pm_bin_kernel runs as chains of strip rows over a grid the chip holds at once (PM_BIN_WG_PER_CU
-    per CU; 0: a workgroup per row) or, for a frame with nothing else in flight, as the three-per-CU
-    variant with a workgroup per row (PM_BIN_SPARSE: 0 never, 1 always, 2 decided per frame).  Same
-    bytes either way, for frames submitted behind one another and for frames waited for one by one."""
-    monkeypatch.setenv("PM_BIN_SPARSE", sparse)
+    per CU, five by default; 0: a workgroup per row whatever their number).  Same bytes whatever the
+    grid, for frames submitted behind one another and for frames waited for one by one."""
     if wg_per_cu is not None:
         monkeypatch.setenv("PM_BIN_WG_PER_CU", wg_per_cu)
     r = pm.Renderer(0)
