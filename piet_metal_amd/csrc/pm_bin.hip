@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         // beyond kSurvLds surviving chunks it continues in the first meta word of the chunk's own
         // slots (read before the vote overwrites it).
         uint32_t sbase = 0;  // surviving chunks so far
-        constexpr uint32_t kCPL = 2;  // chunks tested per lane per round (measured at the Tiger: 1: 35.1 us, 2: 34.5, 4: 35.7, 8: 40.3 -- 116 VGPRs)
+        constexpr uint32_t kCPL = 2;  // chunks tested per lane per round (1, 2, 3, 4: the same within 0.3 us at every configuration; 8: +5 us, 116 VGPRs)
         for (uint32_t r0 = 0; r0 < total_ch; r0 += kBinThreads * kCPL) {
             const uint32_t eb = r0 + kCPL * tid;  // this lane's consecutive chunks (stream order)
             if (kProfile && prof_first && r0 == 0) stamp(8);
