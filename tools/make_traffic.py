@@ -6,6 +6,7 @@ section), so the read side is doubled -- an upper bound for this path, whose rea
 mix of 4..16 B per lane.  bench.py copies the dominant kernel's figure into
 roofline.traffic."""
 import hashlib
+import re
 import json
 import os
 import subprocess
@@ -15,23 +16,33 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = ["pm_bin.hip", "pm_fine.hip", "pm_coarse.hip", "pm_coarse_tile.h", "pm_kernels_common.h", "pm_device.h", "gfx950/pm_pin.h", "gfx950/pm_params.h"]
 
 
+def _code_only(text):
+    """The source without comments and white space: what the compiler sees (a reworded comment does not
+    make a profile stale)."""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", "", text)
+
+
 def kernel_sources_sha16(root=ROOT):
-    """What the PMC figures were measured on: a digest of the kernel sources (bench.py recomputes it and
-    says so when the committed figures are older than the kernels it runs)."""
+    """What the PMC figures were measured on: a digest of the kernel sources, comments and white space
+    aside (bench.py recomputes it and says so when the committed figures are older than the kernels it runs)."""
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
-        with open(os.path.join(root, "piet_metal_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(root, "piet_metal_amd", "csrc", f), "r", encoding="utf-8") as fh:
+            h.update(_code_only(fh.read()).encode())
     return h.hexdigest()[:16]
 
 
 def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     summ = json.load(open(src))
-    try:
-        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
-    except Exception:
-        commit = None
+    commit = sys.argv[4] if len(sys.argv) > 4 else None  # (the commit the passes ran on, when it is not HEAD)
+    if commit is None:
+        try:
+            commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+        except Exception:
+            commit = None
     out = {"_source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes)",
            "_formula": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
            "_kernel_sources_sha16": kernel_sources_sha16(), "_commit": commit}
