@@ -967,3 +967,29 @@ def test_svg_path_grammar_random(pm, seed):
         for g, (t, coords) in zip(got, want):
             assert g["tag"] == tags[t], d
             assert g["p"][: len(coords)].tolist() == coords, d
+
+
+def test_profile_stamp_digest_ignores_comments_but_not_code(tmp_path):
+    """profiles/hbm_traffic.json is stamped with a digest of the kernel sources (tools/make_traffic.py) and
+    bench.py calls the profile stale when the digest of the sources it runs differs: rewording a comment
+    must not do that, changing a token must.  The committed stamp matches the committed sources."""
+    import json
+    import shutil
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_traffic as mt
+
+    src = os.path.join(ROOT, "piet_metal_amd", "csrc")
+    dst = tmp_path / "piet_metal_amd" / "csrc"
+    shutil.copytree(src, dst, ignore=shutil.ignore_patterns("*.o", "*.so"))
+    base = mt.kernel_sources_sha16(str(tmp_path))
+    assert base == mt.kernel_sources_sha16()
+    f = dst / "pm_bin.hip"
+    text = f.read_text()
+    f.write_text("// a new remark\n" + text.replace("// ", "//   ", 5) + "\n/* and\n   another */\n")
+    assert mt.kernel_sources_sha16(str(tmp_path)) == base
+    f.write_text(text.replace("kCPL = 2", "kCPL = 3", 1))
+    assert mt.kernel_sources_sha16(str(tmp_path)) != base
+    stamp = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    assert stamp["_kernel_sources_sha16"] == mt.kernel_sources_sha16(), "profiles/hbm_traffic.json is older than the kernel sources: re-run tools/prof_round.sh"
