@@ -129,6 +129,21 @@ class Job:
         if self.gather_impl not in ("auto", "cabi"):
             return
         ok, why = 1, ""
+        # ncclCommInitRank is a collective: a rank that cannot even load RCCL must be found BEFORE the others
+        # enter it and wait for that rank (every rank makes an id -- which loads the library -- and they agree)
+        try:
+            self.pm.Comm.unique_id()
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, repr(e)
+        t = self.torch.tensor([ok], dtype=self.torch.int32, device=self.band.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        if int(t.item()) != 1:
+            if self.args.gather_impl == "cabi":
+                raise RuntimeError(f"--gather-impl cabi: RCCL cannot be loaded on some rank ({why or 'another rank'})")
+            if self.rank == 0:
+                print(f"bench.py: RCCL not loadable through the C ABI ({why or 'on another rank'}): falling back to torch.distributed send/recv", file=sys.stderr)
+            self.comm, self.gather_impl = None, "sendrecv"
+            return
         try:
             box = [self.pm.Comm.unique_id() if self.rank == 0 else None]
             self.dist.broadcast_object_list(box, src=0)
