@@ -265,12 +265,13 @@ typedef struct {
     uint32_t band_row0, band_row1;
     uint32_t n_items;             /* scene items */
     uint32_t queued_tiles;        /* tiles handed to the per-tile kernel last frame */
-    uint32_t arena_used_dwords;   /* binning arena high-water mark last frame */
+    uint32_t arena_used_dwords;   /* binning arena: dwords of records written last frame */
     uint32_t arena_cap_dwords;
     uint32_t overflow;            /* 1 if the last frame ran out of arena */
     uint32_t scene_bytes;
     uint32_t heavy_tiles;         /* of queued_tiles: scheduled first (long segment streams) */
-    uint32_t ptcl_used_cmds;      /* command-list slots reserved last frame */
+    uint32_t ptcl_used_cmds;      /* tile arena: 16-byte quads reserved last frame (per-tile pieces + command
+                                     lists, a 24-byte command = 1.5 quads), summed over the arena's parts */
 } pm_stats;
 int pm_get_stats(pm_ctx *c, pm_stats *out); /* synchronises */
 
