@@ -201,7 +201,8 @@ int pm_upload_scene(pm_ctx *c, size_t bytes);
 /* flatten.rs moved on-device: flatten + encode make_tiger-style paths directly
  * into the device scene buffer (src/lib.rs:293-327, src/flatten.rs:10-47).
  * affine = kurbo Affine coefficients [a b c d e f]; stroke widths are multiplied
- * by `width_scale` in f32 (src/lib.rs:320).  On return the scene is resident. */
+ * by `width_scale` in f32 (src/lib.rs:320).  On return the scene is resident.
+ * Limits: n_els and n_paths <= 2^26 - 1 (PM_ERR_CAPACITY beyond). */
 int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths,
                           const pm_path_el *els, size_t n_els, const double affine[6],
                           float width_scale, size_t *scene_bytes, uint32_t *n_items);

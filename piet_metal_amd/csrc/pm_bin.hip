@@ -526,7 +526,9 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                     if (ctag == kItemLine) {
                         sv = true;
                     } else if (ctag == kItemFill) {  // necessary part of :264-265 for any segment of the chunk
-                        sv = bb[u].w >= fy0 && bb[u].y < fy1 && bb[u].x < fsx1;
+                        // (a chunk wholly LEFT of the strip can only add to backdrops, :283-286, and only with a segment
+                        //  that reaches the row's top edge: ymin <= y0)
+                        sv = bb[u].w >= fy0 && bb[u].y < fy1 && bb[u].x < fsx1 && (bb[u].z > fsx0 || bb[u].y <= fy0);
                     } else {  // necessary part of :378-379
                         const float hw = HalfWidthOf(L.s_caux0[cc[u]]);
                         sv = bb[u].w > fsy0 - hw && bb[u].y < fsy1 + hw && bb[u].z > fsx0 - hw && bb[u].x < fsx1 + hw;

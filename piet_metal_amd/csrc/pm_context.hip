@@ -286,14 +286,25 @@ void FreeViewport(pm_ctx *c) {
 }
 
 int AllocSlotViewport(pm_ctx *c, FrameSlot *s) {
-    if (s->d_fb) return PM_OK;
+    if (s->d_fb) return PM_OK;  // (all five buffers exist, or none: a partial set is released below)
     const size_t tiles = BandTiles(c);
-    PM_TRY(hipMalloc(&s->d_fb, std::max<size_t>(c->fb_bytes, 16)));
-    PM_TRY(hipMalloc(&s->d_queue, pm::kClasses * tiles * sizeof(uint4)));  // one queue per cost class
-    PM_TRY(hipMalloc(&s->d_tile_state, tiles * sizeof(uint32_t)));
-    PM_TRY(hipMalloc(&s->d_tile_ptcl, tiles * sizeof(uint32_t)));
-    PM_TRY(hipMalloc(&s->d_tile_ncmd, tiles * sizeof(uint32_t)));
+    hipError_t e = hipMalloc(&s->d_fb, std::max<size_t>(c->fb_bytes, 16));
+    if (e == hipSuccess) e = hipMalloc(&s->d_queue, pm::kClasses * tiles * sizeof(uint4));  // one queue per cost class
+    if (e == hipSuccess) e = hipMalloc(&s->d_tile_state, tiles * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&s->d_tile_ptcl, tiles * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&s->d_tile_ncmd, tiles * sizeof(uint32_t));
     s->state_epoch = 0;  // (never initialised)
+    if (e != hipSuccess) {
+        if (s->d_fb) (void)hipFree(s->d_fb);
+        if (s->d_queue) (void)hipFree(s->d_queue);
+        if (s->d_tile_state) (void)hipFree(s->d_tile_state);
+        if (s->d_tile_ptcl) (void)hipFree(s->d_tile_ptcl);
+        if (s->d_tile_ncmd) (void)hipFree(s->d_tile_ncmd);
+        s->d_fb = nullptr;
+        s->d_queue = nullptr;
+        s->d_tile_state = s->d_tile_ptcl = s->d_tile_ncmd = nullptr;
+        return HipFail(e, "hipMalloc(frame slot viewport buffers)");
+    }
     return PM_OK;
 }
 
@@ -442,14 +453,15 @@ int EnsureArena(pm_ctx *c) {
     c->sr_empty_dwords = 0;  // (a strip row no item's bbox reaches has nothing reserved)
     // (the slots' arenas themselves are allocated when a slot is first used, EnsureSlotBuffers: the
     //  first frame of a scene pays for one arena, not for four -- hundreds of MB each at 8K)
-    if (c->ptcl_want == 0) {
+    {
         // Tile arena (per-tile pieces + command lists, 16-byte quads): sized from what binning
-        // actually finds, so there is no static bound; start generously (HBM is 288 GB) and let
-        // pm_sync grow it on overflow.
+        // actually finds, so there is no static bound; start generously (HBM is 288 GB), in proportion
+        // to EVERY scene that comes (a max: what pm_sync grew it to is kept), and let pm_sync grow it on
+        // overflow.
         uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
         if (const char *v = std::getenv("PM_PTCL_INITIAL_CMDS"))  // tests: force the overflow -> grow -> re-render path
             cmds = std::max<uint64_t>(64, std::strtoull(v, nullptr, 10));
-        c->ptcl_want = std::min<uint64_t>(cmds * pm::kCmdQuadsNum / pm::kCmdQuadsDen, 0x7fffffffull);
+        c->ptcl_want = std::max<uint64_t>(c->ptcl_want, std::min<uint64_t>(cmds * pm::kCmdQuadsNum / pm::kCmdQuadsDen, 0x7fffffffull));
     }
     c->arena_cap = std::max<uint32_t>(c->arena_cap, static_cast<uint32_t>(alloc_dwords));
     // The strip rows some item's bbox reaches get a workgroup of pm_bin_kernel each; the others are
@@ -668,8 +680,9 @@ uint32_t FineGrid(const pm_ctx *c) {
 // and viewport last -- set once per slot and arena epoch, in stream order before the frame.
 hipError_t ResetTileState(pm_ctx *c, FrameSlot *s, hipStream_t q) {
     if (s->state_epoch == c->arena_epoch) return hipSuccess;
-    s->state_epoch = c->arena_epoch;
-    return hipMemsetAsync(s->d_tile_state, 0xff, BandTiles(c) * sizeof(uint32_t), q);
+    const hipError_t e = hipMemsetAsync(s->d_tile_state, 0xff, BandTiles(c) * sizeof(uint32_t), q);
+    if (e == hipSuccess) s->state_epoch = c->arena_epoch;
+    return e;
 }
 
 void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t frame_stream) {
@@ -1171,6 +1184,16 @@ pm_ctx *pm_create(int device, int *err) {
         c->width = c->height = c->tiles_x = c->tiles_y = c->strips_x = c->row0 = c->row1 = 0;
         c->frame = 0;
         c->t_flatten_ms = c->t_index_ms = c->t_arena_ms = 0;
+        // ... and without the warm-up scene's arena sizes: the first real scene sizes its own (round-3 advisor
+        // finding: the floor the three-point scene asked for used to stay in force for every scene after it)
+        c->ptcl_want = 0;
+        c->arena_cap = 0;
+        if (std::getenv("PM_PTCL_INITIAL_CMDS"))  // tests of the overflow path: what pm_sync grew during the warm-up goes too
+            for (auto &s : c->slot) {
+                if (s.d_ptcl) (void)hipFree(s.d_ptcl);
+                s.d_ptcl = nullptr;
+                s.ptcl_cap = 0;
+            }
     }
     *err = PM_OK;
     return c;

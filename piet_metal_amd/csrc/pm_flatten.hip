@@ -142,6 +142,7 @@ __global__ void KCount(const pm_path *paths, uint32_t n_paths, const pm_path_el 
 
 // One workgroup.  Exclusive scans with totals at index n.
 constexpr int kScanThreads = 1024;
+constexpr size_t kMaxFlattenEls = (1u << 26) - 1u;  // elements / paths of one pm_flatten_and_encode call
 
 __device__ uint32_t BlockScan1024(uint32_t v, uint32_t *s_w, uint32_t *total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -489,6 +490,9 @@ int FlattenEncodeOnDevice(hipStream_t stream, FlattenCache *cache, bool use_resi
         n_paths = cache->n_paths;
         n_els = cache->n_els;
     }
+    // (KItems runs a wave per sub-path on a 32-bit grid, the scratch offsets are 32-bit too: documented limit,
+    //  include/piet_metal_amd.h)
+    if (n_els > kMaxFlattenEls || n_paths > kMaxFlattenEls) return PM_ERR_CAPACITY;
     pm_path *d_paths = nullptr;
     pm_path_el *d_els = nullptr;
     uint32_t *d_u32 = nullptr;  // el_npts, el_move, el_ptoff(+1), el_mvoff(+1), path_item_base, path_pt_base, sub_first, totals(4), err
