@@ -24,10 +24,13 @@ N > 1 (one process per GPU, torch.distributed.run): STRONG scaling of the same 3
 frame -- rank r renders a band of tile rows (cost-balanced cuts from measured band times),
 and every step ends with the one collective of the design: the bands are gathered straight
 into the final image on rank 0 (one grouped send/recv over RCCL/xGMI).  value is then
-W*H / t_frame_e2e with t_frame_e2e = one step alone, host-timed around render + gather +
-device sync, MAX over ranks; t_render (slowest rank's band), t_gather and the sustained
-end-to-end rate are reported next to it.  A "config5" block carries the same measurements
-for BASELINE config 5 (8192^2 grid of 25 Tigers), where the frame is big enough to shard.
+W*H / t_frame with t_frame = one step alone (band render + gather) between two events on the
+frame's stream -- the GPU's clock, as at N = 1 --, MAX over ranks; the same step host-timed
+(t_frame_e2e), t_render (slowest rank's band), t_gather and the sustained end-to-end rate are
+reported next to it; config.rccl_lib / rccl_ranks name the RCCL the product's collective is
+bound to.  A "config5" block carries the same measurements for BASELINE config 5 (8192^2 grid
+of 25 Tigers), where the frame is big enough to shard; `--workload config5` makes it the main
+line (also with --gpus N).
 """
 from __future__ import annotations
 
@@ -255,6 +258,39 @@ class Job:
             ts.append((time.perf_counter() - t0) * 1e3)
         return self.max_over_ranks(statistics.median(ts))
 
+    def lone_frame_event_ms(self, n: int) -> float:
+        """One step alone on the GPU's own clock: two events on the frame's stream around band render +
+        gather (N > 1: both run on torch's current stream) -- the clock pm_frame_latency uses at N = 1, so
+        that `value` means the same at every N.  Median, MAX over ranks."""
+        e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(n):
+            self.fence()
+            e0.record(self.stream)
+            self.step()
+            e1.record(self.stream)
+            self.r.sync()
+            self.torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return self.max_over_ranks(statistics.median(ts))
+
+    def rccl_info(self) -> dict:
+        """Which RCCL the product's collective is bound to, and the size of its communicator.  At N = 1 a
+        one-rank communicator is made for the purpose (outside every timed region)."""
+        out = {"rccl_lib": None, "rccl_ranks": None}
+        try:
+            if self.comm is not None:
+                out.update(self.comm.info())
+            elif self.world == 1:
+                comm = self.pm.Comm(self.r, self.pm.Comm.unique_id(), 0, 1)
+                out.update(comm.info())
+                comm.close()
+            else:
+                out["rccl_lib"] = self.pm.Comm.library_path()
+        except Exception as e:  # noqa: BLE001 -- a report field, never a reason to lose the line
+            out["rccl_error"] = repr(e)[:200]
+        return out
+
     def gather_alone_ms(self, n: int) -> float:
         if self.world == 1:
             return 0.0
@@ -353,12 +389,13 @@ def main() -> int:
         lat = r.frame_latency(n_lat)
         t_render = job.max_over_ranks(lat["median_ms"])
         t_gather = job.gather_alone_ms(30)
-        t_frame = t_frame_host
+        t_frame = job.lone_frame_event_ms(min(n_lat, 100))
         tm = r.time_frames(max(10, min(args.steps, 500)), pipelined=True)
         alone = r.time_frames(20)
         n_overlapped = n_serial = 1
     st = r.stats()
     value = px / (t_frame * 1e-3) / 1e6
+    rccl = job.rccl_info()
 
     cfg5 = None
     if not args.no_config5:
@@ -430,14 +467,18 @@ def main() -> int:
             "t_frame_ms": round(t_frame, 5),
             "value_definition": ("W*H / t_frame; t_frame = one frame alone, first kernel begin to last kernel end: two HIP events on the frame's stream "
                                  f"around the plain launches pm_render makes (pm_frame_latency), median of {lat['iters']} (SURVEY.md 8d)") if world == 1 else
-                                ("W*H / t_frame_e2e; one step alone = band render + gather into the final image on rank 0 + device sync, host-timed, "
-                                 "median, MAX over ranks (includes launch and RCCL latency; compare with t_frame_host_ms at N=1)"),
+                                ("W*H / t_frame; t_frame = one step alone -- band render + gather into the final image on rank 0 -- between two events on "
+                                 "the frame's stream (the GPU clock of the N=1 figure), median, MAX over ranks; t_frame_host_ms / config.t_frame_e2e_ms is the "
+                                 "same step host-timed incl. launch latency and the device sync"),
             "sustained_mpix_s": round(sustained, 1), "ms_per_step": round(ms_per_step, 5),
             "sustained_definition": "W*H / (wall time of the K timed steps / K), steps submitted back to back, barrier + device sync on both sides, MAX over ranks"
                                     + ("" if world == 1 else "; every step ends with the gather to rank 0"),
             "t_frame_host_ms": round(t_frame_host, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 geometry + f16 accumulators (as the reference)", "data": "synthetic: embedded Ghostscript_Tiger.svg, scale 10.8, flattened on device",
+            "dtype": "f32 geometry + f16 accumulators (as the reference)", "data": {"config2": "synthetic: embedded Ghostscript_Tiger.svg, scale 5.4, fills only, flattened on device",
+                                                                                "config3": "synthetic: embedded Ghostscript_Tiger.svg, scale 10.8, flattened on device",
+                                                                                "config4": "synthetic: 10 000 random closed cubic paths (SplitMix64 seed 0x5EED0004), flattened on device",
+                                                                                "config5": "synthetic: 5x5 grid of the embedded Ghostscript_Tiger.svg at scale 8, flattened on device"}[args.workload],
             "config": {
                 "workload": workload_name,
                 "viewport": [W, H], "items": job.n_items, "scene_bytes": job.scene_bytes,
@@ -445,6 +486,7 @@ def main() -> int:
                                f"{ {'cabi': 'pm_gather (C ABI: grouped RCCL send/recv)', 'sendrecv': 'grouped send/recv (torch.distributed)', 'allgather': 'padded all-gather'}.get(job.gather_impl, job.gather_impl) } "
                                "of the bands into the final image on rank 0 in every step",
                 "gather_impl": None if world == 1 else job.gather_impl,
+                "rccl_lib": rccl.get("rccl_lib"), "rccl_ranks": rccl.get("rccl_ranks"), **({"rccl_error": rccl["rccl_error"]} if "rccl_error" in rccl else {}),
                 "band_cuts": job.cuts, "balance": job.balance_log or None,
                 "t_render_ms": round(t_render, 5), "t_gather_ms": round(t_gather, 5), "t_frame_e2e_ms": round(t_frame_host, 5),
                 "queued_tiles_rank0": st["queued_tiles"], "precondition_steps": precondition,
@@ -463,13 +505,16 @@ def main() -> int:
                 "kernels_alone_ms": {k: round(v, 5) for k, v in alone_ms.items()},
                 "kernels_inflight_ms": {k: round(v, 5) for k, v in kernels.items()},
                 "frac_inflight": round(b_alg / (dom_inflight_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "frac_serial_frame": round(b_alg / (sum(alone_ms.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "trace_average_ms": {k: round((n_overlapped * kernels[k] + n_serial * alone_ms.get(k, 0.0)) / (n_overlapped + (n_serial if k in alone_ms else 0)), 5) for k in kernels},
                 "trace_average_note": "what the AverageNs column of a kernel trace of THIS command shows: the mix of in-flight and serialized launches it makes",
                 "frame_latency_ms": round(t_render, 5),
                 "frac_frame": round(b_alg_frame / world / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "frame_pipelined_ms": round(pipelined_ms, 5),
                 "frac_frame_pipelined": round(b_alg / (pipelined_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "achieved/frac: algorithmic bytes of one launch / the dominant kernel's average launch duration with the kernels serialized on one "
+                "note": "frac credits the whole frame's bytes to ONE of the frame's kernels; frac_serial_frame = the same bytes / the SUM of the kernels' serialized "
+                        "durations (the frame's kernels back to back, no gaps) and frac_frame = / the lone frame: read those as the path's fraction of HBM peak. "
+                        "achieved/frac: algorithmic bytes of one launch / the dominant kernel's average launch duration with the kernels serialized on one "
                         "stream, events carried by the dispatches (what a rocprofv3 --kernel-trace of PM_FRAME_STREAMS=1 PM_SLOTS=1 shows: "
                         "profiles/*_serial_kernel_stats.csv); frac_inflight / kernels_inflight_ms: the same launches inside the overlapping batch of the "
                         "timed steps (four frames in flight: the durations stretch each other and exceed ms_per_step; what the default kernel trace "
@@ -483,6 +528,15 @@ def main() -> int:
             out["config5"] = cfg5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pm, pm.workloads.tiger(3840, 2160))
+        # (RCCL writes a version banner to C stdout when a communicator is made; through a pipe it would come out
+        #  at exit, BEHIND the line: everything buffered so far goes first, the JSON line is the last one printed)
+        sys.stdout.flush()
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
         print(json.dumps(out), flush=True)
     if args.dump:
         # the frame of one more step of the main workload (config 5 may have run in between)
@@ -516,7 +570,7 @@ def config5_block(pm, pmd, torch, dist, r, rank, world, local, args):
     t_render = job.max_over_ranks(lat["median_ms"])
     t_gather = job.gather_alone_ms(10)
     t_e2e = job.lone_frame_host_ms(20)
-    t_frame = t_render if world == 1 else t_e2e
+    t_frame = t_render if world == 1 else job.lone_frame_event_ms(20)  # (the GPU's clock at every N, like the main line)
     b_alg = world * job.scene_bytes + 4 * px
     return {
         "workload": "BASELINE config 5: 5x5 Tigers at scale 8, 8192x8192" + ("" if world == 1 else f", tile rows on {world} GPUs + gather to rank 0"),

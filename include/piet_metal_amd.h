@@ -280,7 +280,8 @@ int pm_get_stats(pm_ctx *c, pm_stats *out); /* synchronises */
  * One process and one pm_ctx per GPU, each rendering a band of tile rows (pm_set_band); the
  * bands meet once, here: a grouped ncclSend/ncclRecv over RCCL (xGMI inside a node) puts every
  * rank's band straight into its rows of the root's final image.  RCCL is bound
- * with dlopen at the first call (PM_RCCL_LIB overrides the library name). */
+ * with dlopen at the first call: the copy the process has mapped already if there is one (a host
+ * that also runs torch.distributed keeps ONE RCCL), else librccl.so.1; PM_RCCL_LIB overrides. */
 #define PM_COMM_ID_BYTES 128 /* = sizeof(ncclUniqueId) */
 typedef struct pm_comm pm_comm;
 /* Rank 0 makes the id; the host carries it to the other ranks (file, env, MPI, a torch store). */
@@ -288,10 +289,18 @@ int pm_comm_unique_id(uint8_t id[PM_COMM_ID_BYTES]);
 /* Collective over all `world` ranks (ncclCommInitRank on the context's device). */
 pm_comm *pm_comm_create(pm_ctx *c, const uint8_t id[PM_COMM_ID_BYTES], int rank, int world, int *err);
 void pm_comm_destroy(pm_comm *m);
+/* What got bound: the path of the shared object ncclCommInitRank came from (lib_path, NUL-terminated,
+ * truncated to lib_path_cap) and ncclCommCount of the communicator (*ranks; 0 when m is NULL).  Either
+ * output may be NULL.  Loads RCCL like the other calls; not a collective. */
+int pm_comm_info(pm_comm *m, char *lib_path, size_t lib_path_cap, int *ranks);
 /* Collective.  band_tile_rows = {row0, row1} per rank (2*world entries, what each rank passed to
  * pm_set_band).  src_band = this rank's band (NULL: the context's last frame), tightly packed
  * rows of width*4 bytes; dst_image (root only) = the full width*4 x height image.  Asynchronous
- * on hip_stream (NULL: the context's stream); ordered behind the last frame when src_band is NULL. */
+ * on hip_stream (NULL: the context's stream); ordered behind the last frame when src_band is NULL.
+ * Errors: an argument error (PM_ERR_INVALID for bad rows, strides or a root without dst_image) is
+ * returned before anything is posted -- if only SOME ranks fail that way the others wait for them, so
+ * tear the communicator down; a root whose own band cannot be placed (overlap, copy failure) still
+ * posts its receives, so that the peers' sends complete, and reports the error afterwards. */
 int pm_gather(pm_ctx *c, pm_comm *m, const void *src_band, size_t src_stride, const uint32_t *band_tile_rows, int root,
               void *dst_image, size_t dst_stride, void *hip_stream);
 

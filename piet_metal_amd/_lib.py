@@ -10,7 +10,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpiet_metal_amd.so")
+# PM_LIB_VARIANT=strict (tests / fuzzing only): the build whose LDS-only barriers are full __syncthreads()
+# (csrc/pm_kernels_common.h, LdsBarrier) -- the same C ABI, the same kernels otherwise
+_VARIANT = os.environ.get("PM_LIB_VARIANT", "")
+if _VARIANT not in ("", "strict"):
+    raise ImportError(f"PM_LIB_VARIANT={_VARIANT!r}: only 'strict' exists")
+LIB_PATH = os.path.join(_HERE, "lib", "libpiet_metal_amd" + ("_" + _VARIANT if _VARIANT else "") + ".so")
 
 PM_OK = 0
 PM_ERR_INVALID = -1
@@ -132,6 +137,7 @@ SIGNATURES = {
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pm_comm_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "pm_comm_destroy": (None, [C.c_void_p]),
+    "pm_comm_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "pm_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "pm_debug_capture_ptcl": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pm_debug_time_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

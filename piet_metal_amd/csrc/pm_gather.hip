@@ -36,6 +36,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -48,11 +49,29 @@ Rccl *LoadRccl() {
     static bool tried = false;
     if (tried) return r.handle ? &r : nullptr;
     tried = true;
-    const char *names[] = {std::getenv("PM_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
-        if (!n || !*n) continue;
-        r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (r.handle) break;
+    // ONE RCCL per process: a host that already carries one (PyTorch maps its own librccl.so, and its process
+    // group runs on it) must get THAT copy -- a second runtime next to it would bring its own proxy threads,
+    // IPC handles and topology state.  So: the file the process has mapped already (by its path in
+    // /proc/self/maps), then the usual names WITHOUT loading (RTLD_NOLOAD answers only for resident objects),
+    // and only then a fresh load.  PM_RCCL_LIB overrides all of it.
+    const char *forced = std::getenv("PM_RCCL_LIB");
+    if (forced && *forced) r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    if (!r.handle && !(forced && *forced)) {
+        if (FILE *maps = std::fopen("/proc/self/maps", "r")) {
+            char line[1024];
+            while (!r.handle && std::fgets(line, sizeof(line), maps)) {
+                char *path = std::strchr(line, '/');
+                if (!path || !std::strstr(path, "librccl")) continue;
+                path[std::strcspn(path, "\n")] = 0;
+                r.handle = dlopen(path, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            }
+            std::fclose(maps);
+        }
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names)
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        for (const char *n : names)
+            if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     }
     if (!r.handle) {
         pm::SetLastError("RCCL not found (dlopen librccl.so.1; set PM_RCCL_LIB)");
@@ -67,6 +86,7 @@ Rccl *LoadRccl() {
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
@@ -155,6 +175,26 @@ void pm_comm_destroy(pm_comm *m) {
     delete m;
 }
 
+int pm_comm_info(pm_comm *m, char *lib_path, size_t lib_path_cap, int *ranks) {
+    Rccl *r = LoadRccl();
+    if (!r) return PM_ERR_NO_DEVICE;
+    if (lib_path && lib_path_cap) {
+        // the shared object ncclCommInitRank was bound from: what a bench line or a bug report should name
+        Dl_info info;
+        const char *name = "";
+        if (dladdr(reinterpret_cast<void *>(r->CommInitRank), &info) && info.dli_fname) name = info.dli_fname;
+        std::snprintf(lib_path, lib_path_cap, "%s", name);
+    }
+    if (ranks) {
+        *ranks = 0;
+        if (m && m->comm) {
+            const ncclResult_t e = r->CommCount(m->comm, ranks);
+            if (e != ncclSuccess) return RcclFail(r, e, "ncclCommCount");
+        }
+    }
+    return PM_OK;
+}
+
 int pm_gather(pm_ctx *c, pm_comm *m, const void *src_band, size_t src_stride, const uint32_t *band_tile_rows, int root, void *dst_image,
               size_t dst_stride, void *hip_stream) {
     if (!c || !m || !band_tile_rows || root < 0 || root >= m->world) return PM_ERR_INVALID;
@@ -190,6 +230,11 @@ int pm_gather(pm_ctx *c, pm_comm *m, const void *src_band, size_t src_stride, co
     // one group: the root's receives all progress concurrently, one xGMI link per peer.  The root's OWN
     // band never goes through RCCL: a frame rendered straight into its rows of dst_image (pm_render_to)
     // is already where it belongs, any other source is one device copy on the same stream.
+    // (A root-side failure found from here on is reported AFTER the group: the peers have posted their sends
+    //  by now, and a root that returned early would leave them waiting on their streams for receives that
+    //  never come -- round-3 advisor finding.  The argument checks above are the same on every rank or
+    //  concern dst_image itself: after a PM_ERR_INVALID from them the communicator has to be torn down.)
+    int late = PM_OK;
     size_t off = 0;
     const size_t mine = band_bytes(m->rank, &off);
     if (m->rank == root && mine) {
@@ -198,9 +243,11 @@ int pm_gather(pm_ctx *c, pm_comm *m, const void *src_band, size_t src_stride, co
             const uint8_t *sb = static_cast<const uint8_t *>(src_band);
             if (sb < place + mine && place < sb + mine) {
                 pm::SetLastError("pm_gather: the root's band overlaps its rows of dst_image without being them");
-                return PM_ERR_INVALID;
+                late = PM_ERR_INVALID;
+            } else if (hipMemcpyAsync(place, src_band, mine, hipMemcpyDeviceToDevice, q) != hipSuccess) {
+                pm::SetLastError("pm_gather: copying the root's own band failed");
+                late = PM_ERR_HIP;
             }
-            if (hipMemcpyAsync(place, src_band, mine, hipMemcpyDeviceToDevice, q) != hipSuccess) return PM_ERR_HIP;
         }
     }
     ncclResult_t e = r->GroupStart();
@@ -216,7 +263,7 @@ int pm_gather(pm_ctx *c, pm_comm *m, const void *src_band, size_t src_stride, co
     const ncclResult_t eg = r->GroupEnd();
     if (e != ncclSuccess) return RcclFail(r, e, "ncclSend/ncclRecv");
     if (eg != ncclSuccess) return RcclFail(r, eg, "ncclGroupEnd");
-    return PM_OK;
+    return late;
 }
 
 }  // extern "C"

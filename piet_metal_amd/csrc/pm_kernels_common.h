@@ -140,10 +140,18 @@ __device__ __forceinline__ void WaveSync() { __builtin_amdgcn_fence(__ATOMIC_ACQ
 // the wave has in flight (s_waitcnt vmcnt(0): their acknowledgements take microseconds), which a
 // barrier between phases that hand each other LDS data does not need.  Global data written before it
 // must not be read by ANOTHER wave after it.
+// PM_STRICT_BARRIERS (libpiet_metal_amd_strict.so, tests only): every one of them is a full __syncthreads().
+// If a phase ever comes to read global data another wave wrote before such a barrier, the two builds render
+// different bytes (tests/test_gpu_parity.py::test_strict_barrier_build_renders_the_same_bytes) instead of one
+// pixel in ten thousand frames.
 __device__ __forceinline__ void LdsBarrier() {
+#ifdef PM_STRICT_BARRIERS
+    __syncthreads();
+#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
 }
 
 __device__ __forceinline__ float Sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }

@@ -232,6 +232,20 @@ class Comm:
             "pm_gather",
         )
 
+    @staticmethod
+    def library_path() -> str:
+        """The RCCL shared object the C ABI bound (loads it if it has not yet)."""
+        buf = C.create_string_buffer(1024)
+        _lib.check(_lib.load().pm_comm_info(None, buf, len(buf), None), "pm_comm_info")
+        return buf.value.decode()
+
+    def info(self) -> dict:
+        """{"rccl_lib": path of the bound library, "rccl_ranks": ncclCommCount of this communicator}"""
+        buf = C.create_string_buffer(1024)
+        n = C.c_int(0)
+        _lib.check(self._lib.pm_comm_info(self._h, buf, len(buf), C.byref(n)), "pm_comm_info")
+        return {"rccl_lib": buf.value.decode(), "rccl_ranks": int(n.value)}
+
     def close(self) -> None:
         if getattr(self, "_h", None):
             self._lib.pm_comm_destroy(self._h)

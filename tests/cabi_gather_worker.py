@@ -59,6 +59,10 @@ def main():
         uid = open(uid_path, "rb").read()
     comm = pm.Comm(r, uid, rank, world)
     root = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+    # what bench.py records in its line: the library that got bound and the communicator's size
+    info = comm.info()
+    assert info["rccl_ranks"] == world, info
+    assert os.path.samefile(info["rccl_lib"], os.environ["PM_RCCL_LIB"]) and pm.Comm.library_path() == info["rccl_lib"], info
     # 1. every rank's LAST FRAME (the context's own framebuffer) -> the root's image
     r.render()
     full = np.zeros((height, width, 4), np.uint8) if rank == root else None
@@ -85,6 +89,19 @@ def main():
     except pm.PietMetalError as e:
         refused = e.status == _lib.PM_ERR_INVALID
     assert refused
+    # 4. a root whose own band overlaps its rows of the image without being them: the error comes AFTER the
+    #    root has posted its receives -- the peers' sends complete (and the test below finds no message left)
+    if rows >= 2 or rank != root:
+        shifted = full2[r0 * 16 + 1 : r0 * 16 + 1 + rows] if rank == root else target
+        if rank == root and shifted.shape[0] < rows:  # (the last band: shift up instead)
+            shifted = full2[r0 * 16 - 1 : r0 * 16 - 1 + rows]
+        try:
+            comm.gather(layout, root=root, full=HostBuf(full2) if full2 is not None else None, band=HostBuf(np.ascontiguousarray(shifted) if rank != root else shifted))
+            late = rank != root
+        except pm.PietMetalError as e:
+            late = rank == root and e.status == _lib.PM_ERR_INVALID
+        assert late
+        r.sync()
     comm.close()
     r.close()
     print("rank", rank, "ok", flush=True)

@@ -52,6 +52,12 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int world, ncclUniqueId id, int 
     return 0;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
+    if (!comm || !count) return 4;
+    *count = ((const struct mock_comm *)comm)->world;
+    return 0;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     free(comm);
     return 0;

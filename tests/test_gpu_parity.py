@@ -429,6 +429,8 @@ def test_bench_two_rank_path_rehearsal_on_one_gpu(pm, pmo, tmp_path):
     cfg = js["config"]
     assert cfg["viewport"] == [3840, 2160] and cfg["band_cuts"][0] == 0 and cfg["band_cuts"][-1] == 135 and len(cfg["band_cuts"]) == 3
     assert cfg["t_render_ms"] > 0 and cfg["t_gather_ms"] > 0 and cfg["t_frame_e2e_ms"] > 0
+    assert "rccl_lib" in cfg and "rccl_ranks" in cfg and 0 < js["roofline"]["frac_serial_frame"] <= js["roofline"]["frac"]
+    assert 0 < js["t_frame_ms"] <= cfg["t_frame_e2e_ms"] * 1.5  # (event-timed step vs the same step host-timed)
     wl = pm.workloads.tiger(3840, 2160)
     scene, _ = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
     got = np.load(dump)
@@ -447,6 +449,11 @@ def test_c_abi_gather_single_rank(pm, pmo, renderer):
     renderer.set_scene_bytes(scene)
     comm = pm.Comm(renderer, pm.Comm.unique_id(), 0, 1)
     try:
+        # ONE RCCL per process: the copy torch mapped (its process group would run on it) is the one bound
+        info = comm.info()
+        assert info["rccl_ranks"] == 1 and "rccl" in os.path.basename(info["rccl_lib"]), info
+        mapped = {l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l}
+        assert len({os.path.realpath(m) for m in mapped}) == 1 and os.path.realpath(info["rccl_lib"]) in {os.path.realpath(m) for m in mapped}, (info, mapped)
         full = torch.zeros((600, 1000, 4), dtype=torch.uint8, device="cuda:0")
         renderer.render()
         comm.gather([(0, 38)], root=0, full=full)  # src = the context's last frame
@@ -1102,3 +1109,25 @@ def test_fuzz_regressions(pm, pmo, renderer, seed, n, extent, w, h):
     # (generated with the colour mask the fuzz tool had that day: mostly translucent items)
     scene = encode_ops(pm, random_ops(seed, n, extent=extent, opaque_mask=0xFF000000), cap=4 << 20)
     assert np.array_equal(gpu_render(renderer, scene, w, h), pmo.render(scene, w, h))
+
+
+def test_strict_barrier_build_renders_the_same_bytes(pm, golden):
+    """LdsBarrier() (csrc/pm_kernels_common.h) leaves out the wait for outstanding global stores: global data
+    written before it must not be read by another wave after it.  libpiet_metal_amd_strict.so is the same
+    library with every such barrier a full __syncthreads(): BASELINE configs 2-4 at full size must come out
+    byte for byte the same from both builds -- and equal to the committed goldens."""
+    import subprocess
+    import sys
+
+    outs = {}
+    for variant in ("", "strict"):
+        env = dict(os.environ, PM_LIB_VARIANT=variant)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "render_hashes.py"), "config2", "config3", "config4"],
+                           env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        lines = dict(l.split(" ", 1) for l in p.stdout.strip().splitlines())
+        assert lines.pop("lib") == ("libpiet_metal_amd_strict.so" if variant else "libpiet_metal_amd.so")
+        outs[variant] = lines
+    assert outs[""] == outs["strict"]
+    for cfg, name in (("config2", "tiger_1920x1080_fills"), ("config3", "tiger_3840x2160"), ("config4", "blobs_10000_4096")):
+        assert outs[""][cfg] == golden[name]["rgba_sha256"], cfg
