@@ -9,46 +9,47 @@ namespace pm {
 // K0: scene index, once per scene
 // =====================================================================================
 
-__global__ void pm_index_kernel(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, const uint32_t *chunk_base,
-                                uint32_t n_chunks, float4 *chunk_bbox) {
+__global__ __launch_bounds__(256) void pm_index_kernel(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, const uint32_t *chunk_base,
+                                                       uint32_t n_chunks, float4 *chunk_bbox, float4 *sup_bbox) {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= n_chunks) return;
-    const uint32_t item = FindOwner(chunk_base, n_items, ch);
-    const uint8_t *it = scene + items_ix + static_cast<size_t>(item) * kItemSize;
-    const uint32_t tag = LoadU32(it) & 0xffffu;
-    const uint32_t npt = LoadU32(it + 12);
-    const uint8_t *pts = scene + LoadU32(it + 16);
-    const uint32_t nseg = (tag == kItemFill) ? FillSegs(npt) : PolySegs(npt);
-    const uint32_t k0 = (ch - chunk_base[item]) * kChunkSegs;
-    const uint32_t k1 = min(k0 + kChunkSegs, nseg);
-    float xmin = 0.f, ymin = 0.f, xmax = 0.f, ymax = 0.f;
-    if (tag == kItemFill && (LoadU32(it + 4) & kFillCompound)) {
-        // compound fill: the box of the segments that exist (a chunk of separators only keeps an
-        // empty box no strip row can pass)
-        xmin = ymin = 3.0e38f;
-        xmax = ymax = -3.0e38f;
-        for (uint32_t k = k0; k < k1; ++k) {
-            float2 a, b;
-            if (!FillSegmentEnds(pts, npt, true, k, a, b)) continue;
-            xmin = fminf(xmin, fminf(a.x, b.x)); ymin = fminf(ymin, fminf(a.y, b.y));
-            xmax = fmaxf(xmax, fmaxf(a.x, b.x)); ymax = fmaxf(ymax, fmaxf(a.y, b.y));
+    // an empty box no strip row can pass (also what a chunk of nothing but separators keeps)
+    float xmin = 3.0e38f, ymin = 3.0e38f, xmax = -3.0e38f, ymax = -3.0e38f;
+    if (ch < n_chunks) {
+        const uint32_t item = FindOwner(chunk_base, n_items, ch);
+        const uint8_t *it = scene + items_ix + static_cast<size_t>(item) * kItemSize;
+        const uint32_t tag = LoadU32(it) & 0xffffu;
+        const uint32_t npt = LoadU32(it + 12);
+        const uint8_t *pts = scene + LoadU32(it + 16);
+        const uint32_t nseg = (tag == kItemFill) ? FillSegs(npt) : PolySegs(npt);
+        const uint32_t k0 = (ch - chunk_base[item]) * kChunkSegs;
+        const uint32_t k1 = min(k0 + kChunkSegs, nseg);
+        if (tag == kItemFill && (LoadU32(it + 4) & kFillCompound)) {
+            // compound fill: the box of the segments that exist
+            for (uint32_t k = k0; k < k1; ++k) {
+                float2 a, b;
+                if (!FillSegmentEnds(pts, npt, true, k, a, b)) continue;
+                xmin = fminf(xmin, fminf(a.x, b.x)); ymin = fminf(ymin, fminf(a.y, b.y));
+                xmax = fmaxf(xmax, fmaxf(a.x, b.x)); ymax = fmaxf(ymax, fmaxf(a.y, b.y));
+            }
+        } else {
+            // points k0 .. k1 (the fill's closing segment wraps to point 0)
+            for (uint32_t k = k0; k <= k1; ++k) {
+                const uint32_t pi = (tag == kItemFill && k == npt) ? 0u : k;
+                const float2 p = LoadF2(pts + static_cast<size_t>(pi) * 8);
+                xmin = fminf(xmin, p.x); ymin = fminf(ymin, p.y);
+                xmax = fmaxf(xmax, p.x); ymax = fmaxf(ymax, p.y);
+            }
         }
         chunk_bbox[ch] = make_float4(xmin, ymin, xmax, ymax);
-        return;
     }
-    // points k0 .. k1 (the fill's closing segment wraps to point 0)
-    for (uint32_t k = k0; k <= k1; ++k) {
-        const uint32_t pi = (tag == kItemFill && k == npt) ? 0u : k;
-        const float2 p = LoadF2(pts + static_cast<size_t>(pi) * 8);
-        if (k == k0) {
-            xmin = xmax = p.x;
-            ymin = ymax = p.y;
-        } else {
-            xmin = fminf(xmin, p.x); ymin = fminf(ymin, p.y);
-            xmax = fmaxf(xmax, p.x); ymax = fmaxf(ymax, p.y);
-        }
+    // the super-chunk's box: union over the kSuperChunks consecutive lanes that hold its chunks (of whatever items)
+    static_assert(kSuperChunks == 8, "three butterfly steps");
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        xmin = fminf(xmin, __shfl_xor(xmin, d)); ymin = fminf(ymin, __shfl_xor(ymin, d));
+        xmax = fmaxf(xmax, __shfl_xor(xmax, d)); ymax = fmaxf(ymax, __shfl_xor(ymax, d));
     }
-    chunk_bbox[ch] = make_float4(xmin, ymin, xmax, ymax);
+    if ((ch & (kSuperChunks - 1u)) == 0u && ch < n_chunks) sup_bbox[ch / kSuperChunks] = make_float4(xmin, ymin, xmax, ymax);
 }
 
 // =====================================================================================
@@ -108,6 +109,10 @@ constexpr uint32_t kCtStride = kStripTiles + 1;  // row stride 17: a thread per 
 #define PM_BIN_SURV_LDS 512
 #endif
 constexpr uint32_t kSurvLds = PM_BIN_SURV_LDS;
+constexpr uint32_t kSupCPL = 2;                         // super-chunks tested per lane and round
+constexpr uint32_t kSupLds = kBinThreads * kSupCPL;     // ... so a round leaves at most this many survivors
+constexpr uint32_t kChunkCPL = 4;                       // chunks tested per lane and round: half a super-chunk
+static_assert(kSuperChunks == 2 * kChunkCPL && kSupLds <= kThreads * kCtStride, "two lanes per surviving super; the list fits in s_ct");
 // 0.5 * width + 0.5 of a polyline / line candidate, from the width bits its aux0 word carries (the
 // expression the header phase used to store per candidate: one LDS array less)
 __device__ __forceinline__ float HalfWidthOf(uint32_t aux0) { return 0.5f * __uint_as_float(aux0) + 0.5f; }
@@ -119,9 +124,11 @@ struct BinLds {
     uint32_t s_cpts[kThreads];   // points_ix (or byte offset of start/end for lines)
     uint32_t s_cnpt[kThreads];
     uint32_t s_cchunk[kThreads]; // first chunk-table entry of the item
-    uint32_t s_choff[kThreads + 1];  // chunk-stream offsets
+    uint32_t s_soff[kThreads + 1];   // super-chunk stream offsets (a candidate's supers: those its chunk range touches)
     // per (candidate, tile): backdrop steps << 20 | relevant segments.  Row stride 17: a thread per
     // candidate walking its row, and 16 lanes adding to one row, are both free of bank conflicts.
+    // (while the chunks are tested its first kSupLds words hold the surviving super-chunks of a test round, c << 24 | index
+    //  in the candidate's range of supers: the counters are zeroed when the last round is through)
     uint32_t s_ct[kThreads * kCtStride];
     uint32_t s_surv[kSurvLds];  // surviving chunks of the record (c << 24 | j), while they fit
     uint32_t s_est[kStripTiles];  // per tile: stream elements the tile kernel will see
@@ -243,6 +250,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
     uint32_t cursor = __builtin_amdgcn_readfirstlane(srd.y);
     const uint32_t region_begin = cursor;
     const uint32_t region_end = __builtin_amdgcn_readfirstlane(srd.z);
+    uint32_t cursor_back = region_end;  // (the records' meta words grow down from here)
 
     // ---- the strip row's tail (one wave): queue the tiles with something to draw, mark the others ----
     // Lane t owns tile t of the strip row; the class masks are ballots, the command-list offsets a
@@ -455,8 +463,9 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
             L.s_cpts[tid] = pts;
             L.s_cnpt[tid] = npt;
             L.s_cchunk[tid] = cbase;
-#pragma unroll
-            for (uint32_t t = 0; t < kStripTiles; ++t) L.s_ct[tid * kCtStride + t] = 0;
+            // the super-chunks the item's chunks [cbase, cbase + nch) lie in (a line: one, never culled)
+            if (tag == kItemLine) nch = 1;
+            else if (nch) nch = (cbase + nch - 1u) / kSuperChunks - cbase / kSuperChunks + 1u;
         }
         {   // per tile: how many of the wave's candidates reach it with their bbox (an upper bound of the
             // candidates of the tile's piece); the per-share segment counters start at zero
@@ -471,85 +480,126 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                 L.s_wcnt[wave][lane] = 0;
             }
         }
-        uint32_t total_ch;
-        const uint32_t choff = BlockExclusiveScan<kBinWaves>(nch, L.s_part, &total_ch);
-        total_ch = __builtin_amdgcn_readfirstlane(total_ch);
-        if (tid < ncand) L.s_choff[tid] = choff;
-        if (tid == 0) L.s_choff[ncand] = total_ch;
+        uint32_t total_sup;
+        const uint32_t soff = BlockExclusiveScan<kBinWaves>(nch, L.s_part, &total_sup);
+        total_sup = __builtin_amdgcn_readfirstlane(total_sup);
+        if (tid < ncand) L.s_soff[tid] = soff;
+        if (tid == 0) L.s_soff[ncand] = total_sup;
 
-        // ---- the record: segment slots + meta words (uniform arithmetic, no allocation traffic) ----
-        const uint32_t rec = cursor;
-        const uint32_t size = kSlotDwords * kChunkSegs * total_ch;
-        if (rec + size > region_end) {  // cannot happen unless the host bound is wrong
+        // ---- the record: meta words from the front of the strip row's region (ascending with the slot: dword
+        //      accesses of neighbouring lanes coalesce), segment slots from its back (uniform arithmetic, no
+        //      allocation traffic; nothing depends on the record's size) ----
+        uint32_t *const meta = PM_PP(arena) + cursor;
+        float4 *const segs_top = reinterpret_cast<float4 *>(PM_PP(arena) + cursor_back) - 1;  // slot f's segment: segs_top[-f]
+#define PM_META(f) meta[f]
+#define PM_SEG(f) segs_top[-static_cast<ptrdiff_t>(f)]
+        LdsBarrier();  // L.s_soff, s_c* visible to every wave
+        if (kProfile && prof_first) stamp(2);  // headers + scan done
+
+        // ---- super-chunk stream -> surviving chunks --------------------------------------------------
+        // Two levels.  Rounds of kSupLds super-chunks (the supers the candidates' chunk ranges touch form one
+        // flat stream): those whose box cannot reach the strip row are dropped, the survivors are listed in
+        // stream order; then their chunks are tested the same way, half a super per lane, and the surviving
+        // chunks get consecutive indices (paint order).  Every surviving chunk OWNS kChunkSegs segment slots
+        // (slot = chunk_index * kChunkSegs + segment_in_chunk), so the expansion needs no compaction at all.
+        // The list of surviving chunks (c << 24 | j) lives in LDS; beyond kSurvLds of them it continues in the
+        // first meta word of the chunk's own slots (read before the vote overwrites it).
+        uint32_t sbase = 0;  // surviving chunks so far
+        // what survives: the necessary part of the segment pre-conditions for ANY segment inside the box
+        auto box_survives = [&](uint32_t ctag, float4 bb, uint32_t aux0) -> bool {
+            if (ctag == kItemLine) return true;  // never culled at strip level (PietRender.metal:223-247)
+            if (ctag == kItemFill)  // :264-265; a box wholly LEFT of the strip can only add to backdrops (:283-286),
+                                    // and only with a segment that reaches the row's top edge: ymin <= y0
+                return bb.w >= fy0 && bb.y < fy1 && bb.x < fsx1 && (bb.z > fsx0 || bb.y <= fy0);
+            const float hw = HalfWidthOf(aux0);  // :378-379
+            return bb.w > fsy0 - hw && bb.y < fsy1 + hw && bb.z > fsx0 - hw && bb.x < fsx1 + hw;
+        };
+        uint32_t *const s_sup = L.s_ct;  // (kSupLds words; the counters are zeroed below)
+        for (uint32_t r0 = 0; r0 < total_sup; r0 += kSupLds) {
+            if (kProfile && prof_first && r0 == 0) stamp(8);
+            uint32_t n_sup_surv;
+            {
+                const uint32_t eb = r0 + kSupCPL * tid;  // this lane's consecutive supers (stream order)
+                uint32_t svb = 0;
+                uint32_t pk[kSupCPL];
+                if (eb < total_sup) {
+                    uint32_t c = FindOwner(L.s_soff, ncand, eb);
+                    uint32_t cc[kSupCPL];
+                    float4 bb[kSupCPL];
+#pragma unroll
+                    for (uint32_t u = 0; u < kSupCPL; ++u) {
+                        const uint32_t e = eb + u;
+                        while (c + 1 < ncand && L.s_soff[c + 1] <= e) ++c;  // owners only move forward
+                        cc[u] = c;
+                        const uint32_t j = e - L.s_soff[c];
+                        pk[u] = (c << 24) | j;
+                        bb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (e < total_sup && (L.s_cmask[c] >> 16) != kItemLine) bb[u] = PM_PP(sup_bbox)[L.s_cchunk[c] / kSuperChunks + j];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < kSupCPL; ++u)
+                        if (eb + u < total_sup && box_survives(L.s_cmask[cc[u]] >> 16, bb[u], L.s_caux0[cc[u]])) svb |= 1u << u;
+                }
+                uint32_t srank = BlockExclusiveScan<kBinWaves>(static_cast<uint32_t>(__popc(svb)), L.s_part, &n_sup_surv);
+                n_sup_surv = __builtin_amdgcn_readfirstlane(n_sup_surv);
+#pragma unroll
+                for (uint32_t u = 0; u < kSupCPL; ++u)
+                    if ((svb >> u) & 1u) s_sup[srank++] = pk[u];
+            }
+            LdsBarrier();  // the round's surviving supers are listed
+            if (kProfile && prof_first && r0 == 0) stamp(9);
+            // their chunks: lane -> (surviving super, half of it)
+            for (uint32_t q0 = 0; q0 < n_sup_surv * 2u; q0 += kBinThreads) {
+                const uint32_t h = q0 + tid;
+                uint32_t svb = 0;
+                uint32_t pk[kChunkCPL];
+                if (h < n_sup_surv * 2u) {
+                    const uint32_t spk = s_sup[h >> 1];
+                    const uint32_t c = spk >> 24;
+                    const uint32_t ctag = L.s_cmask[c] >> 16;
+                    const uint32_t cbase = L.s_cchunk[c];
+                    const uint32_t nch = (SegsOf(ctag, L.s_cnpt[c]) + kChunkSegs - 1u) / kChunkSegs;  // (a line: its one)
+                    // global chunk-table entries of this half super; a line's one chunk is entry 0 of its one super
+                    const uint32_t g0 = ctag == kItemLine ? cbase : (cbase / kSuperChunks + (spk & 0xffffffu)) * kSuperChunks + (h & 1u) * kChunkCPL;
+                    float4 bb[kChunkCPL];
+                    bool in[kChunkCPL];
+#pragma unroll
+                    for (uint32_t u = 0; u < kChunkCPL; ++u) {
+                        const uint32_t jg = g0 + u;
+                        in[u] = jg >= cbase && jg - cbase < nch && (ctag != kItemLine || (h & 1u) == 0u);  // the item's own chunks
+                        pk[u] = (c << 24) | (jg - cbase);
+                        bb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (in[u] && ctag != kItemLine) bb[u] = PM_PP(chunk_bbox)[jg];
+                    }
+                    const uint32_t aux0 = L.s_caux0[c];
+#pragma unroll
+                    for (uint32_t u = 0; u < kChunkCPL; ++u)
+                        if (in[u] && box_survives(ctag, bb[u], aux0)) svb |= 1u << u;
+                }
+                uint32_t ns;
+                uint32_t srank = BlockExclusiveScan<kBinWaves>(static_cast<uint32_t>(__popc(svb)), L.s_part, &ns);
+                ns = __builtin_amdgcn_readfirstlane(ns);
+#pragma unroll
+                for (uint32_t u = 0; u < kChunkCPL; ++u)
+                    if ((svb >> u) & 1u) {
+                        const uint32_t ix = sbase + srank++;
+                        if (ix < kSurvLds) L.s_surv[ix] = pk[u];
+                        else if (cursor + kSlotDwords * kChunkSegs * (ix + 1u) <= cursor_back) PM_META(ix * kChunkSegs) = pk[u];  // (else: the overflow check below)
+                    }
+                sbase += ns;
+            }
+        }
+        // the per (candidate, tile) counters start at zero (their first words held the supers until now: every
+        // lane is past its last look at them -- the scans above end in a barrier)
+        if (tid < ncand) {
+#pragma unroll
+            for (uint32_t t = 0; t < kStripTiles; ++t) L.s_ct[tid * kCtStride + t] = 0;
+        }
+        const uint32_t n_slots = sbase * kChunkSegs;  // slots of the record in use
+        if (cursor + n_slots > cursor_back - 4u * n_slots || cursor_back - 4u * n_slots > cursor_back) {  // cannot happen unless the host bound is wrong
             if (tid == 0) PM_PP(ctr_cur)->overflow = 1;
             break;
         }
-        cursor += size;
-        float4 *segs = reinterpret_cast<float4 *>(PM_PP(arena) + rec);
-        uint32_t *meta = reinterpret_cast<uint32_t *>(segs + kChunkSegs * total_ch);
-        LdsBarrier();  // L.s_choff, s_c* visible to every wave
-        if (kProfile && prof_first) stamp(2);  // headers + scan done
-
-        // ---- chunk stream -> surviving chunks ------------------------------------------------------
-        // Block rounds of 1024 chunks: chunks whose box cannot reach the strip row are dropped and
-        // the survivors get consecutive indices (paint order).  Every surviving chunk OWNS
-        // kChunkSegs segment slots (slot = chunk_index * kChunkSegs + segment_in_chunk), so the
-        // expansion needs no compaction at all.  The list of survivors (c << 24 | j) lives in LDS;
-        // beyond kSurvLds surviving chunks it continues in the first meta word of the chunk's own
-        // slots (read before the vote overwrites it).
-        uint32_t sbase = 0;  // surviving chunks so far
-        constexpr uint32_t kCPL = 2;  // chunks tested per lane per round (1, 2, 3, 4: the same within 0.3 us at every configuration; 8: +5 us, 116 VGPRs)
-        for (uint32_t r0 = 0; r0 < total_ch; r0 += kBinThreads * kCPL) {
-            const uint32_t eb = r0 + kCPL * tid;  // this lane's consecutive chunks (stream order)
-            if (kProfile && prof_first && r0 == 0) stamp(8);
-            uint32_t svb = 0;
-            uint32_t pk[kCPL];
-            if (eb < total_ch) {
-                uint32_t c = FindOwner(L.s_choff, ncand, eb);
-                uint32_t cc[kCPL];
-                float4 bb[kCPL];
-#pragma unroll
-                for (uint32_t u = 0; u < kCPL; ++u) {
-                    const uint32_t e = eb + u;
-                    while (c + 1 < ncand && L.s_choff[c + 1] <= e) ++c;  // owners only move forward
-                    cc[u] = c;
-                    const uint32_t j = e - L.s_choff[c];
-                    pk[u] = (c << 24) | j;
-                    bb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (e < total_ch && (L.s_cmask[c] >> 16) != kItemLine) bb[u] = PM_PP(chunk_bbox)[L.s_cchunk[c] + j];
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < kCPL; ++u) {
-                    if (eb + u >= total_ch) continue;
-                    const uint32_t ctag = L.s_cmask[cc[u]] >> 16;
-                    bool sv;
-                    if (ctag == kItemLine) {
-                        sv = true;
-                    } else if (ctag == kItemFill) {  // necessary part of :264-265 for any segment of the chunk
-                        // (a chunk wholly LEFT of the strip can only add to backdrops, :283-286, and only with a segment
-                        //  that reaches the row's top edge: ymin <= y0)
-                        sv = bb[u].w >= fy0 && bb[u].y < fy1 && bb[u].x < fsx1 && (bb[u].z > fsx0 || bb[u].y <= fy0);
-                    } else {  // necessary part of :378-379
-                        const float hw = HalfWidthOf(L.s_caux0[cc[u]]);
-                        sv = bb[u].w > fsy0 - hw && bb[u].y < fsy1 + hw && bb[u].z > fsx0 - hw && bb[u].x < fsx1 + hw;
-                    }
-                    if (sv) svb |= 1u << u;
-                }
-            }
-            uint32_t ns;
-            uint32_t srank = BlockExclusiveScan<kBinWaves>(static_cast<uint32_t>(__popc(svb)), L.s_part, &ns);
-            ns = __builtin_amdgcn_readfirstlane(ns);
-            if (kProfile && prof_first && r0 == 0) stamp(9);
-#pragma unroll
-            for (uint32_t u = 0; u < kCPL; ++u)
-                if ((svb >> u) & 1u) {
-                    const uint32_t ix = sbase + srank++;
-                    if (ix < kSurvLds) L.s_surv[ix] = pk[u];
-                    else meta[ix * kChunkSegs] = pk[u];
-                }
-            sbase += ns;
-        }
-        const uint32_t n_slots = sbase * kChunkSegs;  // slots of the record in use
         // the heaviest strip rows set the span of the launch: their waves win the issue arbitration
         if (n_slots >= PM_PU(bin_prio_slots)) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(0);
@@ -563,7 +613,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         // ---- segment votes: a wave owns a CONTIGUOUS share of the slots (so that what it counts and
         //      later places follows slot = paint order); each lane votes one segment (phase 1), writes
         //      its slot's meta word (0 = no vote) and, if voted, the segment -------------------------------
-        const uint32_t q_share = ((n_slots + kBinWaves * 64u - 1u) / (kBinWaves * 64u)) * 64u;  // slots per wave, a multiple of 64
+        const uint32_t q_share = ((n_slots + kBinWaves * 64u - 1u) / (kBinWaves * 64u)) * 64u;  // slots per wave, a multiple of 64 (equal shares of whole chunks: measured no better)
         const uint32_t w_lo = min(n_slots, wave * q_share), w_hi = min(n_slots, w_lo + q_share);
         {
             // The loop is software-pipelined by hand: the NEXT round's segment end points are requested
@@ -579,7 +629,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                 a = b = make_float2(0.f, 0.f);
                 if (f < w_hi) {
                     const uint32_t six = f / kChunkSegs;
-                    const uint32_t spk = six < kSurvLds ? L.s_surv[six] : meta[six * kChunkSegs];
+                    const uint32_t spk = six < kSurvLds ? L.s_surv[six] : PM_META(six * kChunkSegs);
                     vc = spk >> 24;
                     k = (spk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
                     const uint32_t vtag = L.s_cmask[vc] >> 16;
@@ -694,35 +744,34 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                             M = 0xffffu;  // a line is tested by every tile its bbox hits (:223-247)
                         }
                         M &= hm;
-                        segs[f] = seg;
+                        PM_SEG(f) = seg;
                         mword = M | (vc << 16) | 0x80000000u;  // bit 31: a voted segment lives here
                     }
-                    meta[f] = mword;
+                    PM_META(f) = mword;
                 }
-                // relevant-segment counts per (candidate, tile).  The 8 lanes of a chunk share one
-                // candidate: spread the 16 tile bits to 16 nibbles (64 bits), add the 8 lanes with
-                // three DPP steps (8 <= 15 fits a nibble), and let lane j of the chunk add the counts
-                // of tiles 2j and 2j+1 -- ~40 instructions instead of 16 ballots per distinct candidate.
+                // relevant-segment counts per (candidate, tile).  The 4 lanes of a chunk (a quad) share one
+                // candidate: spread the 16 tile bits to 16 nibbles (64 bits), add the 4 lanes with two DPP
+                // steps (4 <= 15 fits a nibble), and let lane j of the quad add the counts of tiles 4j .. 4j+3
+                // -- instead of 16 ballots per distinct candidate.
                 const uint32_t mm = mword & 0xffffu;
                 {
-                    static_assert(kChunkSegs == 8, "one chunk = 8 lanes");
+                    static_assert(kChunkSegs == 4, "one chunk = one quad of lanes");
                     uint32_t lo8 = SpreadNibbles(mm & 0xffu), hi8 = SpreadNibbles(mm >> 8);
                     lo8 += DppQuadXor1(lo8); hi8 += DppQuadXor1(hi8);
                     lo8 += DppQuadXor2(lo8); hi8 += DppQuadXor2(hi8);
-                    lo8 += DppHalfMirror(lo8); hi8 += DppHalfMirror(hi8);
-                    const uint32_t j = lane & 7u;
-                    const uint32_t two = (((j < 4u) ? lo8 : hi8) >> (8u * (j & 3u))) & 0xffu;
-                    if (f < w_hi && two) {
+                    const uint32_t j = lane & 3u;
+                    const uint32_t four = (((j < 2u) ? lo8 : hi8) >> (16u * (j & 1u))) & 0xffffu;  // tiles 4j .. 4j+3, a nibble each
+                    if (f < w_hi && four) {
                         // (and per wave share and tile: what the scatter below starts from)
-                        uint32_t *row = &L.s_ct[vc * kCtStride + 2u * j];
-                        uint32_t *wrow = &L.s_wcnt[wave][2u * j];
-                        if (two & 15u) {
-                            atomicAdd(row, two & 15u);
-                            atomicAdd(wrow, two & 15u);
-                        }
-                        if (two >> 4) {
-                            atomicAdd(row + 1, two >> 4);
-                            atomicAdd(wrow + 1, two >> 4);
+                        uint32_t *row = &L.s_ct[vc * kCtStride + 4u * j];
+                        uint32_t *wrow = &L.s_wcnt[wave][4u * j];
+#pragma unroll
+                        for (uint32_t t = 0; t < 4u; ++t) {
+                            const uint32_t n = (four >> (4u * t)) & 15u;
+                            if (n) {
+                                atomicAdd(row + t, n);
+                                atomicAdd(wrow + t, n);
+                            }
                         }
                     }
                 }
@@ -730,7 +779,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         }
         LdsBarrier();  // every wave's L.s_ct contributions and L.s_wcnt are in
         stamp(3);  // segment stream done
-        if (kProfile) prof_chunks += total_ch;
+        if (kProfile) prof_chunks += total_sup;
 
         // ---- the tiles' pieces of this record: reserved NOW (tail wave), so that the atomic's round trip
         //      runs under the candidates pass.  Segments per tile are known (L.s_wcnt); candidates only by
@@ -895,8 +944,8 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
             uint32_t mw_n = 0;
             float4 seg_n = make_float4(0.f, 0.f, 0.f, 0.f);
             if (w_lo + lane < w_hi) {
-                mw_n = meta[w_lo + lane];  // (this wave wrote it)
-                seg_n = segs[w_lo + lane];
+                mw_n = PM_META(w_lo + lane);  // (this wave wrote it)
+                seg_n = PM_SEG(w_lo + lane);
             }
             // ---- candidate entries, the same way: lane = candidate, the wave's quarter of the tiles for every
             //      group of 64 candidates; a candidate's rank in a tile's piece is the hits of the earlier
@@ -937,6 +986,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                     }
                 }
             }
+            if (kProfile) stamp(13);  // candidate entries written
             // ---- scatter: every relevant (segment, tile) pair to its place in the tile's piece; lane
             //      t < 16 keeps the quad of the next segment of tile t written by this wave.  The next
             //      round's slots are fetched while this round's are placed ------------------------------------
@@ -953,8 +1003,8 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                     const uint32_t fn = f0 + 64u + lane;
                     mw_n = 0;
                     if (fn < w_hi) {
-                        mw_n = meta[fn];
-                        seg_n = segs[fn];
+                        mw_n = PM_META(fn);
+                        seg_n = PM_SEG(fn);
                     }
                     // the tiles present among the 64 slots, one round each
                     uint32_t present = 0;
@@ -981,6 +1031,8 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                 }
             }
         }
+        cursor += n_slots;   // (uniform: the next record's meta words and segs)
+        cursor_back -= 4u * n_slots;
         if (!more) {  // the strip row's last record: nothing left to wait for (its stores drain on their own)
             if (wave == kTailWave) RowTailFinish(tail_state);
             tail_done = true;
@@ -997,7 +1049,9 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         }
         ncand = nb;
     }
-    if (tid == 0) atomicAdd(&PM_PP(ctr_cur)->ptcl[shard].bin_dwords, cursor - region_begin);  // dwords used (stats only)
+    if (tid == 0) atomicAdd(&PM_PP(ctr_cur)->ptcl[shard].bin_dwords, (cursor - region_begin) + (region_end - cursor_back));  // dwords used (stats only)
+#undef PM_META
+#undef PM_SEG
     // the strip row's tail, unless its last record took care of it
     if (!tail_done) {  // uniform
         LdsBarrier();  // L.s_est, s_last_*, s_head_* of the last record are in
@@ -1019,10 +1073,10 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
 // ---- launch wrappers (called from pm_context.hip) -----------------------------------------
 
 void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, const uint32_t *chunk_base, uint32_t n_chunks,
-                 float4 *chunk_bbox, hipStream_t stream) {
+                 float4 *chunk_bbox, float4 *sup_bbox, hipStream_t stream) {
     if (n_chunks == 0) return;
     hipLaunchKernelGGL(pm_index_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, stream, scene, n_items, items_ix, chunk_base,
-                       n_chunks, chunk_bbox);
+                       n_chunks, chunk_bbox, sup_bbox);
 }
 
 void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {

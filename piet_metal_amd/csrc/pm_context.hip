@@ -204,7 +204,8 @@ struct pm_ctx {
     size_t row_base_cap = 0;
     uint32_t *d_chunk_base = nullptr;  // scene index: first chunk of every item (+ total)
     float4 *d_chunk_bbox = nullptr;    // scene index: bounding box of every chunk of segments
-    size_t chunk_base_cap = 0, chunk_bbox_cap = 0;
+    float4 *d_sup_bbox = nullptr;      // ... and of every super-chunk (kSuperChunks consecutive chunk-table entries)
+    size_t chunk_base_cap = 0, chunk_bbox_cap = 0, sup_bbox_cap = 0;
     uint32_t n_chunks = 0;
 
     // viewport
@@ -215,7 +216,7 @@ struct pm_ctx {
 
     // binning state shared by the slots
     size_t sr_desc_cap = 0, band_cap = 0;
-    uint4 *d_sr_desc = nullptr;     // strip rows some item reaches: {strip row, arena region begin, end, 0}
+    uint4 *d_sr_desc = nullptr;     // strip rows some item reaches: {strip row, arena region begin, end, next of the chain}
     uint32_t n_sr_active = 0;
     uint32_t bin_grid = 1;          // workgroups of pm_bin_kernel (each walks a chain of strip rows)
     uint32_t bin_prio_slots = 1024; // PM_BIN_PRIO_SLOTS
@@ -435,81 +436,13 @@ int EnsureArena(pm_ctx *c) {
     // (host work first: the scene-index kernel of a scene replacement is still running on the device)
     std::vector<uint64_t> need;
     StripRowBounds(c, &need);
-    std::vector<uint32_t> base(need.size() + 1);
-    uint64_t total = pm::kArenaBase;  // offset 0 means "no record"
-    for (size_t i = 0; i < need.size(); ++i) {
-        base[i] = static_cast<uint32_t>(total);
-        total += (need[i] + 3u) & ~3ull;
-        if (total > 0xfffffff0ull) {
-            SetError("scene x viewport needs a binning arena beyond 16 GiB");
-            return PM_ERR_CAPACITY;
-        }
-    }
-    base[need.size()] = static_cast<uint32_t>(total);
-    // what StripRowBounds gives a strip row before any item adds to it
-    // (exact for a context's first scene; a quarter of headroom when it has to GROW: an animation's
-    //  demand creeps from frame to frame, and re-allocating four 100 MB arenas costs milliseconds)
-    const uint64_t alloc_dwords = total <= c->arena_cap ? c->arena_cap : (c->arena_cap == 0 ? total : std::min<uint64_t>(0xfffffff0ull, total + total / 4));
+    // (host work before any upload: the band's item list, the arena regions)
     c->sr_empty_dwords = 0;  // (a strip row no item's bbox reaches has nothing reserved)
-    // (the slots' arenas themselves are allocated when a slot is first used, EnsureSlotBuffers: the
-    //  first frame of a scene pays for one arena, not for four -- hundreds of MB each at 8K)
-    {
-        // Tile arena (per-tile pieces + command lists, 16-byte quads): sized from what binning
-        // actually finds, so there is no static bound; start generously (HBM is 288 GB), in proportion
-        // to EVERY scene that comes (a max: what pm_sync grew it to is kept), and let pm_sync grow it on
-        // overflow.
-        uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
-        if (const char *v = std::getenv("PM_PTCL_INITIAL_CMDS"))  // tests: force the overflow -> grow -> re-render path
-            cmds = std::max<uint64_t>(64, std::strtoull(v, nullptr, 10));
-        c->ptcl_want = std::max<uint64_t>(c->ptcl_want, std::min<uint64_t>(cmds * pm::kCmdQuadsNum / pm::kCmdQuadsDen, 0x7fffffffull));
-    }
-    c->arena_cap = std::max<uint32_t>(c->arena_cap, static_cast<uint32_t>(alloc_dwords));
-    // The strip rows some item's bbox reaches get a workgroup of pm_bin_kernel each; the others are
-    // background for as long as this scene and viewport last: their tile_state is set to white
-    // once, here.  (An empty list still launches one workgroup: it resets the frame counters.)
-    std::vector<uint4> &desc = c->stage_desc;  // (sources of asynchronous uploads live in the context)
-    desc.clear();
-    for (size_t i = 0; i < need.size(); ++i)
-        if (((need[i] + 3u) & ~3ull) != c->sr_empty_dwords) desc.push_back(make_uint4(static_cast<uint32_t>(i), base[i], base[i + 1], 0u));
-    // (strip rows stay in their natural order: heaviest-first was measured 2.5 us slower -- the heavy
-    //  ones then share CUs -- and so was a snake order over CU periods; neighbouring strip rows share
-    //  data and belong together)
-    if (desc.empty()) desc.push_back(make_uint4(0u, base[0], need.empty() ? base[0] : base[1], 0u));
-    c->n_sr_active = static_cast<uint32_t>(desc.size());
-    {
-        // pm_bin_kernel's grid is no larger than what the chip holds at once: five workgroups per CU (its LDS
-        // is sized for that).  A workgroup walks a chain of strip rows (desc.w = index of the next one, 0 =
-        // none): row b, b + grid, b + 2 grid ... in natural order -- a grid larger than the residency would
-        // start its last workgroups when the first END their chains.  (While the tile arena had ONE allocation
-        // counter, fewer resident workgroups were faster -- three per CU for the Tiger, four for config 4 --:
-        // less contention on that cache line, not a property of the kernel; pm_device.h, Counters.  Measured
-        // and not kept: any permutation of ALL rows, +25 % -- neighbouring strip rows share data; pairing
-        // the lightest rows by their arena need, +9 % -- the need is the worst case of the chunk test, not
-        // the work.)
-        uint32_t per_cu = c->bin_wg_per_cu;
-        if (per_cu == 0xffu) per_cu = 5u;
-        const size_t n = desc.size();
-        const size_t grid = per_cu == 0 ? n : std::min<size_t>(n, static_cast<size_t>(c->n_cus) * per_cu);
-        if (n > grid) {
-            for (size_t i = 0; i + grid < n; ++i) desc[i].w = static_cast<uint32_t>(i + grid);
-        }
-        c->bin_grid = static_cast<uint32_t>(grid);
-    }
-    PM_TRY(SyncAll(c) == PM_OK ? hipSuccess : hipErrorUnknown);  // frames in flight still read the lists replaced below
-    if (desc.size() > c->sr_desc_cap) {  // (grow only: an animation re-sizes every frame)
-        if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
-        c->d_sr_desc = nullptr;
-        c->sr_desc_cap = 0;
-        PM_TRY(hipMalloc(&c->d_sr_desc, (desc.size() + desc.size() / 4 + 16) * sizeof(uint4)));
-        c->sr_desc_cap = desc.size() + desc.size() / 4 + 16;
-    }
-    PM_TRY(hipMemcpyAsync(c->d_sr_desc, desc.data(), desc.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
-    c->arena_epoch += 1;  // (a slot's tile_state is reset to "background" on the frame's own stream when the slot is next used)
-    // the items whose bbox reaches the band (rows: bw >= y0 && by < y1, PietRender.metal:198/:214)
+    // the items whose bbox reaches the band (rows: bw >= y0 && by < y1, PietRender.metal:198/:214), paint order
+    std::vector<uint2> &bbs = c->stage_bbs;
+    std::vector<uint32_t> &ids = c->stage_ids;
     {
         const uint8_t *meta = c->item_meta.data();
-        std::vector<uint2> &bbs = c->stage_bbs;
-        std::vector<uint32_t> &ids = c->stage_ids;
         bbs.clear();
         ids.clear();
         const uint32_t y0 = c->row0 * pm::kTileH, y1 = c->row1 * pm::kTileH;
@@ -523,6 +456,78 @@ int EnsureArena(pm_ctx *c) {
             }
         }
         c->n_band_items = static_cast<uint32_t>(ids.size());
+        const int min_items = EnvInt("PM_ROW_LIST_MIN_ITEMS", 2048, 0, 1 << 30);
+        c->use_row_lists = static_cast<int>(ids.size()) >= min_items && !ids.empty();
+    }
+    // The strip rows some item's bbox reaches get a workgroup of pm_bin_kernel each; the others are
+    // background for as long as this scene and viewport last: their tile_state is set to white
+    // once, here.  (An empty list still launches one workgroup: it resets the frame counters.)
+    std::vector<uint4> &desc = c->stage_desc;  // (sources of asynchronous uploads live in the context)
+    desc.clear();
+    uint64_t total = pm::kArenaBase;  // offset 0 means "no record"
+    for (size_t i = 0; i < need.size(); ++i) {
+        const uint64_t sz = (need[i] + 3u) & ~3ull;
+        if (sz == c->sr_empty_dwords) continue;
+        const uint64_t begin = total;
+        total += sz;
+        if (total > 0xfffffff0ull) {
+            SetError("scene x viewport needs a binning arena beyond 16 GiB");
+            return PM_ERR_CAPACITY;
+        }
+        desc.push_back(make_uint4(static_cast<uint32_t>(i), static_cast<uint32_t>(begin), static_cast<uint32_t>(total), 0u));
+    }
+    if (desc.empty()) desc.push_back(make_uint4(0u, pm::kArenaBase, pm::kArenaBase, 0u));
+    uint32_t per_cu = c->bin_wg_per_cu;
+    if (per_cu == 0xffu) per_cu = 5u;
+    // (exact for a context's first scene; a quarter of headroom when it has to GROW: an animation's
+    //  demand creeps from frame to frame, and re-allocating four 100 MB arenas costs milliseconds)
+    const uint64_t alloc_dwords = total <= c->arena_cap ? c->arena_cap : (c->arena_cap == 0 ? total : std::min<uint64_t>(0xfffffff0ull, total + total / 4));
+    // (the slots' arenas themselves are allocated when a slot is first used, EnsureSlotBuffers: the
+    //  first frame of a scene pays for one arena, not for four -- hundreds of MB each at 8K)
+    {
+        // Tile arena (per-tile pieces + command lists, 16-byte quads): sized from what binning
+        // actually finds, so there is no static bound; start generously (HBM is 288 GB), in proportion
+        // to EVERY scene that comes (a max: what pm_sync grew it to is kept), and let pm_sync grow it on
+        // overflow.
+        uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
+        if (const char *v = std::getenv("PM_PTCL_INITIAL_CMDS"))  // tests: force the overflow -> grow -> re-render path
+            cmds = std::max<uint64_t>(64, std::strtoull(v, nullptr, 10));
+        c->ptcl_want = std::max<uint64_t>(c->ptcl_want, std::min<uint64_t>(cmds * pm::kCmdQuadsNum / pm::kCmdQuadsDen, 0x7fffffffull));
+    }
+    c->arena_cap = std::max<uint32_t>(c->arena_cap, static_cast<uint32_t>(alloc_dwords));
+    // (strip rows stay in their natural order: heaviest-first was measured 2.5 us slower -- the heavy
+    //  ones then share CUs -- and so was a snake order over CU periods; neighbouring strip rows share
+    //  data and belong together)
+    c->n_sr_active = static_cast<uint32_t>(desc.size());
+    {
+        // pm_bin_kernel's grid is no larger than what the chip holds at once: five workgroups per CU (its LDS
+        // is sized for that).  A workgroup walks a chain of strip rows (desc.w = index of the next one, 0 =
+        // none): row b, b + grid, b + 2 grid ... in natural order -- a grid larger than the residency would
+        // start its last workgroups when the first END their chains.  (While the tile arena had ONE allocation
+        // counter, fewer resident workgroups were faster -- three per CU for the Tiger, four for config 4 --:
+        // less contention on that cache line, not a property of the kernel; pm_device.h, Counters.  Measured
+        // and not kept: any permutation of ALL rows, +25 % -- neighbouring strip rows share data; pairing
+        // the lightest rows by their arena need, +9 % -- the need is the worst case of the chunk test, not
+        // the work.)
+        const size_t n = desc.size();
+        const size_t grid = per_cu == 0 ? n : std::min<size_t>(n, static_cast<size_t>(c->n_cus) * per_cu);
+        if (n > grid) {
+            for (size_t i = 0; i + grid < n; ++i) desc[i].w = static_cast<uint32_t>(i + grid);
+        }
+        c->bin_grid = static_cast<uint32_t>(grid);
+    }
+    PM_TRY(SyncAll(c) == PM_OK ? hipSuccess : hipErrorUnknown);  // frames in flight still read the lists replaced below
+    if (desc.size() > c->sr_desc_cap) {  // (grow only: an animation re-sizes every frame)
+        if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
+        c->d_sr_desc = nullptr;
+        c->sr_desc_cap = 0;
+        const size_t want = desc.size() + desc.size() / 4 + 16;
+        PM_TRY(hipMalloc(&c->d_sr_desc, want * sizeof(uint4)));
+        c->sr_desc_cap = want;
+    }
+    PM_TRY(hipMemcpyAsync(c->d_sr_desc, desc.data(), desc.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    c->arena_epoch += 1;  // (a slot's tile_state is reset to "background" on the frame's own stream when the slot is next used)
+    {
         if (ids.size() > c->band_cap || !c->d_band_bbox) {
             if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
             if (c->d_band_item) (void)hipFree(c->d_band_item);
@@ -540,8 +545,6 @@ int EnsureArena(pm_ctx *c) {
         }
         // Large scenes: every tile row gets its own item list each frame (pm_rowcull_kernel); the
         // host only sizes the lists, with the kernel's predicate.
-        const int min_items = EnvInt("PM_ROW_LIST_MIN_ITEMS", 2048, 0, 1 << 30);
-        c->use_row_lists = static_cast<int>(ids.size()) >= min_items && !ids.empty();
         if (c->use_row_lists) {
             const uint32_t rows = BandRows(c);
             std::vector<uint32_t> &rb = c->stage_rb;
@@ -656,6 +659,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->row_item = s->d_row_item;
     p->chunk_base = c->d_chunk_base;
     p->chunk_bbox = c->d_chunk_bbox;
+    p->sup_bbox = c->d_sup_bbox;
     p->lut_srgb2lin = c->d_lut_srgb2lin;
     p->lut_unorm2h = c->d_lut_unorm2h;
     p->lut_lin2srgb = c->d_lut_lin2srgb;
@@ -796,8 +800,8 @@ int BuildSceneIndex(pm_ctx *c) {
         total += (nseg + pm::kChunkSegs - 1) / pm::kChunkSegs;
     }
     base[n] = static_cast<uint32_t>(total);
-    if (total > 0xffffffu * 16ull) {
-        SetError("scene has too many segments for the chunk index");
+    if (total > 0xffffffull) {  // (a chunk's index inside its item travels in 24 bits, pm_bin_kernel's survivor lists)
+        SetError("scene has too many segments for the chunk index (2^24 chunks of 4 segments)");
         return PM_ERR_CAPACITY;
     }
     if (base.size() > c->chunk_base_cap) {
@@ -812,9 +816,16 @@ int BuildSceneIndex(pm_ctx *c) {
         PM_TRY(hipMalloc(&c->d_chunk_bbox, std::max<uint64_t>(total, 1) * sizeof(float4)));
         c->chunk_bbox_cap = std::max<uint64_t>(total, 1);
     }
+    const uint64_t n_sup = (total + pm::kSuperChunks - 1) / pm::kSuperChunks;
+    if (n_sup > c->sup_bbox_cap || !c->d_sup_bbox) {
+        if (c->d_sup_bbox) (void)hipFree(c->d_sup_bbox);
+        c->d_sup_bbox = nullptr;
+        PM_TRY(hipMalloc(&c->d_sup_bbox, std::max<uint64_t>(n_sup, 1) * sizeof(float4)));
+        c->sup_bbox_cap = std::max<uint64_t>(n_sup, 1);
+    }
     c->n_chunks = static_cast<uint32_t>(total);
     PM_TRY(hipMemcpyAsync(c->d_chunk_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    pm::LaunchIndex(c->d_scene, n, c->dev_items_ix, c->d_chunk_base, c->n_chunks, c->d_chunk_bbox, c->stream);
+    pm::LaunchIndex(c->d_scene, n, c->dev_items_ix, c->d_chunk_base, c->n_chunks, c->d_chunk_bbox, c->d_sup_bbox, c->stream);
     PM_TRY(hipGetLastError());
     // (no wait: frames run on streams that are ordered behind c->stream where it matters -- Enqueue below --
     //  and the next scene replacement starts with SyncAll before `base` is touched again)
@@ -1135,8 +1146,10 @@ pm_ctx *pm_create(int device, int *err) {
         e = c->flatten_cache.Reserve(4096, 65536);
         if (e == hipSuccess) e = hipMalloc(&c->d_chunk_base, (65536 + 1) * sizeof(uint32_t));
         if (e == hipSuccess) c->chunk_base_cap = 65536 + 1;
-        if (e == hipSuccess) e = hipMalloc(&c->d_chunk_bbox, (1u << 18) * sizeof(float4));
-        if (e == hipSuccess) c->chunk_bbox_cap = 1u << 18;
+        if (e == hipSuccess) e = hipMalloc(&c->d_chunk_bbox, (1u << 19) * sizeof(float4));
+        if (e == hipSuccess) c->chunk_bbox_cap = 1u << 19;
+        if (e == hipSuccess) e = hipMalloc(&c->d_sup_bbox, (1u << 16) * sizeof(float4));
+        if (e == hipSuccess) c->sup_bbox_cap = 1u << 16;
         if (e == hipSuccess) e = hipMalloc(&c->d_sr_desc, 65536 * sizeof(uint4));
         if (e == hipSuccess) c->sr_desc_cap = 65536;
         if (e == hipSuccess) e = hipMalloc(&c->d_band_bbox, 65536 * sizeof(uint2));
@@ -1221,6 +1234,7 @@ void pm_destroy(pm_ctx *c) {
     if (c->h_scene) (void)hipHostFree(c->h_scene);
     if (c->d_chunk_base) (void)hipFree(c->d_chunk_base);
     if (c->d_chunk_bbox) (void)hipFree(c->d_chunk_bbox);
+    if (c->d_sup_bbox) (void)hipFree(c->d_sup_bbox);
     if (c->d_lut_srgb2lin) (void)hipFree(c->d_lut_srgb2lin);
     if (c->d_lut_unorm2h) (void)hipFree(c->d_lut_unorm2h);
     if (c->d_lut_lin2srgb) (void)hipFree(c->d_lut_lin2srgb);

@@ -32,6 +32,9 @@ print("finalise       :", ph(3, 4, m))
 if t.shape[1] >= 16 and (t[:, 12] > 0).any():
     print("   candidates pass (backdrops, hit bits, ballots) :", ph(3, 12, m))
     print("   entries + scatter (wave 0)                     :", ph(12, 4, m))
+    if (t[:, 13] > 0).any():
+        m13 = m & (t[:, 13] > 0)
+        print("      entries :", ph(12, 13, m13), "| scatter :", ph(13, 4, m13))
 print("wave 0 exit     :", ph(4, 7, m))
 if t.shape[1] >= 16 and (t[:, 14] > 0).any():
     print("tail wave ends after wave 0's scatter by:", ph(4, 14, m))
