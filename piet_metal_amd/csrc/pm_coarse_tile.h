@@ -9,20 +9,19 @@ namespace {
 
 constexpr uint32_t kWaveCands = 64;  // candidates handled per pass
 
+// (3 076 bytes: it shares its bytes with the renderer's fragment tables, not with the staged commands -- the first
+//  chunk of a tile's list is built INTO the LDS the renderer reads it from, pm_fine.hip, WaveLds.  What only the
+//  closing command of an item needs -- colour words, bbox word, backdrop -- stays in the registers of the lane that
+//  loaded the candidate and travels by ds_bpermute.)
 struct CoarseLds {
     float4 segw[64];          // the first 64 segments of a piece, fetched together with its candidates
     uint32_t htag[kWaveCands];
-    uint32_t hrgba[kWaveCands];
     uint32_t haux0[kWaveCands];
-    uint32_t haux1[kWaveCands];
     uint32_t hrel[kWaveCands];   // relevant segments of the candidate in this tile
     uint32_t hwoff[kWaveCands];  // index of its first relevant segment in the piece
     uint32_t hcnt[kWaveCands];   // stream elements (relevant segments, or 1 pseudo element)
-    uint32_t hrg[kWaveCands];
-    uint32_t hba[kWaveCands];
     uint32_t hoff[kWaveCands + 1];
     uint32_t own[64];            // stream position of a round -> candidate that starts there
-    int backdrop[kWaveCands];
     uint32_t any[kWaveCands];
 };
 
@@ -42,19 +41,25 @@ struct CoarseTicks {
 #define PM_CT_TICK(v) \
     if (kProf) v = wall_clock64()
 
-// lds_chunks != nullptr (a tile the whole workgroup will render): the first kLdsChunks * 64 commands
-// of the list are ALSO left in LDS, 64 per chunk, chunk k at lds_chunks + k * lds_stride bytes -- the
-// staged-command areas of the workgroup's other waves, idle while this wave builds the list.  The
-// renderer then starts from LDS instead of reading the list back chunk by chunk.
+// lds_chunks != nullptr (the fused tile kernel): the first lds_n * 64 commands of the list are left in LDS ONLY,
+// 64 per chunk, chunk k at lds_chunks + k * lds_stride bytes -- the wave's own staged-command area (one chunk), or,
+// for a tile the whole workgroup will render, the areas of the workgroup's other waves, idle while this wave
+// builds the list (kLdsChunks of them).  The renderer starts from LDS; only what lies beyond goes to the tile's
+// list in HBM and is read back chunk by chunk (round 3 wrote every command there and read the single-wave
+// tiles' lists straight back: 113 MB each way at config 4).
 constexpr uint32_t kLdsChunks = 3;
 
 template <bool kCapture, bool kProf = false>
 __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &L, const uint4 qe,
                                                const uint32_t lane, const uint64_t lanes_below, CoarseTicks *ticks = nullptr,
-                                               uint8_t *const lds_chunks = nullptr, const uint32_t lds_stride = 0) {
-    auto lds_put = [&](uint32_t q, const Cmd &c) {
-        if (lds_chunks != nullptr && q < kLdsChunks * 64u)
+                                               uint8_t *const lds_chunks = nullptr, const uint32_t lds_stride = 0, const uint32_t lds_n = 0) {
+    const uint32_t lds_cmds = lds_chunks != nullptr ? lds_n * 64u : 0u;  // list positions below this live in LDS
+    Cmd *out_cmds = nullptr;  // (set below)
+    auto put = [&](uint32_t q, const Cmd &c) {
+        if (q < lds_cmds)
             *reinterpret_cast<Cmd *>(lds_chunks + (q >> 6) * lds_stride + (q & 63u) * static_cast<uint32_t>(sizeof(Cmd))) = c;
+        else
+            out_cmds[q] = c;
     };
     unsigned long long tk0 = 0, tk1 = 0;
     const uint32_t tile = qe.x;
@@ -62,7 +67,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
         if (lane == 0) P.tile_ncmd[tile] = 0;
         return 0;
     }
-    Cmd *const out_cmds = reinterpret_cast<Cmd *>(P.tarena + qe.y);  // this tile's private command slots
+    out_cmds = reinterpret_cast<Cmd *>(P.tarena + qe.y);  // this tile's private command slots
     const uint32_t tx = tile % P.tiles_x;
     const uint32_t ty_rel = tile / P.tiles_x;
     const uint32_t ty = P.row0 + ty_rel;
@@ -96,20 +101,24 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
         for (uint32_t cb = 0; cb < nhit; cb += kWaveCands) {
             if (cb != 0) PM_CT_TICK(tk0);
             const uint32_t nh = min(kWaveCands, nhit - cb);
+            // this lane's candidate: what only an item's closing command needs stays here (fetched by the owner's
+            // last element with ds_bpermute, below)
+            uint32_t my_rgba = 0, my_aux1 = 0, my_rg = 0, my_ba = 0;
+            int my_backdrop = 0;
             if (lane < nh) {
                 const uint4 *cr = cands + 2u * (cb + lane);
                 const uint4 a = cr[0];
                 const uint4 b = cr[1];
                 L.htag[lane] = a.x & 0xffffu;
-                L.hrgba[lane] = a.y;
+                my_rgba = a.y;
                 L.haux0[lane] = a.z;
-                L.haux1[lane] = a.w;
+                my_aux1 = a.w;
                 const uint32_t rel = b.x & kCtCountMask;
                 L.hrel[lane] = rel;
                 L.hcnt[lane] = rel ? rel : 1u;  // circle / backdrop-only fill: one pseudo element
-                L.hrg[lane] = b.z;
-                L.hba[lane] = b.w;
-                L.backdrop[lane] = static_cast<int>(b.x) >> kCtShift;
+                my_rg = b.z;
+                my_ba = b.w;
+                my_backdrop = static_cast<int>(b.x) >> kCtShift;
                 L.any[lane] = 0;
             }
             if (cb == 0) L.segw[lane] = seg_first;
@@ -157,17 +166,24 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                 bool is_last = false;
                 bool draws = false;  // any of this lane's commands clears solidColor
                 uint32_t c = 0, ctag = 0;
+                if (e < stream_len) c = owner;
+                // the owner's colour / bbox words and backdrop, from the lane that loaded the candidate (every lane
+                // takes part: a lane that is switched off hands nothing over)
+                const uint32_t frgba = static_cast<uint32_t>(__shfl(static_cast<int>(my_rgba), static_cast<int>(c)));
+                const uint32_t faux1 = static_cast<uint32_t>(__shfl(static_cast<int>(my_aux1), static_cast<int>(c)));
+                const uint32_t frg = static_cast<uint32_t>(__shfl(static_cast<int>(my_rg), static_cast<int>(c)));
+                const uint32_t fba = static_cast<uint32_t>(__shfl(static_cast<int>(my_ba), static_cast<int>(c)));
+                const int fbackdrop = __shfl(my_backdrop, static_cast<int>(c));
                 if (e < stream_len) {
-                    c = owner;
                     const uint32_t k = e - L.hoff[c];
                     is_last = (k + 1 == L.hcnt[c]);
                     ctag = L.htag[c];
                     if (ctag == kItemCircle) {  // :218-222
                         n_em = 1;
                         c0.tag = kCmdCircle;
-                        c0.body[0] = L.hrgba[c];  // CmdCircle.flags (extension: bit 0 = ellipse)
+                        c0.body[0] = frgba;  // CmdCircle.flags (extension: bit 0 = ellipse)
                         c0.body[1] = L.haux0[c];
-                        c0.body[2] = L.haux1[c];
+                        c0.body[2] = faux1;
                         c0.body[3] = 0;
                         c0.body[4] = 0;
                         draws = true;
@@ -283,10 +299,9 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                 fin.tag = 0;
                 fin.body[0] = fin.body[1] = fin.body[2] = fin.body[3] = fin.body[4] = 0;
                 if (is_last) {
-                    const uint32_t frgba = L.hrgba[c];
-                    const uint32_t rg = L.hrg[c], ba = L.hba[c];
+                    const uint32_t rg = frg, ba = fba;
                     if (ctag == kItemFill) {  // :359-363
-                        const int backdrop = L.backdrop[c];
+                        const int backdrop = fbackdrop;
                         const uint32_t even_odd = L.haux0[c] & kFillEvenOdd;  // PietFill.flags (extension)
                         // (closing commands are built by the writers pm_layoutgen emits from the layout description)
                         if (L.any[c]) {
@@ -336,8 +351,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                     uint32_t p = pos;
                     if (n_em >= 1) {
                         if (p >= first_kept) {
-                            out_cmds[base + p] = c0;
-                            lds_put(base + p, c0);
+                            put(base + p, c0);
                             if (kCapture) {
                                 const uint32_t li = list_len + p - first_kept;
                                 if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = c0;
@@ -347,8 +361,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                     }
                     if (n_em == 2) {
                         if (p >= first_kept) {
-                            out_cmds[base + p] = c1;
-                            lds_put(base + p, c1);
+                            put(base + p, c1);
                             if (kCapture) {
                                 const uint32_t li = list_len + p - first_kept;
                                 if (li < P.dbg_max) P.dbg_cmds[static_cast<size_t>(tile) * P.dbg_max + li] = c1;
@@ -357,8 +370,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                         ++p;
                     }
                     if (has_fin && p >= first_kept) {
-                        out_cmds[base + p] = fin;
-                        lds_put(base + p, fin);
+                        put(base + p, fin);
                         if (kCapture) {
                             const uint32_t li = list_len + p - first_kept;
                             if (li < P.dbg_max) {

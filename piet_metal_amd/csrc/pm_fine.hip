@@ -124,18 +124,23 @@ constexpr uint32_t kSpChunk = 64;     // commands staged per chunk
 constexpr uint32_t kMaxFrag = 64;     // fragment slots per wave (one step of pass 1 adds <= 64)
 constexpr uint32_t kAlphaSlots = 16;  // workgroup mode: items evaluated ahead per round
 
-// Per wave: the staged chunk and the fragment region of its Fills.  The fused kernel builds the
-// tile's list first (CoarseTile) in the same bytes.
+// Per wave: the staged chunk of commands, and the fragment region of its Fills.  The fused kernel builds the
+// tile's list first (CoarseTile): its scratch shares the fragment region's bytes, and the first chunk of the
+// list is built straight into `cmds` -- what the renderer interprets never leaves the CU.
 struct WaveFineLds {
-    Cmd cmds[kSpChunk];
-    float4 fparam[kMaxFrag];        // {tx, ty, wx - wy, bits(command index)}
+    float4 fparam[kMaxFrag];        // {tx, ty, wx - wy, bits(command index | first hot pixel << 8 | hot pixels before this fragment << 16)}
     uint2 contrib[kMaxFrag][4];     // 16 binary16 contributions per fragment (x = 0..15)
     uint8_t fill_ix[kSpChunk];      // indices of the chunk's Fill commands, in order
+    uint8_t hot_own[64];            // pass 2: position in a step of hot pixels -> fragment that starts there
 };
-union WaveLds {
-    WaveFineLds f;
-    CoarseLds c;
+struct WaveLds {
+    Cmd cmds[kSpChunk];
+    union {
+        WaveFineLds f;
+        CoarseLds c;
+    };
 };
+static_assert(sizeof(CoarseLds) <= sizeof(WaveFineLds), "list building fits in the fragment region: five workgroups per CU");
 
 struct SparseLds {
     WaveLds w[kWaves];
@@ -199,25 +204,78 @@ __device__ __forceinline__ bool FillStep(WaveFineLds &W, Cmd *cmds, const uint8_
     return true;
 }
 
-// Pass 2 over this wave's fragments [0, nfrag)
+// Pass 2 over this wave's fragments [0, nfrag) (nfrag <= kMaxFrag = one lane each).
+//
+// Of a fragment's 16 pixels only those the segment's piece of the pixel row passes over need the area integral:
+//   * a pixel wholly to the RIGHT of it has xmax <= 0, so b = xmax, c = d = 0 and area = (xmax - xmin) / (xmax - xmin),
+//     exactly 1.0f (the very same subtraction twice; xmax - xmin >= 1e-6 as long as |x| < 32, where 1e-6 is not
+//     absorbed) -- its contribution is half(wx - wy);
+//   * a pixel wholly to the LEFT has min(xs) >= 1, so xmin = fl(1 - 1e-6) =: X, b = c = 1, d = X, and the numerator
+//     1 + 0.5 (X X - 1) - X is exactly 0 in binary32 (X X rounds to 1 - 34 ulp, half of that is X - 1): area = +0,
+//     the contribution +-0, which changes no binary16 sum (the sign of a zero signedArea is never looked at).
+// Which pixels are wholly left / right is decided from the piece's x extent in tile coordinates with 1/8 pixel of
+// slack on either side -- the roundings of `xs` (a few ulp of a coordinate < 65 536: < 0.03) cannot carry a
+// pixel across -- and everything in between, or anything not finite, or a piece that begins 30 pixels left of the
+// tile's last column, goes through FillContribution() as written.  (Checked against the full evaluation of all 16
+// pixels: tests/test_oracle_cpu.py::test_fill_pixel_classes and every GPU parity test.)
+// Step A, lane = fragment: the hot range, the constants of the other pixels into `contrib`.  Step B, lane = hot
+// pixel (64 per step, owners by scatter + prefix maximum): the x part :517-527 exactly as written.
+// Tiger 4K: 2.5 of a fragment's 16 pixels are hot; config 4: 2.2.
 __device__ __forceinline__ void FillPass2(WaveFineLds &W, const Cmd *cmds, uint32_t nfrag, uint32_t x0) {
     const uint32_t lane = LaneId();
-#pragma unroll 1
-    for (uint32_t f0 = 0; f0 < nfrag; f0 += 16u) {
-        const uint32_t f = f0 + (lane >> 2), g = lane & 3u;
-        if (f < nfrag) {
-            const float4 p = W.fparam[f];
-            const uint32_t ci = __float_as_uint(p.w);
-            const float fsx = __uint_as_float(cmds[ci].body[1]), fex = __uint_as_float(cmds[ci].body[3]);
-            const float px0 = static_cast<float>(x0 + 4u * g);
-            _Float16 h[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) h[k] = FillContribution(fsx, fex, px0 + static_cast<float>(k), p.x, p.y, p.z);
-            uint2 v;
-            v.x = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[0])) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[1])) << 16);
-            v.y = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[2])) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, h[3])) << 16);
-            W.contrib[f][g] = v;
+    // ---- A ----
+    uint32_t n_hot = 0, hot0 = 0;
+    if (lane < nfrag) {
+        const float4 p = W.fparam[lane];
+        const uint32_t ci = __float_as_uint(p.w);
+        const float fsx = __uint_as_float(cmds[ci].body[1]), fex = __uint_as_float(cmds[ci].body[3]);
+        const float xa = fsx + (fex - fsx) * p.x, xb = fsx + (fex - fsx) * p.y;  // the piece's ends (tile coordinates, approximate)
+        const float lo = fminf(xa, xb), hi = fmaxf(xa, xb);
+        const float fx0 = static_cast<float>(x0);
+        uint32_t n_left = 0, first_right = 16;
+        if (lo >= -1e30f && hi <= 1e30f) {  // (false for NaN)
+            n_left = static_cast<uint32_t>(fminf(fmaxf(floorf((lo - fx0) - 1.125f) + 1.0f, 0.0f), 16.0f));
+            if ((fx0 + 15.0f) - lo < 30.0f) first_right = static_cast<uint32_t>(fminf(fmaxf(ceilf((hi - fx0) + 0.125f), 0.0f), 16.0f));
         }
+        first_right = max(first_right, n_left);
+        hot0 = n_left;
+        n_hot = first_right - n_left;
+        // pixels [first_right, 16): half(1.0f * (wx - wy)); the others 0 (the hot ones are overwritten in step B)
+        const uint32_t cw = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, ToHalf(p.z)));
+        const uint32_t cw2 = cw | (cw << 16);
+        uint32_t d[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) d[k] = first_right <= 2u * k ? cw2 : (first_right == 2u * k + 1u ? cw << 16 : 0u);
+        W.contrib[lane][0] = make_uint2(d[0], d[1]);
+        W.contrib[lane][1] = make_uint2(d[2], d[3]);
+        W.contrib[lane][2] = make_uint2(d[4], d[5]);
+        W.contrib[lane][3] = make_uint2(d[6], d[7]);
+    }
+    const uint32_t incl = WaveInclusiveScan(n_hot);
+    const uint32_t total = WaveLast(incl);
+    const uint32_t excl = incl - n_hot;
+    if (lane < nfrag) reinterpret_cast<uint32_t *>(&W.fparam[lane])[3] = (__float_as_uint(W.fparam[lane].w) & 0xffu) | (hot0 << 8) | (excl << 16);
+    // ---- B ----
+    uint32_t own_carry = 0;
+#pragma unroll 1
+    for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
+        W.hot_own[lane] = 0;
+        WaveSync();
+        if (n_hot != 0u && excl - e0 < 64u) W.hot_own[excl - e0] = static_cast<uint8_t>(lane);
+        WaveSync();
+        const uint32_t f = max(WaveInclusiveMax(W.hot_own[lane]), own_carry);
+        own_carry = WaveLast(f);
+        const uint32_t e = e0 + lane;
+        if (e < total) {
+            const float4 p = W.fparam[f];
+            const uint32_t w = __float_as_uint(p.w);
+            const uint32_t ci = w & 0xffu;
+            const uint32_t j = ((w >> 8) & 0xffu) + (e - (w >> 16));
+            const float fsx = __uint_as_float(cmds[ci].body[1]), fex = __uint_as_float(cmds[ci].body[3]);
+            const _Float16 h = FillContribution(fsx, fex, static_cast<float>(x0 + j), p.x, p.y, p.z);
+            reinterpret_cast<_Float16 *>(&W.contrib[f][0])[j] = h;
+        }
+        WaveSync();
     }
 }
 
@@ -727,13 +785,14 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
             // (a workgroup tile: chunks 0..2 of the list also go to the staged-command areas of waves 1..3)
             if (!wg_mode || wave == 0)
                 n_cmd = CoarseTile<kCapture, kProf>(P, S.w[wave].c, cur, lane, lanes_below, &ct,
-                                                 wg_mode ? reinterpret_cast<uint8_t *>(S.w[1].f.cmds) : nullptr, static_cast<uint32_t>(sizeof(WaveLds)));
+                                                 reinterpret_cast<uint8_t *>(wg_mode ? S.w[1].cmds : S.w[wave].cmds), static_cast<uint32_t>(sizeof(WaveLds)),
+                                                 wg_mode ? kLdsChunks : 1u);
             if (wg_mode) {
                 if (wave == 0 && lane == 0) S.wg_ncmd[pass & 1u] = n_cmd;
                 __syncthreads();  // (workgroup-scope release/acquire: the list wave 0 wrote is visible)
                 n_cmd = S.wg_ncmd[pass & 1u];
             } else {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's list stores before its loads
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's list stores (LDS; beyond a chunk: HBM) before its loads
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             if (kProf) prof.c = wall_clock64();
@@ -760,13 +819,13 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                 uint32_t parity = 0;
                 for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk, parity ^= 1u) {
                     const uint32_t m = min(kSpChunk, n_cmd - c0);
-                    Cmd *chunk = S.w[0].f.cmds;
+                    Cmd *chunk = S.w[0].cmds;
                     if (!kFused || c0 != 0) __syncthreads();  // the previous chunk (or tile) is done with the shared tables
                     if (kFused && c0 < kLdsChunks * kSpChunk) {
-                        chunk = S.w[1u + c0 / kSpChunk].f.cmds;  // CoarseTile left it there (visible since the barrier after it)
+                        chunk = S.w[1u + c0 / kSpChunk].cmds;  // CoarseTile left it there (visible since the barrier after it)
                     } else {
                         const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
-                        uint2 *l = reinterpret_cast<uint2 *>(S.w[0].f.cmds);
+                        uint2 *l = reinterpret_cast<uint2 *>(S.w[0].cmds);
                         for (uint32_t w = threadIdx.x; w < 3u * m; w += kThreads) l[w] = g[w];
                         __syncthreads();
                     }
@@ -784,7 +843,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                 const uint32_t pxi = x0 + (lane & 3u) * 4u;
                 const uint32_t prow = lane >> 2;
                 const uint32_t pyi = y0 + prow;
-                Cmd *const cmds = S.w[wave].f.cmds;
+                Cmd *const cmds = S.w[wave].cmds;
                 PixelStateS st;
                 st.r01 = st.r23 = st.g01 = st.g23 = st.b01 = st.b23 = Splat(static_cast<_Float16>(1.0f));
                 st.sa01 = st.sa23 = Splat(static_cast<_Float16>(0.0f));
@@ -793,7 +852,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                 for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk) {
                     const uint32_t m = min(kSpChunk, n_cmd - c0);
                     WaveSync();
-                    {
+                    if (!kFused || c0 != 0) {  // (the fused kernel's CoarseTile left the first chunk right here)
                         const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
                         uint2 *l = reinterpret_cast<uint2 *>(cmds);
                         for (uint32_t w = Opaque(lane); w < 3u * m; w += 64u) l[w] = g[w];  // (Opaque: no hoisted address to spill)

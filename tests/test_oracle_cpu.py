@@ -587,3 +587,63 @@ def test_scene_builder_matches_independent_python_restatement(pm, pmo):
         sp = pmo.scaled_paths(P, s)
         ref, _ = pmo.scene_from_paths(sp, E, aff)
         assert np.array_equal(np.frombuffer(np_scene.scene_from_paths(sp, E, aff), np.uint8), ref), _case
+
+
+def test_fill_pixel_classes():
+    """pm_fine.hip FillPass2 evaluates the area integral of renderKernel's Fill (PietRender.metal:517-527) only for
+    the pixels the segment's piece of a pixel row passes over; a pixel wholly right of it gets half(wx - wy)
+    (area is exactly 1.0f), a pixel wholly left +0 (the numerator is exactly 0 in binary32).  Here the rule the kernel
+    uses to tell the three classes apart -- the piece's x extent with 1/8 pixel of slack -- is held against the
+    full evaluation of all 16 pixels in numpy binary32, every operation rounded once as in the kernel, over
+    coordinates up to 60 000, integer and vertical edges, pieces far left of the tile."""
+    f32 = np.float32
+    rng = np.random.default_rng(20260927)
+
+    def contrib(fsx, fex, px, tx, ty, wd):
+        with np.errstate(all="ignore"):
+            sx, ex = f32(fsx - px), f32(fex - px)
+            xsx = f32(sx + f32(f32(ex - sx) * tx))
+            xsy = f32(sx + f32(f32(ex - sx) * ty))
+            xmin = f32(np.fmin(np.fmin(xsx, xsy), f32(1.0)) - f32(1e-6))
+            xmax = np.fmax(xsx, xsy)
+            b = np.fmin(xmax, f32(1.0))
+            c = np.fmax(b, f32(0.0))
+            d = np.fmax(xmin, f32(0.0))
+            area = f32(f32(f32(b + f32(f32(0.5) * f32(f32(d * d) - f32(c * c)))) - xmin) / f32(xmax - xmin))
+            return np.float16(f32(area * wd))
+
+    n = 120000
+    scale = rng.choice([16.0, 256.0, 4096.0, 60000.0], n).astype(f32)
+    x0 = np.floor(rng.uniform(0, 1, n) * scale / 16).astype(f32) * f32(16)
+    fsx = np.where(rng.uniform(0, 1, n) < 0.3, np.round(x0 + rng.uniform(-40, 60, n)), x0 + rng.uniform(-40, 60, n)).astype(f32)
+    fex = np.where(rng.uniform(0, 1, n) < 0.2, fsx, fsx + rng.normal(0, 1, n) * rng.choice([0.01, 1, 5, 30, 200], n)).astype(f32)
+    y0 = np.floor(rng.uniform(0, 1, n) * scale / 16).astype(f32) * 16
+    fsy = (y0 + rng.uniform(-20, 36, n)).astype(f32)
+    fey = (fsy + rng.normal(0, 1, n) * rng.choice([0.001, 0.3, 3, 20], n)).astype(f32)
+    py = (y0 + rng.integers(0, 16, n)).astype(f32)
+    with np.errstate(all="ignore"):
+        sy, ey = (fsy - py).astype(f32), (fey - py).astype(f32)
+        wx, wy = np.clip(sy, 0, 1).astype(f32), np.clip(ey, 0, 1).astype(f32)
+        live = wx != wy
+        tx = ((wx - sy).astype(f32) / (ey - sy).astype(f32)).astype(f32)
+        ty = ((wy - sy).astype(f32) / (ey - sy).astype(f32)).astype(f32)
+        wd = (wx - wy).astype(f32)
+        xa = (fsx + ((fex - fsx).astype(f32) * tx).astype(f32)).astype(f32)
+        xb = (fsx + ((fex - fsx).astype(f32) * ty).astype(f32)).astype(f32)
+        lo, hi = np.fmin(xa, xb), np.fmax(xa, xb)
+        ok = (lo >= f32(-1e30)) & (hi <= f32(1e30))
+        n_left = np.where(ok, np.clip(np.floor((lo - x0).astype(f32) - f32(1.125)) + 1, 0, 16), 0).astype(int)
+        far = ((x0 + f32(15)) - lo).astype(f32) >= f32(30.0)
+        first_right = np.where(ok & ~far, np.clip(np.ceil((hi - x0).astype(f32) + f32(0.125)), 0, 16), 16).astype(int)
+    first_right = np.maximum(first_right, n_left)
+    checked = hot = 0
+    for i in np.nonzero(live)[0][:6000]:
+        for j in range(16):
+            if n_left[i] <= j < first_right[i]:
+                hot += 1
+                continue
+            want = contrib(fsx[i], fex[i], f32(x0[i] + j), tx[i], ty[i], wd[i])
+            got = np.float16(0) if j < n_left[i] else np.float16(wd[i])
+            assert want == got, (i, j, float(fsx[i]), float(fex[i]), float(tx[i]), float(ty[i]), float(wd[i]), want, got)
+            checked += 1
+    assert checked > 50000 and hot < 6 * 6000
