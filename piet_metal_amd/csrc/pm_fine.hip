@@ -77,6 +77,20 @@ __device__ __forceinline__ _Float16 FillAlpha(_Float16 a, bool even_odd) {
     return static_cast<_Float16>(f);
 }
 
+// ... the same for two pixels at once: min(abs(alpha), 1.0h) (:538) is exact in binary16 itself -- |x| flips a
+// bit, and minNum of two binary16 values is one of them -- so the non-zero rule needs no trip through binary32.
+__device__ __forceinline__ half2_t FillAlpha2(half2_t a, bool even_odd) {
+    if (even_odd) {
+        half2_t r;
+        r.x = FillAlpha(a.x, true);
+        r.y = FillAlpha(a.y, true);
+        return r;
+    }
+    half2_t one;
+    one.x = one.y = static_cast<_Float16>(1.0f);
+    return __builtin_elementwise_min(__builtin_elementwise_abs(a), one);
+}
+
 // Coverage of Cmd_Circle for one pixel (d = pixel - centre; rx, ry = centre - bbox corner): the
 // circle of PietRender.metal:486-490, or -- extension D10, CmdCircle.flags bit 0 -- the ellipse
 // inscribed in the bbox with the first-order distance F / |grad F| of F = x^2/rx^2 + y^2/ry^2 - 1
@@ -324,7 +338,7 @@ __device__ __forceinline__ void AddFillRun(const WaveFineLds &W, const Cmd *cmds
     }
 }
 
-// Fill commands in a row from command i on (bit i of fm, the chunk's Fill mask, is set)
+// Commands of one kind in a row from command i on (bit i of fm, the chunk's mask of that kind, is set)
 __device__ __forceinline__ uint32_t FillRunLength(uint64_t fm, uint32_t i) {
     const uint64_t rest = ~(fm >> i);
     return rest ? static_cast<uint32_t>(__builtin_ctzll(rest)) : 64u - i;
@@ -359,9 +373,12 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
     const uint32_t nfill = static_cast<uint32_t>(__popcll(fm));
     WaveSync();
     uint32_t fo = 0, prepared = 0;
+    // the chunk's Solid commands: runs of them (a tile inside several translucent shapes) are blended without the dispatch
+    const uint64_t sm = __ballot(lane < n && cmds[lane].tag == kCmdSolid);
     for (uint32_t i = 0; i < n; ++i) {
         const Cmd cmd = cmds[i];
-        switch (cmd.tag) {
+        // (every lane reads the same command: the tag goes to a scalar register and the dispatch to the scalar unit)
+        switch (__builtin_amdgcn_readfirstlane(cmd.tag)) {
             case kCmdCircle: {
                 const float bx0 = static_cast<float>(cmd.body[1] & 0xffffu), by0 = static_cast<float>(cmd.body[1] >> 16);
                 const float bx1 = static_cast<float>(cmd.body[2] & 0xffffu), by1 = static_cast<float>(cmd.body[2] >> 16);
@@ -432,18 +449,24 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
                 const half2_t s01 = st.sa01 + Splat(bd), s23 = st.sa23 + Splat(bd);
                 const bool eo = (cmd.body[4] & kFillEvenOdd) != 0;
-                half2_t a01, a23;
-                a01.x = FillAlpha(s01.x, eo);
-                a01.y = FillAlpha(s01.y, eo);
-                a23.x = FillAlpha(s23.x, eo);
-                a23.y = FillAlpha(s23.y, eo);
+                const half2_t a01 = FillAlpha2(s01, eo), a23 = FillAlpha2(s23, eo);
                 st.sa01 = st.sa23 = Splat(static_cast<_Float16>(0.0f));
                 Blend4S(st, cmd.body[2], cmd.body[3], a01, a23);
                 break;
             }
             case kCmdSolid: {
-                const half2_t one = Splat(static_cast<_Float16>(1.0f));
-                Blend4S(st, cmd.body[1], cmd.body[2], one, one);
+                // rgb = mix(rgb, fg.rgb, fg.a) (:546-549) for the whole run of Solids from here on
+                const uint32_t run = FillRunLength(sm, i);  // >= 1
+#pragma unroll 1
+                for (uint32_t r = 0; r < run; ++r) {
+                    const uint32_t rg = __builtin_amdgcn_readfirstlane(cmds[i + r].body[1]), ba = __builtin_amdgcn_readfirstlane(cmds[i + r].body[2]);
+                    const half2_t a = Splat(HalfFromBits(ba >> 16));  // (alpha 1: fg.a * 1 is fg.a)
+                    const half2_t fr = Splat(HalfFromBits(rg)), fg = Splat(HalfFromBits(rg >> 16)), fb = Splat(HalfFromBits(ba));
+                    st.r01 = st.r01 + (fr - st.r01) * a; st.r23 = st.r23 + (fr - st.r23) * a;
+                    st.g01 = st.g01 + (fg - st.g01) * a; st.g23 = st.g23 + (fg - st.g23) * a;
+                    st.b01 = st.b01 + (fb - st.b01) * a; st.b23 = st.b23 + (fb - st.b23) * a;
+                }
+                i += run - 1u;
                 break;
             }
             default:
@@ -593,10 +616,11 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
                 const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
                 const half2_t s01 = sa01 + Splat(bd), s23 = sa23 + Splat(bd);
                 const bool eo = (cmd.body[4] & kFillEvenOdd) != 0;
-                al[0] = FillAlpha(s01.x, eo);
-                al[1] = FillAlpha(s01.y, eo);
-                al[2] = FillAlpha(s23.x, eo);
-                al[3] = FillAlpha(s23.y, eo);
+                const half2_t q01 = FillAlpha2(s01, eo), q23 = FillAlpha2(s23, eo);
+                al[0] = q01.x;
+                al[1] = q01.y;
+                al[2] = q23.x;
+                al[3] = q23.y;
             } else if (cmd.tag == kCmdStroke) {  // :500-504
                 const float half_width = __uint_as_float(cmd.body[0]);
 #pragma unroll
