@@ -1115,7 +1115,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 5, 1, 16));
     c->fine_wg_per_cu_inflight = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU_INFLIGHT", 3, 1, 16));
     c->bin_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_BIN_WG_PER_CU", 0xff, 0, 0xff));
-    c->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 1024, 0, 1 << 30));
+    c->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 320, 0, 1 << 30));
 
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");

@@ -39,7 +39,7 @@ coarse = np.where(t[:, 6] > 0, (t[:, 6].astype(np.int64) - start) * us, 0.0)
 if (t[:, 6] > 0).any():
     print(f"fused: list building per slot us: mean {coarse.mean():.2f} p90 {np.percentile(coarse,90):.2f} max {coarse.max():.2f}, total {coarse.sum():.0f} us of {dur.sum():.0f}")
 worst = np.argsort(-dur)[:8]
-for i in worst: print(f"  slot {i} tile {tile[i]} q={quarter[i]} ncmd {ncmd[i]} dur {dur[i]:.1f} us start {(start[i]-t0)*us:.1f}  phase A {t[i,4]*us:.1f} us  phase B {t[i,5]*us:.1f} us  list {coarse[i]:.1f} us  own items {t[i,7]*us:.1f} us")
+for i in worst: print(f"  worst slot {i} tile {tile[i]} q={quarter[i]} ncmd {ncmd[i]} dur {dur[i]:.1f} us start {(start[i]-t0)*us:.1f}  phase A {t[i,4]*us:.1f} us  phase B {t[i,5]*us:.1f} us  list {coarse[i]:.1f} us  own items {t[i,7]*us:.1f} us")
 q = quarter & (ncmd > 0)
 if q.any(): print(f"workgroup-mode slots: {q.sum()}, mean dur {dur[q].mean():.2f} us, phase A {t[q,4].mean()*us:.2f} us, phase B {t[q,5].mean()*us:.2f} us, other {(dur[q]-(t[q,4]+t[q,5])*us).mean():.2f} us")
 
@@ -60,4 +60,4 @@ if t.shape[1] >= 12 and (t[:, 11] > 0).any():
 
 last = np.argsort(-end)[:10]
 print("slots that end last:")
-for i in last: print(f"  slot {i} tile {tile[i]} q={quarter[i]} ncmd {ncmd[i]} start {(start[i]-t0)*us:.1f} end {(end[i]-t0)*us:.1f} dur {dur[i]:.1f} list {coarse[i]:.1f}")
+for i in last: print(f"  last slot {i} tile {tile[i]} q={quarter[i]} ncmd {ncmd[i]} start {(start[i]-t0)*us:.1f} end {(end[i]-t0)*us:.1f} dur {dur[i]:.1f} list {coarse[i]:.1f}")
