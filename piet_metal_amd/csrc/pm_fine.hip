@@ -366,24 +366,31 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
     const uint32_t lane = LaneId();
     const uint32_t row = lane >> 2, g = lane & 3u;
     const float px0 = static_cast<float>(x0 + 4u * g), py = static_cast<float>(y0 + row);
+    // Lane i keeps command i of the chunk in registers; the loop below picks the command's words out with v_readlane
+    // into SCALAR registers.  (Read from LDS command by command, every command began with a round trip to the LDS --
+    // tag, then the words its case needs -- on the wave's critical path: 0.1 us each with twenty waves on the CU.)
+    Cmd mine;
+    mine.tag = 0;
+    mine.body[0] = mine.body[1] = mine.body[2] = mine.body[3] = mine.body[4] = 0;
+    if (lane < n) mine = cmds[lane];
     // the chunk's Fill commands, in order
-    const bool isf = lane < n && cmds[lane].tag == kCmdFill;
+    const bool isf = mine.tag == kCmdFill;
     const uint64_t fm = __ballot(isf);
     if (isf) const_cast<uint8_t *>(fill_ix)[RankBelow(fm)] = static_cast<uint8_t>(lane);
     const uint32_t nfill = static_cast<uint32_t>(__popcll(fm));
     WaveSync();
     uint32_t fo = 0, prepared = 0;
     // the chunk's Solid commands: runs of them (a tile inside several translucent shapes) are blended without the dispatch
-    const uint64_t sm = __ballot(lane < n && cmds[lane].tag == kCmdSolid);
+    const uint64_t sm = __ballot(mine.tag == kCmdSolid);
     for (uint32_t i = 0; i < n; ++i) {
-        const Cmd cmd = cmds[i];
-        // (every lane reads the same command: the tag goes to a scalar register and the dispatch to the scalar unit)
-        switch (__builtin_amdgcn_readfirstlane(cmd.tag)) {
+        auto word = [&](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(i))); };
+        switch (word(mine.tag)) {
             case kCmdCircle: {
-                const float bx0 = static_cast<float>(cmd.body[1] & 0xffffu), by0 = static_cast<float>(cmd.body[1] >> 16);
-                const float bx1 = static_cast<float>(cmd.body[2] & 0xffffu), by1 = static_cast<float>(cmd.body[2] >> 16);
+                const uint32_t b1 = word(mine.body[1]), b2 = word(mine.body[2]);
+                const float bx0 = static_cast<float>(b1 & 0xffffu), by0 = static_cast<float>(b1 >> 16);
+                const float bx1 = static_cast<float>(b2 & 0xffffu), by1 = static_cast<float>(b2 >> 16);
                 const float cx = bx0 + (bx1 - bx0) * 0.5f, cy = by0 + (by1 - by0) * 0.5f;
-                const bool ellipse = (cmd.body[0] & kCmdCircleEllipse) != 0;
+                const bool ellipse = (word(mine.body[0]) & kCmdCircleEllipse) != 0;
                 const float dy = py - cy;
                 _Float16 alpha[4];
 #pragma unroll
@@ -400,8 +407,8 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 break;
             }
             case kCmdLine: {
-                const float sx = __uint_as_float(cmd.body[1]), sy = __uint_as_float(cmd.body[2]);
-                const float ex = __uint_as_float(cmd.body[3]), ey = __uint_as_float(cmd.body[4]);
+                const float sx = __uint_as_float(word(mine.body[1])), sy = __uint_as_float(word(mine.body[2]));
+                const float ex = __uint_as_float(word(mine.body[3])), ey = __uint_as_float(word(mine.body[4]));
                 const float lx = ex - sx, ly = ey - sy;
                 const float den = lx * lx + ly * ly;
                 const float dy = py - sy;
@@ -416,7 +423,7 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 break;
             }
             case kCmdStroke: {
-                const float half_width = __uint_as_float(cmd.body[0]);
+                const float half_width = __uint_as_float(word(mine.body[0]));
                 _Float16 alpha[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -425,7 +432,7 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 }
                 half2_t a01, a23;
                 a01.x = alpha[0]; a01.y = alpha[1]; a23.x = alpha[2]; a23.y = alpha[3];
-                Blend4S(st, cmd.body[2], cmd.body[3], a01, a23);
+                Blend4S(st, word(mine.body[2]), word(mine.body[3]), a01, a23);
                 break;
             }
             case kCmdFill: {
@@ -437,8 +444,8 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 break;
             }
             case kCmdFillEdge: {
-                const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
-                const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
+                const float sgn = static_cast<float>(static_cast<int>(word(mine.body[0])));
+                const float v = sgn * Sat(py - __uint_as_float(word(mine.body[1])) + 1.0f);
                 st.sa01.x = ToHalf(static_cast<float>(st.sa01.x) + v);
                 st.sa01.y = ToHalf(static_cast<float>(st.sa01.y) + v);
                 st.sa23.x = ToHalf(static_cast<float>(st.sa23.x) + v);
@@ -446,12 +453,12 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 break;
             }
             case kCmdDrawFill: {
-                const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
+                const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(word(mine.body[0]))));
                 const half2_t s01 = st.sa01 + Splat(bd), s23 = st.sa23 + Splat(bd);
-                const bool eo = (cmd.body[4] & kFillEvenOdd) != 0;
+                const bool eo = (word(mine.body[4]) & kFillEvenOdd) != 0;
                 const half2_t a01 = FillAlpha2(s01, eo), a23 = FillAlpha2(s23, eo);
                 st.sa01 = st.sa23 = Splat(static_cast<_Float16>(0.0f));
-                Blend4S(st, cmd.body[2], cmd.body[3], a01, a23);
+                Blend4S(st, word(mine.body[2]), word(mine.body[3]), a01, a23);
                 break;
             }
             case kCmdSolid: {
@@ -459,7 +466,8 @@ __device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const u
                 const uint32_t run = FillRunLength(sm, i);  // >= 1
 #pragma unroll 1
                 for (uint32_t r = 0; r < run; ++r) {
-                    const uint32_t rg = __builtin_amdgcn_readfirstlane(cmds[i + r].body[1]), ba = __builtin_amdgcn_readfirstlane(cmds[i + r].body[2]);
+                    const uint32_t rg = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.body[1]), static_cast<int>(i + r)));
+                    const uint32_t ba = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.body[2]), static_cast<int>(i + r)));
                     const half2_t a = Splat(HalfFromBits(ba >> 16));  // (alpha 1: fg.a * 1 is fg.a)
                     const half2_t fr = Splat(HalfFromBits(rg)), fg = Splat(HalfFromBits(rg >> 16)), fb = Splat(HalfFromBits(ba));
                     st.r01 = st.r01 + (fr - st.r01) * a; st.r23 = st.r23 + (fr - st.r23) * a;
