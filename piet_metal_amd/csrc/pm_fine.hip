@@ -505,7 +505,8 @@ struct PixelRGB {
 
 // Commands [s, e) of one item, whole tile per wave (lane -> row lane / 4, 4 pixels): Fill,
 // FillEdge and Line exactly as in InterpretSparse(); fm = the chunk's Fill commands.
-__device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint64_t fm, uint32_t s, uint32_t e,
+// mine = the chunk's commands, lane i holding command i (their words reach the loop through v_readlane).
+__device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const Cmd &mine, const uint8_t *fill_ix, uint64_t fm, uint32_t s, uint32_t e,
                                                 uint32_t x0, uint32_t y0, half2_t &sa01, half2_t &sa23, float (&df)[4]) {
     if (s >= e) return;
     const uint32_t lane = LaneId();
@@ -516,23 +517,24 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const u
     uint32_t prepared = fo;
 #pragma unroll 1
     for (uint32_t i = s; i < e; ++i) {
-        const Cmd cmd = cmds[i];
-        if (cmd.tag == kCmdFill) {
+        auto word = [&](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(i))); };
+        const uint32_t tag = word(mine.tag);
+        if (tag == kCmdFill) {
             if (fo >= prepared) prepared = PrepareFills(S, cmds, fill_ix, flimit, fo, x0, y0);  // uniform
             const uint32_t run = min(min(FillRunLength(fm, i), e - i), prepared - fo);  // >= 1
             AddFillRun(S.w[WaveId()].f, cmds, i, run, row, g, sa01, sa23);
             fo += run;
             i += run - 1u;
-        } else if (cmd.tag == kCmdFillEdge) {
-            const float sgn = static_cast<float>(static_cast<int>(cmd.body[0]));
-            const float v = sgn * Sat(py - __uint_as_float(cmd.body[1]) + 1.0f);
+        } else if (tag == kCmdFillEdge) {
+            const float sgn = static_cast<float>(static_cast<int>(word(mine.body[0])));
+            const float v = sgn * Sat(py - __uint_as_float(word(mine.body[1])) + 1.0f);
             sa01.x = ToHalf(static_cast<float>(sa01.x) + v);
             sa01.y = ToHalf(static_cast<float>(sa01.y) + v);
             sa23.x = ToHalf(static_cast<float>(sa23.x) + v);
             sa23.y = ToHalf(static_cast<float>(sa23.y) + v);
-        } else if (cmd.tag == kCmdLine) {
-            const float sx = __uint_as_float(cmd.body[1]), sy = __uint_as_float(cmd.body[2]);
-            const float ex = __uint_as_float(cmd.body[3]), ey = __uint_as_float(cmd.body[4]);
+        } else if (tag == kCmdLine) {
+            const float sx = __uint_as_float(word(mine.body[1])), sy = __uint_as_float(word(mine.body[2]));
+            const float ex = __uint_as_float(word(mine.body[3])), ey = __uint_as_float(word(mine.body[4]));
             const float lx = ex - sx, ly = ey - sy;
             const float den = lx * lx + ly * ly;
             const float dy = py - sy;
@@ -558,7 +560,11 @@ template <bool kProf>
 __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *fill_ix, uint32_t n, uint32_t parity, uint32_t x0,
                                               uint32_t y0, uint32_t pix, PixelRGB &st, PhaseTicks &prof) {
     const uint32_t lane = LaneId(), wave = WaveId();
-    const uint32_t tag = lane < n ? cmds[lane].tag : 0u;
+    Cmd mine;  // lane i: command i of the chunk
+    mine.tag = 0;
+    mine.body[0] = mine.body[1] = mine.body[2] = mine.body[3] = mine.body[4] = 0;
+    if (lane < n) mine = cmds[lane];
+    const uint32_t tag = mine.tag;
     const uint64_t fm = __ballot(tag == kCmdFill);
     const uint64_t bm = __ballot(tag == kCmdDrawFill || tag == kCmdStroke || tag == kCmdSolid || tag == kCmdCircle);
     if (tag == kCmdFill) fill_ix[RankBelow(fm)] = static_cast<uint8_t>(lane);  // (every wave keeps its own copy)
@@ -569,8 +575,8 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
         if ((bm >> lane) & 1ull) {
             // the item's colour, as the blend takes it: Circle is black with alpha exactly `alpha` (:491)
             uint2 c = make_uint2(0u, 0x3c000000u);
-            if (tag == kCmdSolid) c = make_uint2(cmds[lane].body[1], cmds[lane].body[2]);
-            if (tag == kCmdDrawFill || tag == kCmdStroke) c = make_uint2(cmds[lane].body[2], cmds[lane].body[3]);
+            if (tag == kCmdSolid) c = make_uint2(mine.body[1], mine.body[2]);
+            if (tag == kCmdDrawFill || tag == kCmdStroke) c = make_uint2(mine.body[2], mine.body[3]);
             S.rec[RankBelow(bm)] = c;
             S.item_se[RankBelow(bm)] = static_cast<uint16_t>(begin | (lane << 8));
         }
@@ -610,7 +616,7 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
                 sa01 = Half2FromBits(cs.x); sa23 = Half2FromBits(cs.y);
                 df[0] = cd.x; df[1] = cd.y; df[2] = cd.z; df[3] = cd.w;
             }
-            RunItemCommands(S, cmds, fill_ix, fm, s0, e0, x0, y0, sa01, sa23, df);
+            RunItemCommands(S, cmds, mine, fill_ix, fm, s0, e0, x0, y0, sa01, sa23, df);
             if (is_tail) {  // (also when the tail is empty: the next chunk starts from a clean state)
                 uint2 cs;
                 cs.x = __builtin_bit_cast(uint32_t, sa01); cs.y = __builtin_bit_cast(uint32_t, sa23);
@@ -618,7 +624,10 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
                 S.carry_df[parity ^ 1u][lane] = make_float4(df[0], df[1], df[2], df[3]);
                 continue;
             }
-            const Cmd cmd = cmds[e0];
+            Cmd cmd;  // the item's closing command, from lane e0
+            cmd.tag = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.tag), static_cast<int>(e0)));
+#pragma unroll
+            for (int w = 0; w < 5; ++w) cmd.body[w] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mine.body[w]), static_cast<int>(e0)));
             _Float16 al[4];
             if (cmd.tag == kCmdDrawFill) {  // :535-542
                 const _Float16 bd = static_cast<_Float16>(static_cast<float>(static_cast<int>(cmd.body[0])));
