@@ -26,6 +26,14 @@ struct CoarseLds {
 };
 
 
+// What the four waves of a workgroup exchange when they build ONE tile's list together (CoarseTile<..., kPar>):
+// a candidate pass whose stream is 65 .. 256 elements long is cut into its rounds of 64, a wave each.
+struct CoarseShared {
+    uint32_t any_mask[2];    // per candidate of the pass: one of its elements emitted a command
+    uint32_t state[4];       // wave 0's {n_pending, list_len, solid_color, rel_done} when the pass begins
+    uint4 rec[kWaves];       // per wave: {commands of its round, position of its last opaque Solid + 1, of its last drawing command + 1, that Solid's colour}
+};
+
 // Returns the number of commands left in the tile's list for the fine stage (0: nothing to
 // interpret -- empty, Bail tile already painted here, or arena overflow).
 // Developer timeline (kProf instantiations only): 10 ns ticks per stage of the list building
@@ -49,10 +57,20 @@ struct CoarseTicks {
 // tiles' lists straight back: 113 MB each way at config 4).
 constexpr uint32_t kLdsChunks = 3;
 
-template <bool kCapture, bool kProf = false>
+// kPar (a tile the whole workgroup will render; ALL FOUR waves call, with the same arguments but their own L): the
+// longest lists -- the 4K Tiger's longest, 166 commands from 150 stream elements, took one wave 7.5 us to build and
+// ended the launch -- are built by the four waves together: every wave loads the pass's candidates, wave w runs the
+// phase-2 tests of elements [64 w, 64 w + 64), the waves exchange what they emit (CoarseShared) and each writes its
+// own commands at their place in the list.  Passes of at most 64 (or more than 256) elements are wave 0's alone, the
+// others walk the pieces without touching them; only wave 0's return value counts.
+template <bool kCapture, bool kProf = false, bool kPar = false>
 __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &L, const uint4 qe,
                                                const uint32_t lane, const uint64_t lanes_below, CoarseTicks *ticks = nullptr,
-                                               uint8_t *const lds_chunks = nullptr, const uint32_t lds_stride = 0, const uint32_t lds_n = 0) {
+                                               uint8_t *const lds_chunks = nullptr, const uint32_t lds_stride = 0, const uint32_t lds_n = 0,
+                                               CoarseShared *const sh = nullptr) {
+    // (kPar instantiations serve single-wave tiles too: sh == nullptr, one copy of the code in the kernel)
+    const bool wg = kPar && sh != nullptr;
+    const uint32_t pw = wg ? WaveId() : 0u;  // this wave's place among the workgroup's
     const uint32_t lds_cmds = lds_chunks != nullptr ? lds_n * 64u : 0u;  // list positions below this live in LDS
     Cmd *out_cmds = nullptr;  // (set below)
     auto put = [&](uint32_t q, const Cmd &c) {
@@ -93,6 +111,13 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
         const uint4 *const cands = pc + 1u + nrel;
         // header (the next piece), the first 64 candidates and the first 64 segments: all in flight together
         const uint4 hdr = Scalar4(*pc);
+        // (kPar: a piece whose passes cannot be longer than a round is wave 0's alone)
+        const bool piece_shared = wg && nrel + nhit > 64u;
+        if (pw != 0u && !piece_shared) {
+            piece = hdr.x;
+            piece_n = hdr.y;
+            continue;
+        }
         float4 seg_first = make_float4(0.f, 0.f, 0.f, 0.f);
         if (Opaque(lane) < nrel) seg_first = segs[Opaque(lane)];
         uint32_t rel_done = 0;  // relevant segments owned by earlier candidate passes
@@ -143,9 +168,43 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                 tk1 = wall_clock64();
                 ticks->cand += tk1 - tk0;
             }
+            // (uniform over the workgroup: every wave computed the same stream)
+            const bool par = piece_shared && stream_len > 64u && stream_len <= 64u * static_cast<uint32_t>(kWaves);
+            if (pw != 0u && !par) {  // wave 0's pass
+                rel_done += pass_rel;
+                continue;
+            }
+            if (par) {
+                if (pw == 0u) {
+                    if (lane < 2u) sh->any_mask[lane] = 0u;
+                    if (lane == 0u) {
+                        sh->state[0] = n_pending;
+                        sh->state[1] = list_len;
+                        sh->state[2] = solid_color;
+                        sh->state[3] = rel_done;
+                    }
+                }
+                __syncthreads();  // (a full barrier: commands of earlier passes that went to HBM are behind every wave too -- a restarted list reuses their slots)
+                n_pending = sh->state[0];
+                list_len = sh->state[1];
+                solid_color = sh->state[2];
+                if (pw != 0u) {  // (the segment offsets were computed from this wave's own idea of rel_done)
+                    const uint32_t d = sh->state[3] - rel_done;
+                    if (lane < nh) L.hwoff[lane] += d;
+                    rel_done = sh->state[3];
+                    WaveSync();
+                }
+            }
+            auto mark_any = [&](uint32_t cc) {
+                if (par) atomicOr(&sh->any_mask[cc >> 5], 1u << (cc & 31u));
+                else atomicOr(&L.any[cc], 1u);
+            };
+            auto get_any = [&](uint32_t cc) -> bool { return par ? ((sh->any_mask[cc >> 5] >> (cc & 31u)) & 1u) != 0u : L.any[cc] != 0u; };
             // ---- stream rounds: phase-2 tests -> ordered commands --------------------------
+            // (par: this wave's one round; the owner of the element before it is the last candidate that starts earlier)
             uint32_t own_carry = 0;  // owner of the last element of the previous round
-            for (uint32_t e0 = 0; e0 < stream_len; e0 += 64) {
+            if (par && pw != 0u) own_carry = static_cast<uint32_t>(__popcll(__ballot(lane < nh && L.hoff[lane < nh ? lane : 0u] < 64u * pw))) - 1u;
+            for (uint32_t e0 = par ? 64u * pw : 0u; par ? e0 == 64u * pw : e0 < stream_len; e0 += par ? 0x40000000u : 64u) {
                 PM_CT_TICK(tk0);
                 const uint32_t e = e0 + lane;
                 // Owner of every element without a search: each candidate marks the stream
@@ -252,7 +311,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                                 c0.body[1] = __float_as_uint(s.x); c0.body[2] = __float_as_uint(s.y);
                                 c0.body[3] = __float_as_uint(s.z); c0.body[4] = __float_as_uint(s.w);
                             }
-                            if (n_em) atomicOr(&L.any[c], 1u);
+                            if (n_em) mark_any(c);
                         } else {
                             // Line (:223-247) and Poly phase 2 (:406-440) share the inflated-box test
                             const float width = __uint_as_float(L.haux0[c]);
@@ -281,12 +340,13 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                                 c0.body[1] = __float_as_uint(s.x); c0.body[2] = __float_as_uint(s.y);
                                 c0.body[3] = __float_as_uint(s.z); c0.body[4] = __float_as_uint(s.w);
                                 draws = true;
-                                atomicOr(&L.any[c], 1u);
+                                mark_any(c);
                             }
                         }
                     }
                 }
-                WaveSync();  // per-candidate accumulators complete for elements <= this round
+                if (par) LdsBarrier();  // per-candidate accumulators complete (every wave's round)
+                else WaveSync();        // ... for elements <= this round
                 if (kProf) {
                     tk1 = wall_clock64();
                     ticks->seg += tk1 - tk0;
@@ -304,7 +364,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                         const int backdrop = fbackdrop;
                         const uint32_t even_odd = L.haux0[c] & kFillEvenOdd;  // PietFill.flags (extension)
                         // (closing commands are built by the writers pm_layoutgen emits from the layout description)
-                        if (L.any[c]) {
+                        if (get_any(c)) {
                             has_fin = true;
                             fin = gen::ptcl::Cmd_DrawFill_pack(backdrop, frgba, rg, ba, even_odd);
                             draws = true;
@@ -314,7 +374,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                             opaque_solid = (frgba & 0xff000000u) == 0xff000000u;  // :132
                         }
                     } else if (ctag == kItemPoly || ctag == kItemLine) {  // :441-443, :243
-                        if (L.any[c]) {
+                        if (get_any(c)) {
                             has_fin = true;
                             fin = gen::ptcl::Cmd_Stroke_pack(0.5f * __uint_as_float(L.haux0[c]), frgba, rg, ba);
                             draws = true;
@@ -326,14 +386,40 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                 // ---- wave-wide slots (ballots + popcounts, no scan network) ---------------------
                 const uint64_t m0 = __ballot((lane_total & 1u) != 0);
                 const uint64_t m1 = __ballot((lane_total & 2u) != 0);
-                const uint32_t pos = static_cast<uint32_t>(__popcll(m0 & lanes_below)) + 2u * static_cast<uint32_t>(__popcll(m1 & lanes_below));
-                const uint32_t round_total = static_cast<uint32_t>(__popcll(m0)) + 2u * static_cast<uint32_t>(__popcll(m1));
-                if (round_total == 0) continue;  // uniform
+                uint32_t pos = static_cast<uint32_t>(__popcll(m0 & lanes_below)) + 2u * static_cast<uint32_t>(__popcll(m1 & lanes_below));
+                uint32_t round_total = static_cast<uint32_t>(__popcll(m0)) + 2u * static_cast<uint32_t>(__popcll(m1));
+                if (!par && round_total == 0) continue;  // uniform
                 const uint64_t ms = __ballot(opaque_solid);
                 const uint64_t md = __ballot(draws);
                 int last_solid = -1, last_draw = -1;
-                if (ms) last_solid = static_cast<int>(WaveAtHighest(pos + n_em, ms));
+                uint32_t solid_rgba = 0;  // colour of the round's last opaque Solid
+                if (ms) {
+                    last_solid = static_cast<int>(WaveAtHighest(pos + n_em, ms));
+                    solid_rgba = WaveAtHighest(fin.body[0], ms);
+                }
                 if (md) last_draw = static_cast<int>(WaveAtHighest(pos + lane_total, md)) - 1;
+                if (par) {
+                    // the four rounds as ONE: positions count from the first wave's first command, the last opaque Solid
+                    // and the last drawing command are the last ones of any wave
+                    if (lane == 0) sh->rec[pw] = make_uint4(round_total, static_cast<uint32_t>(last_solid + 1), static_cast<uint32_t>(last_draw + 1), solid_rgba);
+                    LdsBarrier();
+                    uint32_t before = 0, all = 0;
+                    last_solid = last_draw = -1;
+#pragma unroll
+                    for (uint32_t v = 0; v < static_cast<uint32_t>(kWaves); ++v) {
+                        const uint4 r = sh->rec[v];
+                        if (v < pw) before += r.x;
+                        if (r.y) {
+                            last_solid = static_cast<int>(all + r.y) - 1;
+                            solid_rgba = r.w;
+                        }
+                        if (r.z) last_draw = static_cast<int>(all + r.z) - 1;
+                        all += r.x;
+                    }
+                    pos += before;
+                    round_total = all;
+                    if (round_total == 0) continue;  // uniform over the workgroup
+                }
 
                 uint32_t base;        // list slot of round position 0 (may be "negative")
                 uint32_t first_kept;  // round positions below this are dropped
@@ -385,7 +471,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                 }
                 n_pending = base + round_total;
                 list_len += round_total - first_kept;
-                if (last_solid >= 0) solid_color = WaveAtHighest(fin.body[0], ms);
+                if (last_solid >= 0) solid_color = solid_rgba;
                 if (last_draw > last_solid) solid_color = 0;  // encodeCircle/Line/Stroke/DrawFill (:81,:90,:99,:124)
                 WaveSync();
                 if (kProf) ticks->emit += wall_clock64() - tk1;
@@ -396,9 +482,12 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
         piece_n = hdr.y;
     }
 
+    // (capture: wave 0's closing record of the list may land on a slot another wave captured a dropped command in)
+    if (kCapture && wg) __syncthreads();
+    if (pw != 0u) return 0;  // (wave 0 finishes the tile)
     // ---- TileEncoder::end() (:144-151): Bail tiles are finished here (composite :34-44) ----
-    if (lane == 0) {
-        P.tile_ncmd[tile] = solid_color ? 0u : n_pending;  // what a stand-alone pm_fine_kernel reads
+    if (lane == 0 && lds_chunks == nullptr) {
+        P.tile_ncmd[tile] = solid_color ? 0u : n_pending;  // what a stand-alone pm_fine_kernel reads (the fused kernel has the return value)
     }
     if (solid_color != 0) {
         // the tile is one opaque colour, bytes as stored: 64 lanes x 16 B = the whole tile

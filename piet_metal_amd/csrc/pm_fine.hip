@@ -164,6 +164,7 @@ struct SparseLds {
     uint2 carry_sa[2][64];                // signedArea / distance state of an item cut by the chunk boundary
     float4 carry_df[2][64];               //   (two copies, alternating per chunk)
     uint32_t wg_ncmd[2];                  // fused kernel: list length found by wave 0 (alternating per pass)
+    CoarseShared coarse_shared;           // fused kernel: what the four waves exchange while they build a long list together
     uint32_t next_item;                   // next item of the round nobody has taken yet
     uint16_t item_se[kSpChunk + 1];       // per item: first command | blend command << 8 (last entry: the open tail)
 };
@@ -824,16 +825,18 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
         if (kFused) {
             // (wave 0 of a workgroup-mode tile has wave == 0: its region is S.w[0] either way)
             // (a workgroup tile: chunks 0..2 of the list also go to the staged-command areas of waves 1..3)
-            if (!wg_mode || wave == 0)
-                n_cmd = CoarseTile<kCapture, kProf>(P, S.w[wave].c, cur, lane, lanes_below, &ct,
-                                                 reinterpret_cast<uint8_t *>(wg_mode ? S.w[1].cmds : S.w[wave].cmds), static_cast<uint32_t>(sizeof(WaveLds)),
-                                                 wg_mode ? kLdsChunks : 1u);
+            // (a workgroup tile: all four waves -- the longest lists are built a round of 64 stream elements per wave)
+            n_cmd = CoarseTile<kCapture, kProf, true>(P, S.w[wave].c, cur, lane, lanes_below, &ct, reinterpret_cast<uint8_t *>(wg_mode ? S.w[1].cmds : S.w[wave].cmds),
+                                                      static_cast<uint32_t>(sizeof(WaveLds)), wg_mode ? kLdsChunks : 1u, wg_mode ? &S.coarse_shared : nullptr);
             if (wg_mode) {
                 if (wave == 0 && lane == 0) S.wg_ncmd[pass & 1u] = n_cmd;
                 __syncthreads();  // (workgroup-scope release/acquire: the list wave 0 wrote is visible)
                 n_cmd = S.wg_ncmd[pass & 1u];
-            } else {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's list stores (LDS; beyond a chunk: HBM) before its loads
+            } else if (n_cmd > kSpChunk) {
+                // (only a list longer than the chunk in LDS is read back from HBM: this wave's stores before its loads.  The
+                //  release waits for EVERY store the wave has in flight -- the previous tile's pixels among them, microseconds
+                //  under load -- so the tiles that need no read-back skip it)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             if (kProf) prof.c = wall_clock64();
