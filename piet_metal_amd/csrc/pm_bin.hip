@@ -194,13 +194,13 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
     const uint4 srd = PM_PP(sr_desc)[rix];
     rix_next = __builtin_amdgcn_readfirstlane(srd.w);
     if (rix_next == 0) rix_next = 0xffffffffu;
-    const uint32_t sr = __builtin_amdgcn_readfirstlane(srd.x);
+    // (the strip row by strip | tile row of the band << 16: no division by the number of strips)
+    const uint32_t strip = __builtin_amdgcn_readfirstlane(srd.x) & 0xffffu, row_rel = __builtin_amdgcn_readfirstlane(srd.x) >> 16;
+    const uint32_t sr = row_rel * PM_PU(strips_x) + strip;
     // this strip row's part of the tile arena (pm_device.h, Counters)
     const uint32_t shard = rix % kArenaShards;
     const uint32_t shard_quads = PM_PU(tarena_cap) / kArenaShards;
     const uint32_t shard_base = shard * shard_quads;
-    const uint32_t strip = sr % PM_PU(strips_x);
-    const uint32_t row_rel = sr / PM_PU(strips_x);
     const uint32_t ty = PM_PU(row0) + row_rel;
     const int sx0 = static_cast<int>(strip * kGroupW);
     const int y0 = static_cast<int>(ty * kTileH);
@@ -323,9 +323,9 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
             const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + lane;
             const uint32_t list_slot = fits ? base + ts.list_off : 0xffffffffu;
             PM_PP(tile_ptcl)[tile] = list_slot;
-            // A queue entry is everything the tile kernels need to start: {tile, first quad of its
-            // command list, its first piece, that piece's candidates | segments << 9}
-            const uint4 entry = make_uint4(tile, list_slot, L.s_head_q[lane], L.s_head_n[lane]);
+            // A queue entry is everything the tile kernels need to start: {tile (column | row of the band << 16), first
+            // quad of its command list, its first piece, that piece's candidates | segments << 9}
+            const uint4 entry = make_uint4((strip * kStripTiles + lane) | (row_rel << 16), list_slot, L.s_head_q[lane], L.s_head_n[lane]);
             PM_PP(queue)[cls * PM_PU(queue_cap) + q_base + (ts.packed >> 4)] = entry;
         }
     };

@@ -80,14 +80,14 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
             out_cmds[q] = c;
     };
     unsigned long long tk0 = 0, tk1 = 0;
-    const uint32_t tile = qe.x;
+    // (the entry names the tile by column | row << 16: no division by the width of the grid on the way to its pixels)
+    const uint32_t tx = qe.x & 0xffffu, ty_rel = qe.x >> 16;
+    const uint32_t tile = ty_rel * P.tiles_x + tx;
     if (qe.y == 0xffffffffu) {  // the command-list arena overflowed (pm_sync re-renders the frame)
         if (lane == 0) P.tile_ncmd[tile] = 0;
         return 0;
     }
     out_cmds = reinterpret_cast<Cmd *>(P.tarena + qe.y);  // this tile's private command slots
-    const uint32_t tx = tile % P.tiles_x;
-    const uint32_t ty_rel = tile / P.tiles_x;
     const uint32_t ty = P.row0 + ty_rel;
     const int x0 = static_cast<int>(tx * kTileW);
     const int y0 = static_cast<int>(ty * kTileH);

@@ -474,7 +474,8 @@ int EnsureArena(pm_ctx *c) {
             SetError("scene x viewport needs a binning arena beyond 16 GiB");
             return PM_ERR_CAPACITY;
         }
-        desc.push_back(make_uint4(static_cast<uint32_t>(i), static_cast<uint32_t>(begin), static_cast<uint32_t>(total), 0u));
+        desc.push_back(make_uint4(static_cast<uint32_t>(i % c->strips_x) | (static_cast<uint32_t>(i / c->strips_x) << 16), static_cast<uint32_t>(begin),
+                                  static_cast<uint32_t>(total), 0u));
     }
     if (desc.empty()) desc.push_back(make_uint4(0u, pm::kArenaBase, pm::kArenaBase, 0u));
     uint32_t per_cu = c->bin_wg_per_cu;

@@ -79,7 +79,7 @@ struct Counters {
 //     command list -- the tile's 24-byte Cmd records (TestApp/GenTypes.h:430-495), space claimed from
 //       the estimate (3 x stream elements + 1).
 //
-// Tile queues: kClasses class queues of 16-byte entries {tile, first quad of the command list,
+// Tile queues: kClasses class queues of 16-byte entries {tile (column | row of the band << 16), first quad of the command list,
 // first piece, candidates | segments << kPieceHitBits of that piece}; the tile kernels walk them
 // statically, longest first, so the expensive tiles start first and the cheap ones fill the tail.
 //
@@ -120,7 +120,7 @@ struct FrameParams {
     uint32_t fb_bgra;     // 1: pixels are stored B,G,R,A (MTLPixelFormatBGRA8Unorm, PietRenderer.m:29) instead of R,G,B,A
     uint32_t *arena;
     uint32_t arena_cap;   // dwords
-    const uint4 *sr_desc;     // [n_sr_active] {strip row, its private arena region begin, end, next entry of the workgroup's chain}
+    const uint4 *sr_desc;     // [n_sr_active] {strip | tile row of the band << 16, its private arena region begin, end, next entry of the workgroup's chain}
     uint32_t n_sr_active;     // strip rows some item reaches: pm_bin_kernel's work list
     uint32_t bin_grid;        // its grid: what the chip holds at once (five workgroups per CU), or a workgroup per strip row
     uint32_t bin_prio_slots;  // strip rows with at least this many segment slots raise their waves' issue priority

@@ -815,7 +815,8 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
             }
         };
         const bool wg_mode = cur_slot < s_h && sh != 0;  // uniform over the workgroup (slots are aligned)
-        const uint32_t tile = cur.x;
+        const uint32_t tx = cur.x & 0xffffu, ty_rel = cur.x >> 16;  // (queue entries name a tile by column | row << 16)
+        const uint32_t tile = ty_rel * P.tiles_x + tx;
         unsigned long long t_begin = 0;
         PhaseTicks prof;
         CoarseTicks ct;
@@ -844,8 +845,6 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
         if (n_cmd == 0) next_card();
         if (n_cmd != 0) {  // 0: the coarse kernel found one opaque colour and wrote it
             const uint32_t *src = reinterpret_cast<const uint32_t *>(P.tarena + cur.y);
-            const uint32_t tx = tile % P.tiles_x;
-            const uint32_t ty_rel = tile / P.tiles_x;
             const uint32_t x0 = tx * kTileW;
             const uint32_t y0 = (P.row0 + ty_rel) * kTileH;
             if (wg_mode) {
