@@ -629,7 +629,9 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                 a = b = make_float2(0.f, 0.f);
                 if (f < w_hi) {
                     const uint32_t six = f / kChunkSegs;
-                    const uint32_t spk = six < kSurvLds ? L.s_surv[six] : PM_META(six * kChunkSegs);
+                    // (two plain accesses, not a select of two pointers: that becomes a FLAT load, which waits on both counters)
+                    uint32_t spk = Opaque(L.s_surv[min(six, kSurvLds - 1u)]);
+                    if (six >= kSurvLds) spk = PM_META(six * kChunkSegs);
                     vc = spk >> 24;
                     k = (spk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
                     const uint32_t vtag = L.s_cmask[vc] >> 16;
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                 ne = L.s_we[lane];
                 lkm = L.s_wlk[lane];
                 lsm = L.s_wls[lane];
-                L.s_est[lane] += nrel_t + ne;
+                L.s_est[lane] += nrel_t + nh;  // (segments + closing commands: what the list will be about as long as -- and an upper bound basis for its space, 3 x this + 1)
                 if (lkm) L.s_last_kept[lane] = L.s_cidx[lkm - 1u] + 1u;  // records come in paint order
                 if (lsm) {
                     L.s_last_solid[lane] = L.s_cidx[lsm - 1u] + 1u;

@@ -179,7 +179,7 @@ struct pm_ctx {
     int handout = 0;         // tile hand-out: 0 = drawn for a lone frame, static when frames overlap; 1 = static; 2 = drawn
     int target_fmt = PM_FMT_RGBA8;  // byte order the kernels store pixels in (pm_set_target_format)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
-    uint32_t heavy_stream = 64, heavy_stream_lone = 24, vheavy_stream = 96;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
+    uint32_t heavy_stream = 72, heavy_stream_lone = 40, vheavy_stream = 112;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
     uint32_t bin_wg_per_cu = 0xff;  // pm_bin_kernel's workgroups per CU (PM_BIN_WG_PER_CU; 0 = one per strip row, default: by the number of strip rows)
     uint32_t coarse_wg_per_cu = 5, fine_wg_per_cu = 5;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
     uint32_t fine_wg_per_cu_inflight = 3;               // ... of a frame behind other frames (PM_FINE_WG_PER_CU_INFLIGHT)
@@ -1106,9 +1106,9 @@ pm_ctx *pm_create(int device, int *err) {
     c->stream = c->streams[0];
     c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 5, 1, 16));
     c->split_mode = static_cast<uint32_t>(EnvInt("PM_FINE_SPLIT", 1, 0, 1));
-    c->heavy_stream = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM", 64, 1, 1 << 20));
-    c->heavy_stream_lone = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM_LONE", std::min<int>(24, static_cast<int>(c->heavy_stream)), 1, 1 << 20));
-    c->vheavy_stream = static_cast<uint32_t>(EnvInt("PM_VHEAVY_STREAM", 96, 1, 1 << 20));
+    c->heavy_stream = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM", 72, 1, 1 << 20));
+    c->heavy_stream_lone = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM_LONE", std::min<int>(40, static_cast<int>(c->heavy_stream)), 1, 1 << 20));
+    c->vheavy_stream = static_cast<uint32_t>(EnvInt("PM_VHEAVY_STREAM", 112, 1, 1 << 20));
     c->fold_clear_mode = EnvInt("PM_FOLD_CLEAR", 2, 0, 2);
     c->fold_clear = c->fold_clear_mode != 0;
     c->fused = EnvInt("PM_FUSED", 1, 0, 1) != 0;

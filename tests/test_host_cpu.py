@@ -989,7 +989,7 @@ def test_profile_stamp_digest_ignores_comments_but_not_code(tmp_path):
     text = f.read_text()
     f.write_text("// a new remark\n" + text.replace("// ", "//   ", 5) + "\n/* and\n   another */\n")
     assert mt.kernel_sources_sha16(str(tmp_path)) == base
-    f.write_text(text.replace("kCPL = 2", "kCPL = 3", 1))
+    f.write_text(text.replace("kSupCPL = 2", "kSupCPL = 3", 1))
     assert mt.kernel_sources_sha16(str(tmp_path)) != base
     stamp = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     assert stamp["_kernel_sources_sha16"] == mt.kernel_sources_sha16(), "profiles/hbm_traffic.json is older than the kernel sources: re-run tools/prof_round.sh"
