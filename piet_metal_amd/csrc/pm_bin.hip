@@ -192,6 +192,27 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
     if (rix != blockIdx.x) LdsBarrier();  // the previous strip row's LDS is done with
     // One 16-byte load: {strip row, region, end, next strip row of this workgroup (0: none)}.
     const uint4 srd = PM_PP(sr_desc)[rix];
+    // In flight together with it: where the strip row's item list is (large scenes: its tile row's list), or -- the
+    // band's list does not depend on the strip row -- the first 256 boxes of the list themselves.  Every dependent
+    // access the item scan does not make is half a microsecond of every strip row.
+    uint32_t n_band = PM_PU(n_band_items);
+    const uint2 *band_bbox = PM_PP(band_bbox);
+    const uint32_t *band_item = PM_PP(band_item);
+    uint2 bb_next = make_uint2(0u, 0u);
+    uint32_t it_next = 0;
+    if (PM_PU(use_row_lists)) {  // large scene: this tile row's list from pm_rowcull_kernel
+        const uint2 srl = PM_PP(sr_list)[rix];
+        const uint32_t lo = __builtin_amdgcn_readfirstlane(srl.x);
+        n_band = __builtin_amdgcn_readfirstlane(srl.y);
+        band_bbox = PM_PP(row_bbox) + lo;
+        band_item = PM_PP(row_item) + lo;
+    }
+    if (tid < n_band) {
+        bb_next = band_bbox[tid];
+        it_next = band_item[tid];
+    }
+    // the two colour tables ride along with the first bbox load (finalisation reads them from LDS)
+    const uint32_t lut_word = PM_PP(lut_srgb2lin)[tid] | (PM_PP(lut_unorm2h)[tid] << 16);
     rix_next = __builtin_amdgcn_readfirstlane(srd.w);
     if (rix_next == 0) rix_next = 0xffffffffu;
     // (the strip row by strip | tile row of the band << 16: no division by the number of strips)
@@ -340,27 +361,10 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
     // paint-ordered subset the host lists once per scene / viewport; with one GPU it is every
     // item in view), not over the whole scene: with the rows sharded over N GPUs each rank
     // looks at its own share only.
-    uint32_t n_band = PM_PU(n_band_items);
-    const uint2 *band_bbox = PM_PP(band_bbox);
-    const uint32_t *band_item = PM_PP(band_item);
-    if (PM_PU(use_row_lists)) {  // large scene: this tile row's list from pm_rowcull_kernel
-        const uint32_t *rb = PM_PP(row_base);
-        const uint32_t lo = __builtin_amdgcn_readfirstlane(rb[row_rel]);
-        n_band = __builtin_amdgcn_readfirstlane(rb[row_rel + 1]) - lo;
-        band_bbox = PM_PP(row_bbox) + lo;
-        band_item = PM_PP(row_item) + lo;
-    }
     // The host sized this strip row's arena region from the same bbox predicate: a region that
     // only holds the fixed header allowance means no item can land here -- nothing to scan.
     if (region_end - cursor == PM_PU(sr_empty_dwords)) n_band = 0;
-    uint2 bb_next = make_uint2(0u, 0u);
-    uint32_t it_next = 0;
-    if (tid < n_band) {
-        bb_next = band_bbox[tid];
-        it_next = band_item[tid];
-    }
-    // the two colour tables ride along with the first bbox load (finalisation reads them from LDS)
-    if (n_band) L.s_lut[tid] = PM_PP(lut_srgb2lin)[tid] | (PM_PP(lut_unorm2h)[tid] << 16);
+    L.s_lut[tid] = lut_word;
     for (uint32_t ib = 0;; ib += kBatch) {
         const bool more = ib < n_band;  // uniform
         const uint32_t j = ib + tid;

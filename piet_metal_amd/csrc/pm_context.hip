@@ -199,6 +199,7 @@ struct pm_ctx {
     std::vector<uint32_t> chunk_base_host;  // source of the asynchronous upload of the chunk table
     std::vector<uint64_t> stage_need_diff;  // StripRowBounds' scratch
     std::vector<uint4> stage_desc;          // ... of the strip-row work list,
+    std::vector<uint2> stage_list;          // ... its rows' item lists,
     std::vector<uint2> stage_bbs;           // ... the band's item boxes
     std::vector<uint32_t> stage_ids, stage_rb;  // ... and indices, the per-row list offsets
     size_t row_base_cap = 0;
@@ -217,6 +218,7 @@ struct pm_ctx {
     // binning state shared by the slots
     size_t sr_desc_cap = 0, band_cap = 0;
     uint4 *d_sr_desc = nullptr;     // strip rows some item reaches: {strip row, arena region begin, end, next of the chain}
+    uint2 *d_sr_list = nullptr;     // ... and, for large scenes, where their tile row's item list is
     uint32_t n_sr_active = 0;
     uint32_t bin_grid = 1;          // workgroups of pm_bin_kernel (each walks a chain of strip rows)
     uint32_t bin_prio_slots = 1024; // PM_BIN_PRIO_SLOTS
@@ -518,12 +520,15 @@ int EnsureArena(pm_ctx *c) {
         c->bin_grid = static_cast<uint32_t>(grid);
     }
     PM_TRY(SyncAll(c) == PM_OK ? hipSuccess : hipErrorUnknown);  // frames in flight still read the lists replaced below
-    if (desc.size() > c->sr_desc_cap) {  // (grow only: an animation re-sizes every frame)
+    if (desc.size() > c->sr_desc_cap || !c->d_sr_list) {  // (grow only: an animation re-sizes every frame)
         if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
+        if (c->d_sr_list) (void)hipFree(c->d_sr_list);
         c->d_sr_desc = nullptr;
+        c->d_sr_list = nullptr;
         c->sr_desc_cap = 0;
-        const size_t want = desc.size() + desc.size() / 4 + 16;
+        const size_t want = std::max<size_t>(desc.size() + desc.size() / 4 + 16, c->sr_desc_cap);
         PM_TRY(hipMalloc(&c->d_sr_desc, want * sizeof(uint4)));
+        PM_TRY(hipMalloc(&c->d_sr_list, want * sizeof(uint2)));
         c->sr_desc_cap = want;
     }
     PM_TRY(hipMemcpyAsync(c->d_sr_desc, desc.data(), desc.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
@@ -575,6 +580,14 @@ int EnsureArena(pm_ctx *c) {
                 c->row_base_cap = rb.size() + 64;
             }
             PM_TRY(hipMemcpyAsync(c->d_row_base, rb.data(), rb.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            // every strip row's descriptor gets its tile row's {first entry, entries} next to it
+            std::vector<uint2> &sl = c->stage_list;
+            sl.resize(c->stage_desc.size());
+            for (size_t i = 0; i < sl.size(); ++i) {
+                const uint32_t r = c->stage_desc[i].x >> 16;
+                sl[i] = r < rows ? make_uint2(rb[r], rb[r + 1] - rb[r]) : make_uint2(0u, 0u);
+            }
+            PM_TRY(hipMemcpyAsync(c->d_sr_list, sl.data(), sl.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
             const uint64_t want = std::max<uint64_t>(run, 1);
             for (auto &s : c->slot) {
                 if (s.row_cap >= want && s.d_row_bbox) continue;
@@ -631,6 +644,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->arena = s->d_arena;
     p->arena_cap = s->arena_cap;
     p->sr_desc = c->d_sr_desc;
+    p->sr_list = c->d_sr_list;
     p->n_sr_active = c->n_sr_active;
     p->bin_prio_slots = c->bin_prio_slots;
     p->bin_grid = c->bin_grid;
@@ -1152,6 +1166,7 @@ pm_ctx *pm_create(int device, int *err) {
         if (e == hipSuccess) e = hipMalloc(&c->d_sup_bbox, (1u << 16) * sizeof(float4));
         if (e == hipSuccess) c->sup_bbox_cap = 1u << 16;
         if (e == hipSuccess) e = hipMalloc(&c->d_sr_desc, 65536 * sizeof(uint4));
+        if (e == hipSuccess) e = hipMalloc(&c->d_sr_list, 65536 * sizeof(uint2));
         if (e == hipSuccess) c->sr_desc_cap = 65536;
         if (e == hipSuccess) e = hipMalloc(&c->d_band_bbox, 65536 * sizeof(uint2));
         if (e == hipSuccess) e = hipMalloc(&c->d_band_item, 65536 * sizeof(uint32_t));
@@ -1227,6 +1242,7 @@ void pm_destroy(pm_ctx *c) {
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
     if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
+    if (c->d_sr_list) (void)hipFree(c->d_sr_list);
     if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
     if (c->d_band_item) (void)hipFree(c->d_band_item);
     if (c->d_row_base) (void)hipFree(c->d_row_base);
