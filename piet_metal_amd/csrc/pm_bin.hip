@@ -339,7 +339,10 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         const bool fits = used + ts.qtotal <= shard_quads && used + ts.qtotal >= used && L.s_alloc[1] == 0u;
         // (on overflow the tiles are still queued but marked "no list": the tile kernels skip
         //  them, the frame has holes, and pm_sync re-renders it with a larger arena)
-        if (!fits && lane == 0) PM_PP(ctr_cur)->overflow = 1;
+        if (!fits && lane == 0) {
+            PM_PP(ctr_cur)->overflow = 1;
+            *PM_PP(host_overflow) = 1;
+        }
         if (ts.packed & 1u) {
             const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + lane;
             const uint32_t list_slot = fits ? base + ts.list_off : 0xffffffffu;
@@ -601,7 +604,10 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         }
         const uint32_t n_slots = sbase * kChunkSegs;  // slots of the record in use
         if (cursor + n_slots > cursor_back - 4u * n_slots || cursor_back - 4u * n_slots > cursor_back) {  // cannot happen unless the host bound is wrong
-            if (tid == 0) PM_PP(ctr_cur)->overflow = 1;
+            if (tid == 0) {
+                PM_PP(ctr_cur)->overflow = 1;
+                *PM_PP(host_overflow) = 1;
+            }
             break;
         }
         // the heaviest strip rows set the span of the launch: their waves win the issue arbitration

@@ -159,7 +159,10 @@ struct FrameSlot {
     uint32_t *d_row_item = nullptr;
     uint64_t row_cap = 0;         // entries allocated for them
     uint32_t state_epoch = 0;     // arena_epoch its tile_state was last reset for (0: never)
+    uint32_t vp_epoch = 0;        // viewport its buffers were allocated for (pm_ctx::vp_epoch; stale ones go when the slot is next used)
     pm::Counters *d_ctr = nullptr;  // two: a frame's binning kernel zeroes the one the slot's next frame uses
+    uint32_t *h_overflow = nullptr;  // pinned: raised by a frame of this slot whose tile arena ran out (what pm_sync looks at first)
+    uint32_t *d_overflow = nullptr;  // ... as the device sees it
     uint32_t parity = 0;
     hipEvent_t ev_done = nullptr;  // end of the slot's last frame
     bool in_flight = false;        // a frame using this slot was submitted; ev_done marks its end
@@ -214,6 +217,7 @@ struct pm_ctx {
     uint32_t row0 = 0, row1 = 0;
     size_t fb_stride = 0;
     size_t fb_bytes = 0;
+    uint32_t vp_epoch = 1;  // bumped by every resize / band change
 
     // binning state shared by the slots
     size_t sr_desc_cap = 0, band_cap = 0;
@@ -271,25 +275,31 @@ int SyncAll(pm_ctx *c) {
     return PM_OK;
 }
 
+void FreeSlotViewport(FrameSlot *s) {
+    if (s->d_fb) (void)hipFree(s->d_fb);
+    if (s->d_queue) (void)hipFree(s->d_queue);
+    if (s->d_tile_state) (void)hipFree(s->d_tile_state);
+    if (s->d_tile_ptcl) (void)hipFree(s->d_tile_ptcl);
+    if (s->d_tile_ncmd) (void)hipFree(s->d_tile_ncmd);
+    s->d_fb = nullptr;
+    s->d_queue = nullptr;
+    s->d_tile_state = s->d_tile_ptcl = s->d_tile_ncmd = nullptr;
+    s->state_epoch = 0;
+}
+
 void FreeViewport(pm_ctx *c) {
     for (auto &s : c->slot) {
-        if (s.d_fb) (void)hipFree(s.d_fb);
-        if (s.d_queue) (void)hipFree(s.d_queue);
-        if (s.d_tile_state) (void)hipFree(s.d_tile_state);
-        if (s.d_tile_ptcl) (void)hipFree(s.d_tile_ptcl);
-        if (s.d_tile_ncmd) (void)hipFree(s.d_tile_ncmd);
-        s.d_fb = nullptr;
-        s.d_queue = nullptr;
-        s.d_tile_state = s.d_tile_ptcl = s.d_tile_ncmd = nullptr;
+        FreeSlotViewport(&s);
         s.in_flight = false;
         s.needs_check = false;
-        s.state_epoch = 0;
     }
     c->last_slot = -1;
 }
 
 int AllocSlotViewport(pm_ctx *c, FrameSlot *s) {
-    if (s->d_fb) return PM_OK;  // (all five buffers exist, or none: a partial set is released below)
+    if (s->d_fb && s->vp_epoch == c->vp_epoch) return PM_OK;  // (all five buffers exist, or none: a partial set is released below)
+    FreeSlotViewport(s);  // (buffers of an earlier viewport: released now, when the slot is used again, not by the resize)
+    s->vp_epoch = c->vp_epoch;
     const size_t tiles = BandTiles(c);
     hipError_t e = hipMalloc(&s->d_fb, std::max<size_t>(c->fb_bytes, 16));
     if (e == hipSuccess) e = hipMalloc(&s->d_queue, pm::kClasses * tiles * sizeof(uint4));  // one queue per cost class
@@ -312,7 +322,14 @@ int AllocSlotViewport(pm_ctx *c, FrameSlot *s) {
 }
 
 int AllocViewport(pm_ctx *c) {
-    FreeViewport(c);
+    // (a resize releases and re-allocates frame slot 0's buffers only -- twenty hipFree of a large viewport are 1.5 ms --:
+    //  the other slots' go when a frame next uses them, AllocSlotViewport)
+    c->vp_epoch += 1;
+    for (auto &s : c->slot) {
+        s.in_flight = false;
+        s.needs_check = false;
+    }
+    c->last_slot = -1;
     const uint32_t rows = BandRows(c);
     c->fb_stride = static_cast<size_t>(c->width) * 4;
     c->fb_bytes = c->fb_stride * static_cast<size_t>(rows) * pm::kTileH;
@@ -658,6 +675,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->tile_ncmd = s->d_tile_ncmd;
     p->ctr_cur = s->d_ctr + s->parity;
     p->ctr_next = s->d_ctr + (s->parity ^ 1u);
+    p->host_overflow = s->d_overflow;
     p->band_bbox = c->d_band_bbox;
     p->band_item = c->d_band_item;
     p->n_band_items = c->n_band_items;
@@ -1138,6 +1156,11 @@ pm_ctx *pm_create(int device, int *err) {
         if ((e = hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming)) != hipSuccess) return fail(e, "hipEventCreate");
         if ((e = hipMalloc(&s.d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
         if ((e = hipMemset(s.d_ctr, 0, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMemset(counters)");
+        if ((e = hipHostMalloc(&s.h_overflow, 64, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(overflow word)");
+        *s.h_overflow = 0;
+        void *dp = nullptr;
+        if ((e = hipHostGetDevicePointer(&dp, s.h_overflow, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer");
+        s.d_overflow = static_cast<uint32_t *>(dp);
     }
     Luts *l = new (std::nothrow) Luts();
     if (!l) {
@@ -1239,6 +1262,7 @@ void pm_destroy(pm_ctx *c) {
         if (s.d_row_bbox) (void)hipFree(s.d_row_bbox);
         if (s.d_row_item) (void)hipFree(s.d_row_item);
         if (s.d_ctr) (void)hipFree(s.d_ctr);
+        if (s.h_overflow) (void)hipHostFree(s.h_overflow);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
     }
     if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
@@ -1436,6 +1460,9 @@ int pm_sync(pm_ctx *c) {
         uint64_t want = 0;
         for (int si : latest) {
             const FrameSlot &s = c->slot[si];
+            // (the slot's pinned word first: no frame of the slot has run out of arena since it was last cleared -- the usual
+            //  case -- and pm_sync costs no copy from the device, 15 us each)
+            if (*static_cast<volatile uint32_t *>(s.h_overflow) == 0u) continue;
             uint32_t overflow = 0;
             PM_TRY(hipMemcpy(&overflow, &s.params.ctr_cur->overflow, sizeof(overflow), hipMemcpyDeviceToHost));
             if (!overflow) continue;
@@ -1448,6 +1475,7 @@ int pm_sync(pm_ctx *c) {
             want = std::max<uint64_t>(want, std::max<uint64_t>(4ull * s.ptcl_cap, 2ull * top));
             redo.push_back(s.params);
         }
+        for (auto &t : c->slot) *t.h_overflow = 0;  // (nothing is in flight: every frame that raised one has been looked at or superseded)
         if (redo.empty()) return PM_OK;
         want = std::min<uint64_t>(0x7fffffffull, want);
         if (want <= c->ptcl_want) break;
@@ -1562,8 +1590,10 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
     if (r == PM_OK) e = hipEventRecord(c->ev[0], c->stream);
     // (every frame of the batch as a frame among others is launched: the per-frame decision would fold the
     //  first one's clearing into its tile kernel and leave that frame's clear events unrecorded)
+    // ... as Enqueue launches frames behind other frames: clearing in a launch of its own for large viewports, folded into
+    // the tile kernel's for small ones (round-3 advisor finding: the batch used to be timed unfolded at every size)
     const int fold_mode = c->fold_clear_mode;
-    if (fold_mode == 2) c->fold_clear_mode = 0;
+    if (fold_mode == 2) c->fold_clear_mode = BandTiles(c) < 16384u ? 1 : 0;
     const bool folded = c->fold_clear_mode == 1;
     for (int i = 0; i < iters && r == PM_OK; ++i) r = Enqueue(c, nullptr, c->fb_stride, nullptr, &tev[static_cast<size_t>(i) * 8]);
     c->fold_clear_mode = fold_mode;

@@ -135,6 +135,7 @@ struct FrameParams {
     uint32_t *tile_ncmd;      // [tiles] commands in the list (0: resolved to one colour)
     Counters *ctr_cur;
     Counters *ctr_next;
+    uint32_t *host_overflow;  // pinned host word the kernels ALSO raise when the tile arena runs out: pm_sync looks there, no copy from the device
     const uint2 *band_bbox;        // [n_band_items] bboxes of the items that reach this band, paint order
     const uint32_t *band_item;     // [n_band_items] their scene indices
     uint32_t n_band_items;

@@ -162,6 +162,7 @@ hipError_t hipGetLastError();
 hipError_t pm_emu_malloc(void **p, size_t n);
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return pm_emu_malloc(reinterpret_cast<void **>(p), n); }
 template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { return pm_emu_malloc(reinterpret_cast<void **>(p), n); }
+static inline hipError_t hipHostGetDevicePointer(void **dev, void *host, unsigned) { *dev = host; return hipSuccess; }
 hipError_t hipFree(void *p);
 hipError_t hipHostFree(void *p);
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
