@@ -68,23 +68,37 @@ __global__ __launch_bounds__(kBinThreads) void pm_rowcull_kernel(FrameParams P) 
     const uint32_t row_rel = blockIdx.x;
     const int y0 = static_cast<int>((P.row0 + row_rel) * kTileH);
     uint32_t out = P.row_base[row_rel];
-    for (uint32_t jb = 0; jb < P.n_band_items; jb += kBinThreads) {
-        const uint32_t j = jb + tid;
-        bool hit = false;
-        uint2 bb = make_uint2(0u, 0u);
-        uint32_t it = 0;
-        if (j < P.n_band_items) {
-            bb = P.band_bbox[j];
-            it = P.band_item[j];
-            const int by = static_cast<int>(bb.x >> 16), bw = static_cast<int>(bb.y >> 16);
-            hit = bw >= y0 && by < y0 + static_cast<int>(kTileH);  // row part of :198 / :214
+    // A lane tests kPer consecutive items per step (paint order = lane order = item order), one block scan per 2 048
+    // items: with one item per lane the 10 000 items of config 4 were 40 dependent steps, 30 us in front of every frame.
+    constexpr uint32_t kPer = 8;
+    for (uint32_t jb = 0; jb < P.n_band_items; jb += kBinThreads * kPer) {
+        const uint32_t j0 = jb + tid * kPer;
+        uint2 bb[kPer];
+        uint32_t it[kPer];
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            bb[u] = make_uint2(0u, 0u);
+            it[u] = 0;
+            if (j0 + u < P.n_band_items) {
+                bb[u] = P.band_bbox[j0 + u];
+                it[u] = P.band_item[j0 + u];
+            }
+        }
+        uint32_t hits = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u) {
+            const int by = static_cast<int>(bb[u].x >> 16), bw = static_cast<int>(bb[u].y >> 16);
+            if (j0 + u < P.n_band_items && bw >= y0 && by < y0 + static_cast<int>(kTileH)) hits |= 1u << u;  // row part of :198 / :214
         }
         uint32_t total;
-        const uint32_t pos = BlockRank<kBinWaves>(hit, s_part, &total);
-        if (hit) {
-            P.row_bbox[out + pos] = bb;
-            P.row_item[out + pos] = it;
-        }
+        uint32_t pos = out + BlockExclusiveScan<kBinWaves>(static_cast<uint32_t>(__popc(hits)), s_part, &total);
+#pragma unroll
+        for (uint32_t u = 0; u < kPer; ++u)
+            if ((hits >> u) & 1u) {
+                P.row_bbox[pos] = bb[u];
+                P.row_item[pos] = it[u];
+                ++pos;
+            }
         out += total;
     }
 }
