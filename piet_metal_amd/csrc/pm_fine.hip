@@ -771,7 +771,9 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     // P.handout_static: the host saw other frames in flight -- with neighbours filling the idle
     // SIMDs a drawn hand-out only adds contention (sustained throughput -3.5 %), alone it ends the
     // launch 4.6 us earlier.
-    const uint32_t static_passes = P.handout_static ? 0x7fffffffu / n_waves : max(1u, (s_h + n_waves - 1u) / n_waves);
+    // (a dense frame -- every tile a single wave's, s_h = its long lists -- deals the first pass only: thirteen static
+    //  passes of config 4's 65 k tiles left the slowest wave 40 % behind the mean)
+    const uint32_t static_passes = P.handout_static ? 0x7fffffffu / n_waves : (dense ? 1u : max(1u, (s_h + n_waves - 1u) / n_waves));
     const uint32_t n_static = static_passes * n_waves;
     // (a grid with fewer waves than decks -- a small device or partition -- uses as many decks as it
     //  has waves: a deck nobody draws from would leave its tiles unrendered)
