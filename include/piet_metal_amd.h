@@ -314,6 +314,9 @@ int pm_gather(pm_ctx *c, pm_comm *m, const void *src_band, size_t src_stride, co
  *                      first pm_render after a scene or viewport change */
 typedef struct {
     float flatten_encode_ms, scene_index_ms, arena_setup_ms;
+    uint32_t binning_plans; /* binning plans made since pm_create (strip-row regions sized, lists uploaded): a scene
+                             * after pm_reflatten keeps the plan in force while every item stays inside the box
+                             * -- one tile wider on each side -- and the segment count it was planned with */
 } pm_scene_timings;
 int pm_get_scene_timings(pm_ctx *c, pm_scene_timings *out);
 

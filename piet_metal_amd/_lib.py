@@ -68,7 +68,7 @@ class Stats(C.Structure):
 
 
 class SceneTimings(C.Structure):
-    _fields_ = [("flatten_encode_ms", C.c_float), ("scene_index_ms", C.c_float), ("arena_setup_ms", C.c_float)]
+    _fields_ = [("flatten_encode_ms", C.c_float), ("scene_index_ms", C.c_float), ("arena_setup_ms", C.c_float), ("binning_plans", C.c_uint32)]
 
 
 class Cmd(C.Structure):

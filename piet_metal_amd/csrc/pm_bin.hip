@@ -162,7 +162,7 @@ struct BinLds {
     uint32_t s_wcnt[kBinWaves][kStripTiles];  // relevant segments per tile in each wave's share of the slots
     // finalisation, per wave of candidates and tile: candidates that can emit, their relevant segments,
     // pseudo elements (candidates without segments), last candidate that can emit / last opaque Solid (index + 1)
-    uint32_t s_wh[kStripTiles], s_we[kStripTiles];
+    uint32_t s_wh[kStripTiles];
     uint32_t s_wlk[kStripTiles], s_wls[kStripTiles];
     uint32_t s_whub[kBinWaves][kStripTiles];  // per wave of candidates and tile: candidates whose bbox reaches the tile
     uint32_t s_alloc[2];  // {first quad of this record's pieces (0xffffffff: the tile arena ran out), overflow seen}
@@ -221,9 +221,10 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         band_bbox = PM_PP(row_bbox) + lo;
         band_item = PM_PP(row_item) + lo;
     }
+    // (band_item == nullptr: the list is the scene's item list itself, band_bbox its ShortBbox array)
     if (tid < n_band) {
         bb_next = band_bbox[tid];
-        it_next = band_item[tid];
+        it_next = band_item != nullptr ? band_item[tid] : tid;
     }
     // the two colour tables ride along with the first bbox load (finalisation reads them from LDS)
     const uint32_t lut_word = PM_PP(lut_srgb2lin)[tid] | (PM_PP(lut_unorm2h)[tid] << 16);
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         const uint32_t i = it_next;  // scene index of band item j
         if (j + kBatch < n_band) {
             bb_next = band_bbox[j + kBatch];
-            it_next = band_item[j + kBatch];
+            it_next = band_item != nullptr ? band_item[j + kBatch] : j + kBatch;
         }
         if (more && tid < kBatch && j < n_band) {
             const int bx = static_cast<int>(bb.x & 0xffffu), by = static_cast<int>(bb.x >> 16);
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
             rule = (L.s_caux0[c] & kFillEvenOdd) ? 1u : 0xffffffffu;
         };
         {
-            uint32_t nh_q[4] = {0u, 0u, 0u, 0u}, ne_q[4] = {0u, 0u, 0u, 0u}, lk_q[4] = {0u, 0u, 0u, 0u}, ls_q[4] = {0u, 0u, 0u, 0u};  // (uniform)
+            uint32_t nh_q[4] = {0u, 0u, 0u, 0u}, lk_q[4] = {0u, 0u, 0u, 0u}, ls_q[4] = {0u, 0u, 0u, 0u};  // (uniform)
 #pragma unroll 1
             for (uint32_t g = 0; g < n_groups; ++g) {
                 const uint32_t c = g * 64u + Opaque(lane);
@@ -884,9 +885,8 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                     const uint32_t hit = some & (cm >> t) & 1u;
                     const uint32_t nos = cnt == 0u ? hit : 0u;
                     hb |= hit << j;
-                    const uint64_t bh = __ballot(hit), bz = __ballot(nos), bs = __ballot(nos & opaque_bit);
+                    const uint64_t bh = __ballot(hit), bs = __ballot(nos & opaque_bit);
                     nh_q[j] += static_cast<uint32_t>(__popcll(bh));
-                    ne_q[j] += static_cast<uint32_t>(__popcll(bz));
                     if (bh) lk_q[j] = g * 64u + 64u - static_cast<uint32_t>(__builtin_clzll(bh));  // candidate index + 1
                     if (bs) ls_q[j] = g * 64u + 64u - static_cast<uint32_t>(__builtin_clzll(bs));
                 }
@@ -900,7 +900,6 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
             if (lane < 4u) {
                 const uint32_t j = lane, t = t0 + lane;
                 L.s_wh[t] = j == 0 ? nh_q[0] : (j == 1 ? nh_q[1] : (j == 2 ? nh_q[2] : nh_q[3]));
-                L.s_we[t] = j == 0 ? ne_q[0] : (j == 1 ? ne_q[1] : (j == 2 ? ne_q[2] : ne_q[3]));
                 L.s_wlk[t] = j == 0 ? lk_q[0] : (j == 1 ? lk_q[1] : (j == 2 ? lk_q[2] : lk_q[3]));
                 L.s_wls[t] = j == 0 ? ls_q[0] : (j == 1 ? ls_q[1] : (j == 2 ? ls_q[2] : ls_q[3]));
             }
@@ -930,11 +929,10 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         //      LAST record also the row's tail -- classes, command-list space, queue entries -- while
         //      the other waves already place candidates and segments --------------------------------------
         if (wave == kTailWave) {
-            uint32_t nh = 0, ne = 0, lkm = 0, lsm = 0;
+            uint32_t nh = 0, lkm = 0, lsm = 0;
             uint32_t hdr_q = 0, hdr_prev = 0, hdr_n = 0;
             if (lane < kStripTiles) {
                 nh = L.s_wh[lane];
-                ne = L.s_we[lane];
                 lkm = L.s_wlk[lane];
                 lsm = L.s_wls[lane];
                 L.s_est[lane] += nrel_t + nh;  // (segments + closing commands: what the list will be about as long as -- and an upper bound basis for its space, 3 x this + 1)

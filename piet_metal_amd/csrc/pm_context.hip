@@ -194,6 +194,10 @@ struct pm_ctx {
     size_t scene_cap = 0;        // its capacity
     uint8_t *d_scene = nullptr;
     size_t dev_scene_cap = 0;    // >= scene_cap: the device copy also grows on its own (flat groups, device flatten)
+    // what the flatten kernels write while frames in flight still read d_scene; the two change places when the new scene is in
+    // (a view change then no longer begins by waiting for the previous frame: 0.197 -> 0.15 ms per re-encoded 4K Tiger frame)
+    uint8_t *d_scene_alt = nullptr;
+    size_t dev_scene_alt_cap = 0;
     size_t scene_bytes = 0;       // resident bytes (with the flat form of nested groups appended)
     size_t user_scene_bytes = 0;  // what the caller uploaded / the flatten kernels wrote
     uint32_t dev_bbox_ix = 8, dev_items_ix = 0;  // the drawn group's ShortBbox / item arrays in d_scene
@@ -236,6 +240,15 @@ struct pm_ctx {
     uint32_t arena_cap = 0;         // dwords per slot
     uint64_t ptcl_want = 0;         // commands a slot's list arena starts with / was grown to
     bool arena_dirty = true;
+    // The plan in force (strip-row work list, arena regions, band list) and the item boxes it was made for.  A view change
+    // (pm_reflatten) plans with every box widened by a tile, so that the scenes that follow can keep the plan while their boxes
+    // stay inside the widened ones and their items keep their segment counts: no host sizing, no uploads, no waits
+    // (0.04 of an animated frame's 0.18 ms).
+    std::vector<uint16_t> plan_box;   // [4 n] widened boxes
+    std::vector<uint32_t> plan_per;   // [n] arena dwords per item
+    bool plan_reusable = false;       // the plan was made with widened boxes, for the whole item list in scene order, without per-row lists
+    bool replan_wide = false;         // the next plan widens the boxes (set by pm_reflatten)
+    bool band_identity = false;       // the band's item list IS the scene's item list: the kernels read the scene's own boxes
     uint32_t arena_epoch = 0;       // bumped whenever the set of strip rows without a workgroup changes (EnsureArena)
 
     std::vector<FrameSlot> slot;
@@ -246,6 +259,7 @@ struct pm_ctx {
 
     // wall-clock cost of the last scene replacement, host view (pm_get_scene_timings)
     float t_flatten_ms = 0, t_index_ms = 0, t_arena_ms = 0;
+    uint32_t plans_made = 0;
 
     // tables
     uint32_t *d_lut_srgb2lin = nullptr;
@@ -338,6 +352,7 @@ int AllocViewport(pm_ctx *c) {
     const int r0 = AllocSlotViewport(c, &c->slot[0]);
     if (r0 != PM_OK) return r0;
     c->arena_dirty = true;
+    c->plan_reusable = false;  // (another viewport or band: the plan goes with it)
     return PM_OK;
 }
 
@@ -403,7 +418,7 @@ int EnsureSlotBuffers(pm_ctx *c, FrameSlot *s) {
 // costs kChunkSegs segment slots (16 B) + meta words per chunk (every chunk surviving), plus a token
 // amount that tells a strip row some item reaches from one nothing reaches.  The binning kernel
 // bump-allocates inside these private regions, so the bound must be exact or larger.
-void StripRowBounds(pm_ctx *c, std::vector<uint64_t> *need) {
+void StripRowBounds(pm_ctx *c, std::vector<uint64_t> *need, int margin) {
     const uint8_t *meta = c->item_meta.data();
     uint32_t n, items_ix;
     std::memcpy(&n, meta, 4);
@@ -413,9 +428,17 @@ void StripRowBounds(pm_ctx *c, std::vector<uint64_t> *need) {
     const size_t w = static_cast<size_t>(c->strips_x) + 1;
     std::vector<uint64_t> &diff = c->stage_need_diff;
     diff.assign((static_cast<size_t>(rows) + 1) * w, 0);
+    c->plan_box.resize(4ull * n);
+    c->plan_per.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
         uint16_t bb[4];
         std::memcpy(bb, meta + 8 + 8ull * i, 8);
+        // (the box the plan is made for: the item's own, or widened by `margin` pixels on every side)
+        bb[0] = static_cast<uint16_t>(std::max(0, static_cast<int>(bb[0]) - margin));
+        bb[1] = static_cast<uint16_t>(std::max(0, static_cast<int>(bb[1]) - margin));
+        bb[2] = static_cast<uint16_t>(std::min(65535, static_cast<int>(bb[2]) + margin));
+        bb[3] = static_cast<uint16_t>(std::min(65535, static_cast<int>(bb[3]) + margin));
+        std::memcpy(&c->plan_box[4ull * i], bb, 8);
         const uint8_t *it = meta + items_ix + 32ull * i;
         uint32_t tag, npt = 0;
         std::memcpy(&tag, it, 4);
@@ -425,8 +448,10 @@ void StripRowBounds(pm_ctx *c, std::vector<uint64_t> *need) {
         if (tag == pm::kItemFill) nseg = npt;
         if (tag == pm::kItemPoly && npt >= 2) nseg = npt - 1;
         if (tag == pm::kItemLine) nseg = 1;
+        if (margin > 0 && tag != pm::kItemLine) nseg += nseg / 4 + 2 * pm::kChunkSegs;  // (a zooming view: curves flatten into more segments as they grow)
         const uint64_t nch = (nseg + pm::kChunkSegs - 1) / pm::kChunkSegs;
         const uint64_t per = 4u + static_cast<uint64_t>(pm::kSlotDwords) * pm::kChunkSegs * nch;
+        c->plan_per[i] = static_cast<uint32_t>(std::min<uint64_t>(per, 0xffffffffull));
         // strips: bz >= sx0 && bx < sx0 + 256 ; rows: bw >= y0 && by < y0 + 16
         const int64_t s_lo = bb[0] / 256, s_hi = std::min<int64_t>(bb[2] / 256, static_cast<int64_t>(c->strips_x) - 1);
         const int64_t r_lo = std::max<int64_t>(bb[1] / 16, c->row0), r_hi = std::min<int64_t>(bb[3] / 16, static_cast<int64_t>(c->row1) - 1);
@@ -452,9 +477,42 @@ int EnsureArena(pm_ctx *c) {
     if (!c->arena_dirty && c->arena_cap != 0) return PM_OK;
     if (c->item_meta.empty() || c->tiles_x == 0) return PM_OK;  // nothing to size against yet
     const WallTimer timer;
+    {
+        // Does the plan in force still hold?  Same items in the same order, every item with the arena need it was planned with
+        // and its box inside the (widened) box it was planned with.
+        const uint8_t *meta = c->item_meta.data();
+        uint32_t n, items_ix;
+        std::memcpy(&n, meta, 4);
+        std::memcpy(&items_ix, meta + 4, 4);
+        bool ok = c->plan_reusable && c->arena_cap != 0 && c->band_identity && n == c->plan_per.size() && n == c->n_band_items;
+        for (uint32_t i = 0; i < n && ok; ++i) {
+            uint16_t bb[4];
+            std::memcpy(bb, meta + 8 + 8ull * i, 8);
+            const uint16_t *pb = &c->plan_box[4ull * i];
+            const uint8_t *it = meta + items_ix + 32ull * i;
+            uint32_t tag, npt = 0;
+            std::memcpy(&tag, it, 4);
+            tag &= 0xffffu;
+            std::memcpy(&npt, it + 12, 4);
+            uint64_t nseg = 0;
+            if (tag == pm::kItemFill) nseg = npt;
+            if (tag == pm::kItemPoly && npt >= 2) nseg = npt - 1;
+            if (tag == pm::kItemLine) nseg = 1;
+            const uint64_t per = 4u + static_cast<uint64_t>(pm::kSlotDwords) * pm::kChunkSegs * ((nseg + pm::kChunkSegs - 1) / pm::kChunkSegs);
+            ok = per <= c->plan_per[i] && bb[0] >= pb[0] && bb[1] >= pb[1] && bb[2] <= pb[2] && bb[3] <= pb[3] && bb[2] >= bb[0] && bb[3] >= bb[1];
+        }
+        if (ok) {
+            // (the scene index of the new scene is still being built on the context's stream; frames run on the others)
+            PM_TRY(hipStreamSynchronize(c->stream));
+            c->arena_dirty = false;
+            c->t_arena_ms = timer.ms();
+            return PM_OK;
+        }
+    }
     // (host work first: the scene-index kernel of a scene replacement is still running on the device)
+    const int margin = c->replan_wide ? static_cast<int>(pm::kTileW) : 0;
     std::vector<uint64_t> need;
-    StripRowBounds(c, &need);
+    StripRowBounds(c, &need, margin);
     // (host work before any upload: the band's item list, the arena regions)
     c->sr_empty_dwords = 0;  // (a strip row no item's bbox reaches has nothing reserved)
     // the items whose bbox reaches the band (rows: bw >= y0 && by < y1, PietRender.metal:198/:214), paint order
@@ -468,15 +526,19 @@ int EnsureArena(pm_ctx *c) {
         for (uint32_t i = 0; i < c->n_items; ++i) {
             uint32_t w[2];
             std::memcpy(w, meta + 8 + 8ull * i, 8);
-            const uint32_t bx = w[0] & 0xffffu, by = w[0] >> 16, bw = w[1] >> 16;
+            const uint16_t *pb = &c->plan_box[4ull * i];  // (the box the plan is made for: widened for a view change)
+            const uint32_t bx = pb[0], by = pb[1], bw = pb[3];
             if (bw >= y0 && by < y1 && bx < c->strips_x * pm::kGroupW) {
                 bbs.push_back(make_uint2(w[0], w[1]));
                 ids.push_back(i);
             }
         }
         c->n_band_items = static_cast<uint32_t>(ids.size());
+        // every item of the scene, in scene order: the kernels can read the scene's own boxes (nothing to upload, and the
+        // list stays right for the next scene with the same items)
         const int min_items = EnvInt("PM_ROW_LIST_MIN_ITEMS", 2048, 0, 1 << 30);
         c->use_row_lists = static_cast<int>(ids.size()) >= min_items && !ids.empty();
+        c->band_identity = ids.size() == c->n_items && !c->use_row_lists;
     }
     // The strip rows some item's bbox reaches get a workgroup of pm_bin_kernel each; the others are
     // background for as long as this scene and viewport last: their tile_state is set to white
@@ -562,7 +624,7 @@ int EnsureArena(pm_ctx *c) {
             PM_TRY(hipMalloc(&c->d_band_item, want * sizeof(uint32_t)));
             c->band_cap = want;
         }
-        if (!ids.empty()) {
+        if (!ids.empty() && !c->band_identity) {
             PM_TRY(hipMemcpyAsync(c->d_band_bbox, bbs.data(), ids.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
             PM_TRY(hipMemcpyAsync(c->d_band_item, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         }
@@ -620,6 +682,8 @@ int EnsureArena(pm_ctx *c) {
         }
     }
     PM_TRY(hipStreamSynchronize(c->stream));  // ONE wait: the lists are in place before a frame on any stream reads them
+    c->plan_reusable = margin > 0 && c->band_identity;
+    c->plans_made += 1;
     c->arena_dirty = false;
     c->t_arena_ms = timer.ms();
     return PM_OK;
@@ -676,8 +740,9 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->ctr_cur = s->d_ctr + s->parity;
     p->ctr_next = s->d_ctr + (s->parity ^ 1u);
     p->host_overflow = s->d_overflow;
-    p->band_bbox = c->d_band_bbox;
-    p->band_item = c->d_band_item;
+    // (the whole item list in scene order: the scene's own boxes, no list of indices)
+    p->band_bbox = c->band_identity ? reinterpret_cast<const uint2 *>(c->d_scene + c->dev_bbox_ix) : c->d_band_bbox;
+    p->band_item = c->band_identity ? nullptr : c->d_band_item;
     p->n_band_items = c->n_band_items;
     p->split_mode = c->split_mode;
     {
@@ -1272,6 +1337,7 @@ void pm_destroy(pm_ctx *c) {
     if (c->d_row_base) (void)hipFree(c->d_row_base);
     c->flatten_cache.Free();
     if (c->d_scene) (void)hipFree(c->d_scene);
+    if (c->d_scene_alt) (void)hipFree(c->d_scene_alt);
     if (c->h_scene) (void)hipHostFree(c->h_scene);
     if (c->d_chunk_base) (void)hipFree(c->d_chunk_base);
     if (c->d_chunk_bbox) (void)hipFree(c->d_chunk_bbox);
@@ -1330,6 +1396,8 @@ int pm_upload_scene(pm_ctx *c, size_t bytes) {
     int r = SyncAll(c);  // frames in flight still read the old scene
     if (r != PM_OK) return r;
     InvalidateScene(c);
+    c->replan_wide = false;
+    c->plan_reusable = false;
     c->t_flatten_ms = 0;
     PM_TRY(hipMemcpyAsync(c->d_scene, c->h_scene, bytes, hipMemcpyHostToDevice, c->stream));
     return SetScene(c, bytes, c->h_scene);  // (stream order: the appended flat group follows the upload)
@@ -1343,6 +1411,8 @@ int FlattenAndEncode(pm_ctx *c, bool resident, const pm_path *paths, size_t n_pa
 int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const pm_path_el *els, size_t n_els,
                           const double affine[6], float width_scale, size_t *scene_bytes, uint32_t *n_items) {
     if (!c || !affine || (n_paths && !paths) || (n_els && !els)) return PM_ERR_INVALID;
+    c->replan_wide = false;
+    c->plan_reusable = false;  // (new paths: planned afresh, for their own boxes)
     return FlattenAndEncode(c, false, paths, n_paths, els, n_els, affine, width_scale, scene_bytes, n_items);
 }
 
@@ -1350,30 +1420,50 @@ namespace {
 int FlattenAndEncode(pm_ctx *c, bool resident, const pm_path *paths, size_t n_paths, const pm_path_el *els, size_t n_els,
                      const double affine[6], float width_scale, size_t *scene_bytes, uint32_t *n_items) {
     PM_TRY(hipSetDevice(c->device));
-    {
-        const int rs = SyncAll(c);  // frames in flight still read the old scene
-        if (rs != PM_OK) return rs;
-    }
     size_t bytes = 0;
     uint32_t items = 0;
     hipError_t he = hipSuccess;
-    InvalidateScene(c);  // the kernels below overwrite d_scene
     const WallTimer timer;
-    int r = pm::FlattenEncodeOnDevice(c->stream, &c->flatten_cache, resident, paths, n_paths, els, n_els, affine, width_scale, c->d_scene,
-                                      c->dev_scene_cap, &bytes, &items, &he);
-    if (r == PM_ERR_CAPACITY && bytes > c->dev_scene_cap) {
-        // grow the device copy (the kernels write it; nothing is staged on the host) and retry once
-        const int rr = ReserveDevice(c, bytes + (bytes >> 3));
-        if (rr != PM_OK) return rr;
-        r = pm::FlattenEncodeOnDevice(c->stream, &c->flatten_cache, resident, paths, n_paths, els, n_els, affine, width_scale, c->d_scene,
-                                      c->dev_scene_cap, &bytes, &items, &he);
+    // The kernels write the OTHER scene buffer: frames in flight keep reading the current one meanwhile (nothing reads
+    // the other one: every scene replacement ends with all frames waited for, below).
+    auto grow_alt = [&](size_t cap) -> int {
+        if (cap <= c->dev_scene_alt_cap && c->d_scene_alt) return PM_OK;
+        const int rc = CheckSceneCap(cap);
+        if (rc != PM_OK) return rc;
+        if (c->d_scene_alt) (void)hipFree(c->d_scene_alt);
+        c->d_scene_alt = nullptr;
+        c->dev_scene_alt_cap = 0;
+        PM_TRY(hipMalloc(&c->d_scene_alt, cap));
+        c->dev_scene_alt_cap = cap;
+        return PM_OK;
+    };
+    int r = grow_alt(c->dev_scene_cap);
+    if (r == PM_OK)
+        r = pm::FlattenEncodeOnDevice(c->stream, &c->flatten_cache, resident, paths, n_paths, els, n_els, affine, width_scale, c->d_scene_alt,
+                                      c->dev_scene_alt_cap, &bytes, &items, &he);
+    if (r == PM_ERR_CAPACITY && bytes > c->dev_scene_alt_cap) {
+        // grow it (the kernels write it; nothing is staged on the host) and retry once
+        r = grow_alt(bytes + (bytes >> 3));
+        if (r == PM_OK)
+            r = pm::FlattenEncodeOnDevice(c->stream, &c->flatten_cache, resident, paths, n_paths, els, n_els, affine, width_scale, c->d_scene_alt,
+                                          c->dev_scene_alt_cap, &bytes, &items, &he);
+    }
+    const float flatten_ms = timer.ms();
+    {
+        // ... and only now the frames in flight are waited for: they read the current scene buffer, and the scene index and
+        // binning lists SetScene / the next frame replace.  Whatever happened above, the old scene is gone after this call.
+        const int rs = SyncAll(c);
+        InvalidateScene(c);
+        if (rs != PM_OK) return rs;
     }
     if (r == PM_ERR_HIP) return HipFail(he, "flatten kernels");
     if (r != PM_OK) {
-        SetError("flatten/encode rejected the paths");
+        if (r != PM_ERR_CAPACITY || g_last_error.empty()) SetError("flatten/encode rejected the paths");
         return r;
     }
-    c->t_flatten_ms = timer.ms();
+    std::swap(c->d_scene, c->d_scene_alt);
+    std::swap(c->dev_scene_cap, c->dev_scene_alt_cap);
+    c->t_flatten_ms = flatten_ms;
     r = SetScene(c, bytes, nullptr);
     if (r != PM_OK) return r;
     if (scene_bytes) *scene_bytes = bytes;
@@ -1388,6 +1478,7 @@ int pm_reflatten(pm_ctx *c, const double affine[6], float width_scale, size_t *s
         SetError("pm_reflatten: no paths resident (pm_flatten_and_encode first)");
         return PM_ERR_INVALID;
     }
+    c->replan_wide = true;  // (a view change: the next plan is made to last, EnsureArena)
     return FlattenAndEncode(c, true, nullptr, 0, nullptr, 0, affine, width_scale, scene_bytes, n_items);
 }
 
@@ -1547,7 +1638,7 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             const int si = static_cast<int>(c->frame % c->slot.size());
             FrameSlot *s = &c->slot[si];
             pm::FrameParams p;
-            if ((r = BuildParams(c, s, s->d_fb, c->fb_stride, &p)) != PM_OK) return r;
+            if ((r = BuildParams(c, s, nullptr, c->fb_stride, &p)) != PM_OK) return r;
             // each dispatch carries its own begin / end events: pure kernel durations
             PM_TRY(ResetTileState(c, s, c->stream));
             pm::LaunchBin(p, c->stream, c->ev[0], c->ev[1]);
@@ -1725,6 +1816,7 @@ int pm_get_scene_timings(pm_ctx *c, pm_scene_timings *out) {
     out->flatten_encode_ms = c->t_flatten_ms;
     out->scene_index_ms = c->t_index_ms;
     out->arena_setup_ms = c->t_arena_ms;
+    out->binning_plans = c->plans_made;
     return PM_OK;
 }
 
@@ -1786,7 +1878,7 @@ int pm_fill_coverage(pm_ctx *c, uint32_t item_ix, float *dst, size_t dst_stride_
         const int si = static_cast<int>(c->frame % c->slot.size());
         FrameSlot *s = &c->slot[si];
         pm::FrameParams p;
-        status = BuildParams(c, s, s->d_fb, c->fb_stride, &p);
+        status = BuildParams(c, s, nullptr, c->fb_stride, &p);
         if (status == PM_OK) {
             p.dbg_counts = d_counts;
             p.dbg_solid = d_solid;
@@ -1893,7 +1985,7 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
     const int si = static_cast<int>(c->frame % c->slot.size());
     FrameSlot *s = &c->slot[si];
     pm::FrameParams p;
-    r = BuildParams(c, s, s->d_fb, c->fb_stride, &p);
+    r = BuildParams(c, s, nullptr, c->fb_stride, &p);
     if (r == PM_OK) {
         p.dbg_bin = d;
         hipError_t e = ResetTileState(c, s, c->stream);

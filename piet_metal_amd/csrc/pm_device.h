@@ -137,7 +137,7 @@ struct FrameParams {
     Counters *ctr_next;
     uint32_t *host_overflow;  // pinned host word the kernels ALSO raise when the tile arena runs out: pm_sync looks there, no copy from the device
     const uint2 *band_bbox;        // [n_band_items] bboxes of the items that reach this band, paint order
-    const uint32_t *band_item;     // [n_band_items] their scene indices
+    const uint32_t *band_item;     // [n_band_items] their scene indices (nullptr: every item in scene order -- band_bbox is the scene's own ShortBbox array)
     uint32_t n_band_items;
     uint32_t fine_grid;            // persistent workgroups of pm_fine_kernel (blocks beyond it clear strip rows)
     uint32_t split_mode;           // fine kernel: 0 = one wave per tile always, 1 = a workgroup per tile with a long list

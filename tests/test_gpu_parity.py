@@ -1131,3 +1131,42 @@ def test_strict_barrier_build_renders_the_same_bytes(pm, golden):
     assert outs[""] == outs["strict"]
     for cfg, name in (("config2", "tiger_1920x1080_fills"), ("config3", "tiger_3840x2160"), ("config4", "blobs_10000_4096")):
         assert outs[""][cfg] == golden[name]["rgba_sha256"], cfg
+
+
+def test_view_changes_keep_their_plan_while_the_boxes_stay_inside(pm, pmo, renderer):
+    """A view change (pm_reflatten) plans binning for item boxes widened by a tile; the scenes that follow keep that
+    plan -- no host sizing, no uploads -- while their boxes stay inside the widened ones, and get a new one when an
+    item leaves its box, changes its segment count, or the viewport changes.  Forty small steps of a drifting, slowly
+    zooming Tiger, then a jump: every frame equals the oracle's render of the scene bytes the device flattened."""
+    wl = pm.workloads.tiger(560, 352)
+    renderer.resize(wl.width, wl.height)
+    renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    renderer.render()
+    a = list(wl.affine)
+    plans = []
+    for k in range(44):
+        if k == 40:  # a jump: boxes leave the plan's
+            a[4] += 90.0
+            a[5] += 37.0
+        a[4] += 0.37
+        a[5] -= 0.21
+        a[0] *= 1.0007
+        a[3] *= 1.0007
+        renderer.reflatten(tuple(a), wl.width_scale * a[0] / wl.affine[0])
+        scene = renderer.download_scene()
+        for _ in range(1 + k % 3):  # frames in flight on several slots
+            renderer.render()
+        assert np.array_equal(renderer.read_pixels(), pmo.render(scene, wl.width, wl.height)), k
+        plans.append(renderer.scene_timings()["binning_plans"])
+        if k == 20:
+            assert_ptcl_equal(renderer, pmo, scene, wl.width, wl.height)
+    # the first view change plans (wide boxes); the steps up to the jump keep that plan but for the few where the zoom has
+    # pushed an item out of its box; the jump plans again
+    assert plans[0] == plans[3] and plans[39] - plans[0] <= 4, plans
+    assert plans[40] == plans[39] + 1, plans
+    renderer.resize(wl.width + 64, wl.height)  # another viewport: the plan goes
+    renderer.reflatten(tuple(a), wl.width_scale * a[0] / wl.affine[0])
+    scene = renderer.download_scene()
+    renderer.render()
+    assert np.array_equal(renderer.read_pixels(), pmo.render(scene, wl.width + 64, wl.height))
+
