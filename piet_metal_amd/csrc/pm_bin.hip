@@ -123,15 +123,21 @@ constexpr uint32_t kCtStride = kStripTiles + 1;  // row stride 17: a thread per 
 #define PM_BIN_SURV_LDS 512
 #endif
 constexpr uint32_t kSurvLds = PM_BIN_SURV_LDS;
-constexpr uint32_t kSupCPL = 2;                         // super-chunks tested per lane and round
-constexpr uint32_t kSupLds = kBinThreads * kSupCPL;     // ... so a round leaves at most this many survivors
+constexpr uint32_t kSupCPL = 2;                         // super-chunks tested per lane and round (a round leaves at most threads x this many survivors)
 constexpr uint32_t kChunkCPL = 4;                       // chunks tested per lane and round: half a super-chunk
-static_assert(kSuperChunks == 2 * kChunkCPL && kSupLds <= kThreads * kCtStride, "two lanes per surviving super; the list fits in s_ct");
+static_assert(kSuperChunks == 2 * kChunkCPL && kSupCPL <= kCtStride, "two lanes per surviving super; the list fits in s_ct");
 // 0.5 * width + 0.5 of a polyline / line candidate, from the width bits its aux0 word carries (the
 // expression the header phase used to store per candidate: one LDS array less)
 __device__ __forceinline__ float HalfWidthOf(uint32_t aux0) { return 0.5f * __uint_as_float(aux0) + 0.5f; }
 
+// kW = waves that share one strip row: 4 (a workgroup per strip row), or 1 -- a wave per strip row, no workgroup
+// barrier anywhere, four times as many strip rows resident (frames with many more strip rows than the chip holds
+// workgroups, config 5: every phase of a light row is a chain of dependent round trips, not work).
+template <int kW>
 struct BinLds {
+    static constexpr int kThreads = 64 * kW;   // (hides pm::kThreads: candidates of a record = threads of the group)
+    static constexpr int kBinWaves = kW;
+    static constexpr uint32_t kSurvLds = kW == 1 ? (pm::kSurvLds < 256u ? pm::kSurvLds : 256u) : pm::kSurvLds;
     uint32_t s_part[kBinWaves];
     uint32_t s_cidx[kThreads];   // candidate item index
     uint32_t s_cmask[kThreads];  // candidate per-tile hit mask (16 bits) | item tag << 16
@@ -170,20 +176,36 @@ struct BinLds {
 
 };
 
-// BinLds is kept at 30.5 KB (tag and bbox mask share a word, segment counts and stroke half-widths are
+// BinLds<4> is kept at 30.5 KB (tag and bbox mask share a word, segment counts and stroke half-widths are
 // derived, 512 survivors in LDS): FIVE workgroups then share a CU -- measured: 31 184 B does, 32 208 B does
 // not -- its own, or the tile kernel's (30.6 KB each) of the neighbouring frames.  Config 5 alone: binning
 // 0.313 -> 0.270 ms; sustained throughput +4 % in every configuration.
-static_assert(sizeof(BinLds) <= 31232 || kSurvLds != 512, "five workgroups per CU");
+static_assert(sizeof(BinLds<4>) <= 31232 || kSurvLds != 512, "five workgroups per CU");
+static_assert(sizeof(BinLds<1>) <= 10240, "sixteen one-wave groups per CU");
 
-template <bool kProfile>
-__global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
+template <bool kProfile, int kW>
+__global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
+    // (the names the body was written with, for kW waves per strip row: they hide the namespace's)
+    constexpr int kBinWaves = kW;
+    constexpr int kBinThreads = 64 * kW;
+    constexpr uint32_t kBatch = 64u * kW;               // candidates per record
+    constexpr uint32_t kSupLds = kBinThreads * kSupCPL;  // surviving supers a round can leave
+    constexpr uint32_t kSurvLds = BinLds<kW>::kSurvLds;
+    constexpr uint32_t kTPW = kStripTiles / kW;          // tiles per wave in the candidates pass
+    static_assert(kW == 1 || kW == 4, "one wave or one workgroup per strip row");
+    // a barrier among the waves that share the strip row: with one wave, program order (and a compiler fence)
+    auto LdsBarrier = [] {
+        if constexpr (kW == 1) WaveSync();
+        else pm::LdsBarrier();
+    };
     const ParamRegs PR = LoadParams(P);
-    __shared__ BinLds L;
+    __shared__ BinLds<kW> L;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = LaneId();
-    const uint32_t wave = tid >> 6;
-    if (blockIdx.x == 0 && tid < kTicketParts) PM_PP(ctr_next)->ticket[tid].count = 0;
+    const uint32_t wave = kW == 1 ? 0u : tid >> 6;
+    if (blockIdx.x == 0) {
+        for (uint32_t k = tid; k < kTicketParts; k += kBinThreads) PM_PP(ctr_next)->ticket[k].count = 0;
+    }
     if (blockIdx.x == 0 && tid == 0) {
         // The counters of the NEXT frame (the other parity) are idle now: reset them
         // here so that no separate memset launch is needed.
@@ -204,7 +226,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
     // of rows the host linked (the lightest rows share workgroups: pm_context.hip, EnsureArena).
     for (uint32_t rix = blockIdx.x, rix_next = 0; rix < PM_PU(n_sr_active); rix = rix_next) {
     if (rix != blockIdx.x) LdsBarrier();  // the previous strip row's LDS is done with
-    // One 16-byte load: {strip row, region, end, next strip row of this workgroup (0: none)}.
+    // One 16-byte load: {strip | tile row << 16, region, end, next strip row of this group (0: none)}.
     const uint4 srd = PM_PP(sr_desc)[rix];
     // In flight together with it: where the strip row's item list is (large scenes: its tile row's list), or -- the
     // band's list does not depend on the strip row -- the first 256 boxes of the list themselves.  Every dependent
@@ -226,10 +248,12 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         bb_next = band_bbox[tid];
         it_next = band_item != nullptr ? band_item[tid] : tid;
     }
-    // the two colour tables ride along with the first bbox load (finalisation reads them from LDS)
-    const uint32_t lut_word = PM_PP(lut_srgb2lin)[tid] | (PM_PP(lut_unorm2h)[tid] << 16);
     rix_next = __builtin_amdgcn_readfirstlane(srd.w);
     if (rix_next == 0) rix_next = 0xffffffffu;
+    // the two colour tables ride along with the first bbox load (finalisation reads them from LDS)
+    uint32_t lut_word[256 / kBinThreads];
+#pragma unroll
+    for (uint32_t u = 0; u < 256u / kBinThreads; ++u) lut_word[u] = PM_PP(lut_srgb2lin)[tid + u * kBinThreads] | (PM_PP(lut_unorm2h)[tid + u * kBinThreads] << 16);
     // (the strip row by strip | tile row of the band << 16: no division by the number of strips)
     const uint32_t strip = __builtin_amdgcn_readfirstlane(srd.x) & 0xffffu, row_rel = __builtin_amdgcn_readfirstlane(srd.x) >> 16;
     const uint32_t sr = row_rel * PM_PU(strips_x) + strip;
@@ -382,7 +406,8 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
     // The host sized this strip row's arena region from the same bbox predicate: a region that
     // only holds the fixed header allowance means no item can land here -- nothing to scan.
     if (region_end - cursor == PM_PU(sr_empty_dwords)) n_band = 0;
-    L.s_lut[tid] = lut_word;
+#pragma unroll
+    for (uint32_t u = 0; u < 256u / kBinThreads; ++u) L.s_lut[tid + u * kBinThreads] = lut_word[u];
     for (uint32_t ib = 0;; ib += kBatch) {
         const bool more = ib < n_band;  // uniform
         const uint32_t j = ib + tid;
@@ -838,9 +863,9 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
         //      last opaque Solid.  (Most strip rows have well under 64 candidates: split by candidates,
         //      one wave would walk all 16 tiles while three wait.)
         constexpr uint32_t kGroups = kBatch / 64u;
-        static_assert(kGroups * 4u <= 32u, "hit bits of a lane's candidates: four per group in one register");
-        const uint32_t wq = WaveId();   // this wave's tiles: 4 * wq .. 4 * wq + 3
-        const uint32_t t0 = 4u * wq;
+        static_assert(kGroups * kTPW <= 32u, "hit bits of a lane's candidates: kTPW per group in one register");
+        const uint32_t wq = wave;       // this wave's tiles: kTPW * wq .. kTPW * wq + kTPW - 1
+        const uint32_t t0 = kTPW * wq;
         const uint32_t n_groups = (ncand + 63u) / 64u;  // (uniform)
         uint32_t hq = 0;                // this lane's candidates (one per group): hit bits in the wave's tiles, 4 bits per group
         // per candidate: what both passes need
@@ -856,7 +881,7 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
             rule = (L.s_caux0[c] & kFillEvenOdd) ? 1u : 0xffffffffu;
         };
         {
-            uint32_t nh_q[4] = {0u, 0u, 0u, 0u}, lk_q[4] = {0u, 0u, 0u, 0u}, ls_q[4] = {0u, 0u, 0u, 0u};  // (uniform)
+            uint32_t nh_q[kTPW] = {}, lk_q[kTPW] = {}, ls_q[kTPW] = {};  // (uniform)
 #pragma unroll 1
             for (uint32_t g = 0; g < n_groups; ++g) {
                 const uint32_t c = g * 64u + Opaque(lane);
@@ -867,13 +892,13 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                 // (all twelve words requested at once, whatever the wave's quarter: one LDS round trip instead of
                 //  up to twelve dependent ones on the wave the others then wait for)
 #pragma unroll
-                for (uint32_t t = 0; t < 12u; ++t) {
+                for (uint32_t t = 0; t < kStripTiles - kTPW; ++t) {
                     const int v = static_cast<int>(ct_row[t]) >> kCtShift;
                     run += t < t0 ? v : 0;
                 }
                 uint32_t hb = 0;
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j) {
+                for (uint32_t j = 0; j < kTPW; ++j) {
                     const uint32_t t = t0 + j;
                     const uint32_t raw = ct_row[t];
                     run += static_cast<int>(raw) >> kCtShift;
@@ -890,18 +915,24 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                     if (bh) lk_q[j] = g * 64u + 64u - static_cast<uint32_t>(__builtin_clzll(bh));  // candidate index + 1
                     if (bs) ls_q[j] = g * 64u + 64u - static_cast<uint32_t>(__builtin_clzll(bs));
                 }
-                hq |= hb << (4u * g);
-                if (wq == (g & 3u) && c < ncand) {  // (one wave per group) the colour already through unpack_unorm4x8_srgb_to_half
+                hq |= hb << (kTPW * g);
+                if (wq == g % kBinWaves && c < ncand) {  // (one wave per group) the colour already through unpack_unorm4x8_srgb_to_half
                     const uint32_t rgba = L.s_crgba[c];
                     L.s_cpts[c] = (L.s_lut[rgba & 0xffu] & 0xffffu) | (L.s_lut[(rgba >> 8) & 0xffu] << 16);         // rg
                     L.s_cnpt[c] = (L.s_lut[(rgba >> 16) & 0xffu] & 0xffffu) | (L.s_lut[rgba >> 24] & 0xffff0000u);  // ba
                 }
             }
-            if (lane < 4u) {
-                const uint32_t j = lane, t = t0 + lane;
-                L.s_wh[t] = j == 0 ? nh_q[0] : (j == 1 ? nh_q[1] : (j == 2 ? nh_q[2] : nh_q[3]));
-                L.s_wlk[t] = j == 0 ? lk_q[0] : (j == 1 ? lk_q[1] : (j == 2 ? lk_q[2] : lk_q[3]));
-                L.s_wls[t] = j == 0 ? ls_q[0] : (j == 1 ? ls_q[1] : (j == 2 ? ls_q[2] : ls_q[3]));
+            if (lane < kTPW) {
+                uint32_t v_h = 0, v_lk = 0, v_ls = 0;  // (lane j takes the j-th of the uniform values)
+#pragma unroll
+                for (uint32_t j = 0; j < kTPW; ++j) {
+                    v_h = lane == j ? nh_q[j] : v_h;
+                    v_lk = lane == j ? lk_q[j] : v_lk;
+                    v_ls = lane == j ? ls_q[j] : v_ls;
+                }
+                L.s_wh[t0 + lane] = v_h;
+                L.s_wlk[t0 + lane] = v_lk;
+                L.s_wls[t0 + lane] = v_ls;
             }
         }
         // the tail wave: where the pieces went
@@ -978,10 +1009,10 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                 // lane t < 16: quad of the tile's first candidate entry
                 uint32_t cq = 0;
                 if (lane < kStripTiles) cq = L.s_piece_q[lane] + 1u + L.s_piece_n[lane];
-                uint32_t rank_q[4] = {0u, 0u, 0u, 0u};  // (uniform) entries written so far in the wave's tiles
+                uint32_t rank_q[kTPW] = {};  // (uniform) entries written so far in the wave's tiles
 #pragma unroll 1
                 for (uint32_t g = 0; g < n_groups; ++g) {
-                    const uint32_t hb = (hq >> (4u * g)) & 15u;
+                    const uint32_t hb = (hq >> (kTPW * g)) & ((1u << kTPW) - 1u);
                     if (__ballot(hb != 0u) == 0ull) continue;  // uniform: nothing of this group in the wave's tiles
                     const uint32_t c = min(g * 64u + Opaque(lane), ncand - 1u);
                     const uint4 e0 = make_uint4(L.s_cmask[c] >> 16, L.s_crgba[c], L.s_caux0[c], L.s_caux1[c]);
@@ -989,12 +1020,12 @@ __global__ __launch_bounds__(kBinThreads, 5) void pm_bin_kernel(FrameParams P) {
                     const uint32_t *const ct_row = &L.s_ct[c * kCtStride];
                     int run = 0;
 #pragma unroll
-                    for (uint32_t t = 0; t < 12u; ++t) {
+                    for (uint32_t t = 0; t < kStripTiles - kTPW; ++t) {
                         const int v = static_cast<int>(ct_row[t]) >> kCtShift;
                         run += t < t0 ? v : 0;
                     }
 #pragma unroll
-                    for (uint32_t j = 0; j < 4u; ++j) {
+                    for (uint32_t j = 0; j < kTPW; ++j) {
                         const uint32_t t = t0 + j;
                         const uint32_t raw = ct_row[t];
                         run += static_cast<int>(raw) >> kCtShift;
@@ -1106,10 +1137,15 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, cons
 void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
     const uint32_t n_striprows = p.bin_grid;
     if (p.use_row_lists) hipLaunchKernelGGL(pm_rowcull_kernel, dim3(p.row1 - p.row0), dim3(kBinThreads), 0, stream, p);
-    if (p.dbg_bin)
-        PM_LAUNCH(pm_bin_kernel<true>, dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
+    if (p.bin_waves == 1) {
+        if (p.dbg_bin)
+            PM_LAUNCH((pm_bin_kernel<true, 1>), dim3(n_striprows), dim3(64), stream, t0, t1, p);
+        else
+            PM_LAUNCH((pm_bin_kernel<false, 1>), dim3(n_striprows), dim3(64), stream, t0, t1, p);
+    } else if (p.dbg_bin)
+        PM_LAUNCH((pm_bin_kernel<true, 4>), dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
     else
-        PM_LAUNCH(pm_bin_kernel<false>, dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
+        PM_LAUNCH((pm_bin_kernel<false, 4>), dim3(n_striprows), dim3(kBinThreads), stream, t0, t1, p);
 }
 
 }  // namespace pm

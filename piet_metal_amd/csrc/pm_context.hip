@@ -183,6 +183,9 @@ struct pm_ctx {
     int target_fmt = PM_FMT_RGBA8;  // byte order the kernels store pixels in (pm_set_target_format)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
     uint32_t heavy_stream = 72, heavy_stream_lone = 40, vheavy_stream = 112;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
+    uint32_t bin_waves_env = 0;     // PM_BIN_WAVES: 4 / 1 waves per strip row in pm_bin_kernel (0: by the number of strip rows, EnsureArena)
+    uint32_t bin_waves = 4;
+    uint64_t plan_cands = 0;        // (item, strip row) pairs of the plan in force: candidates the strip rows will look at
     uint32_t bin_wg_per_cu = 0xff;  // pm_bin_kernel's workgroups per CU (PM_BIN_WG_PER_CU; 0 = one per strip row, default: by the number of strip rows)
     uint32_t coarse_wg_per_cu = 5, fine_wg_per_cu = 5;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
     uint32_t fine_wg_per_cu_inflight = 3;               // ... of a frame behind other frames (PM_FINE_WG_PER_CU_INFLIGHT)
@@ -430,6 +433,7 @@ void StripRowBounds(pm_ctx *c, std::vector<uint64_t> *need, int margin) {
     diff.assign((static_cast<size_t>(rows) + 1) * w, 0);
     c->plan_box.resize(4ull * n);
     c->plan_per.resize(n);
+    c->plan_cands = 0;
     for (uint32_t i = 0; i < n; ++i) {
         uint16_t bb[4];
         std::memcpy(bb, meta + 8 + 8ull * i, 8);
@@ -456,6 +460,7 @@ void StripRowBounds(pm_ctx *c, std::vector<uint64_t> *need, int margin) {
         const int64_t s_lo = bb[0] / 256, s_hi = std::min<int64_t>(bb[2] / 256, static_cast<int64_t>(c->strips_x) - 1);
         const int64_t r_lo = std::max<int64_t>(bb[1] / 16, c->row0), r_hi = std::min<int64_t>(bb[3] / 16, static_cast<int64_t>(c->row1) - 1);
         if (r_lo > r_hi || s_lo > s_hi) continue;
+        c->plan_cands += static_cast<uint64_t>(r_hi - r_lo + 1) * static_cast<uint64_t>(s_hi - s_lo + 1);
         // (a 2-D difference array: four updates per item instead of one per strip row it covers -- config 5's
         //  7 600 items cover millions of them: arena sizing 0.26 -> 0.10 ms)
         const size_t a = static_cast<size_t>(r_lo - c->row0), b = static_cast<size_t>(r_hi - c->row0) + 1;
@@ -583,15 +588,23 @@ int EnsureArena(pm_ctx *c) {
     c->n_sr_active = static_cast<uint32_t>(desc.size());
     {
         // pm_bin_kernel's grid is no larger than what the chip holds at once: five workgroups per CU (its LDS
-        // is sized for that).  A workgroup walks a chain of strip rows (desc.w = index of the next one, 0 =
-        // none): row b, b + grid, b + 2 grid ... in natural order -- a grid larger than the residency would
-        // start its last workgroups when the first END their chains.  (While the tile arena had ONE allocation
-        // counter, fewer resident workgroups were faster -- three per CU for the Tiger, four for config 4 --:
-        // less contention on that cache line, not a property of the kernel; pm_device.h, Counters.  Measured
-        // and not kept: any permutation of ALL rows, +25 % -- neighbouring strip rows share data; pairing
-        // the lightest rows by their arena need, +9 % -- the need is the worst case of the chunk test, not
-        // the work.)
+        // is sized for that).  A group walks a chain of strip rows (desc.w = index of the next one, 0 = none):
+        // row b, b + grid, b + 2 grid ... in natural order -- a grid larger than the residency would start its
+        // last groups when the first END their chains.  Measured and not kept: any permutation of ALL rows, +25 %
+        // (neighbouring strip rows share data); pairing the lightest rows by their arena need, +9 % (the need is
+        // the worst case of the chunk test, not the work); rows DRAWN from counters instead of dealt (a returning
+        // atomic per row, sent off a row ahead): config 5 0.229 -> 0.211 ms with a workgroup per row but config 4
+        // 0.140 -> 0.150, and 0.195 -> 0.207 with a wave per row.
         const size_t n = desc.size();
+        // A wave per strip row instead of a workgroup when there are several times more strip rows than the chip holds
+        // workgroups AND the rows are light (a record of 64 candidates holds nearly every row's): sixteen one-wave
+        // groups share a CU, no workgroup barriers, a quarter fewer vector and a third fewer scalar instructions per
+        // strip row -- a row takes twice as long, three times as many are in flight.  Config 5 (16 160 rows of 11
+        // candidates): binning 0.229 -> 0.195 ms, sustained +7 %; config 4 (4 096 rows of 108): 0.140 -> 0.162, stays
+        // with workgroups; so does any frame whose rows all fit the chip at once (the 4K Tiger: 25 -> 52 us).
+        const bool many_light_rows = n >= static_cast<size_t>(c->n_cus) * 5u * 3u && c->plan_cands <= 32ull * n;
+        c->bin_waves = c->bin_waves_env == 1 || c->bin_waves_env == 4 ? c->bin_waves_env : (many_light_rows ? 1u : 4u);
+        if (c->bin_waves == 1 && c->bin_wg_per_cu == 0xffu) per_cu = 16u;
         const size_t grid = per_cu == 0 ? n : std::min<size_t>(n, static_cast<size_t>(c->n_cus) * per_cu);
         if (n > grid) {
             for (size_t i = 0; i + grid < n; ++i) desc[i].w = static_cast<uint32_t>(i + grid);
@@ -744,6 +757,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->band_bbox = c->band_identity ? reinterpret_cast<const uint2 *>(c->d_scene + c->dev_bbox_ix) : c->d_band_bbox;
     p->band_item = c->band_identity ? nullptr : c->d_band_item;
     p->n_band_items = c->n_band_items;
+    p->bin_waves = c->bin_waves;
     p->split_mode = c->split_mode;
     {
         SetClassThresholds(c, p, c->heavy_stream_lone);
@@ -1213,6 +1227,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->fine_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU", 5, 1, 16));
     c->fine_wg_per_cu_inflight = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU_INFLIGHT", 3, 1, 16));
     c->bin_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_BIN_WG_PER_CU", 0xff, 0, 0xff));
+    c->bin_waves_env = static_cast<uint32_t>(EnvInt("PM_BIN_WAVES", 0, 0, 4));
     c->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 320, 0, 1 << 30));
 
     for (auto &ev : c->ev)

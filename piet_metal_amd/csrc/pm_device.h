@@ -139,6 +139,7 @@ struct FrameParams {
     const uint2 *band_bbox;        // [n_band_items] bboxes of the items that reach this band, paint order
     const uint32_t *band_item;     // [n_band_items] their scene indices (nullptr: every item in scene order -- band_bbox is the scene's own ShortBbox array)
     uint32_t n_band_items;
+    uint32_t bin_waves;            // pm_bin_kernel: waves that share one strip row (4: a workgroup per strip row; 1: a wave per strip row)
     uint32_t fine_grid;            // persistent workgroups of pm_fine_kernel (blocks beyond it clear strip rows)
     uint32_t split_mode;           // fine kernel: 0 = one wave per tile always, 1 = a workgroup per tile with a long list
     uint32_t class_thr[kClasses - 1];  // descending: a tile with more stream elements than class_thr[c] is in class <= c

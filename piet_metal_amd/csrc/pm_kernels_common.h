@@ -253,6 +253,10 @@ __device__ __forceinline__ bool VotePoly(float4 s, float hw, int y_test, int sx0
 template <int NW>
 __device__ __forceinline__ uint32_t BlockRank(bool pred, uint32_t *s_part, uint32_t *total) {
     const uint64_t m = __ballot(pred);
+    if constexpr (NW == 1) {  // (a single wave: the ballot is the whole answer)
+        *total = static_cast<uint32_t>(__popcll(m));
+        return RankBelow(m);
+    }
     const uint32_t wave = threadIdx.x >> 6;
     if (LaneId() == 0) s_part[wave] = static_cast<uint32_t>(__popcll(m));
     LdsBarrier();
@@ -272,6 +276,10 @@ __device__ __forceinline__ uint32_t BlockRank(bool pred, uint32_t *s_part, uint3
 template <int NW>
 __device__ __forceinline__ uint32_t BlockExclusiveScan(uint32_t v, uint32_t *s_part, uint32_t *total) {
     const uint32_t incl = WaveInclusiveScan(v);
+    if constexpr (NW == 1) {
+        *total = WaveLast(incl);
+        return incl - v;
+    }
     const uint32_t wave = threadIdx.x >> 6;
     if (LaneId() == 63) s_part[wave] = incl;
     LdsBarrier();

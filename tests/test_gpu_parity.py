@@ -670,6 +670,43 @@ def test_binning_launch_variants(pm, pmo, monkeypatch, wg_per_cu):
         r.close()
 
 
+@pytest.mark.parametrize("wg_per_cu,row_lists", [(None, False), ("1", False), (None, True)])
+def test_a_wave_per_strip_row(pm, pmo, monkeypatch, wg_per_cu, row_lists):
+    """pm_bin_kernel with ONE wave per strip row (what frames with many times more light strip rows than the chip
+    holds workgroups get, config 5; PM_BIN_WAVES=1 forces it): records of 64 candidates instead of 256, so rows
+    with more candidates chain pieces; 16 tiles per wave in the candidates pass; no workgroup barrier.  Same
+    bytes and the same command lists as the oracle -- with chains of strip rows per wave (a small grid), with
+    per-tile-row item lists, over fills, strokes, lines, circles and compound fills."""
+    monkeypatch.setenv("PM_BIN_WAVES", "1")
+    if wg_per_cu is not None:
+        monkeypatch.setenv("PM_BIN_WG_PER_CU", wg_per_cu)
+    if row_lists:
+        monkeypatch.setenv("PM_ROW_LIST_MIN_ITEMS", "1")
+    r = pm.Renderer(0)
+    try:
+        wl = pm.workloads.tiger(960, 540)
+        r.resize(wl.width, wl.height)
+        r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        scene = r.download_scene()
+        for _ in range(3):
+            r.render()
+        assert np.array_equal(r.read_pixels(), pmo.render(scene, wl.width, wl.height))
+        assert_ptcl_equal(r, pmo, scene, wl.width, wl.height)
+        # strip rows with well over 64 candidates (several records per row) and long items (survivor lists beyond LDS)
+        for seed, n, w, h in ((31, 900, 600, 400), (32, 300, 1100, 300)):
+            scene = encode_ops(pm, random_ops(seed, n, extent=float(max(w, h))))
+            r.resize(w, h)
+            r.set_scene_bytes(scene)
+            r.render()
+            assert np.array_equal(r.read_pixels(), pmo.render(scene, w, h)), seed
+            assert_ptcl_equal(r, pmo, scene, w, h)
+        r.set_band(3, 17)
+        r.render()
+        assert np.array_equal(r.read_pixels(), pmo.render(scene, 1100, 300)[48:272])
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("coarse_wg,fine_wg,fused", [("1", "1", "1"), ("7", "3", "0"), ("2", "9", "1")])
 def test_persistent_grid_sizes(pm, pmo, monkeypatch, coarse_wg, fine_wg, fused):
     """PM_COARSE_WG_PER_CU / PM_FINE_WG_PER_CU size the persistent grids; the hand-out must cover
