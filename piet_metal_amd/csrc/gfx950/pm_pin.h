@@ -16,6 +16,16 @@ __device__ __forceinline__ uint32_t OpaqueZero() {
     asm volatile("v_mov_b32 %0, 0" : "=v"(v));
     return v;
 }
+// A returning atomic add issued by ONE lane whose result is looked at LATER.  With a uniform address the compiler's
+// atomic optimizer rewrites the operation for a whole wave (one lane adds the sum, v_readfirstlane hands the result
+// round) -- and the readfirstlane, with the wait for the atomic's round trip in front of it, sits right behind the
+// atomic whatever the source does in between.  An address it cannot prove uniform is left alone.
+__device__ __forceinline__ uint32_t AtomicAddOneLane(uint32_t *p, uint32_t v) {
+    typedef __attribute__((address_space(1))) uint32_t *GlobalU32;
+    unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    asm volatile("" : "+v"(a));
+    return __hip_atomic_fetch_add((uint32_t *)(GlobalU32)a, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ uint32_t Opaque(uint32_t v) {
     asm volatile("" : "+v"(v));
     return v;
@@ -40,6 +50,9 @@ __device__ __forceinline__ void PinLoaded8(uint32_t &a0, uint32_t &a1, uint32_t 
                                            uint32_t &a6, uint32_t &a7) {
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
 }
+
+// A loaded slot of the binning record {meta word, segment}: arrived before anything behind this line is issued.
+__device__ __forceinline__ void PinSlot(uint32_t &m, float4 &s) { asm volatile("" : "+v"(m), "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w)); }
 
 // v_writelane_b32: a wave-uniform value into lane kLane of a VGPR (one instruction; the compiler has
 // no builtin for it and would otherwise build `lane == kLane ? s : v` from a compare and a select).

@@ -328,9 +328,12 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
     auto RowTailIssue = [&]() -> TailState {
         const uint32_t tiles_here = min(kStripTiles, PM_PU(tiles_x) - strip * kStripTiles);
         const bool tile_lane = lane < tiles_here;
-        const uint32_t est = tile_lane ? L.s_est[lane & (kStripTiles - 1u)] : 0u;
+        // (the tile's index made here, from a lane number the compiler cannot see through: hoisted to the kernel's entry it
+        //  is spilled, and the reload's wait also waits for every store the wave has in flight)
+        const uint32_t tl = Opaque(lane) & (kStripTiles - 1u);
+        const uint32_t est = tile_lane ? L.s_est[tl] : 0u;
         // {Solid(opaque)} -> Bail: the tile is one opaque colour (TileEncoder::end, :144-151)
-        const bool is_solid = est != 0 && L.s_last_kept[lane & (kStripTiles - 1u)] == L.s_last_solid[lane & (kStripTiles - 1u)];
+        const bool is_solid = est != 0 && L.s_last_kept[tl] == L.s_last_solid[tl];
         const bool is_queued = est != 0 && !is_solid;
         // cost class of the tile's list (0 = longest): the number of thresholds the estimate does not exceed
         static_assert(kClasses == 8, "seven thresholds spelled out below");
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
         ts.qres = 0;
         if (ts.qtotal) {  // uniform
             if (lane < kClasses && lane_cnt) ts.qres = atomicAdd(&PM_PP(ctr_cur)->cls[lane].count, lane_cnt);
-            if (lane == kClasses) ts.qres = atomicAdd(&PM_PP(ctr_cur)->ptcl[shard].top, ts.qtotal);
+            if (lane == kClasses) ts.qres = AtomicAddOneLane(&PM_PP(ctr_cur)->ptcl[shard].top, ts.qtotal);  // (RowTailFinish looks at it)
         }
         // tiles with nothing to draw are background: no item touches them, or every touching
         // item lost all its segments in phase 1 (the reference writes Bail/white for them).  Their
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
             const uint32_t incl = WaveInclusiveScan(quads);
             alloc_total = WaveLast(incl);
             pq_rel = incl - quads;
-            if (alloc_total && lane == 0) alloc_q = atomicAdd(&PM_PP(ctr_cur)->ptcl[shard].top, alloc_total);  // (looked at after the pass below)
+            if (alloc_total && lane == 0) alloc_q = AtomicAddOneLane(&PM_PP(ctr_cur)->ptcl[shard].top, alloc_total);  // (looked at after the pass below)
         }
 
         // ---- candidates pass.  Lane = candidate (64 at a time), and every wave takes a QUARTER of the
@@ -951,7 +954,28 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
                 if (base_q == 0xffffffffu) L.s_alloc[1] = 1u;
             }
         }
+        // The scatter below reads this wave's slots back (meta word + segment) and stores them into the tiles' pieces.
+        // Vector memory operations complete in order: a load issued behind stores waits for their acknowledgements, and
+        // a wait for loads in front of a run of stores whose number the compiler cannot count becomes vmcnt(0) --
+        // every round of the scatter used to wait for the previous round's stores, 1-1.5 us each.  So the first
+        // kAhead rounds (nearly every wave's whole share) are requested HERE, with nothing else in flight, and waited
+        // for right behind the barrier; later chunks are loaded and waited for in front of their own stores.
+        constexpr uint32_t kAhead = 1;
+        uint32_t mw_a[kAhead];
+        float4 seg_a[kAhead];
+#pragma unroll
+        for (uint32_t u = 0; u < kAhead; ++u) {
+            mw_a[u] = 0;
+            seg_a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const uint32_t fa = w_lo + 64u * u + lane;
+            if (fa < w_hi) {
+                mw_a[u] = PM_META(fa);  // (this wave wrote it)
+                seg_a[u] = PM_SEG(fa);
+            }
+        }
         LdsBarrier();  // hit bits, per-wave totals, pieces
+#pragma unroll
+        for (uint32_t u = 0; u < kAhead; ++u) PinSlot(mw_a[u], seg_a[u]);
         if (kProfile) stamp(12);
         const uint32_t base_q = L.s_alloc[0];
         const bool last_record = !more;  // uniform
@@ -989,19 +1013,12 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
             }
             if (last_record) tail_state = RowTailIssue();
             if (hdr_q) {
-                PM_PP(tarena)[hdr_q] = make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t z = OpaqueZero();  // (a zero made here: as a literal it is hoisted to the kernel's entry and spilled)
+                PM_PP(tarena)[hdr_q] = make_uint4(z, z, z, z);
                 if (hdr_prev) *reinterpret_cast<uint2 *>(PM_PP(tarena) + hdr_prev) = make_uint2(hdr_q, hdr_n);
             }
         }
         if (base_q != 0xffffffffu) {  // uniform (else: the tile arena ran out; the strip row's tiles are marked "no list")
-            // (the scatter's first slots are requested before the candidate entries are stored: loads
-            //  issued after stores wait for the stores' acknowledgements)
-            uint32_t mw_n = 0;
-            float4 seg_n = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (w_lo + lane < w_hi) {
-                mw_n = PM_META(w_lo + lane);  // (this wave wrote it)
-                seg_n = PM_SEG(w_lo + lane);
-            }
             // ---- candidate entries, the same way: lane = candidate, the wave's quarter of the tiles for every
             //      group of 64 candidates; a candidate's rank in a tile's piece is the hits of the earlier
             //      groups plus a ballot; two quads per (candidate, tile) behind the piece's segments --------
@@ -1052,27 +1069,37 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
                     for (uint32_t w = 0; w < wave; ++w) before += L.s_wcnt[w][lane];
                     next_q = L.s_piece_q[lane] + 1u + before;
                 }
-                for (uint32_t f0 = w_lo; f0 < w_hi; f0 += 64u) {
-                    const uint32_t mm = mw_n & 0xffffu;
-                    const float4 seg = seg_n;
-                    const uint32_t fn = f0 + 64u + lane;
-                    mw_n = 0;
-                    if (fn < w_hi) {
-                        mw_n = PM_META(fn);
-                        seg_n = PM_SEG(fn);
+                for (uint32_t f0 = w_lo; f0 < w_hi; f0 += 64u * kAhead) {
+                    if (f0 != w_lo) {  // (uniform) a later chunk: loaded and waited for in front of its own stores
+#pragma unroll
+                        for (uint32_t u = 0; u < kAhead; ++u) {
+                            mw_a[u] = 0;
+                            const uint32_t fa = f0 + 64u * u + lane;
+                            if (fa < w_hi) {
+                                mw_a[u] = PM_META(fa);
+                                seg_a[u] = PM_SEG(fa);
+                            }
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < kAhead; ++u) PinSlot(mw_a[u], seg_a[u]);
                     }
+#pragma unroll
+                    for (uint32_t u = 0; u < kAhead; ++u) {
+                    if (f0 + 64u * u >= w_hi) break;  // uniform
+                    const uint32_t mm = mw_a[u] & 0xffffu;
+                    const float4 seg = seg_a[u];
                     // the tiles present among the 64 slots, one round each
                     uint32_t present = 0;
                     {
-                        uint32_t u = mm;  // OR over the wave (DPP within rows, then the row totals)
-                        u |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), 0x111, 0xf, 0xf, true));
-                        u |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), 0x112, 0xf, 0xf, true));
-                        u |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), 0x114, 0xf, 0xf, true));
-                        u |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(u), 0x118, 0xf, 0xf, true));
-                        present = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(u), 15)) |
-                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(u), 31)) |
-                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(u), 47)) |
-                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(u), 63));
+                        uint32_t o = mm;  // OR over the wave (DPP within rows, then the row totals)
+                        o |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(o), 0x111, 0xf, 0xf, true));
+                        o |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(o), 0x112, 0xf, 0xf, true));
+                        o |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(o), 0x114, 0xf, 0xf, true));
+                        o |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(o), 0x118, 0xf, 0xf, true));
+                        present = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(o), 15)) |
+                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(o), 31)) |
+                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(o), 47)) |
+                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(o), 63));
                     }
                     while (present) {  // uniform
                         const uint32_t t = static_cast<uint32_t>(__builtin_ctz(present));
@@ -1083,6 +1110,7 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
                         if (mine) *reinterpret_cast<float4 *>(PM_PP(tarena) + q0 + RankBelow(b)) = seg;
                         if (lane == t) next_q += static_cast<uint32_t>(__popcll(b));
                     }
+                    }  // rounds of the chunk
                 }
             }
         }

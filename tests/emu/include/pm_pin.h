@@ -10,6 +10,7 @@ namespace {
 
 inline uint32_t OpaqueZero() { return 0u; }
 inline uint32_t Opaque(uint32_t v) { return v; }
+inline uint32_t AtomicAddOneLane(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 inline void PinF32(float &x) {  // (a compiler barrier is all a CPU build needs: no v_fma_mix here)
     asm volatile("" : "+x"(x));
 }
@@ -19,6 +20,7 @@ inline float OpaqueInfinity() {
     std::memcpy(&f, &b, 4);
     return f;
 }
+inline void PinSlot(uint32_t &, float4 &) {}
 inline void PinLoaded8(uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &) {}
 
 template <uint32_t kLane>

@@ -61,3 +61,20 @@ if t.shape[1] >= 12 and (t[:, 11] > 0).any():
 last = np.argsort(-end)[:10]
 print("slots that end last:")
 for i in last: print(f"  last slot {i} tile {tile[i]} q={quarter[i]} ncmd {ncmd[i]} start {(start[i]-t0)*us:.1f} end {(end[i]-t0)*us:.1f} dur {dur[i]:.1f} list {coarse[i]:.1f}")
+
+# first tile of a wave vs. the tiles after it: what the previous tile's pixel stores (in flight when the next tile's piece is
+# requested) cost the next tile, and the gap between a wave's tiles
+if t.shape[1] >= 12 and (t[:, 11] > 0).any():
+    order = np.lexsort((start, wave))
+    first = np.zeros(len(t), bool)
+    prev_end = {}
+    gap = np.zeros(len(t))
+    for i in order:
+        w = wave[i]
+        if w not in prev_end: first[i] = True
+        else: gap[i] = (start[i] - prev_end[w]) * us
+        prev_end[w] = end[i]
+    sw = built & ~quarter
+    for name, m in (("first tile of its wave", sw & first), ("later tiles", sw & ~first)):
+        if m.any():
+            print(f"{name}: {m.sum()} slots, list building mean {coarse[m].mean():.2f} us (candidates stage {stages['candidates'][m].mean():.2f}), duration mean {dur[m].mean():.2f}, mean ncmd {ncmd[m].mean():.1f}, gap before it {gap[m].mean():.2f} us")
