@@ -740,13 +740,9 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     // linear -> sRGB + unorm8 (:563-565): the 65,536-entry table of decision D2.  (A compact
     // LDS-resident form of the table was measured slower: twelve byte loads per lane are fewer
     // instructions than twelve decodes.)
-    const bool bgra = P.fb_bgra != 0;  // (uniform: the swap is two selects per pixel)
-    auto enc = [&](_Float16 r, _Float16 g, _Float16 b) -> uint32_t {
-        const _Float16 lo = bgra ? b : r, hi = bgra ? r : b;
-        return static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, lo)]) |
-               (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, g)]) << 8) |
-               (static_cast<uint32_t>(lut[__builtin_bit_cast(uint16_t, hi)]) << 16) | 0xff000000u;
-    };
+    // A tile's pixels are encoded at its end in two steps: the table reads of all channels, then -- behind the draw of the
+    // next tile -- the packing (StoreOrder's swap for a BGRA8 target: uniform, two selects per pixel).
+    const bool bgra = P.fb_bgra != 0;
     // slot -> queue entry
     auto slot_entry = [&](uint32_t slot) -> uint32_t {
         const uint32_t t = slot < s_h ? (slot >> sh) : n_heavy + (slot - s_h);  // position in [longest ... shortest]
@@ -878,10 +874,14 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                 }
                 __syncthreads();  // the other waves may still read this wave's alpha images
                 __builtin_amdgcn_s_setprio(0);
+                // (the table reads first, the draw while they are in flight: see the single-wave path below)
+                const uint32_t r8 = lut[static_cast<uint32_t>(__builtin_bit_cast(uint16_t, s1.r))];
+                const uint32_t g8 = lut[static_cast<uint32_t>(__builtin_bit_cast(uint16_t, s1.g))];
+                const uint32_t b8 = lut[static_cast<uint32_t>(__builtin_bit_cast(uint16_t, s1.b))];
                 next_card();
                 if (pyi < P.height && pxi < P.width) {
                     uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + (pix >> 4)) * P.fb_stride + static_cast<size_t>(pxi) * 4;
-                    *reinterpret_cast<uint32_t *>(dst) = enc(s1.r, s1.g, s1.b);
+                    *reinterpret_cast<uint32_t *>(dst) = (bgra ? b8 : r8) | (g8 << 8) | ((bgra ? r8 : b8) << 16) | 0xff000000u;
                 }
             } else {
                 // lane -> 4 pixels: x = x0 + 4 * (lane & 3) + k, row = lane / 4
@@ -905,14 +905,30 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
                     WaveSync();
                     InterpretSparse(S, cmds, S.w[wave].f.fill_ix, m, x0, y0, st);
                 }
+                // The twelve table reads of the pixels' encoding are requested FIRST, the draw of the next tile goes out
+                // while they are in flight (its wait is theirs too), and the next tile's queue entry is on its way while the
+                // bytes are packed and stored: two round trips at the end of a tile, not three.
+                uint32_t lv[12];
+                {
+                    const _Float16 pr[4] = {st.r01.x, st.r01.y, st.r23.x, st.r23.y}, pg[4] = {st.g01.x, st.g01.y, st.g23.x, st.g23.y},
+                                   pb[4] = {st.b01.x, st.b01.y, st.b23.x, st.b23.y};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        lv[3 * k] = lut[static_cast<uint32_t>(__builtin_bit_cast(uint16_t, pr[k]))];
+                        lv[3 * k + 1] = lut[static_cast<uint32_t>(__builtin_bit_cast(uint16_t, pg[k]))];
+                        lv[3 * k + 2] = lut[static_cast<uint32_t>(__builtin_bit_cast(uint16_t, pb[k]))];
+                    }
+                }
                 next_card();
                 if (pyi < P.height && pxi < P.width) {
                     uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
                     uint4 out;
-                    out.x = enc(st.r01.x, st.g01.x, st.b01.x);
-                    out.y = enc(st.r01.y, st.g01.y, st.b01.y);
-                    out.z = enc(st.r23.x, st.g23.x, st.b23.x);
-                    out.w = enc(st.r23.y, st.g23.y, st.b23.y);
+                    // (R and B change places for a BGRA8 target: uniform, two selects per pixel)
+                    auto pack = [&](uint32_t r8, uint32_t g8, uint32_t b8) { return (bgra ? b8 : r8) | (g8 << 8) | ((bgra ? r8 : b8) << 16) | 0xff000000u; };
+                    out.x = pack(lv[0], lv[1], lv[2]);
+                    out.y = pack(lv[3], lv[4], lv[5]);
+                    out.z = pack(lv[6], lv[7], lv[8]);
+                    out.w = pack(lv[9], lv[10], lv[11]);
                     if (pxi + 4 <= P.width && P.fb_vec16) {
                         *reinterpret_cast<uint4 *>(dst) = out;
                     } else {
