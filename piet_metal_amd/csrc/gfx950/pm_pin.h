@@ -51,6 +51,15 @@ __device__ __forceinline__ void PinLoaded8(uint32_t &a0, uint32_t &a1, uint32_t 
     asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
 }
 
+// A tile's piece as the list building first sees it -- header, first segments, first candidates: all arrived
+// before anything behind this line is issued (and none of them looked at before all are requested).
+__device__ __forceinline__ void PinPiece(uint32_t &h0, uint32_t &h1, float &s0, float &s1, float &s2, float &s3, uint32_t &a0, uint32_t &a1, uint32_t &a2,
+                                         uint32_t &a3, uint32_t &b0, uint32_t &b1, uint32_t &b2, uint32_t &b3) {
+    // (scalars, not members of the vector structs: an asm operand that is a struct member puts the struct on the stack)
+    asm volatile("" : "+v"(h0), "+v"(h1), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2),
+                 "+v"(b3));
+}
+
 // A loaded slot of the binning record {meta word, segment}: arrived before anything behind this line is issued.
 __device__ __forceinline__ void PinSlot(uint32_t &m, float4 &s) { asm volatile("" : "+v"(m), "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w)); }
 

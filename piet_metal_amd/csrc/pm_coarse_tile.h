@@ -109,8 +109,25 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
         const uint4 *const pc = P.tarena + piece;
         const float4 *const segs = reinterpret_cast<const float4 *>(pc + 1u);  // {header, segments, candidates}
         const uint4 *const cands = pc + 1u + nrel;
-        // header (the next piece), the first 64 candidates and the first 64 segments: all in flight together
-        const uint4 hdr = Scalar4(*pc);
+        // Header (the next piece), the first 64 candidates and the first 64 segments: all REQUESTED before any of them is
+        // looked at, one round trip.  (Written as it reads -- the header through Scalar4, the candidates inside the
+        // pass loop -- the compiler waited for the header before it asked for the segments, and for those before the
+        // candidates: three round trips in front of every tile's list, 1.5-2 us of its 8-11.)
+        const uint2 hdr_l = *reinterpret_cast<const uint2 *>(pc);  // (every lane the same address)
+        // (unconditional, from clamped indices -- a piece has at least one candidate, and what a lane beyond the piece's
+        //  segments or candidates reads is never looked at: a load under `if (lane < n)` merges with a zero behind it, and
+        //  the copy that merge needs waits for the load on the spot)
+        const uint32_t li = Opaque(lane);
+        const float4 seg_l = segs[min(li, nrel)];  // (index nrel: the first candidate's quad -- inside the piece)
+        const uint4 *const cr0 = cands + 2u * min(li, nhit - 1u);
+        const uint4 ca_l = cr0[0], cb_l = cr0[1];
+        uint32_t h0 = hdr_l.x, h1 = hdr_l.y, a0 = ca_l.x, a1 = ca_l.y, a2 = ca_l.z, a3 = ca_l.w, b0 = cb_l.x, b1 = cb_l.y, b2 = cb_l.z, b3 = cb_l.w;
+        float s0 = seg_l.x, s1 = seg_l.y, s2 = seg_l.z, s3 = seg_l.w;
+        PinPiece(h0, h1, s0, s1, s2, s3, a0, a1, a2, a3, b0, b1, b2, b3);
+        const float4 seg_first = make_float4(s0, s1, s2, s3);
+        const uint4 cand_a = make_uint4(a0, a1, a2, a3), cand_b = make_uint4(b0, b1, b2, b3);
+        const uint2 hdr = make_uint2(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(h0))),
+                                     static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(h1))));
         // (kPar: a piece whose passes cannot be longer than a round is wave 0's alone)
         const bool piece_shared = wg && nrel + nhit > 64u;
         if (pw != 0u && !piece_shared) {
@@ -118,8 +135,6 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
             piece_n = hdr.y;
             continue;
         }
-        float4 seg_first = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (Opaque(lane) < nrel) seg_first = segs[Opaque(lane)];
         uint32_t rel_done = 0;  // relevant segments owned by earlier candidate passes
         if (kProf) ticks->records += 1;
 
@@ -131,9 +146,12 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
             uint32_t my_rgba = 0, my_aux1 = 0, my_rg = 0, my_ba = 0;
             int my_backdrop = 0;
             if (lane < nh) {
-                const uint4 *cr = cands + 2u * (cb + lane);
-                const uint4 a = cr[0];
-                const uint4 b = cr[1];
+                uint4 a = cand_a, b = cand_b;  // (the first pass's: requested with the piece's header)
+                if (cb != 0) {
+                    const uint4 *cr = cands + 2u * (cb + lane);
+                    a = cr[0];
+                    b = cr[1];
+                }
                 L.htag[lane] = a.x & 0xffffu;
                 my_rgba = a.y;
                 L.haux0[lane] = a.z;

@@ -21,6 +21,8 @@ inline float OpaqueInfinity() {
     return f;
 }
 inline void PinSlot(uint32_t &, float4 &) {}
+inline void PinPiece(uint32_t &, uint32_t &, float &, float &, float &, float &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &,
+                     uint32_t &) {}
 inline void PinLoaded8(uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &) {}
 
 template <uint32_t kLane>
