@@ -185,6 +185,7 @@ struct pm_ctx {
     uint32_t heavy_stream = 72, heavy_stream_lone = 40, vheavy_stream = 112;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
     uint32_t bin_waves_env = 0;     // PM_BIN_WAVES: 4 / 1 waves per strip row in pm_bin_kernel (0: by the number of strip rows, EnsureArena)
     uint32_t bin_waves = 4;
+    uint32_t bin_waves_inflight = 1;  // PM_BIN_WAVES_INFLIGHT: waves per strip row for frames submitted behind frames still running (1 / 4)
     uint64_t plan_cands = 0;        // (item, strip row) pairs of the plan in force: candidates the strip rows will look at
     uint32_t bin_wg_per_cu = 0xff;  // pm_bin_kernel's workgroups per CU (PM_BIN_WG_PER_CU; 0 = one per strip row, default: by the number of strip rows)
     uint32_t coarse_wg_per_cu = 5, fine_wg_per_cu = 5;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
@@ -863,6 +864,13 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     // waves while its list is built: cheap when the frame is alone and its longest lists set the
     // span, wasteful when neighbours could use the SIMDs): lone frame -1.4 us, sustained +2.6 %
     if (p.handout_static) SetClassThresholds(c, &p, c->heavy_stream);
+    // ... and bin with a wave per strip row: behind other frames what counts is instructions issued, not this frame's
+    // latency (a wave per row: a quarter fewer of them; 4K Tiger sustained 255 -> 266 k Mpix/s).  Only frames with enough
+    // strip rows to fill the chip that way (at 1080p, 544 rows, a row's 50 us then set the pace: 142 -> 96 k), and only where
+    // no workgroup walks a chain of rows -- the chains are linked for one grid (EnsureArena).
+    if (p.handout_static && c->bin_waves_inflight == 1 && c->bin_waves == 4 && c->n_sr_active <= c->bin_grid &&
+        c->n_sr_active >= 4u * static_cast<uint32_t>(c->n_cus))
+        p.bin_waves = 1;
     // ... and a smaller persistent grid: three tile workgroups per CU leave two slots (LDS, VGPRs) to
     // the neighbours' binning workgroups (Tiger 4K sustained 221 -> 227 k Mpix/s, the other configurations
     // unchanged; two cost config 4 2 %; alone, five end the frame 0.8 us earlier)
@@ -1228,6 +1236,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->fine_wg_per_cu_inflight = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU_INFLIGHT", 3, 1, 16));
     c->bin_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_BIN_WG_PER_CU", 0xff, 0, 0xff));
     c->bin_waves_env = static_cast<uint32_t>(EnvInt("PM_BIN_WAVES", 0, 0, 4));
+    c->bin_waves_inflight = c->bin_waves_env ? c->bin_waves_env : static_cast<uint32_t>(EnvInt("PM_BIN_WAVES_INFLIGHT", 1, 1, 4));
     c->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 320, 0, 1 << 30));
 
     for (auto &ev : c->ev)

@@ -217,6 +217,27 @@ def test_baseline_configs(pm, pmo, renderer, golden, cfg):
     assert st["overflow"] == 0 and st["arena_used_dwords"] <= st["arena_cap_dwords"]
 
 
+def test_4k_frames_behind_one_another_bin_with_a_wave_per_strip_row(pm, golden, monkeypatch):
+    """A frame submitted while the previous one is still running bins with a wave per strip row when it has enough strip
+    rows to fill the chip that way (>= 4 per CU and no chains: the 4K Tiger's 1 109), a lone frame with a workgroup
+    per row: eight frames back to back, then one alone, every one of them the committed pin -- on the context's own
+    streams and slots, and with the two ways pinned (PM_BIN_WAVES_INFLIGHT=4: never a wave per row)."""
+    wl = pm.workloads.tiger(3840, 2160)
+    for inflight in (None, "4"):
+        if inflight is not None:
+            monkeypatch.setenv("PM_BIN_WAVES_INFLIGHT", inflight)
+        r = pm.Renderer(0)
+        try:
+            r.resize(wl.width, wl.height)
+            r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+            for burst in (8, 1, 3):
+                for _ in range(burst):
+                    r.render()
+                assert sha(r.read_pixels()) == golden[wl.name]["rgba_sha256"], (inflight, burst)
+        finally:
+            r.close()
+
+
 def test_config4_blobs_reduced_vs_oracle_and_full_properties(pm, pmo, renderer):
     # oracle-sized: 600 blobs at 1024^2, byte-exact
     wl = pm.workloads.config4_blobs(600, 1024)
