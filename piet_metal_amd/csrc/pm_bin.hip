@@ -355,7 +355,7 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
         TailState ts;
         ts.qtotal = WaveLast(slots_incl);
         ts.list_off = slots_incl - slots;
-        ts.packed = (is_queued ? 1u : 0u) | (cls << 1) | (static_cast<uint32_t>(__popc(my_mask & ((1u << lane) - 1u))) << 4);
+        ts.packed = (is_queued ? 1u : 0u) | (cls << 1) | (static_cast<uint32_t>(__popc(my_mask & ((1u << Opaque(lane)) - 1u))) << 4);  // (Opaque: made here, not hoisted to the kernel's entry and spilled)
         // tile-arena space and the class queue positions: ONE atomic instruction, a lane per counter
         ts.qres = 0;
         if (ts.qtotal) {  // uniform
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
         // item lost all its segments in phase 1 (the reference writes Bail/white for them).  Their
         // pixels are written by the clearing workgroups of the tile kernel's launch from tile_state:
         // 25 MB of stores per 4K frame that would otherwise stall these latency-bound workgroups in bursts.
-        const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + lane;
+        const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + Opaque(lane);
         if (tile_lane)  // what this kernel decided per tile: 0 = queued, else the tile's colour
             PM_PP(tile_state)[tile] = is_queued ? 0u : (is_solid ? L.s_solid_rgba[lane] : 0xffffffffu);
         return ts;
@@ -386,12 +386,13 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
             *PM_PP(host_overflow) = 1;
         }
         if (ts.packed & 1u) {
-            const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + lane;
+            const uint32_t ol = Opaque(lane);
+            const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + ol;
             const uint32_t list_slot = fits ? base + ts.list_off : 0xffffffffu;
             PM_PP(tile_ptcl)[tile] = list_slot;
             // A queue entry is everything the tile kernels need to start: {tile (column | row of the band << 16), first
             // quad of its command list, its first piece, that piece's candidates | segments << 9}
-            const uint4 entry = make_uint4((strip * kStripTiles + lane) | (row_rel << 16), list_slot, L.s_head_q[lane], L.s_head_n[lane]);
+            const uint4 entry = make_uint4((strip * kStripTiles + ol) | (row_rel << 16), list_slot, L.s_head_q[ol], L.s_head_n[ol]);
             PM_PP(queue)[cls * PM_PU(queue_cap) + q_base + (ts.packed >> 4)] = entry;
         }
     };
@@ -1088,27 +1089,37 @@ __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(FrameParams P) {
                     if (f0 + 64u * u >= w_hi) break;  // uniform
                     const uint32_t mm = mw_a[u] & 0xffffu;
                     const float4 seg = seg_a[u];
-                    // the tiles present among the 64 slots, one round each
-                    uint32_t present = 0;
-                    {
-                        uint32_t o = mm;  // OR over the wave (DPP within rows, then the row totals)
-                        o |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(o), 0x111, 0xf, 0xf, true));
-                        o |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(o), 0x112, 0xf, 0xf, true));
-                        o |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(o), 0x114, 0xf, 0xf, true));
-                        o |= static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(o), 0x118, 0xf, 0xf, true));
-                        present = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(o), 15)) |
-                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(o), 31)) |
-                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(o), 47)) |
-                                  static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(o), 63));
+                    if (__ballot(mm != 0u) == 0ull) continue;  // uniform: no relevant segment among the 64 slots
+                    // A segment's place in tile t's piece = the wave's running position for t + the number of LOWER lanes
+                    // with a segment for t.  All sixteen tiles at once: a byte per tile, four tiles per word, four prefix
+                    // sums over the wave (counts <= 64 fit a byte) -- then every lane walks the tiles of ITS segment (one or
+                    // two, rarely more) instead of the wave walking every tile present among the 64 slots, 28 instructions
+                    // each, 6-12 of them per round.
+                    uint32_t exc[4], tot[4];  // per word of four tiles: lower lanes' counts (a byte per tile); the wave's totals (uniform)
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) {
+                        const uint32_t cnt = (((mm >> (4u * k)) & 15u) * 0x00204081u) & 0x01010101u;  // bit j of the nibble -> byte j
+                        const uint32_t inc = WaveInclusiveScan(cnt);
+                        tot[k] = WaveLast(inc);
+                        exc[k] = inc - cnt;
                     }
-                    while (present) {  // uniform
-                        const uint32_t t = static_cast<uint32_t>(__builtin_ctz(present));
-                        present &= present - 1u;
-                        const bool mine = (mm >> t) & 1u;
-                        const uint64_t b = __ballot(mine);
-                        const uint32_t q0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(next_q), static_cast<int>(t)));
-                        if (mine) *reinterpret_cast<float4 *>(PM_PP(tarena) + q0 + RankBelow(b)) = seg;
-                        if (lane == t) next_q += static_cast<uint32_t>(__popcll(b));
+                    uint32_t m = mm;
+                    while (__ballot(m != 0u) != 0ull) {  // uniform: as many rounds as the most tiles one segment of the 64 reaches
+                        const uint32_t t = m != 0u ? static_cast<uint32_t>(__builtin_ctz(m)) : 0u;
+                        // (read from lane t by every lane, active or not: a lane outside the exec mask hands over nothing)
+                        const uint32_t q0 = static_cast<uint32_t>(__shfl(static_cast<int>(next_q), static_cast<int>(t)));
+                        if (m != 0u) {
+                            const uint32_t w = t >> 2;
+                            const uint32_t below = w == 0u ? exc[0] : (w == 1u ? exc[1] : (w == 2u ? exc[2] : exc[3]));
+                            *reinterpret_cast<float4 *>(PM_PP(tarena) + q0 + ((below >> (8u * (t & 3u))) & 0xffu)) = seg;
+                            m &= m - 1u;
+                        }
+                    }
+                    // lane t: the wave's position in tile t moves on by the round's total for it
+                    {
+                        const uint32_t w = (lane >> 2) & 3u;
+                        const uint32_t tw = w == 0u ? tot[0] : (w == 1u ? tot[1] : (w == 2u ? tot[2] : tot[3]));
+                        if (lane < kStripTiles) next_q += (tw >> (8u * (lane & 3u))) & 0xffu;
                     }
                     }  // rounds of the chunk
                 }
