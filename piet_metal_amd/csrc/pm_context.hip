@@ -186,6 +186,7 @@ struct pm_ctx {
     uint32_t bin_waves_env = 0;     // PM_BIN_WAVES: 4 / 1 waves per strip row in pm_bin_kernel (0: by the number of strip rows, EnsureArena)
     uint32_t bin_waves = 4;
     uint32_t bin_waves_inflight = 1;  // PM_BIN_WAVES_INFLIGHT: waves per strip row for frames submitted behind frames still running (1 / 4)
+    uint64_t row_want = 0;          // entries of a slot's per-tile-row item lists (use_row_lists)
     uint64_t plan_cands = 0;        // (item, strip row) pairs of the plan in force: candidates the strip rows will look at
     uint32_t bin_wg_per_cu = 0xff;  // pm_bin_kernel's workgroups per CU (PM_BIN_WG_PER_CU; 0 = one per strip row, default: by the number of strip rows)
     uint32_t coarse_wg_per_cu = 5, fine_wg_per_cu = 5;  // persistent grids (PM_COARSE_WG_PER_CU, PM_FINE_WG_PER_CU)
@@ -295,10 +296,7 @@ int SyncAll(pm_ctx *c) {
 
 void FreeSlotViewport(FrameSlot *s) {
     if (s->d_fb) (void)hipFree(s->d_fb);
-    if (s->d_queue) (void)hipFree(s->d_queue);
-    if (s->d_tile_state) (void)hipFree(s->d_tile_state);
-    if (s->d_tile_ptcl) (void)hipFree(s->d_tile_ptcl);
-    if (s->d_tile_ncmd) (void)hipFree(s->d_tile_ncmd);
+    if (s->d_queue) (void)hipFree(s->d_queue);  // (the three per-tile tables live behind the queues: one allocation)
     s->d_fb = nullptr;
     s->d_queue = nullptr;
     s->d_tile_state = s->d_tile_ptcl = s->d_tile_ncmd = nullptr;
@@ -319,18 +317,20 @@ int AllocSlotViewport(pm_ctx *c, FrameSlot *s) {
     FreeSlotViewport(s);  // (buffers of an earlier viewport: released now, when the slot is used again, not by the resize)
     s->vp_epoch = c->vp_epoch;
     const size_t tiles = BandTiles(c);
+    // two allocations (each costs 50-300 us): the pixels, and -- behind one another -- the class queues (one per cost class)
+    // and the three per-tile tables
     hipError_t e = hipMalloc(&s->d_fb, std::max<size_t>(c->fb_bytes, 16));
-    if (e == hipSuccess) e = hipMalloc(&s->d_queue, pm::kClasses * tiles * sizeof(uint4));  // one queue per cost class
-    if (e == hipSuccess) e = hipMalloc(&s->d_tile_state, tiles * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&s->d_tile_ptcl, tiles * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&s->d_tile_ncmd, tiles * sizeof(uint32_t));
+    const size_t tables = std::max<size_t>(tiles, 4);
+    if (e == hipSuccess) e = hipMalloc(&s->d_queue, pm::kClasses * tables * sizeof(uint4) + 3 * tables * sizeof(uint32_t));
+    if (e == hipSuccess) {
+        s->d_tile_state = reinterpret_cast<uint32_t *>(s->d_queue + pm::kClasses * tables);
+        s->d_tile_ptcl = s->d_tile_state + tables;
+        s->d_tile_ncmd = s->d_tile_ptcl + tables;
+    }
     s->state_epoch = 0;  // (never initialised)
     if (e != hipSuccess) {
         if (s->d_fb) (void)hipFree(s->d_fb);
         if (s->d_queue) (void)hipFree(s->d_queue);
-        if (s->d_tile_state) (void)hipFree(s->d_tile_state);
-        if (s->d_tile_ptcl) (void)hipFree(s->d_tile_ptcl);
-        if (s->d_tile_ncmd) (void)hipFree(s->d_tile_ncmd);
         s->d_fb = nullptr;
         s->d_queue = nullptr;
         s->d_tile_state = s->d_tile_ptcl = s->d_tile_ncmd = nullptr;
@@ -406,6 +406,17 @@ int EnsureSlotBuffers(pm_ctx *c, FrameSlot *s) {
         s->arena_cap = 0;
         PM_TRY(hipMalloc(&s->d_arena, static_cast<size_t>(std::max<uint32_t>(c->arena_cap, pm::kArenaBase)) * sizeof(uint32_t)));
         s->arena_cap = c->arena_cap;
+    }
+    if (c->use_row_lists && (!s->d_row_bbox || s->row_cap < c->row_want)) {
+        // per-tile-row item lists of this slot's frames (pm_rowcull_kernel writes them): boxes, then indices, ONE allocation
+        if (s->d_row_bbox) (void)hipFree(s->d_row_bbox);
+        s->d_row_bbox = nullptr;
+        s->d_row_item = nullptr;
+        s->row_cap = 0;
+        const uint64_t cap = c->row_want + c->row_want / 4;
+        PM_TRY(hipMalloc(&s->d_row_bbox, cap * (sizeof(uint2) + sizeof(uint32_t))));
+        s->d_row_item = reinterpret_cast<uint32_t *>(s->d_row_bbox + cap);
+        s->row_cap = cap;
     }
     if (!s->d_ptcl || s->ptcl_cap < c->ptcl_want) {
         if (s->d_ptcl) (void)hipFree(s->d_ptcl);
@@ -681,18 +692,9 @@ int EnsureArena(pm_ctx *c) {
                 sl[i] = r < rows ? make_uint2(rb[r], rb[r + 1] - rb[r]) : make_uint2(0u, 0u);
             }
             PM_TRY(hipMemcpyAsync(c->d_sr_list, sl.data(), sl.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
-            const uint64_t want = std::max<uint64_t>(run, 1);
-            for (auto &s : c->slot) {
-                if (s.row_cap >= want && s.d_row_bbox) continue;
-                if (s.d_row_bbox) (void)hipFree(s.d_row_bbox);
-                if (s.d_row_item) (void)hipFree(s.d_row_item);
-                s.d_row_bbox = nullptr;
-                s.d_row_item = nullptr;
-                s.row_cap = 0;
-                PM_TRY(hipMalloc(&s.d_row_bbox, (want + want / 4) * sizeof(uint2)));
-                PM_TRY(hipMalloc(&s.d_row_item, (want + want / 4) * sizeof(uint32_t)));
-                s.row_cap = want + want / 4;
-            }
+            // (the slots' own list buffers come into being when a slot is next used, EnsureSlotBuffers: the first frame of a
+            //  scene pays for one slot's, not for four -- eight allocations, 0.4 ms of config 5's first frame)
+            c->row_want = std::max<uint64_t>(run, 1);
         }
     }
     PM_TRY(hipStreamSynchronize(c->stream));  // ONE wait: the lists are in place before a frame on any stream reads them
@@ -1348,8 +1350,7 @@ void pm_destroy(pm_ctx *c) {
     for (auto &s : c->slot) {
         if (s.d_arena) (void)hipFree(s.d_arena);
         if (s.d_ptcl) (void)hipFree(s.d_ptcl);
-        if (s.d_row_bbox) (void)hipFree(s.d_row_bbox);
-        if (s.d_row_item) (void)hipFree(s.d_row_item);
+        if (s.d_row_bbox) (void)hipFree(s.d_row_bbox);  // (the indices live behind the boxes)
         if (s.d_ctr) (void)hipFree(s.d_ctr);
         if (s.h_overflow) (void)hipHostFree(s.h_overflow);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
