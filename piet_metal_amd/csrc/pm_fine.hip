@@ -762,7 +762,7 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     // wave that has finished its static share draws from deck wave_global % kTicketParts until the
     // deck is empty.  Per-tile times vary by 2x around what the estimates predict, so a wave's
     // second tile lands on whoever is free instead of on whoever the snake says (one counter for
-    // the whole grid would cap at ~90 draws/us; 128 counters in 128 cache lines cost nothing
+    // the whole grid would cap at ~90 draws/us; 32 counters in 32 cache lines cost nothing
     // measurable, tools/probes/atomic_probe.hip).
     // P.handout_static: the host saw other frames in flight -- with neighbours filling the idle
     // SIMDs a drawn hand-out only adds contention (sustained throughput -3.5 %), alone it ends the
