@@ -1,5 +1,9 @@
 #!/bin/bash
-# A/B of two library builds on ONE box, alternating: tools/gpu_ab.sh <variant> <rounds> [bench flags]
+# Developer A/B of two library builds on ONE box, alternating (boxes differ by +-0.5 us, runs on one box by +-0.15):
+#   tools/gpu_ab.sh <variant> <rounds> [bench flags]
+# <variant> = a second library piet_metal_amd/lib/libpiet_metal_amd_<variant>.so built by hand from modified sources (the
+# objects of `hipcc -c` with the Makefile's flags, linked like the product) and allowed in piet_metal_amd/_lib.py's
+# PM_LIB_VARIANT check for the session -- never committed, never loaded by the product.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 V=$1; R=$2; shift; shift
