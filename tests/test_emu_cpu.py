@@ -43,7 +43,7 @@ def test_parity_subset_under_wave64_emulation(built):
 
 
 def test_every_frame_path_switch_under_emulation(built):
-    out = _run("every_frame_path or persistent_grid or binning_launch_variants or wave_per_strip_row")
+    out = _run("every_frame_path or persistent_grid or binning_launch_variants or wave_per_strip_row or view_changes_keep")
     assert " passed" in out and "failed" not in out
 
 
