@@ -255,6 +255,18 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
  * at all). */
 int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms);
 
+/* One launch per frame (pm_frame_kernel: the two dispatches of PietRenderer.m:69-88 as roles of one resident
+ * grid).  *frames = frames submitted that way since pm_create; *applies = 1 if a frame of the resident scene
+ * and viewport, alone on the device, would be (0: two launches -- PM_ONE_LAUNCH=0, more strip rows than resident
+ * workgroups, per-tile-row item lists, or a one-launch frame once gave up waiting). */
+int pm_one_launch_info(pm_ctx *c, uint32_t *frames, int *applies);
+/* Duration of that launch, frame alone, from events carried by the dispatch itself (what a kernel trace shows);
+ * average over `iters` frames.  PM_ERR_INVALID when *applies is 0. */
+int pm_time_one_launch(pm_ctx *c, int iters, float *kernel_ms);
+/* Developer hook: one one-launch frame by its profiling instantiation -- per workgroup 32 x u64 (10 ns clocks and
+ * counts, layout at pm_frame_kernel in pm_frame.hip); *n_wgs = the launch's workgroups. */
+int pm_debug_time_frame(pm_ctx *c, uint64_t *out, size_t max_wgs, size_t *n_wgs);
+
 /* Developer hook: the lone frame taken apart -- medians over `iters` frames of {pm_bin_kernel,
  * gap, pm_coarse_kernel, gap, pm_fine_kernel, first begin -> last end}, ms, from events attached to
  * the dispatches (which stretch the gaps: a breakdown, not t_frame -- that is pm_frame_latency;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PM_LIB_VARIANT=strict (tests / fuzzing only): the build whose LDS-only barriers are full __syncthreads()
 # (csrc/pm_kernels_common.h, LdsBarrier) -- the same C ABI, the same kernels otherwise
 _VARIANT = os.environ.get("PM_LIB_VARIANT", "")
-if _VARIANT not in ("", "strict"):
+if _VARIANT not in ("", "strict") and not (os.environ.get("PM_LIB_DEV") == "1" and _VARIANT.isalnum()):  # (PM_LIB_DEV: a developer's hand-built A/B library)
     raise ImportError(f"PM_LIB_VARIANT={_VARIANT!r}: only 'strict' exists")
 LIB_PATH = os.path.join(_HERE, "lib", "libpiet_metal_amd" + ("_" + _VARIANT if _VARIANT else "") + ".so")
 
@@ -128,6 +128,9 @@ SIGNATURES = {
     "pm_scene_device_ptr": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "pm_time_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_frame_latency": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pm_one_launch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "pm_time_one_launch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "pm_debug_time_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "pm_time_frames_pipelined": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_debug_frame_timeline": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pm_get_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),

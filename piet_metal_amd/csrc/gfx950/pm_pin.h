@@ -73,5 +73,45 @@ __device__ __forceinline__ void WriteLane(uint32_t &v, uint32_t uniform_value) {
     asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(sv), "n"(kLane));
 }
 
+// ---- hand-overs inside one launch (pm_frame_kernel) --------------------------------------------------------------------
+// The eight XCDs' L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's stores: what one
+// workgroup writes for another is stored WRITE-THROUGH (sc1: the bytes leave the XCD's L2 for memory, the line is dropped)
+// and read with agent-scope (sc1) loads, which are served from memory's side of the fabric, never from a stale line.
+typedef uint32_t pm_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void StoreWT16(uint4 *p, uint4 v) {
+    const pm_u32x4 d = {v.x, v.y, v.z, v.w};
+    // (an asm store is absent from the compiler's count of outstanding memory operations: its waits for its own loads
+    //  only get longer; the data registers must not be rewritten for one more state)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
+}
+__device__ __forceinline__ void StoreWT8(uint2 *p, uint2 v) {
+    typedef __attribute__((address_space(1))) unsigned long long *GlobalU64;
+    __hip_atomic_store((unsigned long long *)(GlobalU64)p, static_cast<unsigned long long>(v.x) | (static_cast<unsigned long long>(v.y) << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void StoreWT4(uint32_t *p, uint32_t v) {
+    typedef __attribute__((address_space(1))) uint32_t *GlobalU32;
+    __hip_atomic_store((uint32_t *)(GlobalU32)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint2 LoadCoherent8(const void *p) {
+    typedef __attribute__((address_space(1))) unsigned long long *GlobalU64;
+    const unsigned long long x = __hip_atomic_load((unsigned long long *)(GlobalU64)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2(static_cast<uint32_t>(x), static_cast<uint32_t>(x >> 32));
+}
+__device__ __forceinline__ uint32_t LoadCoherent4(const uint32_t *p) {
+    typedef __attribute__((address_space(1))) uint32_t *GlobalU32;
+    return __hip_atomic_load((uint32_t *)(GlobalU32)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a 16-byte record as two halves (the data was complete before anybody was told where it is)
+__device__ __forceinline__ uint4 LoadCoherent16(const void *p) {
+    const uint2 a = LoadCoherent8(p), b = LoadCoherent8(static_cast<const uint8_t *>(p) + 8);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+// every store this wave has issued has been acknowledged (also the write-through ones the compiler does not count)
+__device__ __forceinline__ void DrainStores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// between two looks at a word somebody else will write
+__device__ __forceinline__ void SleepPoll() { __builtin_amdgcn_s_sleep(24); }
+__device__ __forceinline__ unsigned long long PollClock() { return wall_clock64(); }
+
 }  // namespace
 }  // namespace pm

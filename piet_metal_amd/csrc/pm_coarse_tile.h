@@ -63,7 +63,9 @@ constexpr uint32_t kLdsChunks = 3;
 // phase-2 tests of elements [64 w, 64 w + 64), the waves exchange what they emit (CoarseShared) and each writes its
 // own commands at their place in the list.  Passes of at most 64 (or more than 256) elements are wave 0's alone, the
 // others walk the pieces without touching them; only wave 0's return value counts.
-template <bool kCapture, bool kProf = false, bool kPar = false>
+// kCoh (one launch per frame, pm_frame_kernel): the pieces were written during THIS launch, possibly by a workgroup on another
+// XCD -- they are read with agent-scope loads (no L1 line, no line of this XCD's L2 can be older than the piece it holds).
+template <bool kCapture, bool kProf = false, bool kPar = false, bool kCoh = false>
 __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &L, const uint4 qe,
                                                const uint32_t lane, const uint64_t lanes_below, CoarseTicks *ticks = nullptr,
                                                uint8_t *const lds_chunks = nullptr, const uint32_t lds_stride = 0, const uint32_t lds_n = 0,
@@ -78,6 +80,18 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
             *reinterpret_cast<Cmd *>(lds_chunks + (q >> 6) * lds_stride + (q & 63u) * static_cast<uint32_t>(sizeof(Cmd))) = c;
         else
             out_cmds[q] = c;
+    };
+    auto quad = [](const uint4 *q) -> uint4 {
+        if constexpr (kCoh) return LoadCoherent16(q);
+        else return *q;
+    };
+    auto quad_f = [&](const float4 *q) -> float4 {
+        if constexpr (kCoh) {
+            const uint4 v = LoadCoherent16(q);
+            return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        } else {
+            return *q;
+        }
     };
     unsigned long long tk0 = 0, tk1 = 0;
     // (the entry names the tile by column | row << 16: no division by the width of the grid on the way to its pixels)
@@ -113,14 +127,16 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
         // looked at, one round trip.  (Written as it reads -- the header through Scalar4, the candidates inside the
         // pass loop -- the compiler waited for the header before it asked for the segments, and for those before the
         // candidates: three round trips in front of every tile's list, 1.5-2 us of its 8-11.)
-        const uint2 hdr_l = *reinterpret_cast<const uint2 *>(pc);  // (every lane the same address)
+        uint2 hdr_l;  // (every lane the same address)
+        if constexpr (kCoh) hdr_l = LoadCoherent8(pc);
+        else hdr_l = *reinterpret_cast<const uint2 *>(pc);
         // (unconditional, from clamped indices -- a piece has at least one candidate, and what a lane beyond the piece's
         //  segments or candidates reads is never looked at: a load under `if (lane < n)` merges with a zero behind it, and
         //  the copy that merge needs waits for the load on the spot)
         const uint32_t li = Opaque(lane);
-        const float4 seg_l = segs[min(li, nrel)];  // (index nrel: the first candidate's quad -- inside the piece)
+        const float4 seg_l = quad_f(segs + min(li, nrel));  // (index nrel: the first candidate's quad -- inside the piece)
         const uint4 *const cr0 = cands + 2u * min(li, nhit - 1u);
-        const uint4 ca_l = cr0[0], cb_l = cr0[1];
+        const uint4 ca_l = quad(cr0), cb_l = quad(cr0 + 1);
         uint32_t h0 = hdr_l.x, h1 = hdr_l.y, a0 = ca_l.x, a1 = ca_l.y, a2 = ca_l.z, a3 = ca_l.w, b0 = cb_l.x, b1 = cb_l.y, b2 = cb_l.z, b3 = cb_l.w;
         float s0 = seg_l.x, s1 = seg_l.y, s2 = seg_l.z, s3 = seg_l.w;
         PinPiece(h0, h1, s0, s1, s2, s3, a0, a1, a2, a3, b0, b1, b2, b3);
@@ -149,8 +165,8 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                 uint4 a = cand_a, b = cand_b;  // (the first pass's: requested with the piece's header)
                 if (cb != 0) {
                     const uint4 *cr = cands + 2u * (cb + lane);
-                    a = cr[0];
-                    b = cr[1];
+                    a = quad(cr);
+                    b = quad(cr + 1);
                 }
                 L.htag[lane] = a.x & 0xffffu;
                 my_rgba = a.y;
@@ -280,7 +296,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                         const uint32_t si = L.hwoff[c] + (e - L.hoff[c]);
                         float4 s;
                         if (si < 64u) s = L.segw[si];
-                        else s = segs[si];
+                        else s = quad_f(segs + si);
                         const float a = s.w - s.y;
                         const float b = s.x - s.z;
                         const float cc = -(a * s.x + b * s.y);
@@ -492,6 +508,14 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                 if (last_solid >= 0) solid_color = solid_rgba;
                 if (last_draw > last_solid) solid_color = 0;  // encodeCircle/Line/Stroke/DrawFill (:81,:90,:99,:124)
                 WaveSync();
+                // A pass the four waves built together ends with every wave's commands stored: wave 0 may run the next pass (of this
+                // piece or the next) alone, and an opaque Solid there restarts the list over the very slots waves 1-3 have just
+                // written -- a store of theirs still in flight would land on top of the newer command.  (Commands beyond the LDS
+                // chunks went to HBM: the full barrier also waits for those stores.)
+                if (par) {
+                    if (n_pending > lds_cmds) __syncthreads();
+                    else LdsBarrier();
+                }
                 if (kProf) ticks->emit += wall_clock64() - tk1;
             }
             rel_done += pass_rel;

@@ -162,7 +162,9 @@ struct FrameSlot {
     uint32_t vp_epoch = 0;        // viewport its buffers were allocated for (pm_ctx::vp_epoch; stale ones go when the slot is next used)
     pm::Counters *d_ctr = nullptr;  // two: a frame's binning kernel zeroes the one the slot's next frame uses
     uint32_t *h_overflow = nullptr;  // pinned: raised by a frame of this slot whose tile arena ran out (what pm_sync looks at first)
-    uint32_t *d_overflow = nullptr;  // ... as the device sees it
+    uint32_t *d_overflow = nullptr;  // ... as the device sees it ([1]: a one-launch frame of this slot gave up waiting)
+    uint4 *d_fifo = nullptr;         // one-launch frames: kFifos x fifo_cap queue entries, all zero between frames (made when first needed)
+    uint32_t fifo_cap = 0;
     uint32_t parity = 0;
     hipEvent_t ev_done = nullptr;  // end of the slot's last frame
     bool in_flight = false;        // a frame using this slot was submitted; ev_done marks its end
@@ -193,6 +195,29 @@ struct pm_ctx {
     uint32_t fine_wg_per_cu_inflight = 3;               // ... of a frame behind other frames (PM_FINE_WG_PER_CU_INFLIGHT)
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_cus = 0;
+    // One launch per frame (pm_frame_kernel, pm_frame.hip): PM_ONE_LAUNCH=1 for every frame that has the device to itself,
+    // whose strip rows fit the resident grid two to a workgroup, and that needs nothing the one kernel does not do (per-tile-row
+    // item lists, a wave per strip row, separate list building).  Off by default: measured slower than two launches on every
+    // scene ("one launch per frame") -- the chains that set a frame's length are strings of memory round trips, and
+    // they stretch when the rest of the chip renders tiles beside them instead of idling.
+    int one_launch_mode = 0;
+    bool one_launch_split = false;    // PM_ONE_LAUNCH_SPLIT=1 (developer experiment): the kernel's two roles as two launches of it
+    bool one_launch_broken = false;   // a frame gave up waiting inside the launch (pm_sync rendered it again): two launches from then on
+    uint32_t frame_wg_per_cu = 0;     // resident workgroups of pm_frame_kernel per CU (0: cannot run five, one-launch frames are off)
+    uint32_t frame_spin_ticks = 200000;  // PM_ONE_LAUNCH_SPIN_US x 100: a wait inside the launch gives up after this long
+    uint32_t *d_sr_next_one = nullptr;  // [n_sr_active] chains of the one-launch grid (0: the workgroup's last strip row)
+    size_t sr_next_one_cap = 0;
+    uint32_t one_grid_rows = 0;       // binning workgroups of a one-launch frame (0: its strip rows do not fit two per workgroup)
+    std::vector<uint32_t> stage_next_one;
+    uint32_t *d_idle_sr = nullptr;    // strip rows of the band no item reaches (the launch writes their pixels too)
+    size_t idle_sr_cap = 0;
+    uint32_t n_idle_sr = 0;
+    std::vector<uint32_t> stage_idle;
+    uint32_t frames_one_launch = 0;   // frames submitted as one launch (pm_one_launch_info)
+    // pm_debug_capture_ptcl of a one-launch frame: the frame is rendered once more with the capture instantiation of its kernel
+    uint32_t *cap_counts = nullptr, *cap_solid = nullptr;
+    pm::Cmd *cap_cmds = nullptr;
+    uint32_t cap_max = 0;
 
     // scene
     uint8_t *h_scene = nullptr;  // pinned staging (pm_scene_buffer): only pm_scene_reserve moves it
@@ -297,6 +322,9 @@ int SyncAll(pm_ctx *c) {
 void FreeSlotViewport(FrameSlot *s) {
     if (s->d_fb) (void)hipFree(s->d_fb);
     if (s->d_queue) (void)hipFree(s->d_queue);  // (the three per-tile tables live behind the queues: one allocation)
+    if (s->d_fifo) (void)hipFree(s->d_fifo);
+    s->d_fifo = nullptr;
+    s->fifo_cap = 0;
     s->d_fb = nullptr;
     s->d_queue = nullptr;
     s->d_tile_state = s->d_tile_ptcl = s->d_tile_ncmd = nullptr;
@@ -636,6 +664,62 @@ int EnsureArena(pm_ctx *c) {
         c->sr_desc_cap = want;
     }
     PM_TRY(hipMemcpyAsync(c->d_sr_desc, desc.data(), desc.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    {
+        // Chains of the one-launch grid (four workgroups per CU, all resident): workgroup b bins strip row b; with more strip rows
+        // than workgroups the rows beyond go, heaviest first, to the workgroups whose own row is lightest (by the arena bound,
+        // the only estimate there is) -- a second light row ends before the frame's heaviest row does.
+        std::vector<uint32_t> &nx = c->stage_next_one;
+        const size_t n = desc.size();
+        nx.assign(n, 0u);
+        const size_t resident = static_cast<size_t>(c->n_cus) * c->frame_wg_per_cu;
+        c->one_grid_rows = 0;
+        if (resident != 0 && n <= 2 * resident) {
+            const size_t rows = std::min(n, resident);
+            c->one_grid_rows = static_cast<uint32_t>(rows);
+            if (n > rows) {
+                std::vector<uint32_t> first(rows), extra(n - rows);
+                for (size_t i = 0; i < rows; ++i) first[i] = static_cast<uint32_t>(i);
+                for (size_t i = rows; i < n; ++i) extra[i - rows] = static_cast<uint32_t>(i);
+                auto weight = [&](uint32_t i) { return desc[i].z - desc[i].y; };
+                std::stable_sort(first.begin(), first.end(), [&](uint32_t a, uint32_t b) { return weight(a) < weight(b); });
+                std::stable_sort(extra.begin(), extra.end(), [&](uint32_t a, uint32_t b) { return weight(a) > weight(b); });
+                for (size_t k = 0; k < extra.size(); ++k) nx[first[k]] = extra[k];
+            }
+        }
+        if (n > c->sr_next_one_cap || !c->d_sr_next_one) {
+            if (c->d_sr_next_one) (void)hipFree(c->d_sr_next_one);
+            c->d_sr_next_one = nullptr;
+            c->sr_next_one_cap = 0;
+            const size_t want = n + n / 4 + 16;
+            PM_TRY(hipMalloc(&c->d_sr_next_one, want * sizeof(uint32_t)));
+            c->sr_next_one_cap = want;
+        }
+        PM_TRY(hipMemcpyAsync(c->d_sr_next_one, nx.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    }
+    {
+        // the strip rows without a workgroup: a one-launch frame writes their (background) pixels from this list
+        std::vector<uint32_t> &idle = c->stage_idle;
+        idle.clear();
+        size_t k = 0;
+        for (size_t i = 0; i < need.size(); ++i) {
+            const uint32_t key = static_cast<uint32_t>(i % c->strips_x) | (static_cast<uint32_t>(i / c->strips_x) << 16);
+            if (k < desc.size() && desc[k].x == key) {  // (the empty list's one workgroup "has" strip row 0)
+                ++k;
+                continue;
+            }
+            idle.push_back(static_cast<uint32_t>(i));
+        }
+        c->n_idle_sr = static_cast<uint32_t>(idle.size());
+        if (idle.size() > c->idle_sr_cap || !c->d_idle_sr) {
+            if (c->d_idle_sr) (void)hipFree(c->d_idle_sr);
+            c->d_idle_sr = nullptr;
+            c->idle_sr_cap = 0;
+            const size_t want = idle.size() + idle.size() / 4 + 16;
+            PM_TRY(hipMalloc(&c->d_idle_sr, want * sizeof(uint32_t)));
+            c->idle_sr_cap = want;
+        }
+        if (!idle.empty()) PM_TRY(hipMemcpyAsync(c->d_idle_sr, idle.data(), idle.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    }
     c->arena_epoch += 1;  // (a slot's tile_state is reset to "background" on the frame's own stream when the slot is next used)
     {
         if (ids.size() > c->band_cap || !c->d_band_bbox) {
@@ -756,6 +840,15 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->ctr_cur = s->d_ctr + s->parity;
     p->ctr_next = s->d_ctr + (s->parity ^ 1u);
     p->host_overflow = s->d_overflow;
+    p->host_fail = s->d_overflow + 1;
+    p->fifo = s->d_fifo;
+    p->fifo_cap = s->fifo_cap;
+    p->one_launch = 0;
+    p->sr_next_one = c->d_sr_next_one;
+    p->one_grid_rows = c->one_grid_rows;
+    p->idle_sr = c->d_idle_sr;
+    p->n_idle_sr = c->n_idle_sr;
+    p->spin_ticks = c->frame_spin_ticks;
     // (the whole item list in scene order: the scene's own boxes, no list of indices)
     p->band_bbox = c->band_identity ? reinterpret_cast<const uint2 *>(c->d_scene + c->dev_bbox_ix) : c->d_band_bbox;
     p->band_item = c->band_identity ? nullptr : c->d_band_item;
@@ -814,6 +907,32 @@ void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t frame_st
     s->parity ^= 1u;
     c->last_slot = si;
     c->frame += 1;
+}
+
+// Workgroups of a one-launch frame (0: this frame takes two launches).  Every strip row some item reaches needs its own
+// workgroup, all resident at once; beyond those, as many as there could be tiles to take from the FIFOs.
+uint32_t OneLaunchGrid(const pm_ctx *c) {
+    if (c->one_launch_mode == 0 || c->frame_wg_per_cu == 0 || !c->fused || c->use_row_lists || c->bin_waves != 4) return 0u;
+    const uint32_t resident = static_cast<uint32_t>(c->n_cus) * c->frame_wg_per_cu;
+    if (c->one_grid_rows == 0u) return 0u;  // (more than two strip rows per resident workgroup: EnsureArena)
+    const uint64_t tiles = BandTiles(c);
+    if (tiles > 0xffffffu) return 0u;
+    return std::max(c->one_grid_rows, std::min(resident, static_cast<uint32_t>((tiles + 3u) / 4u)));
+}
+
+// The slot's FIFO entries (zeroed once: whoever takes an entry leaves a zero behind).
+// (zeroed on the stream the frame is about to run on: the context's streams do not wait for the null stream)
+int EnsureFifo(pm_ctx *c, FrameSlot *s, hipStream_t q) {
+    const uint32_t cap = static_cast<uint32_t>(BandTiles(c));
+    if (s->d_fifo && s->fifo_cap >= cap) return PM_OK;
+    if (s->d_fifo) (void)hipFree(s->d_fifo);
+    s->d_fifo = nullptr;
+    s->fifo_cap = 0;
+    const size_t bytes = static_cast<size_t>(pm::kFifos) * cap * sizeof(uint4);
+    PM_TRY(hipMalloc(&s->d_fifo, bytes));
+    PM_TRY(hipMemsetAsync(s->d_fifo, 0, bytes, q));
+    s->fifo_cap = cap;
+    return PM_OK;
 }
 
 // One frame: its kernels back to back on one in-order stream -- the context's stream
@@ -880,6 +999,41 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
         p.fine_grid = std::max(1u, std::min(p.fine_grid, static_cast<uint32_t>(c->n_cus) * c->fine_wg_per_cu_inflight));
     const uint32_t n_striprows = BandRows(c) * c->strips_x;
     PM_TRY(ResetTileState(c, s, q));
+    // One launch for the whole frame (pm_frame.hip) when the frame has the device to itself -- two such launches at once could
+    // each hold the slots the other's binning workgroups wait for -- and every strip row gets its own resident workgroup.
+    const uint32_t frame_grid = OneLaunchGrid(c);
+    if (frame_grid != 0u && !tev && !p.handout_static && !c->one_launch_broken) {
+        r = EnsureFifo(c, s, q);
+        if (r != PM_OK) return r;
+        p.fifo = s->d_fifo;
+        p.fifo_cap = s->fifo_cap;
+        if (c->cap_counts) {
+            p.dbg_counts = c->cap_counts;
+            p.dbg_solid = c->cap_solid;
+            p.dbg_cmds = c->cap_cmds;
+            p.dbg_max = c->cap_max;
+        }
+#ifdef PM_EMU
+        const bool split = true;  // (the CPU emulation runs workgroups one after the other: the binning roles first, then everybody takes from the FIFOs)
+#else
+        const bool split = c->one_launch_split;
+#endif
+        if (split) {
+            p.one_launch = 1u;
+            pm::LaunchFrame(p, frame_grid, q);
+            p.one_launch = 2u;
+            pm::LaunchFrame(p, frame_grid, q);
+        } else {
+            p.one_launch = 3u;
+            pm::LaunchFrame(p, frame_grid, q);
+        }
+        PM_TRY(hipGetLastError());
+        c->frames_one_launch += 1;
+        Submitted(c, si, p, q);
+        s->user_stream = user_stream != nullptr && std::find(c->streams.begin(), c->streams.end(), q) == c->streams.end();
+        if (s->user_stream) PM_TRY(hipEventRecord(s->ev_done, q));
+        return PM_OK;
+    }
     // The resolved tiles' pixels (26 MB of stores at Tiger 4K): extra workgroups of the tile kernel's
     // launch for a frame alone (one launch less: -7 us), a launch of its own between the two kernels
     // when other frames are in flight -- there it fills the SIMDs binning's tail leaves idle instead of
@@ -1240,6 +1394,16 @@ pm_ctx *pm_create(int device, int *err) {
     c->bin_waves_env = static_cast<uint32_t>(EnvInt("PM_BIN_WAVES", 0, 0, 4));
     c->bin_waves_inflight = c->bin_waves_env ? c->bin_waves_env : static_cast<uint32_t>(EnvInt("PM_BIN_WAVES_INFLIGHT", 1, 1, 4));
     c->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 320, 0, 1 << 30));
+    c->one_launch_mode = EnvInt("PM_ONE_LAUNCH", 0, 0, 1);
+    c->one_launch_split = EnvInt("PM_ONE_LAUNCH_SPLIT", 0, 0, 1) != 0;
+    c->frame_spin_ticks = static_cast<uint32_t>(EnvInt("PM_ONE_LAUNCH_SPIN_US", 2000, 1, 1000000)) * 100u;
+    {
+        // the one-launch grid must be resident as a whole: what the occupancy API says a CU holds, four at most (the
+        // kernel's registers are sized for four)
+        const int res = pm::FrameKernelResidency();
+        c->frame_wg_per_cu = res >= 4 ? 4u : 0u;
+        if (const char *v = std::getenv("PM_FRAME_WG_PER_CU")) c->frame_wg_per_cu = static_cast<uint32_t>(std::max(0, std::min(res, std::atoi(v))));
+    }
 
     for (auto &ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
@@ -1248,7 +1412,7 @@ pm_ctx *pm_create(int device, int *err) {
         if ((e = hipMalloc(&s.d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
         if ((e = hipMemset(s.d_ctr, 0, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMemset(counters)");
         if ((e = hipHostMalloc(&s.h_overflow, 64, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(overflow word)");
-        *s.h_overflow = 0;
+        s.h_overflow[0] = s.h_overflow[1] = 0;
         void *dp = nullptr;
         if ((e = hipHostGetDevicePointer(&dp, s.h_overflow, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer");
         s.d_overflow = static_cast<uint32_t *>(dp);
@@ -1360,6 +1524,8 @@ void pm_destroy(pm_ctx *c) {
     if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
     if (c->d_band_item) (void)hipFree(c->d_band_item);
     if (c->d_row_base) (void)hipFree(c->d_row_base);
+    if (c->d_idle_sr) (void)hipFree(c->d_idle_sr);
+    if (c->d_sr_next_one) (void)hipFree(c->d_sr_next_one);
     c->flatten_cache.Free();
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->d_scene_alt) (void)hipFree(c->d_scene_alt);
@@ -1574,8 +1740,21 @@ int pm_sync(pm_ctx *c) {
         for (auto &t : c->slot) t.needs_check = false;  // (the frames left out of `latest` were superseded on their target)
         std::vector<pm::FrameParams> redo;
         uint64_t want = 0;
+        bool gave_up = false;
         for (int si : latest) {
-            const FrameSlot &s = c->slot[si];
+            FrameSlot &s = c->slot[si];
+            if (static_cast<volatile uint32_t *>(s.h_overflow)[1] != 0u) {
+                // A one-launch frame gave up waiting inside its launch (its workgroups were not all resident, or somebody
+                // else's work held the device): the frame has holes.  Its hand-over state goes back to all zero, the frame is
+                // rendered again with two launches, and so is every frame from now on.
+                gave_up = true;
+                c->one_launch_broken = true;
+                if (s.d_fifo) PM_TRY(hipMemset(s.d_fifo, 0, static_cast<size_t>(pm::kFifos) * s.fifo_cap * sizeof(uint4)));
+                PM_TRY(hipMemset(s.d_ctr, 0, 2 * sizeof(pm::Counters)));
+                PM_TRY(hipDeviceSynchronize());  // (the frame streams do not wait for the null stream's memsets)
+                redo.push_back(s.params);
+                continue;
+            }
             // (the slot's pinned word first: no frame of the slot has run out of arena since it was last cleared -- the usual
             //  case -- and pm_sync costs no copy from the device, 15 us each)
             if (*static_cast<volatile uint32_t *>(s.h_overflow) == 0u) continue;
@@ -1591,11 +1770,11 @@ int pm_sync(pm_ctx *c) {
             want = std::max<uint64_t>(want, std::max<uint64_t>(4ull * s.ptcl_cap, 2ull * top));
             redo.push_back(s.params);
         }
-        for (auto &t : c->slot) *t.h_overflow = 0;  // (nothing is in flight: every frame that raised one has been looked at or superseded)
+        for (auto &t : c->slot) t.h_overflow[0] = t.h_overflow[1] = 0;  // (nothing is in flight: every frame that raised one has been looked at or superseded)
         if (redo.empty()) return PM_OK;
         want = std::min<uint64_t>(0x7fffffffull, want);
-        if (want <= c->ptcl_want) break;
-        c->ptcl_want = want;  // (every slot grows when it is used next, EnsureSlotBuffers)
+        if (want <= c->ptcl_want && !gave_up) break;
+        c->ptcl_want = std::max<uint64_t>(c->ptcl_want, want);  // (every slot grows when it is used next, EnsureSlotBuffers)
         // render the damaged targets again on the context's own streams (a caller's stream may be
         // gone by now; the next pass of this loop waits for them and checks them again)
         for (const pm::FrameParams &p : redo) {
@@ -1770,6 +1949,89 @@ int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms) {
     std::sort(lat.begin(), lat.end());
     if (median_ms) *median_ms = lat[lat.size() / 2];
     if (min_ms) *min_ms = lat.front();
+    return pm_sync(c);
+}
+
+int pm_one_launch_info(pm_ctx *c, uint32_t *frames, int *applies) {
+    if (!c) return PM_ERR_INVALID;
+    if (frames) *frames = c->frames_one_launch;
+    if (applies) {
+        *applies = 0;
+        if (c->d_scene && c->tiles_x != 0) {
+            const int r = EnsureArena(c);
+            if (r != PM_OK) return r;
+            *applies = OneLaunchGrid(c) != 0u && !c->one_launch_broken && c->handout != 1 ? 1 : 0;
+        }
+    }
+    return PM_OK;
+}
+
+int pm_time_one_launch(pm_ctx *c, int iters, float *kernel_ms) {
+    if (!c || iters <= 0 || !kernel_ms) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = SyncAll(c)) != PM_OK) return r;
+    double acc = 0;
+    for (int i = 0; i < iters; ++i) {
+        const int si = static_cast<int>(c->frame % c->slot.size());
+        FrameSlot *s = &c->slot[si];
+        pm::FrameParams p;
+        if ((r = BuildParams(c, s, nullptr, c->fb_stride, &p)) != PM_OK) return r;
+        const uint32_t grid = OneLaunchGrid(c);
+        if (grid == 0u || c->one_launch_broken) return PM_ERR_INVALID;
+        if ((r = EnsureFifo(c, s, c->stream)) != PM_OK) return r;
+        p.fifo = s->d_fifo;
+        p.fifo_cap = s->fifo_cap;
+        p.one_launch = 3u;
+        PM_TRY(ResetTileState(c, s, c->stream));
+        pm::LaunchFrame(p, grid, c->stream, c->ev[0], c->ev[1]);
+        PM_TRY(hipStreamSynchronize(c->stream));
+        Submitted(c, si, p, c->stream);
+        s->in_flight = false;
+        float t = 0;
+        PM_TRY(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
+        acc += t;
+    }
+    *kernel_ms = static_cast<float>(acc / iters);
+    return pm_sync(c);
+}
+
+int pm_debug_time_frame(pm_ctx *c, uint64_t *out, size_t max_wgs, size_t *n_wgs) {
+    if (!c || !out) return PM_ERR_INVALID;
+    PM_TRY(hipSetDevice(c->device));
+    int r;
+    if ((r = SyncAll(c)) != PM_OK) return r;
+    const int si = static_cast<int>(c->frame % c->slot.size());
+    FrameSlot *s = &c->slot[si];
+    pm::FrameParams p;
+    if ((r = BuildParams(c, s, nullptr, c->fb_stride, &p)) != PM_OK) return r;
+    const uint32_t grid = OneLaunchGrid(c);
+    if (n_wgs) *n_wgs = grid;
+    if (grid == 0u || c->one_launch_broken) return PM_ERR_INVALID;
+    if (grid > max_wgs) return PM_ERR_CAPACITY;
+    if ((r = EnsureFifo(c, s, c->stream)) != PM_OK) return r;
+    unsigned long long *d = nullptr;
+    PM_TRY(hipMalloc(&d, static_cast<size_t>(grid) * 32 * sizeof(unsigned long long)));
+    p.fifo = s->d_fifo;
+    p.fifo_cap = s->fifo_cap;
+    p.one_launch = 3u;
+    p.dbg_time = d;
+    hipError_t e = ResetTileState(c, s, c->stream);
+    if (e == hipSuccess) {
+        if (c->one_launch_split) {
+            p.one_launch = 1u;
+            pm::LaunchFrame(p, grid, c->stream);
+            p.one_launch = 2u;
+        }
+        pm::LaunchFrame(p, grid, c->stream);
+        e = hipStreamSynchronize(c->stream);
+    }
+    p.dbg_time = nullptr;
+    Submitted(c, si, p, c->stream);
+    s->in_flight = false;
+    if (e == hipSuccess) e = hipMemcpy(out, d, static_cast<size_t>(grid) * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return HipFail(e, "frame timeline");
     return pm_sync(c);
 }
 
@@ -1972,6 +2234,26 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
     if (e == hipSuccess && max_cmds_per_tile) e = hipMemcpy(d_cmds, h_cmds.data(), h_cmds.size() * sizeof(pm::Cmd), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         pm::FrameParams p = s->params;  // same arena / queues / counters as the last frame
+        if (p.one_launch != 0u) {
+            // the last frame was ONE launch: no queues to replay -- the frame is rendered again (same target, same bytes) by the
+            // capture instantiation of that kernel
+            c->cap_counts = d_counts;
+            c->cap_solid = d_solid;
+            c->cap_cmds = d_cmds;
+            c->cap_max = max_cmds_per_tile;
+            bool own = false;
+            for (auto &t : c->slot) own = own || p.fb == t.d_fb;
+            status = Enqueue(c, own ? nullptr : p.fb, p.fb_stride, nullptr);
+            c->cap_counts = c->cap_solid = nullptr;
+            c->cap_cmds = nullptr;
+            c->cap_max = 0;
+            if (status == PM_OK) status = pm_sync(c);
+            if (status == PM_OK && c->slot[c->last_slot].params.dbg_counts == nullptr) {
+                SetError("pm_debug_capture_ptcl: the frame could not be rendered again as one launch");
+                status = PM_ERR_INVALID;
+            }
+            if (status != PM_OK) e = hipErrorUnknown;
+        } else {
         p.dbg_counts = d_counts;
         p.dbg_solid = d_solid;
         p.dbg_cmds = d_cmds;
@@ -1984,12 +2266,13 @@ int pm_debug_capture_ptcl(pm_ctx *c, uint32_t max_cmds_per_tile, uint32_t *count
         } else {
             pm::LaunchCoarse(p, CoarseGrid(c), true, c->stream);  // replays the last frame's queues
         }
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(counts, d_counts, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(solid, d_solid, tiles * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess && max_cmds_per_tile) e = hipMemcpy(cmds, d_cmds, tiles * max_cmds_per_tile * sizeof(pm::Cmd), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) status = HipFail(e, "ptcl capture");
+    if (e != hipSuccess && status == PM_OK) status = HipFail(e, "ptcl capture");
     (void)hipFree(d_counts);
     (void)hipFree(d_solid);
     (void)hipFree(d_cmds);

@@ -25,6 +25,15 @@ constexpr uint32_t kTicketParts = 32;  // decks of the drawn part of the tile ha
 // Per-frame counters; two copies alternate between frames so that frame N's binning
 // kernel can reset frame N+1's copy (no memset launch on the critical path).
 constexpr uint32_t kArenaShards = 16;  // parts of the tile arena, each with its own allocation counter
+constexpr uint32_t kFifoShards = 8;    // one-launch frames: FIFOs of single-wave tiles, one per XCD
+constexpr uint32_t kFifos = 1 + kFifoShards;
+
+// A FIFO's counters (its entries live in FrameParams::fifo): both on one 128-byte line -- a waiting wave reads them with one load.
+struct Fifo {
+    uint32_t tail;  // entries pushed (reserved: an entry is in place when its words are non-zero)
+    uint32_t head;  // tickets handed out
+    uint32_t pad[30];
+};
 
 struct Counters {
     // Every strip row of a frame adds to these with returning atomics.  The L2 executes
@@ -49,6 +58,19 @@ struct Counters {
         uint32_t count;  // cards drawn from this deck of tiles (pm_fine_kernel's hand-out)
         uint32_t pad[31];
     } ticket[kTicketParts];
+    // One launch per frame (pm_frame_kernel): tiles a strip row's own workgroup does not render itself wait in FIFOs for whoever
+    // is free -- fifo[0] the tiles a whole workgroup renders, fifo[1 + s] the single-wave tiles pushed by the workgroups of XCD s
+    // (block b runs on XCD b % 8).  Pushes reserve places with ONE returning atomic per strip row and FIFO, pops take a ticket each.
+    Fifo fifo[kFifos];
+    struct {
+        uint32_t count;  // workgroups of this part (blockIdx.x % kFifoShards) that have handed their strip row's tiles over
+        uint32_t pad[31];
+    } done_part[kFifoShards];
+    struct {
+        uint32_t parts;  // parts whose workgroups are all through
+        uint32_t done;   // 1: every strip row has been binned and handed over -- the FIFOs' tails are final
+        uint32_t pad[30];
+    } done_top;
 };
 
 // Binning works in two address spaces of HBM (per frame slot):
@@ -169,6 +191,16 @@ struct FrameParams {
     // {start clock, end clock, tile | quarter << 31, wave << 32 | commands interpreted}
     unsigned long long *dbg_time;
     unsigned long long *dbg_bin;  // per strip row of pm_bin_kernel: 8 x u64 phase clocks (developer profiling)
+    // one launch per frame (pm_frame_kernel)
+    uint4 *fifo;               // kFifos x fifo_cap queue entries, all zero between frames (whoever pops an entry zeroes it)
+    uint32_t fifo_cap;
+    uint32_t one_launch;       // roles of the launch's workgroups: bit 0 bin their strip row and render its first tiles, bit 1 take tiles from the FIFOs until the frame is done (the GPU runs both in one launch)
+    const uint32_t *sr_next_one;  // [n_sr_active] the one-launch grid's chains: next strip row of the workgroup (0: none)
+    uint32_t one_grid_rows;    // workgroups of the launch that bin strip rows (the first ones)
+    const uint32_t *idle_sr;   // strip rows no item reaches: their pixels are written by the launch too
+    uint32_t n_idle_sr;
+    uint32_t spin_ticks;       // a wait inside the launch gives up after this many 10 ns ticks (and raises *host_fail)
+    uint32_t *host_fail;       // pinned host word: a one-launch frame gave up waiting -- pm_sync renders it again with two launches
 };
 
 void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, const uint32_t *chunk_base, uint32_t n_chunks,
@@ -181,5 +213,9 @@ void LaunchCoarse(const FrameParams &p, uint32_t grid, bool capture, hipStream_t
 void LaunchCoverage(const FrameParams &p, uint32_t n_tiles, const uint32_t *tile_solid, float *out, uint32_t out_stride, hipStream_t stream);
 // clear_blocks: strip rows whose resolved tiles the launch also writes (0: pm_clear_kernel did)
 void LaunchFine(const FrameParams &p, uint32_t clear_blocks, bool fused, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+// the whole frame in one launch of `grid` resident workgroups (p.one_launch says which roles they play)
+void LaunchFrame(const FrameParams &p, uint32_t grid, hipStream_t stream, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
+// workgroups of pm_frame_kernel one CU holds at once (the occupancy API's answer)
+int FrameKernelResidency();
 
 }  // namespace pm

@@ -160,6 +160,19 @@ class Renderer:
         _lib.check(self._lib.pm_frame_latency(self._h, iters, C.byref(med), C.byref(mn)), "pm_frame_latency")
         return {"median_ms": med.value, "min_ms": mn.value, "iters": iters}
 
+    def one_launch_info(self) -> dict:
+        """Frames rendered as one launch so far, and whether a lone frame of the resident scene would be."""
+        n = C.c_uint32(0)
+        a = C.c_int(0)
+        _lib.check(self._lib.pm_one_launch_info(self._h, C.byref(n), C.byref(a)), "pm_one_launch_info")
+        return {"frames": int(n.value), "applies": bool(a.value)}
+
+    def time_one_launch(self, iters: int = 100) -> float:
+        """Average duration (ms) of pm_frame_kernel, frame alone (dispatch-attached events)."""
+        ms = C.c_float(0)
+        _lib.check(self._lib.pm_time_one_launch(self._h, iters, C.byref(ms)), "pm_time_one_launch")
+        return float(ms.value)
+
     def fill_coverage(self, item_ix: int) -> np.ndarray:
         """f32-accumulated winding coverage of one Fill item over the viewport band (validation)."""
         out = np.zeros((self.band_pixel_rows, self.width), np.float32)

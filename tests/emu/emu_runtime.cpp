@@ -46,7 +46,7 @@ pm_emu_switch:
 .size pm_emu_switch,.-pm_emu_switch
 )");
 
-enum State : int { kRunnable, kWaitWave, kWaitBlock, kDone };
+enum State : int { kRunnable, kWaitWave, kWaitBlock, kDone, kSleeping };
 
 struct Lane {
     void *sp = nullptr;
@@ -199,9 +199,18 @@ void RunBlock() {
     const uint32_t n = g_n_lanes, n_waves = (n + 63) / 64;
     std::vector<uint32_t> order(n_waves);
     for (uint32_t k = 0; k < n_waves; ++k) order[k] = k;
+    unsigned long idle_rounds = 0;  // rounds in which nothing happened but sleepers waking up
     for (;;) {
         bool progress = false;
         uint32_t live = 0, at_barrier = 0;
+        // lanes that slept (a wave polling for another wave of the workgroup) get their next look now that every
+        // other wave has had a turn
+        bool woke = false;
+        for (uint32_t i = 0; i < n; ++i)
+            if (g_lanes[i].state == kSleeping) {
+                g_lanes[i].state = kRunnable;
+                woke = true;
+            }
         if (g_shuffle) std::shuffle(order.begin(), order.end(), g_rng);
         for (uint32_t wk = 0; wk < n_waves; ++wk) {
             const uint32_t base = order[wk] * 64u, cnt = std::min(64u, n - base);
@@ -211,7 +220,7 @@ void RunBlock() {
                     if (g_lanes[base + i].state == kRunnable) {
                         Resume(&g_lanes[base + i]);
                         ran = true;
-                        progress = true;
+                        if (g_lanes[base + i].state != kSleeping) progress = true;
                     }
                 // every lane of the wave is parked or done
                 uint64_t waiting = 0, blocked = 0;
@@ -263,6 +272,11 @@ void RunBlock() {
                 if (g_lanes[i].state == kWaitBlock) g_lanes[i].state = kRunnable;
             continue;
         }
+        bool sleepers = woke;
+        for (uint32_t i = 0; i < n; ++i)
+            if (g_lanes[i].state == kSleeping) sleepers = true;
+        if (!progress && sleepers && ++idle_rounds < (1ul << 22)) continue;  // (only sleepers: they look again)
+        if (progress) idle_rounds = 0;
         if (!progress) {
             std::fprintf(stderr, "pm_emu: deadlock in block %u: %u live lanes, %u at the workgroup barrier\n", g_block_idx.x, live, at_barrier);
             std::abort();
@@ -284,6 +298,13 @@ uint64_t Collective(Op op, uint64_t a, uint64_t b, uint64_t c, void *site) {
     l->state = kWaitWave;
     Yield();
     return l->result;
+}
+
+// A lane that polls for something another wave of its workgroup will do: parked until every other wave has had a turn.
+void Sleep() {
+    Lane *l = g_cur;
+    l->state = kSleeping;
+    Yield();
 }
 
 void BlockBarrier(void *site) {

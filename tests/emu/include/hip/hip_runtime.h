@@ -63,6 +63,7 @@ enum Op : int { kBallot = 1, kReadFirst, kReadLane, kDpp, kShfl, kShflUp, kWaveB
 // (same kind, same call site), then returns this lane's result.
 uint64_t Collective(Op op, uint64_t a, uint64_t b, uint64_t c, void *site);
 void BlockBarrier(void *site);
+void Sleep();
 uint32_t LaneId();
 }  // namespace pm_emu
 

@@ -30,5 +30,21 @@ inline void WriteLane(uint32_t &v, uint32_t uniform_value) {
     if (__lane_id() == kLane) v = uniform_value;
 }
 
+// hand-overs inside one launch: plain accesses (workgroups run one after the other here)
+inline void StoreWT16(uint4 *p, uint4 v) { *p = v; }
+inline void StoreWT8(uint2 *p, uint2 v) { *p = v; }
+inline void StoreWT4(uint32_t *p, uint32_t v) { *p = v; }
+inline uint2 LoadCoherent8(const void *p) { return *static_cast<const uint2 *>(p); }
+inline uint32_t LoadCoherent4(const uint32_t *p) { return *p; }
+inline uint4 LoadCoherent16(const void *p) { return *static_cast<const uint4 *>(p); }
+inline void DrainStores() {}
+// (a lane that waits for another wave of its workgroup lets the scheduler run that wave: tests/emu/emu_runtime.cpp)
+inline void SleepPoll() { pm_emu::Sleep(); }
+// (no clock: a wait counts its own polls -- see PollClock's callers)
+inline unsigned long long PollClock() {
+    static unsigned long long t = 0;
+    return ++t;
+}
+
 }  // namespace
 }  // namespace pm

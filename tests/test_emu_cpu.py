@@ -52,3 +52,16 @@ def test_tiny_device_fewer_waves_than_handout_decks(built):
     finding: decks nobody draws from left their tiles unrendered)."""
     out = _run("persistent_grid_sizes and 1-1-1 or every_frame_path and 2-1-1", {"PM_EMU_CUS": "2"}, workers="")
     assert " passed" in out and "failed" not in out
+
+
+def test_one_launch_frames_under_emulation(built):
+    """PM_ONE_LAUNCH=1: the frame as roles of ONE kernel (csrc/pm_frame.hip).  The emulation runs workgroups one after the
+    other, so the host launches the kernel's two roles in turn (bin + the row's own tiles, then everybody takes from the
+    FIFOs): hand-over bookkeeping, kept / donated tiles, chains of strip rows (two CUs: eight resident workgroups) and the
+    capture instantiation are all the product's code; what only the GPU shows -- visibility across XCDs, waits -- is the
+    -m gpu test test_one_launch_frames_agree_with_the_oracle."""
+    k = "reference_scenes and 300 or random_scenes and 11 or many_items or empty_scene or bgra8"
+    out = _run(k, {"PM_ONE_LAUNCH": "1"})
+    assert " passed" in out and "failed" not in out
+    out = _run("reference_scenes and 300 or even_odd_fills_and_nested_groups and 31", {"PM_ONE_LAUNCH": "1", "PM_EMU_CUS": "2"}, workers="")
+    assert " passed" in out and "failed" not in out

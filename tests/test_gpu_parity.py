@@ -52,6 +52,10 @@ def test_extension_is_loaded_and_device_is_gfx950(pm, renderer):
     assert os.path.exists(pm._lib.LIB_PATH)
     maps = open("/proc/self/maps").read()
     assert "libpiet_metal_amd.so" in maps
+    import torch
+
+    arch = torch.cuda.get_device_properties(0).gcnArchName
+    assert arch.split(":")[0] == "gfx950", arch
 
 
 @pytest.mark.parametrize("name,w,h", [("path_test", 512, 832), ("cardioid", 2048, 1536), ("cardioid", 1999, 1501), ("cardioid", 300, 200)])
@@ -661,6 +665,56 @@ def test_every_frame_path_switch_agrees_with_the_oracle(pm, pmo, monkeypatch, fu
         got = gpu_render(r, scene2, 517, 500)
         assert np.array_equal(got, pmo.render(scene2, 517, 500))
         assert_ptcl_equal(r, pmo, scene2, 517, 500)
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("grid_per_cu", [None, "1"])
+def test_one_launch_frames_agree_with_the_oracle(pm, pmo, monkeypatch, golden, grid_per_cu):
+    """PM_ONE_LAUNCH=1: a lone frame is ONE launch of pm_frame_kernel -- every workgroup bins a strip row, renders that
+    row's first tiles from its own LDS hand-over and then takes tiles other rows left in the frame's FIFOs (pieces stored
+    write-through, read with agent-scope loads; csrc/pm_frame.hip).  Same bytes and the same command lists as the oracle:
+    lists captured from the one-launch kernel's own capture instantiation; scenes with every item type; strip rows with
+    several records; the 4K Tiger, whose 1 109 strip rows are more than the 1 024 resident workgroups (chains of two);
+    a band; frames submitted behind one another (those take two launches) -- and no frame ever gave up waiting.
+    grid_per_cu = 1: a quarter of the grid, so that small scenes chain strip rows too and 4K falls back to two launches."""
+    monkeypatch.setenv("PM_ONE_LAUNCH", "1")
+    if grid_per_cu is not None:
+        monkeypatch.setenv("PM_FRAME_WG_PER_CU", grid_per_cu)
+    r = pm.Renderer(0)
+    try:
+        wl = pm.workloads.tiger(960, 540)
+        r.resize(wl.width, wl.height)
+        r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        scene = r.download_scene()
+        r.render()
+        assert r.one_launch_info()["applies"]
+        assert np.array_equal(r.read_pixels(), pmo.render(scene, wl.width, wl.height))
+        assert_ptcl_equal(r, pmo, scene, wl.width, wl.height)
+        before = r.one_launch_info()["frames"]
+        for _ in range(6):  # back to back: only frames that find the device idle are one launch
+            r.render()
+        assert np.array_equal(r.read_pixels(), pmo.render(scene, wl.width, wl.height))
+        assert r.one_launch_info()["frames"] >= before
+        for seed, n, w, h in ((31, 900, 600, 400), (32, 300, 1100, 300), (33, 120, 928, 912)):
+            scene = encode_ops(pm, random_ops(seed, n, extent=float(max(w, h))))
+            got = gpu_render(r, scene, w, h)
+            assert np.array_equal(got, pmo.render(scene, w, h)), seed
+            assert_ptcl_equal(r, pmo, scene, w, h)
+        r.set_band(3, 17)
+        r.render()
+        assert np.array_equal(r.read_pixels(), pmo.render(scene, 928, 912)[48:272])
+        # full size: the 4K Tiger (chains of strip rows at the default grid) and Tiger 1080p, against the committed goldens
+        for wl, name in ((pm.workloads.tiger(3840, 2160), "tiger_3840x2160"), (pm.workloads.tiger(1920, 1080, fills_only=True), "tiger_1920x1080_fills")):
+            r.resize(wl.width, wl.height)
+            r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+            for _ in range(3):
+                r.render()
+                r.sync()
+            assert hashlib.sha256(r.read_pixels().tobytes()).hexdigest() == golden[name]["rgba_sha256"], name
+        info = r.one_launch_info()
+        assert info["frames"] > before
+        assert info["applies"], "a frame gave up waiting inside its launch"
     finally:
         r.close()
 
