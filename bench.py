@@ -113,6 +113,7 @@ class Job:
         self.stream = torch.cuda.current_stream()
         self.balance_log = []
         self.comm, self.gather_impl = None, args.gather_impl
+        self.chunks = []
         if world > 1:
             self._set_cuts([b[0] for b in self.layout] + [self.layout[-1][1]])
             if not args.equal_bands:
@@ -125,6 +126,7 @@ class Job:
                     self._set_cuts(new)
             self._alloc()
             self._setup_cabi()
+            self._setup_chunks()
 
     # ---- the product's own collective (pm_comm_* / pm_gather): id from rank 0 through the torch store ----
     def _setup_cabi(self):
@@ -167,6 +169,45 @@ class Job:
             print(f"bench.py: pm_gather not usable here ({why or 'another rank failed'}): falling back to torch.distributed send/recv", file=sys.stderr)
         self.comm, self.gather_impl = None, "sendrecv"
 
+    # ---- the gather pipelined under the render (--gather-chunks K) ---------------------------
+    def _setup_chunks(self):
+        """K sub-bands per rank, a renderer context each (a context's band is part of its binning plan: changing it per step
+        would re-plan per step); sub-band k is rendered on the step's stream, its gather goes to a second stream behind an
+        event, sub-band k + 1 is rendered meanwhile.  The step ends when both streams have: the step's stream waits for the
+        exchange stream."""
+        self.chunks = []
+        k_req = max(1, int(getattr(self.args, "gather_chunks", 1)))
+        if self.world == 1 or k_req == 1 or self.gather_impl == "allgather":
+            return
+        torch = self.torch
+        self.xstream = torch.cuda.Stream(device=self.band.device)
+        r0 = self.layout[self.rank][0]
+        for lay in self.pmd.sub_band_layouts(self.layout, self.wl.height, k_req):
+            s0, s1, srows = lay[self.rank]
+            q = None
+            if s1 > s0:
+                q = self.pm.Renderer(self.local)
+                q.resize(self.wl.width, self.wl.height)
+                q.flatten_and_encode(self.wl.paths, self.wl.affine, self.wl.width_scale)
+                q.set_band(s0, s1)
+            view = self.full[s0 * 16 : s0 * 16 + srows] if self.rank == 0 else self.band[(s0 - r0) * 16 : (s0 - r0) * 16 + srows]
+            self.chunks.append((q, lay, view, torch.cuda.Event()))
+
+    def _step_chunked(self):
+        torch = self.torch
+        self.xstream.wait_stream(self.stream)  # (the previous step's frame has been handed on)
+        for q, lay, view, ev in self.chunks:
+            if q is not None:
+                q.render_to(view, self.stream)
+            ev.record(self.stream)
+            self.xstream.wait_event(ev)
+            if self.gather_impl == "cabi":
+                self.comm.gather(lay, root=0, full=self.full, band=view if q is not None else self.band, stream=self.xstream, renderer=q or self.r)
+            else:
+                with torch.cuda.stream(self.xstream):
+                    self.pmd.gather_bands(view, lay, self.wl.height, dst=0, full=self.full)
+        self.stream.wait_stream(self.xstream)
+
     # ---- bands -------------------------------------------------------------------------
     def _set_cuts(self, cuts):
         self.cuts = list(cuts)
@@ -198,6 +239,9 @@ class Job:
         if self.world == 1:
             self.r.render()
             return
+        if self.chunks:
+            self._step_chunked()
+            return
         self.r.render_to(self.band, self.stream)  # caller-owned band on torch's stream: the gather follows in stream order
         self.gather()
 
@@ -220,6 +264,9 @@ class Job:
     def fence(self):
         if self.world > 1:
             self.dist.barrier()
+        for q, *_ in self.chunks:
+            if q is not None:
+                q.sync()
         self.r.sync()
         self.torch.cuda.synchronize()
 
@@ -314,6 +361,9 @@ def main() -> int:
                     help="N>1: cabi = the product's own collective behind the C ABI (pm_comm_create / pm_gather: grouped RCCL send/recv "
                          "into the final image); sendrecv = the same exchange through torch.distributed; allgather = padded all-gather; "
                          "auto (default) = cabi, falling back to sendrecv on every rank if any rank cannot set it up")
+    ap.add_argument("--gather-chunks", type=int, default=1,
+                    help="N>1: every rank renders its band in this many sub-bands (a context each) and posts each sub-band's gather on a "
+                         "second stream while it renders the next: the exchange runs under the render instead of behind it")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 block")
     ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config3",
                     help="the main line's workload (default: BASELINE config 3, the one the metric is quoted on; the others are for profiles/)")
@@ -486,6 +536,7 @@ def main() -> int:
                                f"{ {'cabi': 'pm_gather (C ABI: grouped RCCL send/recv)', 'sendrecv': 'grouped send/recv (torch.distributed)', 'allgather': 'padded all-gather'}.get(job.gather_impl, job.gather_impl) } "
                                "of the bands into the final image on rank 0 in every step",
                 "gather_impl": None if world == 1 else job.gather_impl,
+                "gather_chunks": None if world == 1 else max(1, len(job.chunks)),
                 "rccl_lib": rccl.get("rccl_lib"), "rccl_ranks": rccl.get("rccl_ranks"), **({"rccl_error": rccl["rccl_error"]} if "rccl_error" in rccl else {}),
                 "band_cuts": job.cuts, "balance": job.balance_log or None,
                 "t_render_ms": round(t_render, 5), "t_gather_ms": round(t_gather, 5), "t_frame_e2e_ms": round(t_frame_host, 5),
@@ -543,6 +594,11 @@ def main() -> int:
         import numpy as np
 
         job2 = job if args.no_config5 else Job(pm, pmd, torch, dist, r, wl, rank, world, local, args)
+        if world > 1:
+            job2.fence()
+            if rank == 0:
+                job2.full.zero_()  # (what is saved is what THIS step gathered)
+            job2.fence()
         job2.step()
         job2.fence()
         if rank == 0:

@@ -306,7 +306,8 @@ void pm_comm_destroy(pm_comm *m);
  * output may be NULL.  Loads RCCL like the other calls; not a collective. */
 int pm_comm_info(pm_comm *m, char *lib_path, size_t lib_path_cap, int *ranks);
 /* Collective.  band_tile_rows = {row0, row1} per rank (2*world entries, what each rank passed to
- * pm_set_band).  src_band = this rank's band (NULL: the context's last frame), tightly packed
+ * pm_set_band; a rank whose own entry is empty, row0 == row1, sends nothing and may pass any context
+ * of the device -- a band gathered in sub-bands, one context each, pipelined under the render).  src_band = this rank's band (NULL: the context's last frame), tightly packed
  * rows of width*4 bytes; dst_image (root only) = the full width*4 x height image.  Asynchronous
  * on hip_stream (NULL: the context's stream); ordered behind the last frame when src_band is NULL.
  * Errors: an argument error (PM_ERR_INVALID for bad rows, strides or a root without dst_image) is

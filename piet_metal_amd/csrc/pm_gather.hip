@@ -203,7 +203,8 @@ int pm_gather(pm_ctx *c, pm_comm *m, const void *src_band, size_t src_stride, co
     uint32_t width = 0, height = 0, row0 = 0, row1 = 0;
     if (pm::ContextViewport(c, &width, &height, &row0, &row1) != PM_OK) return PM_ERR_INVALID;
     const size_t tight = static_cast<size_t>(width) * 4;
-    if (band_tile_rows[2 * m->rank] != row0 || band_tile_rows[2 * m->rank + 1] != row1) {
+    // (a rank whose own entry is empty -- a sub-band of a band with fewer tile rows than chunks -- sends nothing: any context of the device does)
+    if (band_tile_rows[2 * m->rank] < band_tile_rows[2 * m->rank + 1] && (band_tile_rows[2 * m->rank] != row0 || band_tile_rows[2 * m->rank + 1] != row1)) {
         pm::SetLastError("pm_gather: band_tile_rows does not name this context's band");
         return PM_ERR_INVALID;
     }

@@ -55,6 +55,24 @@ def band_layout(height: int, world: int, cuts: list[int] | None = None) -> list[
     return _layout_from_cuts(list(cuts), height)
 
 
+def sub_band_layouts(layout: list[tuple[int, int, int]], height: int, chunks: int) -> list[list[tuple[int, int, int]]]:
+    """The gather pipelined under the render: every rank's band cut into `chunks` runs of whole tile rows (as equal
+    as the rows allow; a band with fewer rows than chunks gets empty ones), chunk k of all ranks forming one band table
+    of the shape `band_layout` returns.  A rank renders its sub-band k, posts ITS gather on a second stream and renders
+    sub-band k + 1 meanwhile: at 8 GPUs the 8192^2 frame is 0.07 ms of rendering in front of >= 0.22 ms of wire time
+    (DESIGN.md 6), so what overlaps is nearly all of a rank's rendering.  Deterministic in (layout, chunks): every rank
+    computes every rank's rows."""
+    assert chunks >= 1
+    out = []
+    for k in range(chunks):
+        cuts = []
+        for a, b, _rows in layout:
+            s0, s1 = a + (b - a) * k // chunks, a + (b - a) * (k + 1) // chunks
+            cuts.append((s0, s1, max(0, min(s1 * 16, height) - s0 * 16)))
+        out.append(cuts)
+    return out
+
+
 def balanced_cuts(cuts: list[int], band_ms: list[float]) -> list[int]:
     """Cost-balanced tile-row split ("Tiger rows are uneven").
 

@@ -232,13 +232,15 @@ class Comm:
         if not self._h:
             raise _lib.PietMetalError(err.value, "pm_comm_create")
 
-    def gather(self, layout, root: int = 0, full=None, band=None, stream=None) -> None:
+    def gather(self, layout, root: int = 0, full=None, band=None, stream=None, renderer=None) -> None:
         """layout = [(tile_row0, tile_row1, ...)] per rank; full = torch uint8 [H, W, 4] on the root;
-        band = this rank's band tensor (None: the renderer's last frame)."""
+        band = this rank's band tensor (None: the renderer's last frame).  renderer: another context of the same
+        device whose band the table names (a rank that renders its band in sub-bands, one context each, gathers every
+        sub-band with the one communicator)."""
         rows = (C.c_uint32 * (2 * self.world))(*[v for b in layout for v in (b[0], b[1])])
         _lib.check(
             self._lib.pm_gather(
-                self._r._h, self._h, band.data_ptr() if band is not None else None, band.stride(0) if band is not None else 0, rows, root,
+                (renderer or self._r)._h, self._h, band.data_ptr() if band is not None else None, band.stride(0) if band is not None else 0, rows, root,
                 full.data_ptr() if full is not None else None, full.stride(0) if full is not None else 0,
                 stream.cuda_stream if stream is not None else None,
             ),

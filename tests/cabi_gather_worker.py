@@ -102,6 +102,36 @@ def main():
             late = rank == root and e.status == _lib.PM_ERR_INVALID
         assert late
         r.sync()
+    # 5. the gather pipelined under the render (bench.py --gather-chunks): every band in four sub-bands, a context each,
+    #    ONE communicator; sub-band k of every rank lands in its rows of the image (empty sub-bands send nothing)
+    chunks = 4
+    subs = []
+    for lay in pmd.sub_band_layouts(layout, height, chunks):
+        s0, s1, srows = lay[rank]
+        q = None
+        if s1 > s0:
+            q = pm.Renderer(0)
+            q.resize(width, height)
+            q.set_scene_bytes(scene)
+            q.set_band(s0, s1)
+        subs.append((q, lay, s0, srows))
+    full3 = np.full((height, width, 4), 9, np.uint8) if rank == root else None
+    band3 = np.zeros((max(rows, 1), width, 4), np.uint8)
+    for q, lay, s0, srows in subs:
+        if rank == root:
+            target3 = full3[s0 * 16 : s0 * 16 + srows]
+        else:
+            target3 = band3[(s0 - r0) * 16 : (s0 - r0) * 16 + srows]
+        if q is not None:
+            _lib.check(_lib.load().pm_render_to(q._h, target3.ctypes.data, width * 4, None), "pm_render_to")
+            q.sync()
+        comm.gather(lay, root=root, full=HostBuf(full3) if full3 is not None else None, band=HostBuf(target3) if q is not None else HostBuf(band3), renderer=q or r)
+        (q or r).sync()
+    if rank == root:
+        np.save(os.path.join(box, "full_c.npy"), full3)
+    for q, *_ in subs:
+        if q is not None:
+            q.close()
     comm.close()
     r.close()
     print("rank", rank, "ok", flush=True)

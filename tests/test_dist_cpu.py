@@ -134,4 +134,5 @@ def test_c_abi_gather_across_processes_with_a_mock_rccl(built, tmp_path, world, 
     want = pmo.render(pmo.scene_cardioid(), width, height)
     assert np.array_equal(np.load(box / "full_a.npy"), want)
     assert np.array_equal(np.load(box / "full_b.npy"), want)
+    assert np.array_equal(np.load(box / "full_c.npy"), want), "four sub-bands per rank, one communicator (bench.py --gather-chunks)"
     assert not [f for f in os.listdir(box) if f.startswith("msg_")], "every message was consumed"

@@ -433,8 +433,11 @@ def test_pipelined_frames_every_slot_and_scene_switch(pm, pmo, renderer):
     assert np.array_equal(renderer.read_pixels(), want_b)
 
 
-def test_bench_two_rank_path_rehearsal_on_one_gpu(pm, pmo, tmp_path):
-    """bench.py's N>1 path (cost-balanced bands via pm_set_band, pm_render_to on torch's stream, the
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_bench_two_rank_path_rehearsal_on_one_gpu(pm, pmo, tmp_path, chunks):
+    """(chunks = 3: --gather-chunks, every rank's band rendered in three sub-bands by three contexts, each sub-band's
+    gather posted on a second stream while the next sub-band renders.)
+    bench.py's N>1 path (cost-balanced bands via pm_set_band, pm_render_to on torch's stream, the
     grouped gather straight into the final image on rank 0 inside every step) with both ranks on
     this box's one GPU and gloo as transport: the gathered 3840x2160 frame must equal the
     oracle's render, and rank 0 prints the JSON line with the strong-scaling fields."""
@@ -444,8 +447,8 @@ def test_bench_two_rank_path_rehearsal_on_one_gpu(pm, pmo, tmp_path):
     dump = tmp_path / "frame.npy"
     env = dict(os.environ, PM_BENCH_SHARE_DEVICE="1", PM_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-config5",
-           "--dump", str(dump)]
+           "--master-port", str(29517 + chunks), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-config5",
+           "--gather-chunks", str(chunks), "--dump", str(dump)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -453,7 +456,7 @@ def test_bench_two_rank_path_rehearsal_on_one_gpu(pm, pmo, tmp_path):
     assert js["n_gpus"] == 2 and js["scaling"] == "strong" and js["value"] > 0 and js["sustained_mpix_s"] > 0
     cfg = js["config"]
     assert cfg["viewport"] == [3840, 2160] and cfg["band_cuts"][0] == 0 and cfg["band_cuts"][-1] == 135 and len(cfg["band_cuts"]) == 3
-    assert cfg["t_render_ms"] > 0 and cfg["t_gather_ms"] > 0 and cfg["t_frame_e2e_ms"] > 0
+    assert cfg["t_render_ms"] > 0 and cfg["t_gather_ms"] > 0 and cfg["t_frame_e2e_ms"] > 0 and cfg["gather_chunks"] == chunks
     assert "rccl_lib" in cfg and "rccl_ranks" in cfg and 0 < js["roofline"]["frac_serial_frame"] <= js["roofline"]["frac"]
     assert 0 < js["t_frame_ms"] <= cfg["t_frame_e2e_ms"] * 1.5  # (event-timed step vs the same step host-timed)
     wl = pm.workloads.tiger(3840, 2160)
