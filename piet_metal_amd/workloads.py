@@ -130,6 +130,57 @@ def config5_tiger_grid(size: int = 8192, copies: int = 5, scale: float = 8.0) ->
     return Workload(f"tiger_grid_{size}", size, size, PathSet.concat(sets), (scale, 0.0, 0.0, scale, 0.0, 0.0), scale)
 
 
+def heldout_glyphs(n_paths: int = 20000, width: int = 3840, height: int = 2160, seed: int = 0x5EED0007) -> Workload:
+    """Held-out workload 3 (no threshold of the frame path was chosen on it): ~20 k tiny closed paths, text-like -- lines of
+    "glyphs" 7-15 px high, each a closed outline of two cubics and two or three line segments, opaque dark on white, one
+    in eight translucent and coloured.  Many items, few segments each, nearly every tile touched lightly."""
+    rng = SplitMix64(seed)
+    els = np.zeros(n_paths * 7, PathSet.EL_DTYPE)
+    paths = np.zeros(n_paths, PathSet.PATH_DTYPE)
+    x, y, line_h = 24.0, 30.0, 22.0
+    e = 0
+    for i in range(n_paths):
+        w = 6.0 + rng.uniform() * 8.0
+        h = 7.0 + rng.uniform() * 8.0
+        if x + w > width - 24.0:
+            x = 24.0 + rng.uniform() * 12.0
+            y += line_h
+        if y + h > height - 10.0:
+            y = 30.0 + rng.uniform() * 6.0
+        j = lambda a: (rng.uniform() - 0.5) * a  # noqa: E731
+        x0, y0, x1, y1 = x, y - h, x + w, y
+        start = e
+        els["tag"][e] = _lib.PM_EL_MOVE
+        els["p"][e, 0:2] = (x0 + j(1.5), y1)
+        e += 1
+        els["tag"][e] = _lib.PM_EL_CURVE  # left side up, bowed
+        els["p"][e, 0:6] = (x0 - 1.0 + j(2), y1 - h * 0.4, x0 + j(2), y0 + h * 0.3, x0 + w * 0.3 + j(2), y0 + j(1.5))
+        e += 1
+        els["tag"][e] = _lib.PM_EL_LINE
+        els["p"][e, 0:2] = (x1 - w * 0.25 + j(2), y0 + j(1.5))
+        e += 1
+        els["tag"][e] = _lib.PM_EL_CURVE  # right side down
+        els["p"][e, 0:6] = (x1 + 1.0 + j(2), y0 + h * 0.35, x1 + j(2), y1 - h * 0.3, x1 - w * 0.2 + j(2), y1 + j(1.0))
+        e += 1
+        if rng.uniform() < 0.5:  # a notch in the base line
+            els["tag"][e] = _lib.PM_EL_LINE
+            els["p"][e, 0:2] = (x0 + w * 0.5 + j(1), y1 - h * 0.25 + j(1))
+            e += 1
+        els["tag"][e] = _lib.PM_EL_CLOSE
+        e += 1
+        bits = rng.next()
+        rgba = 0x101018FF if bits & 7 else ((bits >> 8) & 0xFFFFFF) << 8 | (0x60 + ((bits >> 32) & 0x7F))
+        paths[i] = (start, e, _lib.PM_PATH_FILL, rgba, 0, 0.0)
+        x += w + 1.5 + (6.0 if (bits >> 40) % 6 == 0 else 0.0)
+    return Workload(f"glyphs_{n_paths}_{width}x{height}", width, height, PathSet(paths, els[:e].copy()), (1.0, 0.0, 0.0, 1.0, 0.0, 0.0), 1.0)
+
+
+def heldout_workloads() -> dict:
+    """Three scenes that drove no threshold or switch of the frame path: what the policy
+    switches are checked against in tools/heldout_policy.py, with full-size oracle goldens (tests/golden, `--held`)."""
+    return {"held1": tiger(2560, 1440), "held2": config4_blobs(2000, 2048, seed=0x5EED0008), "held3": heldout_glyphs()}
+
+
 def band_rows(tiles_y: int, world: int, rank: int) -> tuple[int, int]:
     """Contiguous tile-row band of `rank`: near-equal split."""
     base, rem = divmod(tiles_y, world)

@@ -76,6 +76,25 @@ def big_main():
             json.dump(out, f, indent=1, sort_keys=True)
 
 
+def held_main():
+    """python tests/golden/make_golden.py --held : full-size pins of the three held-out workloads
+    (piet_metal_amd/workloads.py, heldout_workloads; merged into golden.json)."""
+    import time
+
+    path = os.path.join(os.path.dirname(__file__), "golden.json")
+    out = json.load(open(path))
+    for key, wl in pm.workloads.heldout_workloads().items():
+        t0 = time.time()
+        scene, n_items = pmo.scene_from_paths(pmo.scaled_paths(wl.paths.paths, wl.width_scale), wl.paths.els, wl.affine)
+        e = scene_entry(scene, wl.width, wl.height, with_f32=False)
+        e["n_items"] = n_items
+        e["heldout"] = key
+        out[wl.name] = e
+        print(key, wl.name, e, f"{time.time() - t0:.0f} s", flush=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+
+
 def ext_scenes():
     """The scenes that pin the encoder extensions (even-odd, nested groups, ellipses, compound fills,
     DESIGN.md 2 decisions D9-D11) and the SVG document layer: name -> (scene bytes, width, height)."""
@@ -133,6 +152,8 @@ def main():
         return big_main()
     if "--ext" in sys.argv:
         return ext_main()
+    if "--held" in sys.argv:
+        return held_main()
     out = {}
     out["path_test_512x832"] = scene_entry(pmo.scene_path_test(), 512, 832)
     out["cardioid_2048x1536"] = scene_entry(pmo.scene_cardioid(), 2048, 1536)

@@ -284,6 +284,32 @@ def test_extension_scenes_against_committed_goldens(pm, pmo, renderer, golden):
         assert hsh.hexdigest() == golden[name]["ptcl_sha256"], name
 
 
+@pytest.mark.parametrize("key", ["held1", "held2", "held3"])
+def test_heldout_workloads_full_size_goldens(pm, renderer, golden, key):
+    """The three held-out workloads (piet_metal_amd/workloads.py: Tiger 2560x1440 with strokes, 2 k blobs at 2048^2, 20 k
+    glyph-like paths at 4K -- scenes no threshold of the frame path was chosen on) against the oracle's full-size pins
+    (tests/golden/make_golden.py --held): device-flattened scene bytes, pixels, every tile's list; alone and four in flight."""
+    wl = pm.workloads.heldout_workloads()[key]
+    g = golden[wl.name]
+    renderer.resize(wl.width, wl.height)
+    nbytes, n_items = renderer.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+    assert n_items == g["n_items"] and nbytes == g["scene_bytes"]
+    assert sha(renderer.download_scene()) == g["scene_sha256"]
+    renderer.render()
+    assert sha(renderer.read_pixels()) == g["rgba_sha256"]
+    counts, _solid, cmds = renderer.capture_ptcl(g["max_cmds_per_tile"])
+    hsh = hashlib.sha256()
+    for ty in range(counts.shape[0]):
+        for tx in range(counts.shape[1]):
+            n = int(counts[ty, tx])
+            hsh.update(np.uint32(n).tobytes())
+            hsh.update(np.ascontiguousarray(cmds[ty, tx, :n]).tobytes())
+    assert hsh.hexdigest() == g["ptcl_sha256"]
+    for _ in range(8):
+        renderer.render()
+    assert sha(renderer.read_pixels()) == g["rgba_sha256"]
+
+
 @pytest.mark.parametrize("cfg", ["config4", "config5"])
 def test_baseline_configs_4_and_5_full_size_goldens(pm, pmo, renderer, golden, cfg):
     """BASELINE configs 4 (10 k blobs, 4096^2) and 5 (25 Tigers, 8192^2) at FULL size against the
