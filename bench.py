@@ -110,6 +110,11 @@ class Job:
         self.cuts = None
         self.layout = pmd.band_layout(wl.height, world)
         self.band = self.full = self.pad = self.scratch = None
+        # The step's stream: torch's current stream -- made a stream of its own first.  The legacy default stream's handle is 0,
+        # which pm_render_to / pm_gather read as "the context's own stream": the frame would then run beside torch's collectives
+        # and copies instead of in front of them (found when the dumped frame of the gloo rehearsal was zeroed before its step).
+        if world > 1 and torch.cuda.current_stream().cuda_stream == 0:
+            torch.cuda.set_stream(torch.cuda.Stream(device=f"cuda:{local}"))
         self.stream = torch.cuda.current_stream()
         self.balance_log = []
         self.comm, self.gather_impl = None, args.gather_impl

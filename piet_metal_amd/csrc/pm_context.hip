@@ -184,6 +184,7 @@ struct pm_ctx {
     int handout = 0;         // tile hand-out: 0 = drawn for a lone frame, static when frames overlap; 1 = static; 2 = drawn
     int target_fmt = PM_FMT_RGBA8;  // byte order the kernels store pixels in (pm_set_target_format)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
+    uint32_t dense_factor = 4;  // PM_DENSE_FACTOR: a frame whose long lists x this would fill every wave renders each tile with one wave
     uint32_t heavy_stream = 72, heavy_stream_lone = 40, vheavy_stream = 112;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
     uint32_t bin_waves_env = 0;     // PM_BIN_WAVES: 4 / 1 waves per strip row in pm_bin_kernel (0: by the number of strip rows, EnsureArena)
     uint32_t bin_waves = 4;
@@ -855,6 +856,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->n_band_items = c->n_band_items;
     p->bin_waves = c->bin_waves;
     p->split_mode = c->split_mode;
+    p->dense_factor = c->dense_factor;
     {
         SetClassThresholds(c, p, c->heavy_stream_lone);
         p->n_heavy_classes = 3;
@@ -989,8 +991,11 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     // latency (a wave per row: a quarter fewer of them; 4K Tiger sustained 255 -> 266 k Mpix/s).  Only frames with enough
     // strip rows to fill the chip that way (at 1080p, 544 rows, a row's 50 us then set the pace: 142 -> 96 k), and only where
     // no workgroup walks a chain of rows -- the chains are linked for one grid (EnsureArena).
+    // ... and only LIGHT rows: a wave's record holds 64 candidates, and a strip row with more of them pays a second pass over
+    // everything (held-out workload 2, 2 k blobs at 2048^2, 79 candidates per row: sustained 164 -> 139 us per frame with
+    // workgroups; the rule is the one that picks a wave per row for a frame alone, EnsureArena).
     if (p.handout_static && c->bin_waves_inflight == 1 && c->bin_waves == 4 && c->n_sr_active <= c->bin_grid &&
-        c->n_sr_active >= 4u * static_cast<uint32_t>(c->n_cus))
+        c->n_sr_active >= 4u * static_cast<uint32_t>(c->n_cus) && c->plan_cands <= 32ull * c->n_sr_active)
         p.bin_waves = 1;
     // ... and a smaller persistent grid: three tile workgroups per CU leave two slots (LDS, VGPRs) to
     // the neighbours' binning workgroups (Tiger 4K sustained 221 -> 227 k Mpix/s, the other configurations
@@ -1381,6 +1386,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->stream = c->streams[0];
     c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 5, 1, 16));
     c->split_mode = static_cast<uint32_t>(EnvInt("PM_FINE_SPLIT", 1, 0, 1));
+    c->dense_factor = static_cast<uint32_t>(EnvInt("PM_DENSE_FACTOR", 4, 1, 64));
     c->heavy_stream = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM", 72, 1, 1 << 20));
     c->heavy_stream_lone = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM_LONE", std::min<int>(40, static_cast<int>(c->heavy_stream)), 1, 1 << 20));
     c->vheavy_stream = static_cast<uint32_t>(EnvInt("PM_VHEAVY_STREAM", 112, 1, 1 << 20));
@@ -2325,7 +2331,7 @@ int pm_debug_time_tiles(pm_ctx *c, uint64_t *out, size_t max_slots, size_t *n_sl
         total += k.cls[q].count;
         if (q < 3) heavy += k.cls[q].count;
     }
-    const bool dense = heavy >= FineGrid(c) * 4u || c->split_mode == 0;
+    const bool dense = heavy * c->dense_factor >= static_cast<size_t>(s->params.fine_grid) * 4u || c->split_mode == 0;
     const size_t slots = dense ? total : 4 * heavy + (total - heavy);
     if (n_slots) *n_slots = slots;
     if (slots > max_slots) return PM_ERR_CAPACITY;

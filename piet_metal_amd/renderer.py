@@ -116,7 +116,9 @@ class Renderer:
         _lib.check(self._lib.pm_render(self._h), "pm_render")
 
     def render_to(self, tensor, stream=None) -> None:
-        """Render into a torch uint8 CUDA tensor of shape [band_rows, width, 4]."""
+        """Render into a torch uint8 CUDA tensor of shape [band_rows, width, 4], on `stream` (a torch stream) -- None, or
+        torch's legacy default stream (handle 0), means the context's OWN stream: order later work on torch's side with
+        sync(), or make the current stream a torch.cuda.Stream() first (bench.py does)."""
         if tensor.dtype.__str__() != "torch.uint8" or not tensor.is_cuda or tensor.dim() != 3 or tensor.shape[2] != 4:
             raise TypeError("render_to needs a CUDA uint8 tensor [rows, width, 4]")
         if tensor.shape[1] != self.width or tensor.shape[0] < self.band_pixel_rows or tensor.stride(1) != 4 or tensor.stride(2) != 1:

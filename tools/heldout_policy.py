@@ -23,6 +23,7 @@ SWITCHES = {
     "PM_BIN_PRIO_SLOTS": ["0", "1000000"],       # default 320
     "PM_ROW_LIST_MIN_ITEMS": ["1", "1000000000"],  # default 2048
     "PM_FINE_SPLIT": ["0"],                      # default 1: long lists get a workgroup
+    "PM_DENSE_FACTOR": ["1", "16"],              # default 4: one wave per tile once long lists x 4 fill the grid (1: the rule of rounds 2-4)
     "PM_ONE_LAUNCH": ["1"],                      # default 0: two launches per frame
 }
 
