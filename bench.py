@@ -370,7 +370,7 @@ def main() -> int:
                     help="N>1: every rank renders its band in this many sub-bands (a context each) and posts each sub-band's gather on a "
                          "second stream while it renders the next: the exchange runs under the render instead of behind it")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config 5 block")
-    ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config3",
+    ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5", "held1", "held2", "held3"], default="config3",
                     help="the main line's workload (default: BASELINE config 3, the one the metric is quoted on; the others are for profiles/)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump", default=None, help="rank 0 saves the last gathered frame as .npy (tests)")
@@ -410,12 +410,17 @@ def main() -> int:
             args.gather_impl = "sendrecv"  # (the rehearsal's ranks share one GPU: no RCCL communicator between them)
 
     r = pm.Renderer(local)
+    held = pm.workloads.heldout_workloads()
     wl = {"config2": lambda: pm.workloads.tiger(1920, 1080, fills_only=True), "config3": lambda: pm.workloads.tiger(3840, 2160),
-          "config4": pm.workloads.config4_blobs, "config5": pm.workloads.config5_tiger_grid}[args.workload]()
+          "config4": pm.workloads.config4_blobs, "config5": pm.workloads.config5_tiger_grid,
+          "held1": lambda: held["held1"], "held2": lambda: held["held2"], "held3": lambda: held["held3"]}[args.workload]()
     workload_name = {"config2": "BASELINE config 2: Ghostscript Tiger 1920x1080, solid fills only",
                      "config3": "BASELINE config 3: Ghostscript Tiger 3840x2160, fills + strokes",
                      "config4": "BASELINE config 4: 10k overlapping cubic-Bezier paths, 4096x4096",
-                     "config5": "BASELINE config 5: 5x5 Tigers at scale 8, 8192x8192"}[args.workload]
+                     "config5": "BASELINE config 5: 5x5 Tigers at scale 8, 8192x8192",
+                     "held1": "held-out 1: Ghostscript Tiger 2560x1440, fills + strokes",
+                     "held2": "held-out 2: 2k overlapping cubic-Bezier paths, 2048x2048",
+                     "held3": "held-out 3: 20k glyph-like closed paths, 3840x2160"}[args.workload]
     if args.workload != "config3":
         args.no_config5 = True
         args.no_cpu_baseline = True
@@ -478,8 +483,9 @@ def main() -> int:
         dom_inflight_ms = kernels[dom]
         pipelined_ms = tm["total_ms"] / tm["iters"]
         traffic, traffic_frame, issue, traffic_meta = None, None, None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.workload == "config3":
+        # (one committed PMC digest per workload: the Tiger's is hbm_traffic.json, the others' hbm_traffic_<workload>.json)
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json" if args.workload == "config3" else f"hbm_traffic_{args.workload}.json")
+        if os.path.exists(tpath) and world == 1:
             try:
                 prof = json.load(open(tpath))
                 # the PMC figures are copied from a committed profile, not measured in this run: say which
@@ -533,7 +539,10 @@ def main() -> int:
             "dtype": "f32 geometry + f16 accumulators (as the reference)", "data": {"config2": "synthetic: embedded Ghostscript_Tiger.svg, scale 5.4, fills only, flattened on device",
                                                                                 "config3": "synthetic: embedded Ghostscript_Tiger.svg, scale 10.8, flattened on device",
                                                                                 "config4": "synthetic: 10 000 random closed cubic paths (SplitMix64 seed 0x5EED0004), flattened on device",
-                                                                                "config5": "synthetic: 5x5 grid of the embedded Ghostscript_Tiger.svg at scale 8, flattened on device"}[args.workload],
+                                                                                "config5": "synthetic: 5x5 grid of the embedded Ghostscript_Tiger.svg at scale 8, flattened on device",
+                                                                                "held1": "synthetic: embedded Ghostscript_Tiger.svg, scale 7.2, flattened on device",
+                                                                                "held2": "synthetic: 2 000 random closed cubic paths (SplitMix64 seed 0x5EED0008), flattened on device",
+                                                                                "held3": "synthetic: 20 000 glyph-like closed paths (SplitMix64 seed 0x5EED0007), flattened on device"}[args.workload],
             "config": {
                 "workload": workload_name,
                 "viewport": [W, H], "items": job.n_items, "scene_bytes": job.scene_bytes,

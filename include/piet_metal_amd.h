@@ -233,6 +233,10 @@ int pm_set_target_format(pm_ctx *c, int fmt);
  * (swizzled on the host if the frame was stored in the other order). */
 int pm_read_pixels(pm_ctx *c, uint8_t *dst, size_t dst_stride, int fmt);
 void *pm_framebuffer_device_ptr(pm_ctx *c, size_t *stride_bytes, uint32_t *rows);
+/* The resident scene on the device.  Valid until the scene is next replaced (pm_upload_scene,
+ * pm_flatten_and_encode, pm_reflatten): the device flatten writes the NEXT scene into a second buffer while frames
+ * in flight still read this one, and the two change places -- a pointer kept across a replacement names the
+ * buffer the replacement after that overwrites. */
 void *pm_scene_device_ptr(pm_ctx *c, size_t *bytes);
 
 /* Time `iters` frames with HIP events (any pointer may be NULL).
@@ -327,11 +331,13 @@ int pm_gather(pm_ctx *c, pm_comm *m, const void *src_band, size_t src_stride, co
  *                      first pm_render after a scene or viewport change */
 typedef struct {
     float flatten_encode_ms, scene_index_ms, arena_setup_ms;
-    uint32_t binning_plans; /* binning plans made since pm_create (strip-row regions sized, lists uploaded): a scene
-                             * after pm_reflatten keeps the plan in force while every item stays inside the box
-                             * -- one tile wider on each side -- and the segment count it was planned with */
-} pm_scene_timings;
+} pm_scene_timings; /* 12 bytes, as in round 3: the struct does not grow (a caller built against an older header owns 12 bytes) */
 int pm_get_scene_timings(pm_ctx *c, pm_scene_timings *out);
+/* Binning plans made since pm_create (strip-row regions sized, lists uploaded): a scene after pm_reflatten keeps the
+ * plan in force while every item stays inside the box it was planned with -- one tile wider on each side -- and
+ * keeps its segment count.  (Round 4 had this counter as a fourth member of pm_scene_timings; a getter of its own
+ * since round 5: ABI note in INTEGRATION.md.) */
+int pm_get_binning_plans(pm_ctx *c, uint32_t *plans);
 
 /* Debug/parity hook: re-run the last frame's per-tile kernel with command
  * capture and return every tile's command list in the reference's 24-byte

@@ -68,7 +68,7 @@ class Stats(C.Structure):
 
 
 class SceneTimings(C.Structure):
-    _fields_ = [("flatten_encode_ms", C.c_float), ("scene_index_ms", C.c_float), ("arena_setup_ms", C.c_float), ("binning_plans", C.c_uint32)]
+    _fields_ = [("flatten_encode_ms", C.c_float), ("scene_index_ms", C.c_float), ("arena_setup_ms", C.c_float)]
 
 
 class Cmd(C.Structure):
@@ -137,6 +137,7 @@ SIGNATURES = {
     "pm_fill_coverage": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t]),
     "pm_layout_selfcheck": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "pm_get_scene_timings": (C.c_int, [C.c_void_p, C.POINTER(SceneTimings)]),
+    "pm_get_binning_plans": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "pm_comm_unique_id": (C.c_int, [C.c_void_p]),
     "pm_comm_create": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "pm_comm_destroy": (None, [C.c_void_p]),

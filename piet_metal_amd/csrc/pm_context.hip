@@ -620,6 +620,11 @@ int EnsureArena(pm_ctx *c) {
         uint64_t cmds = std::max<uint64_t>(1u << 22, 64ull * c->n_chunks * pm::kChunkSegs);
         if (const char *v = std::getenv("PM_PTCL_INITIAL_CMDS"))  // tests: force the overflow -> grow -> re-render path
             cmds = std::max<uint64_t>(64, std::strtoull(v, nullptr, 10));
+        // (a frame behind running frames may bin with a wave per strip row, Enqueue: records of 64 candidates instead of 256,
+        //  up to four pieces -- four headers, four times the slack behind the candidates -- where a lone frame leaves one.  The
+        //  arena a plan starts with holds that variant too: a frame that fits alone must not overflow in flight.  Round-4 advisor.)
+        if (c->bin_waves_inflight == 1 && !std::getenv("PM_PTCL_INITIAL_CMDS"))
+            cmds = std::max<uint64_t>(cmds, 80ull * c->n_chunks * pm::kChunkSegs + 4ull * BandTiles(c));
         c->ptcl_want = std::max<uint64_t>(c->ptcl_want, std::min<uint64_t>(cmds * pm::kCmdQuadsNum / pm::kCmdQuadsDen, 0x7fffffffull));
     }
     c->arena_cap = std::max<uint32_t>(c->arena_cap, static_cast<uint32_t>(alloc_dwords));
@@ -1596,6 +1601,12 @@ int pm_upload_scene(pm_ctx *c, size_t bytes) {
     c->replan_wide = false;
     c->plan_reusable = false;
     c->t_flatten_ms = 0;
+    // (a context that goes back to host-encoded scenes gives the device flatten's second scene buffer back: round-4 advisor finding)
+    if (c->d_scene_alt) {
+        (void)hipFree(c->d_scene_alt);
+        c->d_scene_alt = nullptr;
+        c->dev_scene_alt_cap = 0;
+    }
     PM_TRY(hipMemcpyAsync(c->d_scene, c->h_scene, bytes, hipMemcpyHostToDevice, c->stream));
     return SetScene(c, bytes, c->h_scene);  // (stream order: the appended flat group follows the upload)
 }
@@ -2109,7 +2120,12 @@ int pm_get_scene_timings(pm_ctx *c, pm_scene_timings *out) {
     out->flatten_encode_ms = c->t_flatten_ms;
     out->scene_index_ms = c->t_index_ms;
     out->arena_setup_ms = c->t_arena_ms;
-    out->binning_plans = c->plans_made;
+    return PM_OK;
+}
+
+int pm_get_binning_plans(pm_ctx *c, uint32_t *plans) {
+    if (!c || !plans) return PM_ERR_INVALID;
+    *plans = c->plans_made;
     return PM_OK;
 }
 

@@ -18,7 +18,7 @@ constexpr uint32_t kClasses = 8;
 
 // Decks of the drawn part of the tile hand-out (pm_fine_kernel).  A deck is a counter on its own cache line; a wave draws
 // from deck wave % n only, so a deck's cards run out when ITS waves have drawn them: with 128 decks of 40 waves the decks
-// emptied 1.5 us apart and the last cards were drawn late (same-box A/B, tools/gpu_ab.sh: 32 decks end the 4K Tiger's tile
+// emptied 1.5 us apart and the last cards were drawn late (same-box A/B, `tools/gpu.sh ab`: 32 decks end the 4K Tiger's tile
 // kernel 0.4 us earlier than 128, 16 are no different from 32, 8 are slower -- the line then serves 60 draws per us).
 constexpr uint32_t kTicketParts = 32;  // decks of the drawn part of the tile hand-out (pm_fine_kernel)
 

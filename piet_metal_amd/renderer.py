@@ -185,7 +185,11 @@ class Renderer:
         """Host wall-clock cost of the last scene replacement (flatten+encode, index, arena)."""
         t = _lib.SceneTimings()
         _lib.check(self._lib.pm_get_scene_timings(self._h, C.byref(t)), "pm_get_scene_timings")
-        return {name: getattr(t, name) for name, _ in t._fields_}
+        out = {name: getattr(t, name) for name, _ in t._fields_}
+        n = C.c_uint32(0)
+        _lib.check(self._lib.pm_get_binning_plans(self._h, C.byref(n)), "pm_get_binning_plans")
+        out["binning_plans"] = int(n.value)
+        return out
 
     def frame_timeline(self, iters: int = 100) -> dict:
         """The lone frame taken apart (ms, medians): kernels and the gaps between them."""

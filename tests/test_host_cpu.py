@@ -985,7 +985,7 @@ def test_profile_stamp_digest_ignores_comments_but_not_code(tmp_path):
     shutil.copytree(src, dst, ignore=shutil.ignore_patterns("*.o", "*.so"))
     base = mt.kernel_sources_sha16(str(tmp_path))
     assert base == mt.kernel_sources_sha16()
-    f = dst / "pm_bin.hip"
+    f = dst / "pm_bin_rows.h"
     text = f.read_text()
     f.write_text("// a new remark\n" + text.replace("// ", "//   ", 5) + "\n/* and\n   another */\n")
     assert mt.kernel_sources_sha16(str(tmp_path)) == base

@@ -13,7 +13,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["pm_bin.hip", "pm_fine.hip", "pm_coarse.hip", "pm_coarse_tile.h", "pm_kernels_common.h", "pm_device.h", "gfx950/pm_pin.h", "gfx950/pm_params.h"]
+KERNEL_SOURCES = ["pm_bin.hip", "pm_bin_rows.h", "pm_fine.hip", "pm_fine_tile.h", "pm_coarse.hip", "pm_coarse_tile.h", "pm_frame.hip", "pm_frame_row.h",
+                  "pm_kernels_common.h", "pm_device.h", "gfx950/pm_pin.h", "gfx950/pm_params.h"]
 
 
 def _code_only(text):
