@@ -679,7 +679,7 @@ int EnsureArena(pm_ctx *c) {
         nx.assign(n, 0u);
         const size_t resident = static_cast<size_t>(c->n_cus) * c->frame_wg_per_cu;
         c->one_grid_rows = 0;
-        if (resident != 0 && n <= 2 * resident) {
+        if (c->one_launch_mode != 0 && resident != 0 && n <= 2 * resident) {  // (only a context that renders one-launch frames pays for their lists)
             const size_t rows = std::min(n, resident);
             c->one_grid_rows = static_cast<uint32_t>(rows);
             if (n > rows) {
@@ -707,7 +707,7 @@ int EnsureArena(pm_ctx *c) {
         std::vector<uint32_t> &idle = c->stage_idle;
         idle.clear();
         size_t k = 0;
-        for (size_t i = 0; i < need.size(); ++i) {
+        for (size_t i = 0; i < need.size() && c->one_grid_rows != 0; ++i) {
             const uint32_t key = static_cast<uint32_t>(i % c->strips_x) | (static_cast<uint32_t>(i / c->strips_x) << 16);
             if (k < desc.size() && desc[k].x == key) {  // (the empty list's one workgroup "has" strip row 0)
                 ++k;

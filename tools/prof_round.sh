@@ -48,4 +48,6 @@ json.dump(summ, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summ, indent=1))
 PY
 rm -rf $OUT/trace $OUT/trace_serial $OUT/pmc[0-9]
+# (what travels back is capped at 64 MiB for the whole of gpurun_out/: the per-launch counter rows are summarised above)
+[ "${PM_PROF_KEEP_PASSES:-0}" = "1" ] || rm -f $OUT/pmc_pass*.csv
 ls -la $OUT
