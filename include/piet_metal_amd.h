@@ -259,6 +259,10 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
  * at all). */
 int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms);
 
+/* Frames whose tile kernel was the one-wave-per-tile instantiation (six workgroups per CU): what frames get after a frame
+ * of the same scene and viewport whose tile kernel found it dense -- long lists enough to occupy every wave (PM_DENSE_KERNEL=0: never). */
+int pm_tile_kernel_info(pm_ctx *c, uint32_t *dense_frames);
+
 /* One launch per frame (pm_frame_kernel: the two dispatches of PietRenderer.m:69-88 as roles of one resident
  * grid).  *frames = frames submitted that way since pm_create; *applies = 1 if a frame of the resident scene
  * and viewport, alone on the device, would be (0: two launches -- PM_ONE_LAUNCH=0, more strip rows than resident

@@ -184,6 +184,12 @@ struct pm_ctx {
     int handout = 0;         // tile hand-out: 0 = drawn for a lone frame, static when frames overlap; 1 = static; 2 = drawn
     int target_fmt = PM_FMT_RGBA8;  // byte order the kernels store pixels in (pm_set_target_format)
     uint32_t split_mode = 1;  // fine kernel: long lists get 4 waves per tile (16 measured no faster)
+    // A frame whose tile kernel found it dense (above) is followed by frames whose tile kernel is the one-wave-per-tile instantiation:
+    // 80 VGPRs and 19 KB of LDS instead of 96 and 31, six workgroups per CU instead of five (PM_DENSE_KERNEL=0: never).  The verdict is
+    // the kernel's own, left in a pinned word by every frame (FrameSlot::h_overflow[2]); a new scene or viewport starts undecided.
+    int dense_kernel_mode = 1;
+    uint32_t fine_wg_dense = 6, fine_wg_dense_inflight = 4;  // PM_FINE_WG_PER_CU_DENSE, PM_FINE_WG_PER_CU_DENSE_INFLIGHT
+    uint32_t frames_dense_kernel = 0;  // frames whose tile kernel was that instantiation (pm_tile_kernel_info)
     uint32_t dense_factor = 4;  // PM_DENSE_FACTOR: a frame whose long lists x this would fill every wave renders each tile with one wave
     uint32_t heavy_stream = 72, heavy_stream_lone = 40, vheavy_stream = 112;  // list-length classes (PM_HEAVY_STREAM / PM_VHEAVY_STREAM)
     uint32_t bin_waves_env = 0;     // PM_BIN_WAVES: 4 / 1 waves per strip row in pm_bin_kernel (0: by the number of strip rows, EnsureArena)
@@ -375,6 +381,7 @@ int AllocViewport(pm_ctx *c) {
     for (auto &s : c->slot) {
         s.in_flight = false;
         s.needs_check = false;
+        if (s.h_overflow) s.h_overflow[2] = 0;  // (the tile kernel's dense / not dense verdict belongs to the old viewport)
     }
     c->last_slot = -1;
     const uint32_t rows = BandRows(c);
@@ -847,6 +854,8 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->ctr_next = s->d_ctr + (s->parity ^ 1u);
     p->host_overflow = s->d_overflow;
     p->host_fail = s->d_overflow + 1;
+    p->host_dense = s->d_overflow + 2;
+    p->fine_dense = 0;
     p->fifo = s->d_fifo;
     p->fifo_cap = s->fifo_cap;
     p->one_launch = 0;
@@ -914,6 +923,22 @@ void Submitted(pm_ctx *c, int si, const pm::FrameParams &p, hipStream_t frame_st
     s->parity ^= 1u;
     c->last_slot = si;
     c->frame += 1;
+}
+
+// The tile kernel's instantiation for this frame: the one-wave-per-tile one when the latest frame of this scene and viewport that said
+// anything called itself dense (its pinned word; read without waiting -- a verdict a frame or two old is as good).
+void ChooseTileKernel(pm_ctx *c, pm::FrameParams *p) {
+    if (!c->dense_kernel_mode || !c->fused || c->last_slot < 0) return;
+    uint32_t verdict = 0;
+    for (size_t k = 0; k < c->slot.size() && verdict == 0; ++k) {  // newest first
+        const FrameSlot &t = c->slot[(static_cast<size_t>(c->last_slot) + c->slot.size() - k) % c->slot.size()];
+        if (t.h_overflow) verdict = static_cast<volatile uint32_t *>(t.h_overflow)[2];
+    }
+    if (verdict != 2u) return;
+    p->fine_dense = 1u;
+    c->frames_dense_kernel += 1;
+    const uint32_t per_cu = p->handout_static ? c->fine_wg_dense_inflight : c->fine_wg_dense;
+    p->fine_grid = std::max(1u, std::min(static_cast<uint32_t>(BandTiles(c)), static_cast<uint32_t>(c->n_cus) * per_cu));
 }
 
 // Workgroups of a one-launch frame (0: this frame takes two launches).  Every strip row some item reaches needs its own
@@ -1007,6 +1032,7 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     // unchanged; two cost config 4 2 %; alone, five end the frame 0.8 us earlier)
     if (p.handout_static && c->fine_wg_per_cu_inflight < c->fine_wg_per_cu)
         p.fine_grid = std::max(1u, std::min(p.fine_grid, static_cast<uint32_t>(c->n_cus) * c->fine_wg_per_cu_inflight));
+    ChooseTileKernel(c, &p);
     const uint32_t n_striprows = BandRows(c) * c->strips_x;
     PM_TRY(ResetTileState(c, s, q));
     // One launch for the whole frame (pm_frame.hip) when the frame has the device to itself -- two such launches at once could
@@ -1129,6 +1155,8 @@ void InvalidateScene(pm_ctx *c) {
     c->item_meta.clear();
     c->last_slot = -1;
     c->arena_dirty = true;
+    for (auto &t : c->slot)  // (another scene: whether its frames are dense is for its own tile kernels to say)
+        if (t.h_overflow) t.h_overflow[2] = 0;
 }
 
 int ReserveDevice(pm_ctx *c, size_t cap, size_t keep_bytes);
@@ -1392,6 +1420,9 @@ pm_ctx *pm_create(int device, int *err) {
     c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 5, 1, 16));
     c->split_mode = static_cast<uint32_t>(EnvInt("PM_FINE_SPLIT", 1, 0, 1));
     c->dense_factor = static_cast<uint32_t>(EnvInt("PM_DENSE_FACTOR", 4, 1, 64));
+    c->dense_kernel_mode = EnvInt("PM_DENSE_KERNEL", 1, 0, 1);
+    c->fine_wg_dense = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU_DENSE", 6, 1, 16));
+    c->fine_wg_dense_inflight = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU_DENSE_INFLIGHT", 4, 1, 16));
     c->heavy_stream = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM", 72, 1, 1 << 20));
     c->heavy_stream_lone = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM_LONE", std::min<int>(40, static_cast<int>(c->heavy_stream)), 1, 1 << 20));
     c->vheavy_stream = static_cast<uint32_t>(EnvInt("PM_VHEAVY_STREAM", 112, 1, 1 << 20));
@@ -1423,7 +1454,7 @@ pm_ctx *pm_create(int device, int *err) {
         if ((e = hipMalloc(&s.d_ctr, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMalloc(counters)");
         if ((e = hipMemset(s.d_ctr, 0, 2 * sizeof(pm::Counters))) != hipSuccess) return fail(e, "hipMemset(counters)");
         if ((e = hipHostMalloc(&s.h_overflow, 64, hipHostMallocDefault)) != hipSuccess) return fail(e, "hipHostMalloc(overflow word)");
-        s.h_overflow[0] = s.h_overflow[1] = 0;
+        s.h_overflow[0] = s.h_overflow[1] = s.h_overflow[2] = 0;
         void *dp = nullptr;
         if ((e = hipHostGetDevicePointer(&dp, s.h_overflow, 0)) != hipSuccess) return fail(e, "hipHostGetDevicePointer");
         s.d_overflow = static_cast<uint32_t *>(dp);
@@ -1967,6 +1998,12 @@ int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms) {
     if (median_ms) *median_ms = lat[lat.size() / 2];
     if (min_ms) *min_ms = lat.front();
     return pm_sync(c);
+}
+
+int pm_tile_kernel_info(pm_ctx *c, uint32_t *dense_frames) {
+    if (!c || !dense_frames) return PM_ERR_INVALID;
+    *dense_frames = c->frames_dense_kernel;
+    return PM_OK;
 }
 
 int pm_one_launch_info(pm_ctx *c, uint32_t *frames, int *applies) {

@@ -1,6 +1,7 @@
 // pm_fine_kernel (+ pm_clear_kernel, pm_coverage_kernel): the tile stage as launches of its own
 // (see pm_kernels_common.h for the decomposition and the rules shared by the kernel files)
 #include "pm_fine_tile.h"
+#include <type_traits>
 
 namespace pm {
 
@@ -19,9 +20,11 @@ __global__ __launch_bounds__(kBinThreads) void pm_clear_kernel(FrameParams P) { 
 // kProf: the developer timeline build (pm_debug_time_tiles); P.dbg_time is only read there.
 // kCapture (pm_debug_capture_ptcl): the fused kernel also records every list it builds in the
 // reference's layout -- the lists of the frame path itself, LDS drop into the waiting waves included.
-template <bool kFused, bool kProf, bool kCapture = false>
-__global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
-    __shared__ SparseLds S;
+// kDense: every tile one wave's, whatever its list -- the instantiation the host launches for a frame the previous frame of the same
+// scene found dense (below): without the workgroup paths the kernel fits 80 VGPRs and 19 KB of LDS, SIX workgroups per CU instead of five.
+template <bool kFused, bool kProf, bool kCapture = false, bool kDense = false>
+__global__ __launch_bounds__(kThreads, kDense ? 6 : 5) void pm_fine_kernel(FrameParams P) {
+    __shared__ std::conditional_t<kDense, DenseLds, SparseLds> S;
     if (blockIdx.x >= P.fine_grid) {
         ClearStripRow(P, blockIdx.x - P.fine_grid);
         return;
@@ -53,7 +56,9 @@ __global__ __launch_bounds__(kThreads, 5) void pm_fine_kernel(FrameParams P) {
     // workgroup each, would occupy every wave of the grid, splitting a tile only costs work: every tile gets one wave.  (The
     // rule used to be "more long lists than WAVES": held-out workload 2 -- 2 k blobs at 2048^2, 16 k tiles, half of them long --
     // ran its long lists on workgroups with three frames' worth of tiles waiting: sustained 164 -> 133 us per frame without.)
-    const bool dense = n_heavy * P.dense_factor >= n_waves || P.split_mode == 0;
+    const bool dense = kDense || n_heavy * P.dense_factor >= n_waves || P.split_mode == 0;
+    // (what the host picks the next frame's instantiation by: pm_context.hip, Enqueue)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && P.host_dense != nullptr) *P.host_dense = (n_heavy * P.dense_factor >= n_waves || P.split_mode == 0) ? 2u : 1u;
     const uint32_t sh = dense ? 0u : 2u;
     const uint32_t s_h = n_heavy << sh;  // slots of the tiles with long lists: a workgroup (4 slots) each
     const uint32_t n_slots = s_h + (n_tiles - n_heavy);
@@ -230,6 +235,8 @@ void LaunchFine(const FrameParams &p, uint32_t clear_blocks, bool fused, hipStre
             PM_LAUNCH((pm_fine_kernel<true, true>), grid, block, stream, t0, t1, p);
         else
             PM_LAUNCH((pm_fine_kernel<false, true>), grid, block, stream, t0, t1, p);
+    } else if (fused && p.fine_dense) {
+        PM_LAUNCH((pm_fine_kernel<true, false, false, true>), grid, block, stream, t0, t1, p);
     } else if (fused) {
         PM_LAUNCH((pm_fine_kernel<true, false>), grid, block, stream, t0, t1, p);
     } else {

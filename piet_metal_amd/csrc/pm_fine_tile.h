@@ -1,6 +1,7 @@
 // The tile stage: renderKernel (TestApp/PietRender.metal:457-566) and the composite (:16-44) for ONE queued tile, by one wave or by
 // the four waves of a workgroup -- shared by pm_fine_kernel (pm_fine.hip) and the tile role of pm_frame_kernel (pm_frame.hip).
 #pragma once
+#include <type_traits>
 #include "pm_kernels_common.h"
 #include "pm_coarse_tile.h"
 
@@ -171,6 +172,12 @@ struct SparseLds {
 };
 // (five workgroups per CU need <= 31 184 B each -- measured, pm_bin.hip; this one is 30 608 B)
 static_assert(sizeof(SparseLds) <= 40960, "four workgroups per CU");
+// The working set of a kernel that renders EVERY tile with one wave (a dense frame: pm_fine_kernel<.., kDense>): no alpha images,
+// no hand-over words -- 19 KB, so that six workgroups share a CU (and the code without the workgroup paths fits 80 VGPRs).
+struct DenseLds {
+    WaveLds w[kWaves];
+};
+static_assert(sizeof(DenseLds) <= 26624, "six workgroups per CU");
 
 __device__ __forceinline__ half2_t Half2FromBits(uint32_t b) { return __builtin_bit_cast(half2_t, b); }
 
@@ -297,7 +304,8 @@ __device__ __forceinline__ void FillPass2(WaveFineLds &W, const Cmd *cmds, uint3
 
 // Single-wave mode: passes 1 and 2 for the Fill commands [from, ...) of the staged chunk, as many
 // as the wave's fragment region takes.  Returns the ordinal of the first Fill NOT covered.
-__device__ __forceinline__ uint32_t PrepareFills(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t nfill, uint32_t from,
+template <typename Lds>
+__device__ __forceinline__ uint32_t PrepareFills(Lds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t nfill, uint32_t from,
                                                  uint32_t x0, uint32_t y0) {
     WaveFineLds &W = S.w[WaveId()].f;
     uint32_t nfrag = 0;
@@ -363,7 +371,8 @@ __device__ __forceinline__ void Blend4S(PixelStateS &st, uint32_t rg, uint32_t b
 }
 
 // renderKernel's command loop (:474-560), whole tile per wave (lane -> row lane/4, 4 pixels)
-__device__ __forceinline__ void InterpretSparse(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t n, uint32_t x0, uint32_t y0,
+template <typename Lds>
+__device__ __forceinline__ void InterpretSparse(Lds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t n, uint32_t x0, uint32_t y0,
                                                 PixelStateS &st) {
     const uint32_t lane = LaneId();
     const uint32_t row = lane >> 2, g = lane & 3u;
@@ -693,10 +702,13 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
 // workgroup together (all of them call with the same arguments; `quarter` = which 64 of the 256 pixels the wave blends in phase
 // B, `parity` alternates between consecutive workgroup tiles of a workgroup).  next_card() is called once, when only the
 // encoding of the tile's pixels is left: the caller's moment to ask for its next tile.  Returns the commands interpreted.
-template <bool kFused, bool kProf, bool kCapture, bool kCoh, typename Next>
-__device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, SparseLds &S, const uint4 cur, const bool wg_mode, const uint32_t quarter,
+// Lds = DenseLds: every tile is a single wave's (wg_mode_in is false) and the workgroup paths are not even compiled.
+template <bool kFused, bool kProf, bool kCapture, bool kCoh, typename Next, typename Lds>
+__device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &S, const uint4 cur, const bool wg_mode_in, const uint32_t quarter,
                                                      const uint32_t parity, const uint32_t lane, const uint32_t wave, const uint64_t lanes_below,
                                                      Next &&next_card, PhaseTicks &prof, CoarseTicks &ct) {
+    constexpr bool kWg = std::is_same<Lds, SparseLds>::value;
+    const bool wg_mode = kWg && wg_mode_in;
     // linear -> sRGB + unorm8 (:563-565): the 65,536-entry table of decision D2.  (A compact
     // LDS-resident form of the table was measured slower: twelve byte loads per lane are fewer
     // instructions than twelve decodes.)
@@ -713,13 +725,18 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Spars
         // (wave 0 of a workgroup-mode tile has wave == 0: its region is S.w[0] either way)
         // (a workgroup tile: chunks 0..2 of the list also go to the staged-command areas of waves 1..3)
         // (a workgroup tile: all four waves -- the longest lists are built a round of 64 stream elements per wave)
-        n_cmd = CoarseTile<kCapture, kProf, true, kCoh>(P, S.w[wave].c, cur, lane, lanes_below, &ct, reinterpret_cast<uint8_t *>(wg_mode ? S.w[1].cmds : S.w[wave].cmds),
-                                                  static_cast<uint32_t>(sizeof(WaveLds)), wg_mode ? kLdsChunks : 1u, wg_mode ? &S.coarse_shared : nullptr);
-        if (wg_mode) {
-            if (wave == 0 && lane == 0) S.wg_ncmd[parity & 1u] = n_cmd;
-            __syncthreads();  // (workgroup-scope release/acquire: the list wave 0 wrote is visible)
-            n_cmd = S.wg_ncmd[parity & 1u];
-        } else if (n_cmd > kSpChunk) {
+        CoarseShared *shared = nullptr;
+        if constexpr (kWg) shared = wg_mode ? &S.coarse_shared : nullptr;
+        n_cmd = CoarseTile<kCapture, kProf, kWg, kCoh>(P, S.w[wave].c, cur, lane, lanes_below, &ct, reinterpret_cast<uint8_t *>(wg_mode ? S.w[1].cmds : S.w[wave].cmds),
+                                                  static_cast<uint32_t>(sizeof(WaveLds)), wg_mode ? kLdsChunks : 1u, shared);
+        if constexpr (kWg) {
+            if (wg_mode) {
+                if (wave == 0 && lane == 0) S.wg_ncmd[parity & 1u] = n_cmd;
+                __syncthreads();  // (workgroup-scope release/acquire: the list wave 0 wrote is visible)
+                n_cmd = S.wg_ncmd[parity & 1u];
+            }
+        }
+        if (!wg_mode && n_cmd > kSpChunk) {
             // (only a list longer than the chunk in LDS is read back from HBM: this wave's stores before its loads.  The
             //  release waits for EVERY store the wave has in flight -- the previous tile's pixels among them, microseconds
             //  under load -- so the tiles that need no read-back skip it)
@@ -733,7 +750,10 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Spars
         const uint32_t *src = reinterpret_cast<const uint32_t *>(P.tarena + cur.y);
         const uint32_t x0 = tx * kTileW;
         const uint32_t y0 = (P.row0 + ty_rel) * kTileH;
+        bool as_workgroup = false;
+        if constexpr (kWg) {
         if (wg_mode) {
+            as_workgroup = true;
             // the longest lists set the span of the launch: their waves win the issue arbitration
             __builtin_amdgcn_s_setprio(2);
             // phase B: lane -> 1 pixel, pix = 64 * (slot & 3) + lane = row * 16 + x
@@ -771,7 +791,9 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Spars
                 uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + (pix >> 4)) * P.fb_stride + static_cast<size_t>(pxi) * 4;
                 *reinterpret_cast<uint32_t *>(dst) = (bgra ? b8 : r8) | (g8 << 8) | ((bgra ? r8 : b8) << 16) | 0xff000000u;
             }
-        } else {
+        }
+        }
+        if (!as_workgroup) {
             // lane -> 4 pixels: x = x0 + 4 * (lane & 3) + k, row = lane / 4
             const uint32_t pxi = x0 + (lane & 3u) * 4u;
             const uint32_t prow = lane >> 2;

@@ -162,6 +162,12 @@ class Renderer:
         _lib.check(self._lib.pm_frame_latency(self._h, iters, C.byref(med), C.byref(mn)), "pm_frame_latency")
         return {"median_ms": med.value, "min_ms": mn.value, "iters": iters}
 
+    def dense_kernel_frames(self) -> int:
+        """Frames rendered with the one-wave-per-tile instantiation of the tile kernel (dense scenes)."""
+        n = C.c_uint32(0)
+        _lib.check(self._lib.pm_tile_kernel_info(self._h, C.byref(n)), "pm_tile_kernel_info")
+        return int(n.value)
+
     def one_launch_info(self) -> dict:
         """Frames rendered as one launch so far, and whether a lone frame of the resident scene would be."""
         n = C.c_uint32(0)

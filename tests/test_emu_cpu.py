@@ -65,3 +65,11 @@ def test_one_launch_frames_under_emulation(built):
     assert " passed" in out and "failed" not in out
     out = _run("reference_scenes and 300 or even_odd_fills_and_nested_groups and 31", {"PM_ONE_LAUNCH": "1", "PM_EMU_CUS": "2"}, workers="")
     assert " passed" in out and "failed" not in out
+
+
+def test_dense_tile_kernel_under_emulation(built):
+    """pm_fine_kernel's one-wave-per-tile instantiation (what frames get after a frame of their scene called itself dense): on a
+    two-CU "device" with PM_DENSE_FACTOR=64 a single long list makes a frame dense, so the frames behind the first one of the
+    switch test's scenes run it -- same bytes, same lists (captured from the general instantiation)."""
+    out = _run("every_frame_path and 0-1-1 or every_frame_path and 2-1-1", {"PM_DENSE_FACTOR": "64", "PM_EMU_CUS": "2", "PM_EXPECT_DENSE": "1"}, workers="")
+    assert " passed" in out and "failed" not in out

@@ -696,8 +696,51 @@ def test_every_frame_path_switch_agrees_with_the_oracle(pm, pmo, monkeypatch, fu
         got = gpu_render(r, scene2, 517, 500)
         assert np.array_equal(got, pmo.render(scene2, 517, 500))
         assert_ptcl_equal(r, pmo, scene2, 517, 500)
+        if os.environ.get("PM_EXPECT_DENSE") == "1" and fused == "1":  # (tests/test_emu_cpu.py: a device so small that these scenes are dense)
+            assert r.dense_kernel_frames() > 0
     finally:
         r.close()
+
+
+def test_dense_scenes_get_the_one_wave_per_tile_kernel(pm, pmo, monkeypatch):
+    """A frame whose tile kernel finds it dense -- its long lists, at a workgroup each, would occupy every wave -- tells the host
+    (a pinned word), and the frames that follow get the tile kernel's one-wave-per-tile instantiation (80 VGPRs, 19 KB of LDS: six
+    workgroups per CU).  Same bytes from both instantiations, alone and in flight; a new scene starts undecided again; lists are
+    captured from the general kernel; PM_DENSE_KERNEL=0 never switches."""
+    wl = pm.workloads.config4_blobs(3000, 1024, seed=0x5EED0009)
+    tig = pm.workloads.tiger(480, 270)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PM_DENSE_KERNEL", mode)
+        r = pm.Renderer(0)
+        try:
+            r.resize(wl.width, wl.height)
+            r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+            scene = r.download_scene()
+            want = pmo.render(scene, wl.width, wl.height)
+            r.render()
+            assert np.array_equal(r.read_pixels(), want)  # (the scene's first frame: the general kernel)
+            assert r.dense_kernel_frames() == 0
+            for _ in range(3):  # frames alone
+                r.render()
+                assert np.array_equal(r.read_pixels(), want)
+            alone = r.dense_kernel_frames()
+            assert (alone == 3) if mode == "1" else (alone == 0)
+            for _ in range(8):  # ... and behind one another
+                r.render()
+            assert np.array_equal(r.read_pixels(), want)
+            assert_ptcl_equal(r, pmo, scene, wl.width, wl.height)
+            assert np.array_equal(r.read_pixels(), want)
+            before = r.dense_kernel_frames()
+            # a sparse scene: undecided again, and its own frames say "not dense"
+            r.resize(tig.width, tig.height)
+            r.flatten_and_encode(tig.paths, tig.affine, tig.width_scale)
+            tscene = r.download_scene()
+            for _ in range(3):
+                r.render()
+                assert np.array_equal(r.read_pixels(), pmo.render(tscene, tig.width, tig.height))
+            assert r.dense_kernel_frames() == before
+        finally:
+            r.close()
 
 
 @pytest.mark.parametrize("grid_per_cu", [None, "1"])

@@ -24,6 +24,8 @@ SWITCHES = {
     "PM_ROW_LIST_MIN_ITEMS": ["1", "1000000000"],  # default 2048
     "PM_FINE_SPLIT": ["0"],                      # default 1: long lists get a workgroup
     "PM_DENSE_FACTOR": ["1", "16"],              # default 4: one wave per tile once long lists x 4 fill the grid (1: the rule of rounds 2-4)
+    "PM_DENSE_KERNEL": ["0"],                    # default 1: dense frames get the one-wave-per-tile instantiation of the tile kernel
+    "PM_FINE_WG_PER_CU_DENSE_INFLIGHT": ["6"],   # default 4 (that kernel's grid behind other frames)
     "PM_ONE_LAUNCH": ["1"],                      # default 0: two launches per frame
 }
 
