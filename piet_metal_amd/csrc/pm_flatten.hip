@@ -227,6 +227,111 @@ __global__ __launch_bounds__(kScanThreads) void KScan(const pm_path *paths, uint
     }
 }
 
+// ---- the same two prefix sums for LARGE inputs: blocks of 1 024 in parallel (round 5) ------------------------------------
+// One workgroup walking 60 000 elements is 60 dependent steps of two block scans each: 125 us of config 4's 270 us view change,
+// 250 us for 110 000 elements.  Above kScanSplit elements the work is cut into blocks: every block scans its 1 024 values (KScanA,
+// KScanD), ONE workgroup scans the blocks' totals (KScanTops), and a last pass adds each block's base (KScanApply).  Five small
+// launches instead of one long one; below the threshold the single workgroup is quicker (the Tiger's 2 500 elements: 3 us).
+constexpr uint32_t kScanSplit = 16384;
+// (PM_SCAN_SPLIT=<elements> moves the threshold: the tests put small scenes through the block-parallel sums with it)
+static uint32_t ScanSplit() {  // (read per scene, not cached: a flatten is not a per-frame call)
+    const char *e = getenv("PM_SCAN_SPLIT");
+    return e && *e ? static_cast<uint32_t>(strtoul(e, nullptr, 10)) : kScanSplit;
+}
+
+__global__ __launch_bounds__(kScanThreads) void KScanA(uint32_t n_els, const uint32_t *el_npts, const uint32_t *el_move, uint32_t *el_ptoff,
+                                                       uint32_t *el_mvoff, uint32_t *tops) {
+    __shared__ uint32_t s_w[kScanThreads / 64];
+    const uint32_t i = blockIdx.x * kScanThreads + threadIdx.x;
+    const uint32_t vp = (i < n_els) ? el_npts[i] : 0u;
+    const uint32_t vm = (i < n_els) ? el_move[i] : 0u;
+    uint32_t tp, tm;
+    const uint32_t op = BlockScan1024(vp, s_w, &tp);
+    const uint32_t om = BlockScan1024(vm, s_w, &tm);
+    if (i < n_els) {  // (offsets inside the block: KScanApply adds the block's base)
+        el_ptoff[i] = op;
+        el_mvoff[i] = om;
+    }
+    if (threadIdx.x == 0) {
+        tops[2u * blockIdx.x] = tp;
+        tops[2u * blockIdx.x + 1u] = tm;
+    }
+}
+
+// tops[2 b], tops[2 b + 1] (two interleaved arrays of n_blocks totals) -> exclusive prefix sums in place; the grand totals to out0 / out1
+__global__ __launch_bounds__(kScanThreads) void KScanTops(uint32_t n_blocks, uint32_t *tops, uint32_t *out0, uint32_t *out1, uint32_t *out2_copy_of_1) {
+    __shared__ uint32_t s_w[kScanThreads / 64];
+    uint32_t carry_a = 0, carry_b = 0;
+    for (uint32_t base = 0; base < n_blocks; base += kScanThreads) {
+        const uint32_t b = base + threadIdx.x;
+        const uint32_t va = (b < n_blocks) ? tops[2u * b] : 0u;
+        const uint32_t vb = (b < n_blocks) ? tops[2u * b + 1u] : 0u;
+        uint32_t ta, tb;
+        const uint32_t oa = BlockScan1024(va, s_w, &ta);
+        const uint32_t ob = BlockScan1024(vb, s_w, &tb);
+        if (b < n_blocks) {
+            tops[2u * b] = carry_a + oa;
+            tops[2u * b + 1u] = carry_b + ob;
+        }
+        carry_a += ta;
+        carry_b += tb;
+    }
+    if (threadIdx.x == 0) {
+        *out0 = carry_a;
+        *out1 = carry_b;
+        if (out2_copy_of_1) *out2_copy_of_1 = carry_b;
+    }
+}
+
+// per path: items and encoded points (KScan's second loop), scanned inside blocks of 1 024 paths; the element offsets are read as
+// "offset inside the block + the block's base" (KScanApply has not run yet: it must not, other blocks still read the unapplied values)
+__global__ __launch_bounds__(kScanThreads) void KScanD(const pm_path *paths, uint32_t n_paths, uint32_t n_els, const uint32_t *el_ptoff,
+                                                       const uint32_t *el_mvoff, const uint32_t *tops_e, uint32_t *path_item_base,
+                                                       uint32_t *path_pt_base, uint32_t *tops_p) {
+    __shared__ uint32_t s_w[kScanThreads / 64];
+    const uint32_t p = blockIdx.x * kScanThreads + threadIdx.x;
+    auto ptoff = [&](uint32_t i) { return i == n_els ? el_ptoff[n_els] : el_ptoff[i] + tops_e[2u * (i / kScanThreads)]; };
+    auto mvoff = [&](uint32_t i) { return i == n_els ? el_mvoff[n_els] : el_mvoff[i] + tops_e[2u * (i / kScanThreads) + 1u]; };
+    uint32_t vi = 0, vq = 0;
+    if (p < n_paths) {
+        const uint32_t n_sub = mvoff(paths[p].el_end) - mvoff(paths[p].el_begin);
+        const uint32_t n_pts = ptoff(paths[p].el_end) - ptoff(paths[p].el_begin);
+        if (paths[p].flags & PM_PATH_FILL) {
+            const bool compound = (paths[p].flags & PM_PATH_COMPOUND) != 0;
+            vi += compound ? (n_sub ? 1u : 0u) : n_sub;
+            vq += n_pts + (compound ? n_sub : 0u);
+        }
+        if (paths[p].flags & PM_PATH_STROKE) {
+            vi += n_sub;
+            vq += n_pts;
+        }
+    }
+    uint32_t ti, tq;
+    const uint32_t oi = BlockScan1024(vi, s_w, &ti);
+    const uint32_t oq = BlockScan1024(vq, s_w, &tq);
+    if (p < n_paths) {
+        path_item_base[p] = oi;
+        path_pt_base[p] = oq;
+    }
+    if (threadIdx.x == 0) {
+        tops_p[2u * blockIdx.x] = ti;
+        tops_p[2u * blockIdx.x + 1u] = tq;
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void KScanApply(uint32_t n_els, uint32_t *el_ptoff, uint32_t *el_mvoff, const uint32_t *tops_e, uint32_t n_paths,
+                                                           uint32_t *path_item_base, uint32_t *path_pt_base, const uint32_t *tops_p) {
+    const uint32_t i = blockIdx.x * kScanThreads + threadIdx.x;
+    if (i < n_els) {
+        el_ptoff[i] += tops_e[2u * blockIdx.x];
+        el_mvoff[i] += tops_e[2u * blockIdx.x + 1u];
+    }
+    if (i < n_paths) {
+        path_item_base[i] += tops_p[2u * blockIdx.x];
+        path_pt_base[i] += tops_p[2u * blockIdx.x + 1u];
+    }
+}
+
 // (n_items and the other totals are read from device memory: the host does not wait for KScan before
 //  it launches the kernels that depend on them)
 __global__ void KPoints(const pm_path *paths, uint32_t n_paths, const pm_path_el *els, uint32_t n_els, Affine aff,
@@ -467,7 +572,7 @@ hipError_t Grow(T **p, size_t *cap, size_t need) {
 }  // namespace
 
 hipError_t FlattenCache::Reserve(size_t n_paths, size_t n_els) {
-    const size_t n_u32 = n_els * 2 + (n_els + 1) * 2 + n_paths * 2 + n_els + 8;
+    const size_t n_u32 = n_els * 2 + (n_els + 1) * 2 + n_paths * 2 + n_els + 16 + 2 * ((n_els + 1023) / 1024 + (n_paths + 1023) / 1024);
     hipError_t e = Grow(&d_paths, &cap_paths, n_paths);
     if (e == hipSuccess) e = Grow(&d_els, &cap_els, n_els);
     if (e == hipSuccess) e = Grow(&d_u32, &cap_u32, n_u32);
@@ -500,7 +605,9 @@ int FlattenEncodeOnDevice(hipStream_t stream, FlattenCache *cache, bool use_resi
     Affine aff;
     for (int k = 0; k < 6; ++k) aff.m[k] = affine[k];
     const uint32_t ne = static_cast<uint32_t>(n_els), np = static_cast<uint32_t>(n_paths);
-    const size_t n_u32 = static_cast<size_t>(ne) * 2 + (static_cast<size_t>(ne) + 1) * 2 + static_cast<size_t>(np) * 2 + ne + 8;
+    // (+ the parallel scan's block totals: two words per block of 1 024 elements / paths)
+    const size_t n_u32 = static_cast<size_t>(ne) * 2 + (static_cast<size_t>(ne) + 1) * 2 + static_cast<size_t>(np) * 2 + ne + 16 +
+                         2 * ((static_cast<size_t>(ne) + 1023) / 1024 + (static_cast<size_t>(np) + 1023) / 1024);
 
     // host-side structural check: paths must tile the element array in order
     if (!use_resident) {
@@ -568,8 +675,22 @@ int FlattenEncodeOnDevice(hipStream_t stream, FlattenCache *cache, bool use_resi
         const uint32_t tb = 256;
         const uint32_t cap32 = static_cast<uint32_t>(std::min<size_t>(scene_cap, 0xffffffffull));
         hipLaunchKernelGGL(KCount, dim3((ne + tb - 1) / tb), dim3(tb), 0, stream, d_paths, np, d_els, ne, aff, el_npts, el_move, d_err);
-        hipLaunchKernelGGL(KScan, dim3(1), dim3(kScanThreads), 0, stream, d_paths, np, ne, el_npts, el_move, el_ptoff, el_mvoff,
-                           path_item_base, path_pt_base, d_totals);
+        if (ne <= ScanSplit()) {
+            hipLaunchKernelGGL(KScan, dim3(1), dim3(kScanThreads), 0, stream, d_paths, np, ne, el_npts, el_move, el_ptoff, el_mvoff,
+                               path_item_base, path_pt_base, d_totals);
+        } else {
+            const uint32_t nb_e = (ne + kScanThreads - 1u) / kScanThreads, nb_p = (np + kScanThreads - 1u) / kScanThreads;
+            uint32_t *tops_e = d_err + 4;        // [2 nb_e] (behind the totals and the error word)
+            uint32_t *tops_p = tops_e + 2u * nb_e;  // [2 nb_p]
+            hipLaunchKernelGGL(KScanA, dim3(nb_e), dim3(kScanThreads), 0, stream, ne, el_npts, el_move, el_ptoff, el_mvoff, tops_e);
+            // (totals[2] = sub-paths: the grand total of the moves, which also closes el_mvoff)
+            hipLaunchKernelGGL(KScanTops, dim3(1), dim3(kScanThreads), 0, stream, nb_e, tops_e, el_ptoff + ne, el_mvoff + ne, d_totals + 2);
+            hipLaunchKernelGGL(KScanD, dim3(nb_p), dim3(kScanThreads), 0, stream, d_paths, np, ne, el_ptoff, el_mvoff, tops_e, path_item_base,
+                               path_pt_base, tops_p);
+            hipLaunchKernelGGL(KScanTops, dim3(1), dim3(kScanThreads), 0, stream, nb_p, tops_p, d_totals, d_totals + 1, static_cast<uint32_t *>(nullptr));
+            hipLaunchKernelGGL(KScanApply, dim3(std::max(nb_e, nb_p)), dim3(kScanThreads), 0, stream, ne, el_ptoff, el_mvoff, tops_e, np, path_item_base,
+                               path_pt_base, tops_p);
+        }
         hipLaunchKernelGGL(KHeader, dim3(1), dim3(1), 0, stream, d_scene, static_cast<const uint32_t *>(d_totals), 0u, cap32);
         hipLaunchKernelGGL(KPoints, dim3((ne + tb - 1) / tb), dim3(tb), 0, stream, d_paths, np, d_els, ne, aff, el_npts, el_ptoff,
                            el_mvoff, path_pt_base, static_cast<const uint32_t *>(d_totals), d_scene, cap32, d_bbox, sub_first);

@@ -967,6 +967,22 @@ def test_even_odd_through_the_device_flatten(pm, pmo, renderer):
     assert (got != pmo.render(plain, wl.width, wl.height)).any()  # the Tiger has self-overlapping outlines
 
 
+@pytest.mark.parametrize("split", [0, 700])
+def test_flatten_block_parallel_prefix_sums(pm, pmo, renderer, monkeypatch, split):
+    """Above 16 384 elements the flatten stage's two prefix sums run as blocks of 1 024 in parallel (KScanA / KScanTops / KScanD /
+    KScanApply) instead of one workgroup walking the arrays; PM_SCAN_SPLIT moves the threshold so that a scene the oracle encodes in
+    a second goes that way: 2 500 blobs = 2 500 paths (three blocks of paths), 15 000 elements (15 blocks), fills, strokes and
+    compound fills.  Byte for byte the CPU encoder's scene, as every flatten test."""
+    monkeypatch.setenv("PM_SCAN_SPLIT", str(split))
+    wl = pm.workloads.config4_blobs(2500, 512)
+    _flatten_case(pm, pmo, renderer, wl)
+    wl = pm.workloads.heldout_glyphs(1500, 512, 512)
+    _flatten_case(pm, pmo, renderer, wl)
+    monkeypatch.delenv("PM_SCAN_SPLIT")
+    wl = pm.workloads.config4_blobs(2500, 512)  # and the single-workgroup sums on the same input
+    _flatten_case(pm, pmo, renderer, wl)
+
+
 def test_compound_fills_through_the_device_flatten(pm, pmo, renderer):
     """PM_PATH_COMPOUND: the flatten kernels write ONE Fill item per path, its sub-paths separated
     in the point array -- scene bytes equal the oracle's encoder, pixels equal its render (Tiger,
