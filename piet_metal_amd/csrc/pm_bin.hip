@@ -55,25 +55,29 @@ __global__ __launch_bounds__(256) void pm_index_kernel(const uint8_t *scene, uin
 }
 
 // =====================================================================================
-// K1a: per-tile-row item lists (large scenes only), one workgroup per tile row
+// K1a: per-tile-row item lists (large scenes only), row_parts workgroups per tile row
 // =====================================================================================
 //
 // With thousands of items every strip-row workgroup of pm_bin_kernel would scan every bbox of
 // the band (PietRender.metal:191-208 does exactly that per threadgroup).  The row part of that
 // test does not depend on the strip, so for large scenes it is done once per tile row here and
 // the strip rows of the row scan the (much shorter) row list instead.  Lists keep paint order;
-// their sizes are known to the host from the same predicate, so row r writes exactly
-// row_base[r+1] - row_base[r] entries.
+// their sizes are known to the host from the same predicate -- per tile row AND per part of the item range (round 5: a row's
+// scan is cut into row_parts workgroups, each with its own, host-computed place in the row's list; one workgroup walking
+// 20 000 items was ten dependent steps, 24 us in front of a 100 us frame) -- so part p of row r writes exactly
+// row_base[r * parts + p + 1] - row_base[r * parts + p] entries.
 __global__ __launch_bounds__(kBinThreads) void pm_rowcull_kernel(FrameParams P) {
     __shared__ uint32_t s_part[kBinWaves];
     const uint32_t tid = threadIdx.x;
-    const uint32_t row_rel = blockIdx.x;
+    const uint32_t row_rel = blockIdx.x / P.row_parts, part = blockIdx.x % P.row_parts;
     const int y0 = static_cast<int>((P.row0 + row_rel) * kTileH);
-    uint32_t out = P.row_base[row_rel];
+    uint32_t out = P.row_base[blockIdx.x];
     // A lane tests kPer consecutive items per step (paint order = lane order = item order), one block scan per 2 048
     // items: with one item per lane the 10 000 items of config 4 were 40 dependent steps, 30 us in front of every frame.
-    constexpr uint32_t kPer = 8;
-    for (uint32_t jb = 0; jb < P.n_band_items; jb += kBinThreads * kPer) {
+    constexpr uint32_t kPer = kRowCullPer;
+    static_assert(kBinThreads * kPer == kRowCullStep, "what the host sizes a part by");
+    const uint32_t j_end = min(P.n_band_items, (part + 1u) * P.row_part_items);
+    for (uint32_t jb = part * P.row_part_items; jb < j_end; jb += kBinThreads * kPer) {
         const uint32_t j0 = jb + tid * kPer;
         uint2 bb[kPer];
         uint32_t it[kPer];
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_rowcull_kernel(FrameParams P) 
         for (uint32_t u = 0; u < kPer; ++u) {
             bb[u] = make_uint2(0u, 0u);
             it[u] = 0;
-            if (j0 + u < P.n_band_items) {
+            if (j0 + u < j_end) {
                 bb[u] = P.band_bbox[j0 + u];
                 it[u] = P.band_item[j0 + u];
             }
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_rowcull_kernel(FrameParams P) 
 #pragma unroll
         for (uint32_t u = 0; u < kPer; ++u) {
             const int by = static_cast<int>(bb[u].x >> 16), bw = static_cast<int>(bb[u].y >> 16);
-            if (j0 + u < P.n_band_items && bw >= y0 && by < y0 + static_cast<int>(kTileH)) hits |= 1u << u;  // row part of :198 / :214
+            if (j0 + u < j_end && bw >= y0 && by < y0 + static_cast<int>(kTileH)) hits |= 1u << u;  // row part of :198 / :214
         }
         uint32_t total;
         uint32_t pos = out + BlockExclusiveScan<kBinWaves>(static_cast<uint32_t>(__popc(hits)), s_part, &total);
@@ -126,7 +130,7 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, cons
 
 void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
     const uint32_t n_striprows = p.bin_grid;
-    if (p.use_row_lists) hipLaunchKernelGGL(pm_rowcull_kernel, dim3(p.row1 - p.row0), dim3(kBinThreads), 0, stream, p);
+    if (p.use_row_lists) hipLaunchKernelGGL(pm_rowcull_kernel, dim3((p.row1 - p.row0) * p.row_parts), dim3(kBinThreads), 0, stream, p);
     if (p.bin_waves == 1) {
         if (p.dbg_bin)
             PM_LAUNCH((pm_bin_kernel<true, 1>), dim3(n_striprows), dim3(64), stream, t0, t1, p);

@@ -273,6 +273,7 @@ struct pm_ctx {
     uint32_t n_band_items = 0;
     uint32_t *d_row_base = nullptr;  // per-tile-row item lists (large scenes): offsets
     uint32_t row_total = 0;
+    uint32_t row_parts = 1, row_part_items = pm::kRowCullStep;  // pm_rowcull_kernel's workgroups per tile row and their share of the items
     bool use_row_lists = false;
     uint32_t arena_cap = 0;         // dwords per slot
     uint64_t ptcl_want = 0;         // commands a slot's list arena starts with / was grown to
@@ -754,24 +755,36 @@ int EnsureArena(pm_ctx *c) {
         // host only sizes the lists, with the kernel's predicate.
         if (c->use_row_lists) {
             const uint32_t rows = BandRows(c);
+            // A tile row's scan is cut into parts (workgroups of pm_rowcull_kernel), about four workgroups per CU in all, a part no
+            // shorter than one step of the kernel: rb[r * parts + p] = where part p of row r writes.
+            const uint32_t n_it = static_cast<uint32_t>(bbs.size());
+            const uint32_t parts_wanted = std::max<uint32_t>(1u, (4u * static_cast<uint32_t>(c->n_cus)) / std::max<uint32_t>(rows, 1u));
+            const uint64_t per_part = static_cast<uint64_t>(pm::kRowCullStep) * parts_wanted;
+            // (PM_ROW_LIST_PART_ITEMS: the tests cut small scenes into many parts)
+            const uint32_t part_items = static_cast<uint32_t>(EnvInt("PM_ROW_LIST_PART_ITEMS", static_cast<int>(pm::kRowCullStep * static_cast<uint32_t>(std::max<uint64_t>(1u, (n_it + per_part - 1u) / per_part))), 1, 1 << 30));
+            const uint32_t parts = std::max<uint32_t>(1u, (n_it + part_items - 1u) / part_items);
+            c->row_parts = parts;
+            c->row_part_items = part_items;
             std::vector<uint32_t> &rb = c->stage_rb;
-            rb.assign(rows + 1, 0u);
-            for (const uint2 &b : bbs) {
+            rb.assign(static_cast<size_t>(rows) * parts + 1, 0u);
+            for (uint32_t k = 0; k < n_it; ++k) {
+                const uint2 &b = bbs[k];
                 const uint32_t by = b.x >> 16, bw = b.y >> 16;
                 const uint32_t r_lo = std::max(by / pm::kTileH, c->row0), r_hi = std::min(bw / pm::kTileH, c->row1 - 1);
-                for (uint32_t r = r_lo; r <= r_hi && r_hi >= r_lo; ++r) rb[r - c->row0 + 1] += 1;
+                const uint32_t pk = k / part_items;
+                for (uint32_t r = r_lo; r <= r_hi && r_hi >= r_lo; ++r) rb[static_cast<size_t>(r - c->row0) * parts + pk + 1] += 1;
             }
             uint64_t run = 0;
-            for (uint32_t r = 0; r < rows; ++r) {
-                const uint32_t n_r = rb[r + 1];
-                rb[r] = static_cast<uint32_t>(run);
-                run += n_r;
+            for (size_t i = 0; i < static_cast<size_t>(rows) * parts; ++i) {
+                const uint32_t n_i = rb[i + 1];
+                rb[i] = static_cast<uint32_t>(run);
+                run += n_i;
             }
             if (run > 0xfffffff0ull) {
                 SetError("per-row item lists beyond 2^32 entries");
                 return PM_ERR_CAPACITY;
             }
-            rb[rows] = static_cast<uint32_t>(run);
+            rb[static_cast<size_t>(rows) * parts] = static_cast<uint32_t>(run);
             c->row_total = static_cast<uint32_t>(run);
             if (rb.size() > c->row_base_cap || !c->d_row_base) {  // (grow only)
                 if (c->d_row_base) (void)hipFree(c->d_row_base);
@@ -786,7 +799,7 @@ int EnsureArena(pm_ctx *c) {
             sl.resize(c->stage_desc.size());
             for (size_t i = 0; i < sl.size(); ++i) {
                 const uint32_t r = c->stage_desc[i].x >> 16;
-                sl[i] = r < rows ? make_uint2(rb[r], rb[r + 1] - rb[r]) : make_uint2(0u, 0u);
+                sl[i] = r < rows ? make_uint2(rb[static_cast<size_t>(r) * parts], rb[static_cast<size_t>(r + 1) * parts] - rb[static_cast<size_t>(r) * parts]) : make_uint2(0u, 0u);
             }
             PM_TRY(hipMemcpyAsync(c->d_sr_list, sl.data(), sl.size() * sizeof(uint2), hipMemcpyHostToDevice, c->stream));
             // (the slots' own list buffers come into being when a slot is next used, EnsureSlotBuffers: the first frame of a
@@ -879,6 +892,8 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->fine_grid = FineGrid(c);
     p->use_row_lists = c->use_row_lists ? 1u : 0u;
     p->row_base = c->d_row_base;
+    p->row_parts = c->row_parts;
+    p->row_part_items = c->row_part_items;
     p->row_bbox = s->d_row_bbox;
     p->row_item = s->d_row_item;
     p->chunk_base = c->d_chunk_base;

@@ -124,6 +124,8 @@ constexpr uint32_t kChunkSegs = 4;
 constexpr uint32_t kSuperChunks = 8;
 constexpr uint32_t kArenaBase = 4;     // offset 0 means "none"
 constexpr int kBinWaves = 4;           // waves of one binning workgroup
+constexpr uint32_t kRowCullPer = 8;    // pm_rowcull_kernel: items tested per lane and step
+constexpr uint32_t kRowCullStep = 64u * kBinWaves * kRowCullPer;  // ... per workgroup and step
 constexpr uint32_t kCtShift = 20;            // per (candidate, tile): backdrop << 20 | relevant-segment count
 constexpr uint32_t kCtCountMask = (1u << kCtShift) - 1u;
 constexpr uint32_t kSlotDwords = 5;          // binning arena: 16 B segment + 4 B meta word per slot
@@ -176,7 +178,9 @@ struct FrameParams {
     uint32_t handout_static;           // 1: every pass of the tile kernel is handed out statically (other frames in flight)
     // large scenes: per-tile-row item lists written each frame by pm_rowcull_kernel
     uint32_t use_row_lists;
-    const uint32_t *row_base;      // [band rows + 1] list offsets (host-computed sizes)
+    const uint32_t *row_base;      // [band rows x row_parts + 1] list offsets (host-computed sizes): where part p of tile row r writes
+    uint32_t row_parts;            // workgroups of pm_rowcull_kernel per tile row (each scans row_part_items of the band's items)
+    uint32_t row_part_items;       // (multiples of kRowCullStep, unless a test says otherwise)
     uint2 *row_bbox;               // [row_base[rows]]
     uint32_t *row_item;
     const uint32_t *chunk_base;    // [n_items + 1]

@@ -1161,10 +1161,15 @@ def test_animation_reflatten_resident_paths(pm, pmo, renderer, tmp_path):
     assert np.array_equal(a, pmo.render(scene1, 320, 200))
 
 
-def test_per_row_item_lists_large_scene_path(pm, pmo, monkeypatch):
+@pytest.mark.parametrize("part_items", [None, 37])
+def test_per_row_item_lists_large_scene_path(pm, pmo, monkeypatch, part_items):
     """Scenes with thousands of items bin through per-tile-row item lists
-    (pm_rowcull_kernel); forced on here for small scenes, full frame and bands."""
+    (pm_rowcull_kernel); forced on here for small scenes, full frame and bands -- a workgroup per tile row, and
+    (PM_ROW_LIST_PART_ITEMS=37) a row's scan cut into a dozen workgroups with their own places in the row's list,
+    as scenes of > 2 048 items get it."""
     monkeypatch.setenv("PM_ROW_LIST_MIN_ITEMS", "1")
+    if part_items is not None:
+        monkeypatch.setenv("PM_ROW_LIST_PART_ITEMS", str(part_items))
     r = pm.Renderer(0)
     try:
         wl = pm.workloads.tiger(1000, 700)
