@@ -739,6 +739,17 @@ def test_dense_scenes_get_the_one_wave_per_tile_kernel(pm, pmo, monkeypatch):
                 r.render()
                 assert np.array_equal(r.read_pixels(), pmo.render(tscene, tig.width, tig.height))
             assert r.dense_kernel_frames() == before
+            # a scene without a single long list is the one-wave kernel's too (nothing in it would get a workgroup)
+            gl = pm.workloads.heldout_glyphs(500, 512, 512)
+            r.resize(gl.width, gl.height)
+            r.flatten_and_encode(gl.paths, gl.affine, gl.width_scale)
+            gscene = r.download_scene()
+            gwant = pmo.render(gscene, gl.width, gl.height)
+            for k in range(4):
+                r.render()
+                assert np.array_equal(r.read_pixels(), gwant), k
+            assert r.stats()["heavy_tiles"] == 0 and r.stats()["queued_tiles"] > 100
+            assert r.dense_kernel_frames() == (before + 3 if mode == "1" else before)
         finally:
             r.close()
 
