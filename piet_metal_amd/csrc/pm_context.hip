@@ -1434,7 +1434,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->stream = c->streams[0];
     c->coarse_wg_per_cu = static_cast<uint32_t>(EnvInt("PM_COARSE_WG_PER_CU", 5, 1, 16));
     c->split_mode = static_cast<uint32_t>(EnvInt("PM_FINE_SPLIT", 1, 0, 1));
-    c->dense_factor = static_cast<uint32_t>(EnvInt("PM_DENSE_FACTOR", 4, 1, 64));
+    c->dense_factor = static_cast<uint32_t>(EnvInt("PM_DENSE_FACTOR", 4, 1, 1 << 20));
     c->dense_kernel_mode = EnvInt("PM_DENSE_KERNEL", 1, 0, 1);
     c->fine_wg_dense = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU_DENSE", 6, 1, 16));
     c->fine_wg_dense_inflight = static_cast<uint32_t>(EnvInt("PM_FINE_WG_PER_CU_DENSE_INFLIGHT", 4, 1, 16));

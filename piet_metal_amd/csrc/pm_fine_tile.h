@@ -174,8 +174,12 @@ struct SparseLds {
 static_assert(sizeof(SparseLds) <= 40960, "four workgroups per CU");
 // The working set of a kernel that renders EVERY tile with one wave (a dense frame: pm_fine_kernel<.., kDense>): no alpha images,
 // no hand-over words -- 19 KB, so that six workgroups share a CU (and the code without the workgroup paths fits 80 VGPRs).
+// (and room for a second chunk of every wave's list: a dense frame's lists are long -- config 4: 72 commands on average -- and what
+//  does not fit in LDS goes to the tile's list in HBM and comes straight back, a store, a fence and a round trip per tile)
+constexpr uint32_t kDenseLdsChunks = 2;
 struct DenseLds {
     WaveLds w[kWaves];
+    Cmd more[kWaves][(kDenseLdsChunks - 1u) * kSpChunk];  // commands 64 .. 127 of the wave's list
 };
 static_assert(sizeof(DenseLds) <= 26624, "six workgroups per CU");
 
@@ -727,8 +731,15 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &
         // (a workgroup tile: all four waves -- the longest lists are built a round of 64 stream elements per wave)
         CoarseShared *shared = nullptr;
         if constexpr (kWg) shared = wg_mode ? &S.coarse_shared : nullptr;
+        // (chunks of the list that stay in LDS, and the bytes from one to the next: a single wave's first chunk is its own staged-command
+        //  area; the one-wave kernel has a second one per wave, S.more)
+        uint32_t lds_stride = static_cast<uint32_t>(sizeof(WaveLds)), lds_n = wg_mode ? kLdsChunks : 1u;
+        if constexpr (!kWg) {
+            lds_stride = static_cast<uint32_t>(reinterpret_cast<uint8_t *>(S.more[wave]) - reinterpret_cast<uint8_t *>(S.w[wave].cmds));
+            lds_n = kDenseLdsChunks;
+        }
         n_cmd = CoarseTile<kCapture, kProf, kWg, kCoh>(P, S.w[wave].c, cur, lane, lanes_below, &ct, reinterpret_cast<uint8_t *>(wg_mode ? S.w[1].cmds : S.w[wave].cmds),
-                                                  static_cast<uint32_t>(sizeof(WaveLds)), wg_mode ? kLdsChunks : 1u, shared);
+                                                  lds_stride, lds_n, shared);
         if constexpr (kWg) {
             if (wg_mode) {
                 if (wave == 0 && lane == 0) S.wg_ncmd[parity & 1u] = n_cmd;
@@ -736,7 +747,7 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &
                 n_cmd = S.wg_ncmd[parity & 1u];
             }
         }
-        if (!wg_mode && n_cmd > kSpChunk) {
+        if (!wg_mode && n_cmd > (kWg ? 1u : kDenseLdsChunks) * kSpChunk) {
             // (only a list longer than the chunk in LDS is read back from HBM: this wave's stores before its loads.  The
             //  release waits for EVERY store the wave has in flight -- the previous tile's pixels among them, microseconds
             //  under load -- so the tiles that need no read-back skip it)
@@ -807,13 +818,21 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &
             for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk) {
                 const uint32_t m = min(kSpChunk, n_cmd - c0);
                 WaveSync();
-                if (!kFused || c0 != 0) {  // (the fused kernel's CoarseTile left the first chunk right here)
+                Cmd *chunk = cmds;
+                bool in_lds = kFused && c0 == 0;  // (the fused kernel's CoarseTile left the first chunk right here)
+                if constexpr (!kWg) {
+                    if (kFused && c0 == kSpChunk) {  // ... and the one-wave kernel's the second one next to it
+                        chunk = S.more[wave];
+                        in_lds = true;
+                    }
+                }
+                if (!in_lds) {
                     const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
                     uint2 *l = reinterpret_cast<uint2 *>(cmds);
                     for (uint32_t w = Opaque(lane); w < 3u * m; w += 64u) l[w] = g[w];  // (Opaque: no hoisted address to spill)
                 }
                 WaveSync();
-                InterpretSparse(S, cmds, S.w[wave].f.fill_ix, m, x0, y0, st);
+                InterpretSparse(S, chunk, S.w[wave].f.fill_ix, m, x0, y0, st);
             }
             // The twelve table reads of the pixels' encoding are requested FIRST, the draw of the next tile goes out
             // while they are in flight (its wait is theirs too), and the next tile's queue entry is on its way while the

@@ -148,6 +148,37 @@ def test_list_longer_than_the_lds_command_buffer(pm, pmo, renderer):
     assert P.total_cmds()[1] > 1600  # the variant without the opaque fill
 
 
+def test_one_wave_kernel_lists_around_its_lds_chunks(pm, pmo, monkeypatch):
+    """The tile kernel's one-wave-per-tile instantiation keeps the first TWO chunks of 64 commands of a wave's list in LDS and reads only
+    what lies beyond back from the tile's list in HBM: lists that end just below, at and beyond both boundaries (three commands per
+    polyline: 63, 66, 126, 129, 132 ... 900), with and without an opaque fill in the middle (the list restarts there).  PM_DENSE_FACTOR
+    makes any frame with a long list a dense one, so the frames behind a scene's first run that kernel."""
+    monkeypatch.setenv("PM_DENSE_FACTOR", "100000")
+    r = pm.Renderer(0)
+    try:
+        r.resize(192, 160)
+        rng = np.random.default_rng(23)
+        for n in (21, 22, 42, 43, 44, 64, 90, 300):
+            for with_fill in (False, True):
+                ops = []
+                for i in range(n):
+                    a = rng.uniform(67, 77, 2)  # everything inside tile (4, 4)
+                    pts = np.stack([a, a + rng.uniform(-3, 3, 2), a + rng.uniform(-3, 3, 2)])
+                    ops.append(("poly", pts, (int(rng.integers(0, 1 << 24)) << 8) | int(rng.integers(0x10, 0x60)), float(rng.uniform(0.3, 3))))
+                    if with_fill and i == n // 3:
+                        ops.append(("fill", np.array([(70.5, 40.0), (160.0, 75.5), (70.5, 120.0), (20.0, 75.5)]), 0x336699FF))
+                scene = encode_ops(pm, ops, cap=1 << 22)
+                want = pmo.render(scene, 192, 160)
+                r.set_scene_bytes(scene)
+                before = r.dense_kernel_frames()
+                for k in range(3):
+                    r.render()
+                    assert np.array_equal(r.read_pixels(), want), (n, with_fill, k)
+                assert r.dense_kernel_frames() == before + 2, (n, with_fill)
+    finally:
+        r.close()
+
+
 def test_empty_scene_and_tiny_viewports(pm, pmo, renderer):
     empty = np.frombuffer(struct.pack("<II", 0, 8), np.uint8)
     assert (gpu_render(renderer, empty, 40, 24) == 255).all()
