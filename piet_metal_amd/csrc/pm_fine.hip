@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kBinThreads) void pm_clear_kernel(FrameParams P) { 
 // kDense: every tile one wave's, whatever its list -- the instantiation the host launches for a frame the previous frame of the same
 // scene found dense (below): without the workgroup paths the kernel fits 80 VGPRs and 19 KB of LDS, SIX workgroups per CU instead of five.
 template <bool kFused, bool kProf, bool kCapture = false, bool kDense = false>
-__global__ __launch_bounds__(kThreads, kDense ? 6 : kFineMinWg) void pm_fine_kernel(FrameParams P) {
+__global__ __launch_bounds__(kThreads, kDense ? 6 : 5) void pm_fine_kernel(FrameParams P) {
     __shared__ std::conditional_t<kDense, DenseLds, SparseLds> S;
     if (blockIdx.x >= P.fine_grid) {
         ClearStripRow(P, blockIdx.x - P.fine_grid);

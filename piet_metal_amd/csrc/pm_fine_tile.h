@@ -138,14 +138,7 @@ __device__ __forceinline__ half2_t Splat(_Float16 v) { half2_t r; r.x = v; r.y =
 // are split by command batch, pass 3 by pixel rows (1 pixel per lane).
 constexpr uint32_t kSpChunk = 64;     // commands staged per chunk
 constexpr uint32_t kMaxFrag = 64;     // fragment slots per wave (one step of pass 1 adds <= 64)
-#ifndef PM_ALPHA_SLOTS
-#define PM_ALPHA_SLOTS 16
-#endif
-#ifndef PM_FINE_MIN_WG
-#define PM_FINE_MIN_WG 5
-#endif
-constexpr uint32_t kAlphaSlots = PM_ALPHA_SLOTS;  // workgroup mode: items evaluated ahead per round
-constexpr int kFineMinWg = PM_FINE_MIN_WG;        // workgroups per CU the general tile kernel is compiled and sized for
+constexpr uint32_t kAlphaSlots = 16;  // workgroup mode: items evaluated ahead per round
 
 // Per wave: the staged chunk of commands, and the fragment region of its Fills.  The fused kernel builds the
 // tile's list first (CoarseTile): its scratch shares the fragment region's bytes, and the first chunk of the
@@ -178,7 +171,7 @@ struct SparseLds {
     uint16_t item_se[kSpChunk + 1];       // per item: first command | blend command << 8 (last entry: the open tail)
 };
 // (five workgroups per CU need <= 31 184 B each -- measured, pm_bin.hip; this one is 30 608 B)
-static_assert(sizeof(SparseLds) <= (kFineMinWg >= 5 ? 31184 : 40960), "the workgroups per CU it is compiled for");
+static_assert(sizeof(SparseLds) <= 40960, "four workgroups per CU");
 // The working set of a kernel that renders EVERY tile with one wave (a dense frame: pm_fine_kernel<.., kDense>): no alpha images,
 // no hand-over words -- 19 KB, so that six workgroups share a CU (and the code without the workgroup paths fits 80 VGPRs).
 // (and room for a second chunk of every wave's list: a dense frame's lists are long -- config 4: 72 commands on average -- and what
