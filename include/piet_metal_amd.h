@@ -263,6 +263,11 @@ int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms);
  * of the same scene and viewport whose tile kernel found it dense -- long lists enough to occupy every wave (PM_DENSE_KERNEL=0: never). */
 int pm_tile_kernel_info(pm_ctx *c, uint32_t *dense_frames);
 
+/* Frames binned with ONE wave per strip row (pm_bin_kernel<.., 1>) since pm_create: out[0] all of them, out[1] those that got it only
+ * because they were submitted behind running frames, out[2] of those the ones with a wave for EVERY strip row where the plan chains
+ * rows for its own, smaller grid of workgroups (1 280 < strip rows <= 4 096 light ones). */
+int pm_binning_info(pm_ctx *c, uint32_t out[3]);
+
 /* One launch per frame (pm_frame_kernel: the two dispatches of PietRenderer.m:69-88 as roles of one resident
  * grid).  *frames = frames submitted that way since pm_create; *applies = 1 if a frame of the resident scene
  * and viewport, alone on the device, would be (0: two launches -- PM_ONE_LAUNCH=0, more strip rows than resident

@@ -178,7 +178,7 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         it_next = band_item != nullptr ? band_item[tid] : tid;
     }
     if constexpr (kOne) rix_next = __builtin_amdgcn_readfirstlane(PM_PP(sr_next_one)[rix]);  // (the one-launch grid's own chains)
-    else rix_next = __builtin_amdgcn_readfirstlane(srd.w);
+    else rix_next = PM_PU(bin_no_chains) ? 0u : __builtin_amdgcn_readfirstlane(srd.w);
     if (rix_next == 0) rix_next = 0xffffffffu;
     // kOne: the workgroup renders tiles of its LAST strip row itself; an earlier row of its chain hands every tile over
     const bool last_row = rix_next == 0xffffffffu;

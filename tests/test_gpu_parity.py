@@ -336,9 +336,16 @@ def test_heldout_workloads_full_size_goldens(pm, renderer, golden, key):
             hsh.update(np.uint32(n).tobytes())
             hsh.update(np.ascontiguousarray(cmds[ty, tx, :n]).tobytes())
     assert hsh.hexdigest() == g["ptcl_sha256"]
+    before = renderer.binning_info()
     for _ in range(8):
         renderer.render()
     assert sha(renderer.read_pixels()) == g["rgba_sha256"]
+    if key == "held3":
+        # 2 025 light strip rows: alone a workgroup per row, chained over the plan's 1 280 workgroups; behind running frames a
+        # wave for EVERY row (the chains are not walked) -- the policy check found that 14 % faster per frame
+        after = renderer.binning_info()
+        assert after["no_chains"] - before["no_chains"] >= 4
+        assert after["wave_per_row"] - before["wave_per_row"] == after["inflight_only"] - before["inflight_only"]
 
 
 @pytest.mark.parametrize("cfg", ["config4", "config5"])

@@ -26,22 +26,19 @@ SWITCHES = {
     "PM_DENSE_FACTOR": ["1", "16"],              # default 4: one wave per tile once long lists x 4 fill the grid (1: the rule of rounds 2-4)
     "PM_DENSE_KERNEL": ["0"],                    # default 1: dense frames get the one-wave-per-tile instantiation of the tile kernel
     "PM_FINE_WG_PER_CU_DENSE_INFLIGHT": ["6"],   # default 4 (that kernel's grid behind other frames)
+    "PM_ROW_LIST_PART_ITEMS": ["1000000000"],    # default: parts of >= 2 048 items, about four workgroups per CU (this: one workgroup per tile row)
     "PM_ONE_LAUNCH": ["1"],                      # default 0: two launches per frame
 }
 
 
 def measure(wl, env):
+    # (the switches stay set for the whole measurement: pm_create reads most of them, but the ones of the binning plan --
+    #  PM_ROW_LIST_MIN_ITEMS, PM_ROW_LIST_PART_ITEMS -- are read when a scene's first frame is planned)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
+    r = None
     try:
         r = pm.Renderer(0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-    try:
         r.resize(wl.width, wl.height)
         r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
         for _ in range(40):
@@ -59,7 +56,13 @@ def measure(wl, env):
         sus = (time.perf_counter() - t0) / n * 1e3
         return lone, sus
     finally:
-        r.close()
+        if r is not None:
+            r.close()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def main():
