@@ -97,8 +97,21 @@ static_assert(sizeof(BinLds<1>) <= 10240, "sixteen one-wave groups per CU");
 // tiles itself.  What the tile stage reads (pieces, FIFO entries) is stored write-through, because a tile may be rendered by
 // a workgroup on another XCD, whose L2 knows nothing of this one's; the row's tiles are handed over in `R` (the first ones,
 // which this workgroup renders itself) and through the frame's FIFOs (pm_frame_row.h) once every wave's stores have drained.
+// What a strip row's chain of dependent loads STARTS from.  pm_bin_kernel takes these as separate scalar kernel arguments in front of
+// the FrameParams block (the same values as the block's fields of these names): the build preloads the first kernel arguments
+// into SGPRs (-amdgpu-kernarg-preload-count, csrc/Makefile), so the strip row's descriptor, the first boxes of its item list and
+// the colour tables are requested in the kernel's first instructions, next to the load of the parameter block itself, instead
+// of behind it -- one round trip (cold: the first access of a launch) off every strip row's chain.
+struct BinEntry {
+    const uint4 *sr_desc;
+    const uint2 *band_bbox;
+    const uint32_t *band_item;
+    const uint32_t *lut_srgb2lin, *lut_unorm2h;
+    uint32_t n_band_items, use_row_lists;
+};
 template <bool kProfile, int kW, bool kOne = false>
-__device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kProfile || !kOne> &L, FrameRowLds *const R = nullptr) {
+__device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kProfile || !kOne> &L, FrameRowLds *const R = nullptr, const BinEntry *const E = nullptr) {
+    constexpr bool kEntry = !kOne;  // (pm_bin_kernel hands E over; the one-launch kernel reads everything from P)
     // (the names the body was written with, for kW waves per strip row: they hide the namespace's)
     constexpr int kBinWaves = kW;
     constexpr int kBinThreads = 64 * kW;
@@ -114,12 +127,35 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
     };
     const ParamRegs PR = LoadParams(P);
     const uint32_t tid = threadIdx.x;
+    // The first strip row's descriptor and boxes and the colour tables: requested before anything waits for the parameter block.
+    // The boxes wait for the item scan in this thread's own words of the (still unused) counter array: a vector value that lives
+    // from the kernel's entry into the strip-row loop is spilled (the loop's preheader is where register pressure peaks).
+    uint4 srd_e = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (kEntry) {
+        srd_e = E->sr_desc[blockIdx.x];  // (the grid never exceeds the work list: pm_context.hip, EnsureArena)
+        uint2 bb_e = make_uint2(0u, 0u);
+        uint32_t it_e = 0;
+        if (!E->use_row_lists && tid < E->n_band_items) {
+            bb_e = E->band_bbox[tid];
+            it_e = E->band_item != nullptr ? E->band_item[tid] : tid;
+        }
+        // (the tables do not change from row to row: in LDS once, visible behind the first row's first barrier)
+#pragma unroll
+        for (uint32_t u = 0; u < 256u / kBinThreads; ++u)
+            L.s_lut[tid + u * kBinThreads] = E->lut_srgb2lin[tid + u * kBinThreads] | (E->lut_unorm2h[tid + u * kBinThreads] << 16);
+        L.s_ct[tid] = bb_e.x;
+        L.s_ct[kBinThreads + tid] = bb_e.y;
+        L.s_ct[2 * kBinThreads + tid] = it_e;
+    }
     // a 16-byte record of the tile arena that the tile stage reads
-#ifndef PM_EXP_BIN_WT
-#define PM_EXP_BIN_WT 0  // (developer experiment: write-through pieces in the two-launch kernel too, to price them)
-#endif
-    auto put_quad = [](uint4 *q, const uint4 v) {
-        if constexpr (kOne || PM_EXP_BIN_WT) StoreWT16(q, v);
+    // (write-through in the two-launch kernel too where the host asks for it, round 6 -- FrameParams::bin_wt, a frame whose strip rows
+    //  all fit the resident grid: what binning leaves for the tile kernel is read by other XCDs' workgroups anyway, and a line written
+    //  through is not dirty when the kernel ends -- the release at the end of a kernel writes every dirty line of the L2s back before
+    //  the next dispatch starts: 4K Tiger frame -0.5 us.  Large frames keep plain stores: config 4's 70 MB of pieces as 16-byte
+    //  write-through stores took its binning from 0.124 to 0.162 ms.)
+    const bool bin_wt = kOne || PM_PU(bin_wt) != 0u;  // (uniform)
+    auto put_quad = [&](uint4 *q, const uint4 v) {
+        if (bin_wt) StoreWT16(q, v);
         else *q = v;
     };
     const uint32_t lane = LaneId();
@@ -156,7 +192,9 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
     for (uint32_t rix = blockIdx.x, rix_next = 0; rix < PM_PU(n_sr_active); rix = rix_next) {
     if (rix != blockIdx.x) LdsBarrier();  // the previous strip row's LDS is done with
     // One 16-byte load: {strip | tile row << 16, region, end, next strip row of this group (0: none)}.
-    const uint4 srd = PM_PP(sr_desc)[rix];
+    const bool first_row = kEntry && rix == blockIdx.x;  // (uniform) what this row starts from was requested at the kernel's entry
+    uint4 srd = srd_e;
+    if (!first_row) srd = PM_PP(sr_desc)[rix];
     // In flight together with it: where the strip row's item list is (large scenes: its tile row's list), or -- the
     // band's list does not depend on the strip row -- the first 256 boxes of the list themselves.  Every dependent
     // access the item scan does not make is half a microsecond of every strip row.
@@ -173,7 +211,10 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         band_item = PM_PP(row_item) + lo;
     }
     // (band_item == nullptr: the list is the scene's item list itself, band_bbox its ShortBbox array)
-    if (tid < n_band) {
+    if (first_row && !PM_PU(use_row_lists)) {
+        bb_next = make_uint2(L.s_ct[tid], L.s_ct[kBinThreads + tid]);  // (this thread's own words)
+        it_next = L.s_ct[2 * kBinThreads + tid];
+    } else if (tid < n_band) {
         bb_next = band_bbox[tid];
         it_next = band_item != nullptr ? band_item[tid] : tid;
     }
@@ -184,11 +225,19 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
     const bool last_row = rix_next == 0xffffffffu;
     auto one_keep = [&](uint32_t n_heavy, uint32_t n_queued) -> uint32_t { return last_row ? OneLaunchKeep(n_heavy, n_queued) : 0u; };
     // the two colour tables ride along with the first bbox load (finalisation reads them from LDS)
-    uint32_t lut_word[256 / kBinThreads];
+    uint32_t lut_word[256 / kBinThreads] = {};
+    if constexpr (!kEntry) {
 #pragma unroll
-    for (uint32_t u = 0; u < 256u / kBinThreads; ++u) lut_word[u] = PM_PP(lut_srgb2lin)[tid + u * kBinThreads] | (PM_PP(lut_unorm2h)[tid + u * kBinThreads] << 16);
+        for (uint32_t u = 0; u < 256u / kBinThreads; ++u) lut_word[u] = PM_PP(lut_srgb2lin)[tid + u * kBinThreads] | (PM_PP(lut_unorm2h)[tid + u * kBinThreads] << 16);
+    }
     // (the strip row by strip | tile row of the band << 16: no division by the number of strips)
-    const uint32_t strip = __builtin_amdgcn_readfirstlane(srd.x) & 0xffffu, row_rel = __builtin_amdgcn_readfirstlane(srd.x) >> 16;
+    // Bits 8-15: the run of the strip's tiles this entry stands for (first tile | tiles - 1 << 4) -- the whole strip, or, where the
+    // host cut a heavy strip row in two (pm_context.hip, EnsureArena), one HALF of it: two workgroups then bin the row side by
+    // side, each with the candidates, chunks and segments that can matter to its own tiles.
+    const uint32_t srx = __builtin_amdgcn_readfirstlane(srd.x);
+    const uint32_t strip = srx & 0xffu, row_rel = srx >> 16;
+    const uint32_t t_beg = (srx >> 8) & 15u, t_cnt = ((srx >> 12) & 15u) + 1u;
+    const uint32_t run_mask = ((1u << t_cnt) - 1u) << t_beg;  // this entry's tiles of the strip
     const uint32_t sr = row_rel * PM_PU(strips_x) + strip;
     // this strip row's part of the tile arena (pm_device.h, Counters)
     const uint32_t shard = rix % kArenaShards;
@@ -201,7 +250,8 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
     // (wave-uniform floats: converted on the vector unit, then kept in SGPRs -- as VGPRs they are live
     //  through the whole kernel and end up spilled)
     auto uniform_f = [](int v) { return __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(static_cast<float>(v)))))); };
-    const float fsx0 = uniform_f(sx0), fsx1 = uniform_f(sx0 + static_cast<int>(kGroupW));
+    // (the x extent of this entry's run of tiles: what boxes are culled against; the reference's own predicates keep the strip's sx0)
+    const float fsx0 = uniform_f(sx0 + static_cast<int>(t_beg * kTileW)), fsx1 = uniform_f(sx0 + static_cast<int>((t_beg + t_cnt) * kTileW));
     const float fy0 = uniform_f(y0), fy1 = uniform_f(y0 + static_cast<int>(kTileH));
     const float fsy0 = uniform_f(sy0), fsy1 = uniform_f(sy0 + static_cast<int>(kGroupH));
 
@@ -267,7 +317,7 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
     };
     auto RowTailIssue = [&]() -> TailState {
         const uint32_t tiles_here = min(kStripTiles, PM_PU(tiles_x) - strip * kStripTiles);
-        const bool tile_lane = lane < tiles_here;
+        const bool tile_lane = lane < tiles_here && ((run_mask >> (Opaque(lane) & 15u)) & 1u) != 0u;
         // (the tile's index made here, from a lane number the compiler cannot see through: hoisted to the kernel's entry it
         //  is spilled, and the reload's wait also waits for every store the wave has in flight)
         const uint32_t tl = Opaque(lane) & (kStripTiles - 1u);
@@ -333,8 +383,10 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         // 25 MB of stores per 4K frame that would otherwise stall these latency-bound workgroups in bursts.
         const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + Opaque(lane);
         const uint32_t state = is_queued ? 0u : (is_solid ? L.s_solid_rgba[tl] : 0xffffffffu);
-        if (tile_lane)  // what this kernel decided per tile: 0 = queued, else the tile's colour
-            PM_PP(tile_state)[tile] = state;
+        if (tile_lane) {  // what this kernel decided per tile: 0 = queued, else the tile's colour
+            if (bin_wt) StoreWT4(PM_PP(tile_state) + tile, state);
+            else PM_PP(tile_state)[tile] = state;
+        }
         if constexpr (kOne) {  // (the row's workgroup writes the resolved tiles' pixels itself)
             if (last_row) {  // ... in its first idle moment, from here
                 if (lane < kStripTiles) R->state[tl] = tile_lane ? state : 0u;
@@ -403,7 +455,7 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
                     if (ix < cap) StoreWT16(PM_PP(fifo) + static_cast<size_t>(1u + (blockIdx.x & (kFifoShards - 1u))) * cap + ix, entry);
                 }
             } else {
-                PM_PP(queue)[cls * PM_PU(queue_cap) + q_base + (ts.packed >> 4)] = entry;
+                put_quad(PM_PP(queue) + (cls * PM_PU(queue_cap) + q_base + (ts.packed >> 4)), entry);
             }
         }
     };
@@ -421,8 +473,10 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
     // The host sized this strip row's arena region from the same bbox predicate: a region that
     // only holds the fixed header allowance means no item can land here -- nothing to scan.
     if (region_end - cursor == PM_PU(sr_empty_dwords)) n_band = 0;
+    if constexpr (!kEntry) {
 #pragma unroll
-    for (uint32_t u = 0; u < 256u / kBinThreads; ++u) L.s_lut[tid + u * kBinThreads] = lut_word[u];
+        for (uint32_t u = 0; u < 256u / kBinThreads; ++u) L.s_lut[tid + u * kBinThreads] = lut_word[u];
+    }
     for (uint32_t ib = 0;; ib += kBatch) {
         const bool more = ib < n_band;  // uniform
         const uint32_t j = ib + tid;
@@ -443,7 +497,8 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
                 const int t_lo = (bx > sx0) ? ((bx - sx0) >> 4) : 0;
                 int t_hi = (bz - sx0) >> 4;
                 if (t_hi > 15) t_hi = 15;
-                mask = ((2u << t_hi) - 1u) & ~((1u << t_lo) - 1u);
+                mask = ((2u << t_hi) - 1u) & ~((1u << t_lo) - 1u) & run_mask;
+                cand = mask != 0u;
             }
         }
         uint32_t nb = 0;
@@ -684,6 +739,12 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         //      its slot's meta word (0 = no vote) and, if voted, the segment -------------------------------
         const uint32_t q_share = ((n_slots + kBinWaves * 64u - 1u) / (kBinWaves * 64u)) * 64u;  // slots per wave, a multiple of 64 (equal shares of whole chunks: measured no better)
         const uint32_t w_lo = min(n_slots, wave * q_share), w_hi = min(n_slots, w_lo + q_share);
+        // A wave's FIRST 64 slots never leave its registers (round 6): nine strip rows in ten of a 4K Tiger frame have at most 64
+        // slots per wave, and their segments used to go to the binning arena and straight back -- two stores per lane in the vote
+        // round, and in front of the scatter a read-back that waited for those stores' acknowledgements (vector memory completes
+        // in order), a round trip through memory on every row's critical path.  Only the rounds behind the first use the arena.
+        float4 r0_seg = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t r0_mw = 0;
         {
             // The loop is software-pipelined by hand: the NEXT round's segment end points are requested
             // before this round's votes are computed and stored.  Vector memory operations complete in
@@ -722,6 +783,7 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
             fetch(w_lo + lane, vc_n, k_n, ctag_n, a_n, b_n);
             WaveSync();
             for (uint32_t f0 = w_lo; f0 < w_hi; f0 += 64u) {
+                const bool round0 = f0 == w_lo;  // (uniform) the wave's first 64 slots stay in registers: r0_seg, r0_mw
                 const uint32_t f = f0 + lane;
                 const uint32_t vc = vc_n, k = k_n, ctag_f = ctag_n;
                 float2 a = a_n, b = b_n;
@@ -815,10 +877,14 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
                             M = 0xffffu;  // a line is tested by every tile its bbox hits (:223-247)
                         }
                         M &= hm;
-                        PM_SEG(f) = seg;
+                        if (!round0) PM_SEG(f) = seg;
                         mword = M | (vc << 16) | 0x80000000u;  // bit 31: a voted segment lives here
                     }
-                    PM_META(f) = mword;
+                    if (!round0) PM_META(f) = mword;
+                }
+                if (round0) {
+                    r0_seg = seg;
+                    r0_mw = mword;
                 }
                 // relevant-segment counts per (candidate, tile).  The 4 lanes of a chunk (a quad) share one
                 // candidate: spread the 16 tile bits to 16 nibbles (64 bits), add the 4 lanes with two DPP
@@ -970,28 +1036,16 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
                 if (base_q == 0xffffffffu) L.s_alloc[1] = 1u;
             }
         }
-        // The scatter below reads this wave's slots back (meta word + segment) and stores them into the tiles' pieces.
-        // Vector memory operations complete in order: a load issued behind stores waits for their acknowledgements, and
-        // a wait for loads in front of a run of stores whose number the compiler cannot count becomes vmcnt(0) --
-        // every round of the scatter used to wait for the previous round's stores, 1-1.5 us each.  So the first
-        // kAhead rounds (nearly every wave's whole share) are requested HERE, with nothing else in flight, and waited
-        // for right behind the barrier; later chunks are loaded and waited for in front of their own stores.
+        // The scatter below stores this wave's slots (meta word + segment) into the tiles' pieces: the first round's from the
+        // registers they were voted in, later rounds' read back from the arena.  Vector memory operations complete in order: a
+        // load issued behind stores waits for their acknowledgements, and a wait for loads in front of a run of stores whose
+        // number the compiler cannot count becomes vmcnt(0) -- later chunks are loaded and waited for in front of their own stores.
         constexpr uint32_t kAhead = 1;
         uint32_t mw_a[kAhead];
         float4 seg_a[kAhead];
-#pragma unroll
-        for (uint32_t u = 0; u < kAhead; ++u) {
-            mw_a[u] = 0;
-            seg_a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const uint32_t fa = w_lo + 64u * u + lane;
-            if (fa < w_hi) {
-                mw_a[u] = PM_META(fa);  // (this wave wrote it)
-                seg_a[u] = PM_SEG(fa);
-            }
-        }
+        mw_a[0] = r0_mw;  // (the wave's first round: still in its registers)
+        seg_a[0] = r0_seg;
         LdsBarrier();  // hit bits, per-wave totals, pieces
-#pragma unroll
-        for (uint32_t u = 0; u < kAhead; ++u) PinSlot(mw_a[u], seg_a[u]);
         if (kProfile) stamp(12);
         const uint32_t base_q = L.s_alloc[0];
         const bool last_record = !more;  // uniform
@@ -1032,7 +1086,7 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
                 const uint32_t z = OpaqueZero();  // (a zero made here: as a literal it is hoisted to the kernel's entry and spilled)
                 put_quad(PM_PP(tarena) + hdr_q, make_uint4(z, z, z, z));
                 if (hdr_prev) {
-                    if constexpr (kOne) StoreWT8(reinterpret_cast<uint2 *>(PM_PP(tarena) + hdr_prev), make_uint2(hdr_q, hdr_n));
+                    if (bin_wt) StoreWT8(reinterpret_cast<uint2 *>(PM_PP(tarena) + hdr_prev), make_uint2(hdr_q, hdr_n));
                     else *reinterpret_cast<uint2 *>(PM_PP(tarena) + hdr_prev) = make_uint2(hdr_q, hdr_n);
                 }
             }
@@ -1182,9 +1236,9 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         // scatter done, 7 exit), then the tail wave's own end (14)
         stamp(7);
         if constexpr (kProfile) {
-            if (tid < 14) PM_PP(dbg_bin)[16ull * sr + tid] = L.s_stamp[tid];
+            if (tid < 14) PM_PP(dbg_bin)[16ull * rix + tid] = L.s_stamp[tid];
         }
-        if (wave == kBinWaves - 1 && lane == 0) PM_PP(dbg_bin)[16ull * sr + 14] = wall_clock64();
+        if (wave == kBinWaves - 1 && lane == 0) PM_PP(dbg_bin)[16ull * rix + 14] = wall_clock64();
     }
     }  // strip rows of this workgroup
 }

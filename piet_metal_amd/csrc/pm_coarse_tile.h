@@ -540,7 +540,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
             uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;
             const uint32_t px = StoreOrder(solid_color, P.fb_bgra);
             if (pxi + 4 <= P.width && P.fb_vec16) {
-                *reinterpret_cast<uint4 *>(dst) = make_uint4(px, px, px, px);
+                StorePixels4(dst, make_uint4(px, px, px, px));
             } else {
                 for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = px;
             }

@@ -267,6 +267,16 @@ struct pm_ctx {
     uint32_t n_sr_active = 0;
     uint32_t bin_grid = 1;          // workgroups of pm_bin_kernel (each walks a chain of strip rows)
     uint32_t bin_prio_slots = 1024; // PM_BIN_PRIO_SLOTS
+    // Heavy strip rows cut in two (round 6): binning ends with its heaviest strip rows (a 4K Tiger frame: 1 109 rows, the mean one
+    // through at 15 us, the heaviest at 24), and a row's length is dependent steps of its four waves, so the heaviest rows get EIGHT:
+    // two entries of the work list, tiles 0-7 and 8-15, a workgroup each, while the plan's rows leave workgroups of the resident
+    // grid free.  Which rows: those the previous frames of this scene and viewport found heaviest (segment slots per strip row, left
+    // in a pinned array by pm_bin_kernel; before any frame has said anything: by candidates, PM_BIN_SPLIT_CANDS).
+    int bin_wt_mode = 2;             // PM_BIN_WT: binning's output stored write-through: 0 never, 1 always, 2 frames whose strip rows all fit the resident grid
+    int bin_split_mode = 1;          // PM_BIN_SPLIT: 0 never, 1 while the resident grid has room, 2 every strip row (tests)
+    uint32_t bin_split_cands = 28;   // PM_BIN_SPLIT_CANDS: a row with at least this many candidates may be cut before any feedback
+    uint32_t bin_split_slots = 192;  // PM_BIN_SPLIT_SLOTS: ... with at least this many segment slots, once frames have reported
+    uint32_t n_sr_split = 0;         // strip rows of the plan in force that are cut in two
     uint32_t sr_empty_dwords = 0;   // size of a region no item reaches
     uint2 *d_band_bbox = nullptr;   // items that reach the band (bbox, scene index), paint order
     uint32_t *d_band_item = nullptr;
@@ -471,7 +481,9 @@ int EnsureSlotBuffers(pm_ctx *c, FrameSlot *s) {
 // costs kChunkSegs segment slots (16 B) + meta words per chunk (every chunk surviving), plus a token
 // amount that tells a strip row some item reaches from one nothing reaches.  The binning kernel
 // bump-allocates inside these private regions, so the bound must be exact or larger.
-void StripRowBounds(pm_ctx *c, std::vector<uint64_t> *need, int margin) {
+// (need_half, cnt: optional -- the same bound for the two halves of every strip row [2 i], [2 i + 1] (tiles 0-7, 8-15), and the
+//  candidates of every strip row: what EnsureArena cuts heavy strip rows in two with)
+void StripRowBounds(pm_ctx *c, std::vector<uint64_t> *need, int margin, std::vector<uint64_t> *need_half = nullptr, std::vector<uint32_t> *cnt = nullptr) {
     const uint8_t *meta = c->item_meta.data();
     uint32_t n, items_ix;
     std::memcpy(&n, meta, 4);
@@ -481,6 +493,11 @@ void StripRowBounds(pm_ctx *c, std::vector<uint64_t> *need, int margin) {
     const size_t w = static_cast<size_t>(c->strips_x) + 1;
     std::vector<uint64_t> &diff = c->stage_need_diff;
     diff.assign((static_cast<size_t>(rows) + 1) * w, 0);
+    const size_t wh = 2 * static_cast<size_t>(c->strips_x) + 1;
+    std::vector<uint64_t> diff_half;
+    std::vector<int64_t> diff_cnt;
+    if (need_half) diff_half.assign((static_cast<size_t>(rows) + 1) * wh, 0);
+    if (cnt) diff_cnt.assign((static_cast<size_t>(rows) + 1) * w, 0);
     c->plan_box.resize(4ull * n);
     c->plan_per.resize(n);
     c->plan_cands = 0;
@@ -518,6 +535,40 @@ void StripRowBounds(pm_ctx *c, std::vector<uint64_t> *need, int margin) {
         diff[a * w + static_cast<size_t>(s_hi) + 1] -= per;
         diff[b * w + static_cast<size_t>(s_lo)] -= per;
         diff[b * w + static_cast<size_t>(s_hi) + 1] += per;
+        if (cnt) {
+            diff_cnt[a * w + static_cast<size_t>(s_lo)] += 1;
+            diff_cnt[a * w + static_cast<size_t>(s_hi) + 1] -= 1;
+            diff_cnt[b * w + static_cast<size_t>(s_lo)] -= 1;
+            diff_cnt[b * w + static_cast<size_t>(s_hi) + 1] += 1;
+        }
+        if (need_half) {  // half strips: bz >= hx0 && bx < hx0 + 128
+            const size_t h_lo = bb[0] / 128, h_hi = std::min<size_t>(bb[2] / 128, 2 * static_cast<size_t>(c->strips_x) - 1);
+            diff_half[a * wh + h_lo] += per;
+            diff_half[a * wh + h_hi + 1] -= per;
+            diff_half[b * wh + h_lo] -= per;
+            diff_half[b * wh + h_hi + 1] += per;
+        }
+    }
+    if (cnt) {
+        cnt->assign(static_cast<size_t>(rows) * c->strips_x, 0);
+        for (size_t r = 0; r < rows; ++r) {
+            int64_t run = 0;
+            for (size_t sx = 0; sx < c->strips_x; ++sx) {
+                run += diff_cnt[r * w + sx];
+                (*cnt)[r * c->strips_x + sx] = static_cast<uint32_t>(run + (r ? static_cast<int64_t>((*cnt)[(r - 1) * c->strips_x + sx]) : 0));
+            }
+        }
+    }
+    if (need_half) {
+        const size_t hs = 2 * static_cast<size_t>(c->strips_x);
+        need_half->assign(static_cast<size_t>(rows) * hs, 0);
+        for (size_t r = 0; r < rows; ++r) {
+            uint64_t run = 0;
+            for (size_t hx = 0; hx < hs; ++hx) {
+                run += diff_half[r * wh + hx];
+                (*need_half)[r * hs + hx] = run + (r ? (*need_half)[(r - 1) * hs + hx] : 0);
+            }
+        }
     }
     for (size_t r = 0; r < rows; ++r) {  // prefix sums along the strips, then down the rows (mod 2^64: the totals are exact)
         uint64_t run = 0;
@@ -566,8 +617,10 @@ int EnsureArena(pm_ctx *c) {
     }
     // (host work first: the scene-index kernel of a scene replacement is still running on the device)
     const int margin = c->replan_wide ? static_cast<int>(pm::kTileW) : 0;
-    std::vector<uint64_t> need;
-    StripRowBounds(c, &need, margin);
+    std::vector<uint64_t> need, need_half;
+    std::vector<uint32_t> row_cands;
+    const bool may_split = c->bin_split_mode != 0 && c->one_launch_mode == 0;
+    StripRowBounds(c, &need, margin, may_split ? &need_half : nullptr, may_split ? &row_cands : nullptr);
     // (host work before any upload: the band's item list, the arena regions)
     c->sr_empty_dwords = 0;  // (a strip row no item's bbox reaches has nothing reserved)
     // the items whose bbox reaches the band (rows: bw >= y0 && by < y1, PietRender.metal:198/:214), paint order
@@ -600,22 +653,55 @@ int EnsureArena(pm_ctx *c) {
     // once, here.  (An empty list still launches one workgroup: it resets the frame counters.)
     std::vector<uint4> &desc = c->stage_desc;  // (sources of asynchronous uploads live in the context)
     desc.clear();
+    uint32_t per_cu = c->bin_wg_per_cu;
+    if (per_cu == 0xffu) per_cu = 5u;
+    // Which strip rows are cut in two (bin_split_mode): the heaviest ones, as many as the resident grid has workgroups to spare.
+    std::vector<uint8_t> cut(need.size(), 0);
+    c->n_sr_split = 0;
+    if (may_split) {
+        size_t n_rows = 0;
+        for (size_t i = 0; i < need.size(); ++i) n_rows += ((need[i] + 3u) & ~3ull) != c->sr_empty_dwords ? 1u : 0u;
+        const size_t resident = static_cast<size_t>(c->n_cus) * (per_cu ? per_cu : 5u);
+        const size_t room = c->bin_split_mode == 2 ? need.size() : (resident > n_rows ? resident - n_rows : 0u);
+        std::vector<std::pair<uint32_t, uint32_t>> heavy;  // {weight, strip row}
+        for (size_t i = 0; i < need.size() && room != 0; ++i) {
+            if (((need[i] + 3u) & ~3ull) == c->sr_empty_dwords) continue;
+            if (c->bin_split_mode == 2 || row_cands[i] >= c->bin_split_cands) heavy.emplace_back(row_cands[i], static_cast<uint32_t>(i));
+        }
+        if (heavy.size() > room) {
+            std::partial_sort(heavy.begin(), heavy.begin() + static_cast<ptrdiff_t>(room), heavy.end(),
+                              [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+            heavy.resize(room);
+        }
+        for (const auto &h : heavy) cut[h.second] = 1;
+    }
     uint64_t total = pm::kArenaBase;  // offset 0 means "no record"
-    for (size_t i = 0; i < need.size(); ++i) {
-        const uint64_t sz = (need[i] + 3u) & ~3ull;
-        if (sz == c->sr_empty_dwords) continue;
+    constexpr uint32_t kWholeStrip = 15u << 12, kLeftHalf = 7u << 12, kRightHalf = (7u << 12) | (8u << 8);  // tiles - 1 << 12 | first tile << 8
+    auto push = [&](size_t i, uint32_t run, uint64_t need_dwords) -> bool {
+        const uint64_t sz = (need_dwords + 3u) & ~3ull;
+        if (sz == c->sr_empty_dwords) return true;
         const uint64_t begin = total;
         total += sz;
-        if (total > 0xfffffff0ull) {
+        if (total > 0xfffffff0ull) return false;
+        desc.push_back(make_uint4(static_cast<uint32_t>(i % c->strips_x) | run | (static_cast<uint32_t>(i / c->strips_x) << 16), static_cast<uint32_t>(begin),
+                                  static_cast<uint32_t>(total), 0u));
+        return true;
+    };
+    for (size_t i = 0; i < need.size(); ++i) {
+        bool ok = true;
+        if (cut[i]) {
+            const size_t h = (i / c->strips_x) * 2 * c->strips_x + 2 * (i % c->strips_x);
+            ok = push(i, kLeftHalf, need_half[h]) && push(i, kRightHalf, need_half[h + 1]);
+            c->n_sr_split += 1;
+        } else {
+            ok = push(i, kWholeStrip, need[i]);
+        }
+        if (!ok) {
             SetError("scene x viewport needs a binning arena beyond 16 GiB");
             return PM_ERR_CAPACITY;
         }
-        desc.push_back(make_uint4(static_cast<uint32_t>(i % c->strips_x) | (static_cast<uint32_t>(i / c->strips_x) << 16), static_cast<uint32_t>(begin),
-                                  static_cast<uint32_t>(total), 0u));
     }
-    if (desc.empty()) desc.push_back(make_uint4(0u, pm::kArenaBase, pm::kArenaBase, 0u));
-    uint32_t per_cu = c->bin_wg_per_cu;
-    if (per_cu == 0xffu) per_cu = 5u;
+    if (desc.empty()) desc.push_back(make_uint4(kWholeStrip, pm::kArenaBase, pm::kArenaBase, 0u));
     // (exact for a context's first scene; a quarter of headroom when it has to GROW: an animation's
     //  demand creeps from frame to frame, and re-allocating four 100 MB arenas costs milliseconds)
     const uint64_t alloc_dwords = total <= c->arena_cap ? c->arena_cap : (c->arena_cap == 0 ? total : std::min<uint64_t>(0xfffffff0ull, total + total / 4));
@@ -718,7 +804,7 @@ int EnsureArena(pm_ctx *c) {
         size_t k = 0;
         for (size_t i = 0; i < need.size() && c->one_grid_rows != 0; ++i) {
             const uint32_t key = static_cast<uint32_t>(i % c->strips_x) | (static_cast<uint32_t>(i / c->strips_x) << 16);
-            if (k < desc.size() && desc[k].x == key) {  // (the empty list's one workgroup "has" strip row 0)
+            if (k < desc.size() && (desc[k].x & 0xffff00ffu) == key) {  // (the empty list's one workgroup "has" strip row 0; one-launch plans cut no strip row)
                 ++k;
                 continue;
             }
@@ -883,6 +969,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->band_item = c->band_identity ? nullptr : c->d_band_item;
     p->n_band_items = c->n_band_items;
     p->bin_waves = c->bin_waves;
+    p->bin_wt = c->bin_wt_mode == 1 || (c->bin_wt_mode == 2 && c->n_sr_active <= c->bin_grid) ? 1u : 0u;
     p->split_mode = c->split_mode;
     p->dense_factor = c->dense_factor;
     {
@@ -1466,6 +1553,10 @@ pm_ctx *pm_create(int device, int *err) {
     c->bin_waves_env = static_cast<uint32_t>(EnvInt("PM_BIN_WAVES", 0, 0, 4));
     c->bin_waves_inflight = c->bin_waves_env ? c->bin_waves_env : static_cast<uint32_t>(EnvInt("PM_BIN_WAVES_INFLIGHT", 1, 1, 4));
     c->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 320, 0, 1 << 30));
+    c->bin_split_mode = EnvInt("PM_BIN_SPLIT", 1, 0, 2);
+    c->bin_wt_mode = EnvInt("PM_BIN_WT", 2, 0, 2);
+    c->bin_split_cands = static_cast<uint32_t>(EnvInt("PM_BIN_SPLIT_CANDS", 28, 1, 1 << 30));
+    c->bin_split_slots = static_cast<uint32_t>(EnvInt("PM_BIN_SPLIT_SLOTS", 192, 1, 1 << 30));
     c->one_launch_mode = EnvInt("PM_ONE_LAUNCH", 0, 0, 1);
     c->one_launch_split = EnvInt("PM_ONE_LAUNCH_SPLIT", 0, 0, 1) != 0;
     c->frame_spin_ticks = static_cast<uint32_t>(EnvInt("PM_ONE_LAUNCH_SPIN_US", 2000, 1, 1000000)) * 100u;
@@ -2381,7 +2472,9 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
     PM_TRY(hipSetDevice(c->device));
     int r = SyncAll(c);
     if (r != PM_OK) return r;
-    const size_t rows = static_cast<size_t>(BandRows(c)) * c->strips_x;
+    r = EnsureArena(c);  // (the work list: one row of the timeline per entry, in the list's order)
+    if (r != PM_OK) return r;
+    const size_t rows = std::max<size_t>(static_cast<size_t>(BandRows(c)) * c->strips_x, c->n_sr_active);
     if (n_rows) *n_rows = rows;
     if (rows > max_rows) return PM_ERR_CAPACITY;
     unsigned long long *d = nullptr;

@@ -31,7 +31,7 @@ __device__ __forceinline__ void ClearStripRow(const FrameParams &P, uint32_t str
         if (py < P.height && px < P.width) {
             uint8_t *dst = P.fb + static_cast<size_t>(row_rel * kTileH + r) * P.fb_stride + static_cast<size_t>(px) * 4;
             if (px + 4 <= P.width && P.fb_vec16) {
-                *reinterpret_cast<uint4 *>(dst) = make_uint4(col, col, col, col);
+                StorePixels4(dst, make_uint4(col, col, col, col));
             } else {
                 for (uint32_t k = 0; k < 4 && px + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = col;
             }
@@ -800,7 +800,7 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &
             next_card();
             if (pyi < P.height && pxi < P.width) {
                 uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + (pix >> 4)) * P.fb_stride + static_cast<size_t>(pxi) * 4;
-                *reinterpret_cast<uint32_t *>(dst) = (bgra ? b8 : r8) | (g8 << 8) | ((bgra ? r8 : b8) << 16) | 0xff000000u;
+                StorePixel(dst, (bgra ? b8 : r8) | (g8 << 8) | ((bgra ? r8 : b8) << 16) | 0xff000000u);
             }
         }
         }
@@ -859,7 +859,7 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &
                 out.z = pack(lv[6], lv[7], lv[8]);
                 out.w = pack(lv[9], lv[10], lv[11]);
                 if (pxi + 4 <= P.width && P.fb_vec16) {
-                    *reinterpret_cast<uint4 *>(dst) = out;
+                    StorePixels4(dst, out);
                 } else {
                     const uint32_t o[4] = {out.x, out.y, out.z, out.w};
                     for (uint32_t k = 0; k < 4 && pxi + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = o[k];

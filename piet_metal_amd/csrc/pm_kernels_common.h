@@ -169,6 +169,27 @@ __device__ __forceinline__ uint32_t StoreOrder(uint32_t rgba, uint32_t bgra) {
     return bgra ? ((rgba & 0xff00ff00u) | ((rgba & 0xffu) << 16) | ((rgba >> 16) & 0xffu)) : rgba;
 }
 
+// A framebuffer store.  Pixels are written once and never read again by the frame: stored WRITE-THROUGH (sc1) they leave the XCD's
+// L2 as they are written instead of sitting there dirty until the kernel ends -- the release at the end of a kernel writes every dirty
+// line back before the next dispatch (or the frame's end) is signalled, and 33 MB of pixels are most of what a frame leaves dirty.
+#ifndef PM_FB_WT
+#define PM_FB_WT 1
+#endif
+__device__ __forceinline__ void StorePixels4(uint8_t *dst, uint4 v) {
+#if PM_FB_WT
+    StoreWT16(reinterpret_cast<uint4 *>(dst), v);
+#else
+    *reinterpret_cast<uint4 *>(dst) = v;
+#endif
+}
+__device__ __forceinline__ void StorePixel(uint8_t *dst, uint32_t v) {
+#if PM_FB_WT
+    StoreWT4(reinterpret_cast<uint32_t *>(dst), v);
+#else
+    *reinterpret_cast<uint32_t *>(dst) = v;
+#endif
+}
+
 __device__ __forceinline__ uint32_t LoadU32(const uint8_t *p) { return *reinterpret_cast<const uint32_t *>(p); }
 __device__ __forceinline__ float2 LoadF2(const uint8_t *p) { return *reinterpret_cast<const float2 *>(p); }
 

@@ -58,3 +58,15 @@ for nm, a, b in [("headers done -> round start", 2, 8), ("chunk tests + scan (ro
 el = t[big, 6]
 d = (t[big, 3] - t[big, 10]) * us
 print(f"   {big.sum()} WGs, elements mean {el.mean():.0f}; expansion per 256-element step: {(d / np.ceil(el / 256)).mean():.2f} us")
+# finer picture of the rows that set the span: durations in 1 us bins, end times, and what the longest rows have in common
+hist, edges = np.histogram(dur, bins=np.arange(0, 31, 1.0))
+print("WG duration histogram (1 us bins):", " ".join(f"{int(e)}:{h}" for e, h in zip(edges[:-1], hist) if h))
+endt = (end - t0) * us
+hist, edges = np.histogram(endt, bins=np.arange(0, 41, 1.0))
+print("WG end-time histogram (1 us bins):", " ".join(f"{int(e)}:{h}" for e, h in zip(edges[:-1], hist) if h))
+for q in (50, 75, 90, 95, 98, 99, 100):
+    print(f"   p{q}: dur {np.percentile(dur, q):.1f} end {np.percentile(endt, q):.1f}")
+sl = t[:, 6]
+for lo, hi in [(0, 64), (64, 128), (128, 256), (256, 512), (512, 1024), (1024, 2048), (2048, 1 << 30)]:
+    m2 = (sl >= lo) & (sl < hi)
+    if m2.any(): print(f"  rows with {lo}-{hi} slots: {m2.sum()}, dur mean {dur[m2].mean():.2f} max {dur[m2].max():.2f}; stream {((t[m2,3]-t[m2,2])*us).mean():.2f} finalise {((t[m2,4]-t[m2,3])*us).mean():.2f}")
