@@ -116,7 +116,12 @@ __global__ __launch_bounds__(kBinThreads) void pm_rowcull_kernel(FrameParams P) 
 template <bool kProfile, int kW>
 __global__ __launch_bounds__(64 * kW, 5) void pm_bin_kernel(const uint4 *e_sr_desc, const uint2 *e_band_bbox, const uint32_t *e_band_item,
                                                              const uint32_t *e_lut_srgb2lin, const uint32_t *e_lut_unorm2h, uint32_t e_n_band_items,
-                                                             uint32_t e_use_row_lists, FrameParams P) {
+                                                             uint32_t e_use_row_lists, uint32_t e_bin_grid, FrameParams P) {
+    // (blocks beyond the strip rows' grid: the pixels of the strip rows no item reaches -- FrameParams::clear_in_bin)
+    if (blockIdx.x >= e_bin_grid) {
+        ClearStripRow<kW>(P, P.idle_sr[blockIdx.x - e_bin_grid]);
+        return;
+    }
     __shared__ BinLds<kW> L;
     const BinEntry E{e_sr_desc, e_band_bbox, e_band_item, e_lut_srgb2lin, e_lut_unorm2h, e_n_band_items, e_use_row_lists};
     BinStripRows<kProfile, kW, false>(P, L, nullptr, &E);
@@ -133,9 +138,9 @@ void LaunchIndex(const uint8_t *scene, uint32_t n_items, uint32_t items_ix, cons
 }
 
 void LaunchBin(const FrameParams &p, hipStream_t stream, hipEvent_t t0, hipEvent_t t1) {
-    const uint32_t n_striprows = p.bin_grid;
+    const uint32_t n_striprows = p.bin_grid + (p.clear_in_bin ? p.n_idle_sr : 0u);
     if (p.use_row_lists) hipLaunchKernelGGL(pm_rowcull_kernel, dim3((p.row1 - p.row0) * p.row_parts), dim3(kBinThreads), 0, stream, p);
-#define PM_BIN_ARGS p.sr_desc, p.band_bbox, p.band_item, p.lut_srgb2lin, p.lut_unorm2h, p.n_band_items, p.use_row_lists, p
+#define PM_BIN_ARGS p.sr_desc, p.band_bbox, p.band_item, p.lut_srgb2lin, p.lut_unorm2h, p.n_band_items, p.use_row_lists, p.bin_grid, p
     if (p.bin_waves == 1) {
         if (p.dbg_bin)
             PM_LAUNCH((pm_bin_kernel<true, 1>), dim3(n_striprows), dim3(64), stream, t0, t1, PM_BIN_ARGS);

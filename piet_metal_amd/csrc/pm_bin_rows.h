@@ -146,6 +146,7 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         L.s_ct[tid] = bb_e.x;
         L.s_ct[kBinThreads + tid] = bb_e.y;
         L.s_ct[2 * kBinThreads + tid] = it_e;
+        srd_e = Scalar4(srd_e);  // (uniform: in SGPRs -- four VGPRs that live into the loop are spilled)
     }
     // a 16-byte record of the tile arena that the tile stage reads
     // (write-through in the two-launch kernel too where the host asks for it, round 6 -- FrameParams::bin_wt, a frame whose strip rows
@@ -383,6 +384,11 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         // 25 MB of stores per 4K frame that would otherwise stall these latency-bound workgroups in bursts.
         const uint32_t tile = row_rel * PM_PU(tiles_x) + strip * kStripTiles + Opaque(lane);
         const uint32_t state = is_queued ? 0u : (is_solid ? L.s_solid_rgba[tl] : 0xffffffffu);
+        // (clear_in_bin: the workgroup writes the resolved tiles' pixels itself when the row is through -- what it decided per tile
+        //  of ITS run of the strip waits in the row's solid-colour words, which nothing reads any more)
+        if constexpr (!kOne) {
+            if (lane < kStripTiles) L.s_solid_rgba[tl] = tile_lane ? state : 0u;
+        }
         if (tile_lane) {  // what this kernel decided per tile: 0 = queued, else the tile's colour
             if (bin_wt) StoreWT4(PM_PP(tile_state) + tile, state);
             else PM_PP(tile_state)[tile] = state;
@@ -1228,6 +1234,34 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         if constexpr (kOne) DrainStores();  // (pieces of the row's records, in place before its tiles are handed over)
         LdsBarrier();  // L.s_est, s_last_*, s_head_* of the last record are in
         if (wave == kBinWaves - 1) RowTailFinish(RowTailIssue());
+    }
+    // The pixels of the tiles this strip row resolved (background, or one opaque colour): written here, at the row's very end, when
+    // the binning launch does the clearing (FrameParams::clear_in_bin) -- a kilobyte per tile of pure stores from a workgroup that
+    // has nothing left to do, on a chip whose store path binning leaves idle; the tile kernel's launch then starts without 2 025
+    // clearing workgroups beside its first tiles.  (lane -> 4 pixels of tile lane / 4; pixel row it * kW + wave)
+    if constexpr (!kOne) {
+        if (PM_PU(clear_in_bin)) {  // uniform
+            LdsBarrier();  // the row's tail (RowTailIssue, the tail wave) left the states in L.s_solid_rgba
+            const uint32_t ol = Opaque(lane);
+            const uint32_t st = L.s_solid_rgba[ol >> 2];
+            const uint32_t px = strip * kGroupW + ol * 4u;
+            if (st != 0u && px < PM_PU(width)) {
+                const uint32_t col = StoreOrder(st, PM_PU(fb_bgra));
+                const bool vec = px + 4u <= PM_PU(width) && PM_PU(fb_vec16) != 0u;
+                const uint32_t rows_here = min(kTileH, PM_PU(height) - min(PM_PU(height), ty * kTileH));
+                uint8_t *const base = PM_PP(fb) + static_cast<size_t>(row_rel * kTileH) * PM_PU(fb_stride) + static_cast<size_t>(px) * 4;
+#pragma unroll
+                for (uint32_t it = 0; it < kTileH / static_cast<uint32_t>(kW); ++it) {
+                    const uint32_t rr = it * static_cast<uint32_t>(kW) + wave;
+                    if (rr < rows_here) {
+                        uint8_t *dst = base + static_cast<size_t>(rr) * PM_PU(fb_stride);
+                        if (vec) StorePixels4(dst, make_uint4(col, col, col, col));
+                        else
+                            for (uint32_t k = 0; k < 4u && px + k < PM_PU(width); ++k) reinterpret_cast<uint32_t *>(dst)[k] = col;
+                    }
+                }
+            }
+        }
     }
     (void)prof_chunks;
     if (kProfile) {

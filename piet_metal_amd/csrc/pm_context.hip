@@ -689,8 +689,9 @@ int EnsureArena(pm_ctx *c) {
     };
     for (size_t i = 0; i < need.size(); ++i) {
         bool ok = true;
-        if (cut[i]) {
-            const size_t h = (i / c->strips_x) * 2 * c->strips_x + 2 * (i % c->strips_x);
+        const size_t h = (i / c->strips_x) * 2 * c->strips_x + 2 * (i % c->strips_x);
+        // (a half no item reaches gets no entry -- and nobody would write its pixels: such a row stays whole)
+        if (cut[i] && ((need_half[h] + 3u) & ~3ull) != c->sr_empty_dwords && ((need_half[h + 1] + 3u) & ~3ull) != c->sr_empty_dwords) {
             ok = push(i, kLeftHalf, need_half[h]) && push(i, kRightHalf, need_half[h + 1]);
             c->n_sr_split += 1;
         } else {
@@ -798,14 +799,14 @@ int EnsureArena(pm_ctx *c) {
         PM_TRY(hipMemcpyAsync(c->d_sr_next_one, nx.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     }
     {
-        // the strip rows without a workgroup: a one-launch frame writes their (background) pixels from this list
+        // the strip rows without a workgroup: the binning launch (clear_in_bin) or a one-launch frame writes their (background) pixels from this list
         std::vector<uint32_t> &idle = c->stage_idle;
         idle.clear();
         size_t k = 0;
-        for (size_t i = 0; i < need.size() && c->one_grid_rows != 0; ++i) {
+        for (size_t i = 0; i < need.size() && (c->one_grid_rows != 0 || c->fold_clear_mode >= 3); ++i) {
             const uint32_t key = static_cast<uint32_t>(i % c->strips_x) | (static_cast<uint32_t>(i / c->strips_x) << 16);
-            if (k < desc.size() && (desc[k].x & 0xffff00ffu) == key) {  // (the empty list's one workgroup "has" strip row 0; one-launch plans cut no strip row)
-                ++k;
+            if (k < desc.size() && (desc[k].x & 0xffff00ffu) == key) {  // (the empty list's one workgroup "has" strip row 0)
+                while (k < desc.size() && (desc[k].x & 0xffff00ffu) == key) ++k;  // (a strip row cut in two: both entries)
                 continue;
             }
             idle.push_back(static_cast<uint32_t>(i));
@@ -969,6 +970,10 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->band_item = c->band_identity ? nullptr : c->d_band_item;
     p->n_band_items = c->n_band_items;
     p->bin_waves = c->bin_waves;
+    // (PM_FOLD_CLEAR=3: a frame whose strip rows are chained -- config 5: lone frame 0.482 -> 0.456 ms -- and, Enqueue, any frame behind
+    //  running frames: 4K Tiger sustained +1.5 %.  A small frame alone keeps the fold into the tile kernel's launch: with the
+    //  clearing its binning kernel ends a microsecond later, and that is on the frame's critical path.  PM_FOLD_CLEAR=4: always.)
+    p->clear_in_bin = c->fold_clear_mode == 4 || (c->fold_clear_mode == 3 && c->n_sr_active > c->bin_grid) ? 1u : 0u;
     p->bin_wt = c->bin_wt_mode == 1 || (c->bin_wt_mode == 2 && c->n_sr_active <= c->bin_grid) ? 1u : 0u;
     p->split_mode = c->split_mode;
     p->dense_factor = c->dense_factor;
@@ -1193,9 +1198,13 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     // queueing behind the persistent tile workgroups (sustained +3 %).
     // (Small frames keep the fold: at 1080p a pipelined frame is 17 us, about what submitting two launches
     //  costs the host, and a third one took the sustained rate from 122 k to 100 k Mpix/s.)
-    const bool fold = c->fold_clear_mode == 1 || (c->fold_clear_mode == 2 && (!p.handout_static || BandTiles(c) < 16384u));
+    // (round 6, PM_FOLD_CLEAR=3, the default: neither -- the binning launch writes them, every strip row's workgroup its own at the
+    //  row's end and extra workgroups those of the strip rows no item reaches: stores under a kernel of dependent chains, and the
+    //  tile kernel's first tiles no longer share the chip with 2 025 clearing workgroups)
+    if (c->fold_clear_mode == 3 && p.handout_static) p.clear_in_bin = 1u;
+    const bool fold = p.clear_in_bin == 0u && (c->fold_clear_mode == 1 || (c->fold_clear_mode >= 2 && (!p.handout_static || BandTiles(c) < 16384u)));
     pm::LaunchBin(p, q, t[0], t[1]);
-    if (!fold) pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // (needs tile_state)
+    if (!fold && p.clear_in_bin == 0u) pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // (needs tile_state)
     if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, q, t[4], t[5]);
     pm::LaunchFine(p, fold ? n_striprows : 0u, c->fused, q, t[6], t[7]);
     PM_TRY(hipGetLastError());
@@ -1543,7 +1552,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->heavy_stream = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM", 72, 1, 1 << 20));
     c->heavy_stream_lone = static_cast<uint32_t>(EnvInt("PM_HEAVY_STREAM_LONE", std::min<int>(40, static_cast<int>(c->heavy_stream)), 1, 1 << 20));
     c->vheavy_stream = static_cast<uint32_t>(EnvInt("PM_VHEAVY_STREAM", 112, 1, 1 << 20));
-    c->fold_clear_mode = EnvInt("PM_FOLD_CLEAR", 2, 0, 2);
+    c->fold_clear_mode = EnvInt("PM_FOLD_CLEAR", 3, 0, 4);
     c->fold_clear = c->fold_clear_mode != 0;
     c->fused = EnvInt("PM_FUSED", 1, 0, 1) != 0;
     c->handout = EnvInt("PM_HANDOUT", 0, 0, 2);
@@ -2016,8 +2025,8 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             PM_TRY(ResetTileState(c, s, c->stream));
             pm::LaunchBin(p, c->stream, c->ev[0], c->ev[1]);
             if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream, c->ev[2], c->ev[3]);
-            pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->fused, c->stream, c->ev[4], c->ev[5]);
-            if (!c->fold_clear) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream, c->ev[6], c->ev[7]);
+            pm::LaunchFine(p, c->fold_clear && !p.clear_in_bin ? BandRows(c) * c->strips_x : 0u, c->fused, c->stream, c->ev[4], c->ev[5]);
+            if (!c->fold_clear && !p.clear_in_bin) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream, c->ev[6], c->ev[7]);
             PM_TRY(hipStreamSynchronize(c->stream));
             Submitted(c, si, p, c->stream);
             s->in_flight = false;  // (waited for just above: the next frame is alone too, and is launched as such)
@@ -2025,7 +2034,7 @@ int pm_time_frames(pm_ctx *c, int iters, float *total_ms, float *bin_ms, float *
             PM_TRY(hipEventElapsedTime(&t1, c->ev[0], c->ev[1]));
             if (!c->fused) PM_TRY(hipEventElapsedTime(&t2, c->ev[2], c->ev[3]));
             PM_TRY(hipEventElapsedTime(&t3, c->ev[4], c->ev[5]));
-            if (!c->fold_clear) PM_TRY(hipEventElapsedTime(&t4, c->ev[6], c->ev[7]));
+            if (!c->fold_clear && !p.clear_in_bin) PM_TRY(hipEventElapsedTime(&t4, c->ev[6], c->ev[7]));
             a1 += t1;
             a2 += t2;
             a3 += t3;
@@ -2058,7 +2067,7 @@ int pm_time_frames_pipelined(pm_ctx *c, int iters, float *total_ms, float *bin_m
     // the tile kernel's for small ones (round-3 advisor finding: the batch used to be timed unfolded at every size)
     const int fold_mode = c->fold_clear_mode;
     if (fold_mode == 2) c->fold_clear_mode = BandTiles(c) < 16384u ? 1 : 0;
-    const bool folded = c->fold_clear_mode == 1;
+    const bool folded = c->fold_clear_mode == 1 || c->fold_clear_mode >= 3;  // (no clearing launch of its own: folded into the tile kernel's, or into binning's)
     for (int i = 0; i < iters && r == PM_OK; ++i) r = Enqueue(c, nullptr, c->fb_stride, nullptr, &tev[static_cast<size_t>(i) * 8]);
     c->fold_clear_mode = fold_mode;
     if (r == PM_OK) {
@@ -2488,9 +2497,9 @@ int pm_debug_time_bins(pm_ctx *c, uint64_t *out, size_t max_rows, size_t *n_rows
         p.dbg_bin = d;
         hipError_t e = ResetTileState(c, s, c->stream);
         pm::LaunchBin(p, c->stream);
-        if (!c->fold_clear) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
+        if (!c->fold_clear && !p.clear_in_bin) pm::LaunchClear(p, BandRows(c) * c->strips_x, c->stream);
         if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, c->stream);
-        pm::LaunchFine(p, c->fold_clear ? BandRows(c) * c->strips_x : 0u, c->fused, c->stream);
+        pm::LaunchFine(p, c->fold_clear && !p.clear_in_bin ? BandRows(c) * c->strips_x : 0u, c->fused, c->stream);
         p.dbg_bin = nullptr;
         Submitted(c, si, p, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

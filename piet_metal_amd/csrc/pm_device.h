@@ -180,6 +180,7 @@ struct FrameParams {
     uint32_t use_row_lists;
     const uint32_t *row_base;      // [band rows x row_parts + 1] list offsets (host-computed sizes): where part p of tile row r writes
     uint32_t bin_no_chains;        // this launch has a workgroup (wave) for EVERY strip row: the chains linked for the plan's own grid are not walked
+    uint32_t clear_in_bin;         // the binning launch also writes the pixels of the tiles it resolves: every strip row's workgroup its own, extra workgroups (blocks >= bin_grid) those of the strip rows no item reaches (idle_sr)
     uint32_t bin_wt;               // binning stores what it leaves for the tile kernel write-through (a small frame: nothing dirty when the kernel ends)
     uint32_t row_parts;            // workgroups of pm_rowcull_kernel per tile row (each scans row_part_items of the band's items)
     uint32_t row_part_items;       // (multiples of kRowCullStep, unless a test says otherwise)

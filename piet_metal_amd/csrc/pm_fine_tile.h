@@ -7,39 +7,7 @@
 
 namespace pm {
 
-// K1b: pixels of the tiles binning resolved (background or one opaque colour) -- the composite
-// of PietRender.metal:34-44 for tiles that never reach the tile kernels.  Pure store bandwidth;
-// runs next to pm_coarse_kernel / pm_fine_kernel, which write the other tiles.
-// =====================================================================================
-__device__ __forceinline__ void ClearStripRow(const FrameParams &P, uint32_t striprow) {
-    const uint32_t lane = LaneId(), wave = WaveId();
-    const uint32_t strip = striprow % P.strips_x;
-    const uint32_t row_rel = striprow / P.strips_x;
-    const uint32_t t = lane >> 2;  // tile of this lane's 4 pixels
-    const uint32_t tx = strip * kStripTiles + t;
-    if (tx >= P.tiles_x) return;
-    const uint32_t state = P.tile_state[row_rel * P.tiles_x + tx];
-    if (state == 0) return;  // queued: the tile kernels write it
-    const uint32_t col = StoreOrder(state, P.fb_bgra);
-    const uint32_t px = strip * kGroupW + lane * 4u;
-    const uint32_t y0 = (P.row0 + row_rel) * kTileH;
-    // 16 pixel rows x 1024 B per strip row: thread -> (row = it*4 + wave, 16 B = 4 px at lane*4)
-#pragma unroll
-    for (uint32_t it = 0; it < kTileH / kBinWaves; ++it) {
-        const uint32_t r = it * kBinWaves + wave;
-        const uint32_t py = y0 + r;
-        if (py < P.height && px < P.width) {
-            uint8_t *dst = P.fb + static_cast<size_t>(row_rel * kTileH + r) * P.fb_stride + static_cast<size_t>(px) * 4;
-            if (px + 4 <= P.width && P.fb_vec16) {
-                StorePixels4(dst, make_uint4(col, col, col, col));
-            } else {
-                for (uint32_t k = 0; k < 4 && px + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = col;
-            }
-        }
-    }
-}
-
-
+// (K1b, ClearStripRow -- the pixels of the tiles binning resolved: pm_kernels_common.h; the binning launch calls it too)
 
 // =====================================================================================
 namespace {

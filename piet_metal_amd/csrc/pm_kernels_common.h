@@ -193,6 +193,40 @@ __device__ __forceinline__ void StorePixel(uint8_t *dst, uint32_t v) {
 __device__ __forceinline__ uint32_t LoadU32(const uint8_t *p) { return *reinterpret_cast<const uint32_t *>(p); }
 __device__ __forceinline__ float2 LoadF2(const uint8_t *p) { return *reinterpret_cast<const float2 *>(p); }
 
+// K1b: pixels of the tiles binning resolved (background or one opaque colour) -- the composite of PietRender.metal:34-44 for tiles
+// that never reach the tile kernels.  Pure store bandwidth: a launch of its own (pm_clear_kernel), extra workgroups of the tile
+// kernel's launch, or -- round 6, the default -- of the BINNING launch, for the strip rows no item reaches (the others' pixels are
+// written by their own binning workgroups): binning is a kernel of dependent chains that leaves the store path idle.
+// (kW: waves of the calling block -- four, or one for the one-wave blocks of pm_bin_kernel<.., 1>)
+template <int kW = kBinWaves>
+__device__ __forceinline__ void ClearStripRow(const FrameParams &P, uint32_t striprow) {
+    const uint32_t lane = LaneId(), wave = kW == 1 ? 0u : WaveId();
+    const uint32_t strip = striprow % P.strips_x;
+    const uint32_t row_rel = striprow / P.strips_x;
+    const uint32_t t = lane >> 2;  // tile of this lane's 4 pixels
+    const uint32_t tx = strip * kStripTiles + t;
+    if (tx >= P.tiles_x) return;
+    const uint32_t state = P.tile_state[row_rel * P.tiles_x + tx];
+    if (state == 0) return;  // queued: the tile kernels write it
+    const uint32_t col = StoreOrder(state, P.fb_bgra);
+    const uint32_t px = strip * kGroupW + lane * 4u;
+    const uint32_t y0 = (P.row0 + row_rel) * kTileH;
+    // 16 pixel rows x 1024 B per strip row: thread -> (row = it * kW + wave, 16 B = 4 px at lane*4)
+#pragma unroll
+    for (uint32_t it = 0; it < kTileH / kW; ++it) {
+        const uint32_t r = it * kW + wave;
+        const uint32_t py = y0 + r;
+        if (py < P.height && px < P.width) {
+            uint8_t *dst = P.fb + static_cast<size_t>(row_rel * kTileH + r) * P.fb_stride + static_cast<size_t>(px) * 4;
+            if (px + 4 <= P.width && P.fb_vec16) {
+                StorePixels4(dst, make_uint4(col, col, col, col));
+            } else {
+                for (uint32_t k = 0; k < 4 && px + k < P.width; ++k) reinterpret_cast<uint32_t *>(dst)[k] = col;
+            }
+        }
+    }
+}
+
 // Segments of an item as the kernels count them.
 __device__ __forceinline__ uint32_t FillSegs(uint32_t npt) { return npt; }                      // implicitly closed (:262)
 __device__ __forceinline__ uint32_t PolySegs(uint32_t npt) { return npt >= 2 ? npt - 1 : 0; }  // open (:369)
