@@ -268,6 +268,12 @@ int pm_tile_kernel_info(pm_ctx *c, uint32_t *dense_frames);
  * rows for its own, smaller grid of workgroups (1 280 < strip rows <= 4 096 light ones). */
 int pm_binning_info(pm_ctx *c, uint32_t out[3]);
 
+/* The binning plan in force (the host side of tileKernel's dispatch geometry, PietRenderer.m:63-77): out[0] entries of the work list
+ * (strip rows some item reaches; a strip row cut in two counts twice), out[1] strip rows cut in two -- the heaviest rows, binned by two
+ * workgroups side by side (tiles 0-7 and 8-15) while the resident grid has workgroups to spare --, out[2] plans remade since pm_create
+ * from what the frames' binning kernels reported (segment slots per strip row), out[3] 1 if the plan in force was made from such a report. */
+int pm_binning_plan_info(pm_ctx *c, uint32_t out[4]);
+
 /* One launch per frame (pm_frame_kernel: the two dispatches of PietRenderer.m:69-88 as roles of one resident
  * grid).  *frames = frames submitted that way since pm_create; *applies = 1 if a frame of the resident scene
  * and viewport, alone on the device, would be (0: two launches -- PM_ONE_LAUNCH=0, more strip rows than resident

@@ -130,6 +130,7 @@ SIGNATURES = {
     "pm_frame_latency": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "pm_tile_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "pm_binning_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "pm_binning_plan_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "pm_one_launch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "pm_time_one_launch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "pm_debug_time_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

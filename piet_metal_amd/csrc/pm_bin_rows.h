@@ -41,7 +41,8 @@ __device__ __forceinline__ float HalfWidthOf(uint32_t aux0) { return 0.5f * __ui
 // (kStamps: the developer timeline's clocks -- the one-launch kernel, which has its hand-over words beside this struct, goes without)
 template <bool kStamps>
 struct BinStamps {
-    unsigned long long s_stamp[14];  // developer timeline (kProfile builds)
+    uint32_t s_stamp[14];  // developer timeline (kProfile builds): the clock's low 32 bits (43 s at 100 MHz) -- with 64-bit stamps the
+                           // profiled kernel's LDS crossed the five-workgroups-per-CU line and its last workgroups queued behind the first
 };
 template <>
 struct BinStamps<false> {};
@@ -90,7 +91,7 @@ struct BinLds : BinStamps<kStamps> {
 // derived, 512 survivors in LDS): FIVE workgroups then share a CU -- measured: 31 184 B does, 32 208 B does
 // not -- its own, or the tile kernel's (30.6 KB each) of the neighbouring frames.  Config 5 alone: binning
 // 0.313 -> 0.270 ms; sustained throughput +4 % in every configuration.
-static_assert(sizeof(BinLds<4>) <= 31232 || kSurvLds != 512, "five workgroups per CU");
+static_assert((sizeof(BinLds<4>) <= 31184 && sizeof(BinLds<4, false>) <= 31184) || kSurvLds != 512, "five workgroups per CU (the profiled kernel too)");
 static_assert(sizeof(BinLds<1>) <= 10240, "sixteen one-wave groups per CU");
 
 // kOne (pm_frame_kernel, one launch per frame): the workgroup bins ONE strip row -- blockIdx.x's, no chain -- and then renders
@@ -266,7 +267,7 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
     auto stamp = [&](uint32_t k) {
         if (kProfile) {
             if constexpr (kProfile) {
-                if (tid == 0) L.s_stamp[k] = wall_clock64();
+                if (tid == 0) L.s_stamp[k] = static_cast<uint32_t>(wall_clock64());
             }
         }
     };
@@ -1226,7 +1227,10 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         }
         ncand = nb;
     }
-    if (tid == 0) atomicAdd(&PM_PP(ctr_cur)->ptcl[shard].bin_dwords, (cursor - region_begin) + (region_end - cursor_back));  // dwords used (stats only)
+    if (tid == 0) {
+        atomicAdd(&PM_PP(ctr_cur)->ptcl[shard].bin_dwords, (cursor - region_begin) + (region_end - cursor_back));  // dwords used (stats only)
+        if (PM_PP(sr_slots) != nullptr) PM_PP(sr_slots)[rix] = cursor - region_begin;  // the row's segment slots: what the host weighs strip rows by
+    }
 #undef PM_META
 #undef PM_SEG
     // the strip row's tail, unless its last record took care of it
@@ -1272,7 +1276,7 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         if constexpr (kProfile) {
             if (tid < 14) PM_PP(dbg_bin)[16ull * rix + tid] = L.s_stamp[tid];
         }
-        if (wave == kBinWaves - 1 && lane == 0) PM_PP(dbg_bin)[16ull * rix + 14] = wall_clock64();
+        if (wave == kBinWaves - 1 && lane == 0) PM_PP(dbg_bin)[16ull * rix + 14] = static_cast<uint32_t>(wall_clock64());
     }
     }  // strip rows of this workgroup
 }

@@ -274,9 +274,20 @@ struct pm_ctx {
     // in a pinned array by pm_bin_kernel; before any frame has said anything: by candidates, PM_BIN_SPLIT_CANDS).
     int bin_wt_mode = 2;             // PM_BIN_WT: binning's output stored write-through: 0 never, 1 always, 2 frames whose strip rows all fit the resident grid
     int bin_split_mode = 1;          // PM_BIN_SPLIT: 0 never, 1 while the resident grid has room, 2 every strip row (tests)
-    uint32_t bin_split_cands = 28;   // PM_BIN_SPLIT_CANDS: a row with at least this many candidates may be cut before any feedback
-    uint32_t bin_split_slots = 192;  // PM_BIN_SPLIT_SLOTS: ... with at least this many segment slots, once frames have reported
+    uint32_t bin_split_cands = 1u << 30;  // PM_BIN_SPLIT_CANDS: a row with at least this many candidates is cut before any frame has reported (default: none --
+                                          // candidates predict a row's segment slots poorly: of the 4K Tiger's 60 heaviest rows they name 32)
+    uint32_t bin_split_slots = 224;  // PM_BIN_SPLIT_SLOTS: ... with at least this many segment slots, once frames have reported
+    uint32_t bin_split_fill = 15;    // PM_BIN_SPLIT_FILL: cut rows while the work list stays within this many sixteenths of the resident grid
     uint32_t n_sr_split = 0;         // strip rows of the plan in force that are cut in two
+    uint4 *d_sr_desc_whole = nullptr;  // [sr_desc_cap] the same work list with every cut strip row whole again (same arena regions): what frames
+    uint32_t n_sr_whole = 0;           // behind running frames bin from -- there instructions count, not the frame's own latency (sustained -3 % with cuts)
+    std::vector<uint4> stage_desc_whole;
+    uint32_t *d_sr_slots = nullptr;  // [sr_desc_cap] segment slots every entry of the work list found in the latest frame
+    std::vector<uint32_t> fb_slots;  // per strip row of the band: the slots the frames of this scene and viewport reported (empty: nothing yet)
+    std::vector<uint32_t> stage_slots;
+    uint32_t frames_on_plan = 0;     // frames submitted since the plan in force was made
+    bool fb_applied = false;         // the plan in force was made with fb_slots
+    uint32_t plans_fed_back = 0;     // plans remade from the frames' report (pm_binning_info)
     uint32_t sr_empty_dwords = 0;   // size of a region no item reaches
     uint2 *d_band_bbox = nullptr;   // items that reach the band (bbox, scene index), paint order
     uint32_t *d_band_item = nullptr;
@@ -405,6 +416,8 @@ int AllocViewport(pm_ctx *c) {
     if (r0 != PM_OK) return r0;
     c->arena_dirty = true;
     c->plan_reusable = false;  // (another viewport or band: the plan goes with it)
+    c->fb_slots.clear();       // (... and what its frames said about its strip rows)
+    c->fb_applied = false;
     return PM_OK;
 }
 
@@ -619,7 +632,7 @@ int EnsureArena(pm_ctx *c) {
     const int margin = c->replan_wide ? static_cast<int>(pm::kTileW) : 0;
     std::vector<uint64_t> need, need_half;
     std::vector<uint32_t> row_cands;
-    const bool may_split = c->bin_split_mode != 0 && c->one_launch_mode == 0;
+    const bool may_split = c->bin_split_mode != 0 && c->one_launch_mode == 0;  // (scenes with per-tile-row item lists: decided below, once the band's list is made)
     StripRowBounds(c, &need, margin, may_split ? &need_half : nullptr, may_split ? &row_cands : nullptr);
     // (host work before any upload: the band's item list, the arena regions)
     c->sr_empty_dwords = 0;  // (a strip row no item's bbox reaches has nothing reserved)
@@ -658,16 +671,22 @@ int EnsureArena(pm_ctx *c) {
     // Which strip rows are cut in two (bin_split_mode): the heaviest ones, as many as the resident grid has workgroups to spare.
     std::vector<uint8_t> cut(need.size(), 0);
     c->n_sr_split = 0;
-    if (may_split) {
+    if (may_split && !c->use_row_lists) {  // (per-tile-row item lists are addressed by entry of the one work list)
         size_t n_rows = 0;
         for (size_t i = 0; i < need.size(); ++i) n_rows += ((need[i] + 3u) & ~3ull) != c->sr_empty_dwords ? 1u : 0u;
-        const size_t resident = static_cast<size_t>(c->n_cus) * (per_cu ? per_cu : 5u);
+        // (not to the last workgroup the chip holds: with all 1 280 places taken -- 171 rows cut at the 4K Tiger -- binning was 1.7 us
+        //  SLOWER than with 1 214; the dispatcher's placement is not perfectly even, and a workgroup that has to wait for a place
+        //  starts when a first one ends)
+        const size_t resident = static_cast<size_t>(c->n_cus) * (per_cu ? per_cu : 5u) * static_cast<size_t>(c->bin_split_fill) / 16u;
         const size_t room = c->bin_split_mode == 2 ? need.size() : (resident > n_rows ? resident - n_rows : 0u);
         std::vector<std::pair<uint32_t, uint32_t>> heavy;  // {weight, strip row}
+        const bool fed = c->fb_slots.size() == need.size();  // (frames of this scene and viewport have reported)
         for (size_t i = 0; i < need.size() && room != 0; ++i) {
             if (((need[i] + 3u) & ~3ull) == c->sr_empty_dwords) continue;
-            if (c->bin_split_mode == 2 || row_cands[i] >= c->bin_split_cands) heavy.emplace_back(row_cands[i], static_cast<uint32_t>(i));
+            if (c->bin_split_mode == 2) heavy.emplace_back(row_cands[i], static_cast<uint32_t>(i));
+            else if (fed ? c->fb_slots[i] >= c->bin_split_slots : row_cands[i] >= c->bin_split_cands) heavy.emplace_back(fed ? c->fb_slots[i] : row_cands[i], static_cast<uint32_t>(i));
         }
+        c->fb_applied = fed;
         if (heavy.size() > room) {
             std::partial_sort(heavy.begin(), heavy.begin() + static_cast<ptrdiff_t>(room), heavy.end(),
                               [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
@@ -754,7 +773,7 @@ int EnsureArena(pm_ctx *c) {
         c->bin_grid = static_cast<uint32_t>(grid);
     }
     PM_TRY(SyncAll(c) == PM_OK ? hipSuccess : hipErrorUnknown);  // frames in flight still read the lists replaced below
-    if (desc.size() > c->sr_desc_cap || !c->d_sr_list) {  // (grow only: an animation re-sizes every frame)
+    if (desc.size() > c->sr_desc_cap || !c->d_sr_list || !c->d_sr_slots || !c->d_sr_desc_whole) {  // (grow only: an animation re-sizes every frame)
         if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
         if (c->d_sr_list) (void)hipFree(c->d_sr_list);
         c->d_sr_desc = nullptr;
@@ -763,8 +782,28 @@ int EnsureArena(pm_ctx *c) {
         const size_t want = std::max<size_t>(desc.size() + desc.size() / 4 + 16, c->sr_desc_cap);
         PM_TRY(hipMalloc(&c->d_sr_desc, want * sizeof(uint4)));
         PM_TRY(hipMalloc(&c->d_sr_list, want * sizeof(uint2)));
+        if (c->d_sr_slots) (void)hipFree(c->d_sr_slots);
+        c->d_sr_slots = nullptr;
+        PM_TRY(hipMalloc(&c->d_sr_slots, want * sizeof(uint32_t)));
+        if (c->d_sr_desc_whole) (void)hipFree(c->d_sr_desc_whole);
+        c->d_sr_desc_whole = nullptr;
+        PM_TRY(hipMalloc(&c->d_sr_desc_whole, want * sizeof(uint4)));
         c->sr_desc_cap = want;
     }
+    {
+        // the work list without the cuts: the two halves of a cut strip row lie next to each other, in the list and in the arena
+        std::vector<uint4> &whole = c->stage_desc_whole;
+        whole.clear();
+        for (size_t k = 0; k < desc.size() && c->n_sr_split != 0; ++k) {
+            const uint32_t key = desc[k].x & 0xffff00ffu;
+            if (!whole.empty() && (whole.back().x & 0xffff00ffu) == key) whole.back().z = desc[k].z;
+            else whole.push_back(make_uint4(key | (15u << 12), desc[k].y, desc[k].z, 0u));
+        }
+        c->n_sr_whole = static_cast<uint32_t>(whole.size());
+        if (!whole.empty()) PM_TRY(hipMemcpyAsync(c->d_sr_desc_whole, whole.data(), whole.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
+    }
+    PM_TRY(hipMemsetAsync(c->d_sr_slots, 0, desc.size() * sizeof(uint32_t), c->stream));
+    c->frames_on_plan = 0;
     PM_TRY(hipMemcpyAsync(c->d_sr_desc, desc.data(), desc.size() * sizeof(uint4), hipMemcpyHostToDevice, c->stream));
     {
         // Chains of the one-launch grid (four workgroups per CU, all resident): workgroup b bins strip row b; with more strip rows
@@ -941,6 +980,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->sr_desc = c->d_sr_desc;
     p->sr_list = c->d_sr_list;
     p->n_sr_active = c->n_sr_active;
+    p->sr_slots = c->d_sr_slots;
     p->bin_prio_slots = c->bin_prio_slots;
     p->bin_grid = c->bin_grid;
     p->sr_empty_dwords = c->sr_empty_dwords;
@@ -1075,6 +1115,40 @@ int EnsureFifo(pm_ctx *c, FrameSlot *s, hipStream_t q) {
     return PM_OK;
 }
 
+// The third frame of a plan: what the first frames' binning kernels found per strip row (segment slots) comes back, once, and the plan
+// is made again with the heaviest strip rows cut in two (EnsureArena, bin_split_mode).  A wait for the frames in flight and a copy
+// of a few kilobytes: about 0.1 ms, once per scene and viewport.
+int FeedBackStripRows(pm_ctx *c) {
+    if (c->arena_dirty || c->arena_cap == 0) return PM_OK;  // (a new plan is about to be made anyway)
+    if (c->frames_on_plan == 0xffffffffu) return PM_OK;
+    c->frames_on_plan += 1;
+    if (c->frames_on_plan != 3u || c->bin_split_mode != 1 || c->one_launch_mode != 0 || c->fb_applied || !c->d_sr_slots) return PM_OK;
+    // (only where cutting can happen at all: the plan's rows leave workgroups of the resident grid free)
+    if (c->n_sr_active >= static_cast<uint32_t>(c->n_cus) * (c->bin_wg_per_cu == 0xffu ? 5u : std::max(1u, c->bin_wg_per_cu))) return PM_OK;
+    int r = SyncAll(c);
+    if (r != PM_OK) return r;
+    std::vector<uint32_t> &sl = c->stage_slots;
+    sl.resize(c->n_sr_active);
+    PM_TRY(hipMemcpy(sl.data(), c->d_sr_slots, sl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const size_t n_rows = static_cast<size_t>(BandRows(c)) * c->strips_x;
+    c->fb_slots.assign(n_rows, 0u);
+    uint32_t heaviest = 0;
+    for (size_t k = 0; k < sl.size() && k < c->stage_desc.size(); ++k) {
+        const uint32_t x = c->stage_desc[k].x;
+        const size_t i = static_cast<size_t>(x >> 16) * c->strips_x + (x & 0xffu);
+        if (i < n_rows) c->fb_slots[i] += sl[k];  // (a row already cut: its halves' slots)
+        if (i < n_rows) heaviest = std::max(heaviest, c->fb_slots[i]);
+    }
+    if (heaviest < c->bin_split_slots && c->n_sr_split == 0) {  // nothing to cut, nothing cut: the plan stands
+        c->fb_applied = true;
+        return PM_OK;
+    }
+    c->arena_dirty = true;
+    c->plan_reusable = false;
+    c->plans_fed_back += 1;
+    return PM_OK;
+}
+
 // One frame: its kernels back to back on one in-order stream -- the context's stream
 // frame % n, or the caller's.  tev (timing passes): eight events {begin, end} x {bin, clear,
 // coarse, fine} carried by the dispatches themselves, so that a timed frame puts exactly the
@@ -1089,7 +1163,9 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     if (!fb) fb = s->d_fb;
     pm::FrameParams p;
     hipStream_t q = user_stream ? user_stream : c->streams[c->frame % c->streams.size()];
-    int r = BuildParams(c, s, fb, stride, &p);
+    int r = FeedBackStripRows(c);
+    if (r != PM_OK) return r;
+    r = BuildParams(c, s, fb, stride, &p);
     if (r != PM_OK) return r;
     hipEvent_t none[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t *t = tev ? tev : none;
@@ -1135,14 +1211,24 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     // (round 5, found by the held-out policy check: held-out 3 -- 2 025 light strip rows, more than the 1 280 workgroups of the plan's
     //  grid, so its rows are chained -- ran 14 % faster in flight with a wave per row.  Sixteen one-wave groups per CU hold 4 096 rows at
     //  once: such a frame gets a wave for EVERY row and does not walk the chains.)
-    if (p.handout_static && c->bin_waves_inflight == 1 && c->bin_waves == 4 && c->n_sr_active >= 4u * static_cast<uint32_t>(c->n_cus) &&
-        c->plan_cands <= 32ull * c->n_sr_active) {
-        if (c->n_sr_active <= c->bin_grid) {
+    // ... from the work list WITHOUT the cuts (a cut strip row is two rows' worth of fixed work: worth it on a lone frame's critical
+    // path, a loss where frames overlap): the same arena regions, every cut row whole again
+    uint32_t n_rows_frame = c->n_sr_active;
+    if (p.handout_static && c->n_sr_split != 0 && c->n_sr_whole != 0) {
+        p.sr_desc = c->d_sr_desc_whole;
+        p.n_sr_active = c->n_sr_whole;
+        p.bin_grid = std::min(p.bin_grid, c->n_sr_whole);
+        p.sr_slots = nullptr;  // (the report is by entry of the list with the cuts)
+        n_rows_frame = c->n_sr_whole;
+    }
+    if (p.handout_static && c->bin_waves_inflight == 1 && c->bin_waves == 4 && n_rows_frame >= 4u * static_cast<uint32_t>(c->n_cus) &&
+        c->plan_cands <= 32ull * n_rows_frame) {
+        if (n_rows_frame <= p.bin_grid) {
             p.bin_waves = 1;
             c->frames_bin_wave_inflight += 1;
-        } else if (c->n_sr_active <= 16u * static_cast<uint32_t>(c->n_cus) && c->bin_wg_per_cu == 0xffu) {
+        } else if (n_rows_frame <= 16u * static_cast<uint32_t>(c->n_cus) && c->bin_wg_per_cu == 0xffu) {
             p.bin_waves = 1;
-            p.bin_grid = c->n_sr_active;
+            p.bin_grid = n_rows_frame;
             p.bin_no_chains = 1u;
             c->frames_bin_wave_inflight += 1;
             c->frames_bin_no_chains += 1;
@@ -1564,8 +1650,9 @@ pm_ctx *pm_create(int device, int *err) {
     c->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 320, 0, 1 << 30));
     c->bin_split_mode = EnvInt("PM_BIN_SPLIT", 1, 0, 2);
     c->bin_wt_mode = EnvInt("PM_BIN_WT", 2, 0, 2);
-    c->bin_split_cands = static_cast<uint32_t>(EnvInt("PM_BIN_SPLIT_CANDS", 28, 1, 1 << 30));
-    c->bin_split_slots = static_cast<uint32_t>(EnvInt("PM_BIN_SPLIT_SLOTS", 192, 1, 1 << 30));
+    c->bin_split_cands = static_cast<uint32_t>(EnvInt("PM_BIN_SPLIT_CANDS", 1 << 30, 1, 1 << 30));
+    c->bin_split_slots = static_cast<uint32_t>(EnvInt("PM_BIN_SPLIT_SLOTS", 224, 1, 1 << 30));
+    c->bin_split_fill = static_cast<uint32_t>(EnvInt("PM_BIN_SPLIT_FILL", 15, 1, 16));
     c->one_launch_mode = EnvInt("PM_ONE_LAUNCH", 0, 0, 1);
     c->one_launch_split = EnvInt("PM_ONE_LAUNCH_SPLIT", 0, 0, 1) != 0;
     c->frame_spin_ticks = static_cast<uint32_t>(EnvInt("PM_ONE_LAUNCH_SPIN_US", 2000, 1, 1000000)) * 100u;
@@ -1617,6 +1704,8 @@ pm_ctx *pm_create(int device, int *err) {
         if (e == hipSuccess) c->sup_bbox_cap = 1u << 16;
         if (e == hipSuccess) e = hipMalloc(&c->d_sr_desc, 65536 * sizeof(uint4));
         if (e == hipSuccess) e = hipMalloc(&c->d_sr_list, 65536 * sizeof(uint2));
+        if (e == hipSuccess) e = hipMalloc(&c->d_sr_slots, 65536 * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&c->d_sr_desc_whole, 65536 * sizeof(uint4));
         if (e == hipSuccess) c->sr_desc_cap = 65536;
         if (e == hipSuccess) e = hipMalloc(&c->d_band_bbox, 65536 * sizeof(uint2));
         if (e == hipSuccess) e = hipMalloc(&c->d_band_item, 65536 * sizeof(uint32_t));
@@ -1693,6 +1782,8 @@ void pm_destroy(pm_ctx *c) {
     }
     if (c->d_sr_desc) (void)hipFree(c->d_sr_desc);
     if (c->d_sr_list) (void)hipFree(c->d_sr_list);
+    if (c->d_sr_slots) (void)hipFree(c->d_sr_slots);
+    if (c->d_sr_desc_whole) (void)hipFree(c->d_sr_desc_whole);
     if (c->d_band_bbox) (void)hipFree(c->d_band_bbox);
     if (c->d_band_item) (void)hipFree(c->d_band_item);
     if (c->d_row_base) (void)hipFree(c->d_row_base);
@@ -1759,6 +1850,8 @@ int pm_upload_scene(pm_ctx *c, size_t bytes) {
     int r = SyncAll(c);  // frames in flight still read the old scene
     if (r != PM_OK) return r;
     InvalidateScene(c);
+    c->fb_slots.clear();  // (another scene: its own frames will say which strip rows are heavy -- a view change, pm_reflatten, keeps the report)
+    c->fb_applied = false;
     c->replan_wide = false;
     c->plan_reusable = false;
     c->t_flatten_ms = 0;
@@ -1780,6 +1873,8 @@ int FlattenAndEncode(pm_ctx *c, bool resident, const pm_path *paths, size_t n_pa
 int pm_flatten_and_encode(pm_ctx *c, const pm_path *paths, size_t n_paths, const pm_path_el *els, size_t n_els,
                           const double affine[6], float width_scale, size_t *scene_bytes, uint32_t *n_items) {
     if (!c || !affine || (n_paths && !paths) || (n_els && !els)) return PM_ERR_INVALID;
+    c->fb_slots.clear();  // (new paths: their own frames will say which strip rows are heavy)
+    c->fb_applied = false;
     c->replan_wide = false;
     c->plan_reusable = false;  // (new paths: planned afresh, for their own boxes)
     return FlattenAndEncode(c, false, paths, n_paths, els, n_els, affine, width_scale, scene_bytes, n_items);
@@ -2135,6 +2230,15 @@ int pm_binning_info(pm_ctx *c, uint32_t out[3]) {
     out[0] = c->frames_bin_wave;
     out[1] = c->frames_bin_wave_inflight;
     out[2] = c->frames_bin_no_chains;
+    return PM_OK;
+}
+
+int pm_binning_plan_info(pm_ctx *c, uint32_t out[4]) {
+    if (!c || !out) return PM_ERR_INVALID;
+    out[0] = c->n_sr_active;
+    out[1] = c->n_sr_split;
+    out[2] = c->plans_fed_back;
+    out[3] = c->fb_applied ? 1u : 0u;
     return PM_OK;
 }
 

@@ -151,6 +151,7 @@ struct FrameParams {
     const uint4 *sr_desc;     // [n_sr_active] {strip | tile row of the band << 16, its private arena region begin, end, next entry of the workgroup's chain}
     const uint2 *sr_list;     // [n_sr_active] large scenes: {first entry, entries} of the strip row's tile row in row_bbox / row_item (what row_base says, next to the descriptor: one round trip less)
     uint32_t n_sr_active;     // strip rows some item reaches: pm_bin_kernel's work list
+    uint32_t *sr_slots;       // [n_sr_active] what every entry of the work list found: its segment slots (pm_bin_kernel leaves them; the host cuts the heaviest strip rows in two by them)
     uint32_t bin_grid;        // its grid: what the chip holds at once (five workgroups per CU), or a workgroup per strip row
     uint32_t bin_prio_slots;  // strip rows with at least this many segment slots raise their waves' issue priority
     uint32_t sr_empty_dwords; // size of a region no item's bbox reaches

@@ -175,6 +175,13 @@ class Renderer:
         _lib.check(self._lib.pm_binning_info(self._h, out), "pm_binning_info")
         return {"wave_per_row": int(out[0]), "inflight_only": int(out[1]), "no_chains": int(out[2])}
 
+    def binning_plan_info(self) -> dict:
+        """The binning plan in force: entries of the strip-row work list, strip rows cut in two, plans remade from the frames'
+        own report since pm_create, and whether the plan in force is such a plan."""
+        out = (C.c_uint32 * 4)()
+        _lib.check(self._lib.pm_binning_plan_info(self._h, out), "pm_binning_plan_info")
+        return {"entries": int(out[0]), "rows_cut": int(out[1]), "plans_fed_back": int(out[2]), "fed_back": bool(out[3])}
+
     def one_launch_info(self) -> dict:
         """Frames rendered as one launch so far, and whether a lone frame of the resident scene would be."""
         n = C.c_uint32(0)

@@ -9,7 +9,7 @@ print("workload", wl.name, wl.width, wl.height)
 r = pm.Renderer(0)
 r.resize(wl.width, wl.height)
 r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
-for _ in range(3): r.render()
+for _ in range(6): r.render()  # (past the frame at which the plan is remade from the frames' own report)
 r.sync()
 t = r.time_bins().astype(np.int64)
 t = t[t[:, 0] > 0]  # strip rows no item reaches never get a workgroup

@@ -11,7 +11,7 @@ r.resize(wl.width, wl.height)
 r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
 if len(sys.argv) > 2:  # only a band of tile rows: the tiles of the band without the rest of the frame around them
     r.set_band(int(sys.argv[1]), int(sys.argv[2]))
-for _ in range(3):
+for _ in range(6):  # (past the frame at which the plan is remade from the frames' own report)
     r.render()
     if os.environ.get("PM_TIMELINE_LONE", "1") != "0":
         r.sync()  # every frame alone: the hand-out and the class thresholds of a lone frame
