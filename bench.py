@@ -102,11 +102,21 @@ class Job:
         self.r, self.wl, self.rank, self.world, self.local, self.args = r, wl, rank, world, local, args
         t0 = time.perf_counter()
         r.resize(wl.width, wl.height)
+        t1 = time.perf_counter()
         self.scene_bytes, self.n_items = r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        t2 = time.perf_counter()
         r.render()
+        t3 = time.perf_counter()
         r.sync()
-        self.first_frame_ms = (time.perf_counter() - t0) * 1e3  # fused: flatten + encode + index + arena + frame 1
+        t4 = time.perf_counter()
+        self.first_frame_ms = (t4 - t0) * 1e3  # fused: flatten + encode + index + arena + frame 1
         self.scene_t = r.scene_timings()
+        # ... and where it went (host wall clock, the four calls one after the other: they sum to first_frame_ms)
+        self.first_frame_parts = {
+            "resize_ms": round((t1 - t0) * 1e3, 4), "flatten_and_encode_ms": round((t2 - t1) * 1e3, 4),
+            "submit_ms": round((t3 - t2) * 1e3, 4), "of_submit_binning_plan_ms": round(self.scene_t["arena_setup_ms"], 4),
+            "frame_until_synced_ms": round((t4 - t3) * 1e3, 4),
+        }
         self.cuts = None
         self.layout = pmd.band_layout(wl.height, world)
         self.band = self.full = self.pad = self.scratch = None
@@ -559,6 +569,7 @@ def main() -> int:
             "scene": {
                 "flatten_encode_ms": round(job.scene_t["flatten_encode_ms"], 4), "scene_index_host_ms": round(job.scene_t["scene_index_ms"], 4),
                 "arena_setup_host_ms": round(job.scene_t["arena_setup_ms"], 4), "first_frame_ms": round(job.first_frame_ms, 4),
+                "first_frame_parts": job.first_frame_parts,
                 "note": "once per scene, like the reference encodes once per resize (PietRenderer.m:145): flatten_encode = pm_flatten_and_encode's four kernels + "
                         "their read-backs; scene_index = header/item read-back, validation, pm_index_kernel; arena_setup = per-(scene, viewport) sizing on the host, "
                         "paid by the first frame; first_frame = all of it fused, resize -> first frame complete (host wall clock)",
@@ -652,6 +663,7 @@ def config5_block(pm, pmd, torch, dist, r, rank, world, local, args):
         "gather_GBs_into_root": None if world == 1 or t_gather <= 0 else round(4 * px * (world - 1) / world / (t_gather * 1e-3) / 1e9, 1),
         "flatten_encode_ms": round(job.scene_t["flatten_encode_ms"], 3), "scene_index_host_ms": round(job.scene_t["scene_index_ms"], 3),
         "arena_setup_host_ms": round(job.scene_t["arena_setup_ms"], 3), "first_frame_ms": round(job.first_frame_ms, 3),
+        "first_frame_parts": job.first_frame_parts,
     }
 
 

@@ -184,6 +184,12 @@ pm_ctx *pm_create(int device, int *err);
 void pm_destroy(pm_ctx *c);
 const char *pm_last_error(void);
 
+/* The ABI this library was built with, as 100 x round + revision: a caller compiled against this header checks
+ * pm_abi_version() == PM_ABI_VERSION before it hands structs over (round-5 advisor: pm_scene_timings was 16 bytes in round 4 and is 12
+ * again since round 5, and nothing at run time told the two layouts apart).  Libraries before round 6 do not export the symbol. */
+#define PM_ABI_VERSION 600u
+uint32_t pm_abi_version(void);
+
 /* -mtkView:drawableSizeWillChange: (PietRenderer.m:105-146) minus the scene
  * init: (re)allocates the framebuffer and the dynamic tile grid. */
 int pm_resize(pm_ctx *c, uint32_t width, uint32_t height);

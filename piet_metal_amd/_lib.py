@@ -111,6 +111,7 @@ SIGNATURES = {
     "pm_create": (C.c_void_p, [C.c_int, C.POINTER(C.c_int)]),
     "pm_destroy": (None, [C.c_void_p]),
     "pm_last_error": (C.c_char_p, []),
+    "pm_abi_version": (C.c_uint32, []),
     "pm_resize": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "pm_set_band": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "pm_scene_buffer": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
@@ -160,6 +161,9 @@ class PietMetalError(RuntimeError):
         self.status = status
 
 
+PM_ABI_VERSION = 600  # include/piet_metal_amd.h
+
+
 def load() -> C.CDLL:
     """Load libpiet_metal_amd.so (built by __graft_entry__.build()); fail loudly."""
     global _lib
@@ -183,6 +187,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.pm_abi_version() != PM_ABI_VERSION:  # (include/piet_metal_amd.h: the struct layouts this binding hands over)
+        raise ImportError(f"{LIB_PATH}: ABI {lib.pm_abi_version()}, this binding is for {PM_ABI_VERSION} -- rebuild the library")
     _lib = lib
     return lib
 

@@ -111,6 +111,8 @@ __device__ __forceinline__ uint4 LoadCoherent16(const void *p) {
 __device__ __forceinline__ void DrainStores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // between two looks at a word somebody else will write
 __device__ __forceinline__ void SleepPoll() { __builtin_amdgcn_s_sleep(24); }
+// ... between two looks at an LDS word another wave of the workgroup will write (64 cycles)
+__device__ __forceinline__ void SpinPause() { __builtin_amdgcn_s_sleep(1); }
 __device__ __forceinline__ unsigned long long PollClock() { return wall_clock64(); }
 
 }  // namespace

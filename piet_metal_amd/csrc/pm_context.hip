@@ -147,6 +147,8 @@ int EnvInt(const char *name, int dflt, int lo, int hi) {
 
 struct FrameSlot {
     uint8_t *d_fb = nullptr;  // this slot's framebuffer (pm_render); pm_render_to uses the caller's
+    size_t fb_cap = 0;        // bytes allocated for it, and entries the queue / per-tile tables were allocated for: a viewport that
+    size_t tables_cap = 0;    // fits keeps the buffers (grow only: a resize to anything smaller than what came before allocates nothing)
     uint32_t *d_arena = nullptr;
     uint32_t arena_cap = 0;  // dwords allocated for this slot (allocated when the slot is first used)
     uint4 *d_queue = nullptr;
@@ -313,6 +315,10 @@ struct pm_ctx {
 
     std::vector<FrameSlot> slot;
     uint32_t frame = 0;
+    std::chrono::steady_clock::time_point last_submit{};  // when the previous frame was submitted, and what was found then:
+    bool prev_running = false;                            // its predecessor was still running (hipStreamQuery) -- an answer kept for
+    uint32_t query_keep = 0;                              // this many more frames submitted back to back (Enqueue)
+    uint32_t query_every = 8;                             // PM_QUERY_EVERY: ... asked again every this many frames
     int last_slot = -1;  // slot of the most recently submitted frame
 
     pm::FlattenCache flatten_cache;  // resident paths + scratch of the flatten stage
@@ -357,6 +363,7 @@ void FreeSlotViewport(FrameSlot *s) {
     s->fifo_cap = 0;
     s->d_fb = nullptr;
     s->d_queue = nullptr;
+    s->fb_cap = s->tables_cap = 0;
     s->d_tile_state = s->d_tile_ptcl = s->d_tile_ncmd = nullptr;
     s->state_epoch = 0;
 }
@@ -372,14 +379,28 @@ void FreeViewport(pm_ctx *c) {
 
 int AllocSlotViewport(pm_ctx *c, FrameSlot *s) {
     if (s->d_fb && s->vp_epoch == c->vp_epoch) return PM_OK;  // (all five buffers exist, or none: a partial set is released below)
-    FreeSlotViewport(s);  // (buffers of an earlier viewport: released now, when the slot is used again, not by the resize)
-    s->vp_epoch = c->vp_epoch;
     const size_t tiles = BandTiles(c);
-    // two allocations (each costs 50-300 us): the pixels, and -- behind one another -- the class queues (one per cost class)
-    // and the three per-tile tables
-    hipError_t e = hipMalloc(&s->d_fb, std::max<size_t>(c->fb_bytes, 16));
     const size_t tables = std::max<size_t>(tiles, 4);
-    if (e == hipSuccess) e = hipMalloc(&s->d_queue, pm::kClasses * tables * sizeof(uint4) + 3 * tables * sizeof(uint32_t));
+    const size_t fb_want = std::max<size_t>(c->fb_bytes, 16);
+    hipError_t e = hipSuccess;
+    if (s->d_fb && s->d_queue && s->fb_cap >= fb_want && s->tables_cap >= tables) {
+        // the buffers of an earlier (larger or equal) viewport serve this one: nothing is released, nothing allocated -- a one-launch
+        // frame's FIFOs excepted, whose capacity is the viewport's (they come back when they are next needed, EnsureFifo)
+        if (s->d_fifo) (void)hipFree(s->d_fifo);
+        s->d_fifo = nullptr;
+        s->fifo_cap = 0;
+    } else {
+        FreeSlotViewport(s);  // (buffers of an earlier viewport: released now, when the slot is used again, not by the resize)
+        // two allocations (each costs 50-300 us): the pixels, and -- behind one another -- the class queues (one per cost class)
+        // and the three per-tile tables
+        e = hipMalloc(&s->d_fb, fb_want);
+        if (e == hipSuccess) e = hipMalloc(&s->d_queue, pm::kClasses * tables * sizeof(uint4) + 3 * tables * sizeof(uint32_t));
+        if (e == hipSuccess) {
+            s->fb_cap = fb_want;
+            s->tables_cap = tables;
+        }
+    }
+    s->vp_epoch = c->vp_epoch;
     if (e == hipSuccess) {
         s->d_tile_state = reinterpret_cast<uint32_t *>(s->d_queue + pm::kClasses * tables);
         s->d_tile_ptcl = s->d_tile_state + tables;
@@ -391,6 +412,7 @@ int AllocSlotViewport(pm_ctx *c, FrameSlot *s) {
         if (s->d_queue) (void)hipFree(s->d_queue);
         s->d_fb = nullptr;
         s->d_queue = nullptr;
+        s->fb_cap = s->tables_cap = 0;
         s->d_tile_state = s->d_tile_ptcl = s->d_tile_ncmd = nullptr;
         return HipFail(e, "hipMalloc(frame slot viewport buffers)");
     }
@@ -632,8 +654,14 @@ int EnsureArena(pm_ctx *c) {
     const int margin = c->replan_wide ? static_cast<int>(pm::kTileW) : 0;
     std::vector<uint64_t> need, need_half;
     std::vector<uint32_t> row_cands;
-    const bool may_split = c->bin_split_mode != 0 && c->one_launch_mode == 0;  // (scenes with per-tile-row item lists: decided below, once the band's list is made)
-    StripRowBounds(c, &need, margin, may_split ? &need_half : nullptr, may_split ? &row_cands : nullptr);
+    bool may_split = c->bin_split_mode != 0 && c->one_launch_mode == 0;  // (scenes with per-tile-row item lists: decided below, once the band's list is made)
+    StripRowBounds(c, &need, margin);
+    if (may_split && c->bin_split_mode == 1) {  // (cuts only while the plan's rows leave room in the resident grid: large frames pay for no second sizing pass)
+        size_t n_rows = 0;
+        for (size_t i = 0; i < need.size(); ++i) n_rows += need[i] != 0 ? 1u : 0u;
+        may_split = n_rows < static_cast<size_t>(c->n_cus) * 5u;
+    }
+    if (may_split) StripRowBounds(c, &need, margin, &need_half, &row_cands);
     // (host work before any upload: the band's item list, the arena regions)
     c->sr_empty_dwords = 0;  // (a strip row no item's bbox reaches has nothing reserved)
     // the items whose bbox reaches the band (rows: bw >= y0 && by < y1, PietRender.metal:198/:214), paint order
@@ -827,7 +855,7 @@ int EnsureArena(pm_ctx *c) {
                 for (size_t k = 0; k < extra.size(); ++k) nx[first[k]] = extra[k];
             }
         }
-        if (n > c->sr_next_one_cap || !c->d_sr_next_one) {
+        if (c->one_launch_mode != 0 && (n > c->sr_next_one_cap || !c->d_sr_next_one)) {  // (only a context that renders one-launch frames pays for the table)
             if (c->d_sr_next_one) (void)hipFree(c->d_sr_next_one);
             c->d_sr_next_one = nullptr;
             c->sr_next_one_cap = 0;
@@ -835,7 +863,7 @@ int EnsureArena(pm_ctx *c) {
             PM_TRY(hipMalloc(&c->d_sr_next_one, want * sizeof(uint32_t)));
             c->sr_next_one_cap = want;
         }
-        PM_TRY(hipMemcpyAsync(c->d_sr_next_one, nx.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (c->one_launch_mode != 0) PM_TRY(hipMemcpyAsync(c->d_sr_next_one, nx.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     }
     {
         // the strip rows without a workgroup: the binning launch (clear_in_bin) or a one-launch frame writes their (background) pixels from this list
@@ -953,10 +981,13 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
         SetError("no viewport (pm_resize first)");
         return PM_ERR_INVALID;
     }
+    const WallTimer tm;
     int r = EnsureArena(c);
     if (r != PM_OK) return r;
+    const float t_plan = tm.ms();
     r = EnsureSlotBuffers(c, s);  // (the slot's buffers come into being when it is first used)
     if (r != PM_OK) return r;
+    if (tm.ms() > 0.05f && std::getenv("PM_HOST_TIMING")) std::fprintf(stderr, "BuildParams: plan %.3f slot buffers %.3f ms (arena %u dwords, tile arena %llu quads)\n", t_plan, tm.ms() - t_plan, c->arena_cap, static_cast<unsigned long long>(c->ptcl_want));
     if (!fb) fb = s->d_fb;
     std::memset(p, 0, sizeof(*p));
     p->scene = c->d_scene;
@@ -1017,6 +1048,7 @@ int BuildParams(pm_ctx *c, FrameSlot *s, uint8_t *fb, size_t stride, pm::FramePa
     p->bin_wt = c->bin_wt_mode == 1 || (c->bin_wt_mode == 2 && c->n_sr_active <= c->bin_grid) ? 1u : 0u;
     p->split_mode = c->split_mode;
     p->dense_factor = c->dense_factor;
+    p->verdict_waves = static_cast<uint32_t>(c->n_cus) * c->fine_wg_per_cu * 4u;
     {
         SetClassThresholds(c, p, c->heavy_stream_lone);
         p->n_heavy_classes = 3;
@@ -1153,7 +1185,28 @@ int FeedBackStripRows(pm_ctx *c) {
 // frame % n, or the caller's.  tev (timing passes): eight events {begin, end} x {bin, clear,
 // coarse, fine} carried by the dispatches themselves, so that a timed frame puts exactly the
 // same packets on the queue as an untimed one.
+// (developer: PM_HOST_TIMING=2 prints, when the context goes, where pm_render's host time went -- mean microseconds per section)
+struct SubmitProfile {
+    bool on = std::getenv("PM_HOST_TIMING") && std::atoi(std::getenv("PM_HOST_TIMING")) >= 2;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t n = 0;
+    std::chrono::steady_clock::time_point t;
+    void start() { if (on) t = std::chrono::steady_clock::now(); }
+    void mark(int k) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double, std::micro>(now - t).count();
+        t = now;
+    }
+    ~SubmitProfile() {
+        if (on && n) std::fprintf(stderr, "pm_render host time per frame over %llu frames (us): params %.2f | slot/stream order %.2f | in-flight query %.2f | policy %.2f | binning launch %.2f | tile launch + bookkeeping %.2f\n",
+                                  static_cast<unsigned long long>(n), acc[0] / n, acc[1] / n, acc[2] / n, acc[3] / n, acc[4] / n, acc[5] / n);
+    }
+};
+SubmitProfile g_submit_profile;
+
 int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipEvent_t *tev = nullptr) {
+    g_submit_profile.start();
     const int si = static_cast<int>(c->frame % c->slot.size());
     FrameSlot *s = &c->slot[si];
     if (c->tiles_x != 0) {  // (a slot's viewport buffers come into being when the slot is first used)
@@ -1167,6 +1220,7 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     if (r != PM_OK) return r;
     r = BuildParams(c, s, fb, stride, &p);
     if (r != PM_OK) return r;
+    g_submit_profile.mark(0);
     hipEvent_t none[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t *t = tev ? tev : none;
     // the slot's previous frame (same stream unless the caller's streams are involved or the
@@ -1188,15 +1242,31 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     // Tile hand-out: drawn when this frame will have the device to itself, static when the previous
     // frame is still running (the frames then overlap, and neighbours fill what a static hand-out
     // leaves idle): lone frame -4.6 us, sustained throughput as before.  PM_HANDOUT=1 / 2 pins it.
+    g_submit_profile.mark(1);
     p.handout_static = c->handout == 1 ? 1u : 0u;
     if (c->handout == 0 && c->last_slot >= 0) {
         const FrameSlot &l = c->slot[c->last_slot];
         if (l.in_flight) {
-            const hipError_t st = l.user_stream ? hipEventQuery(l.ev_done) : hipStreamQuery(l.frame_stream);
-            p.handout_static = st == hipErrorNotReady && l.frame_stream != q ? 1u : 0u;  // (behind it on the same stream: alone all the same)
-            (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure)
+            // The question "is the previous frame still running?" costs 3.3 us of host time (hipStreamQuery, measured: a quarter of a
+            // pm_render call, and small frames in flight are bound by exactly that).  Frames submitted back to back get the same
+            // answer most of the time: it is asked once in eight such frames and kept in between (a gap of 0.2 ms asks again).
+            const auto now = std::chrono::steady_clock::now();
+            const bool back_to_back = std::chrono::duration<double, std::micro>(now - c->last_submit).count() < 200.0;
+            c->last_submit = now;
+            if (back_to_back && c->query_keep != 0u) {
+                c->query_keep -= 1u;
+            } else {
+                const hipError_t st = l.user_stream ? hipEventQuery(l.ev_done) : hipStreamQuery(l.frame_stream);
+                c->prev_running = st == hipErrorNotReady;
+                c->query_keep = c->query_every - 1u;
+                (void)hipGetLastError();  // (hipErrorNotReady is an answer, not a failure)
+            }
+            p.handout_static = c->prev_running && l.frame_stream != q ? 1u : 0u;  // (behind it on the same stream: alone all the same)
+        } else {
+            c->query_keep = 0u;
         }
     }
+    g_submit_profile.mark(2);
     // overlapping frames also keep fewer tiles for whole workgroups (a workgroup tile idles three
     // waves while its list is built: cheap when the frame is alone and its longest lists set the
     // span, wasteful when neighbours could use the SIMDs): lone frame -1.4 us, sustained +2.6 %
@@ -1240,6 +1310,10 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     // unchanged; two cost config 4 2 %; alone, five end the frame 0.8 us earlier)
     if (p.handout_static && c->fine_wg_per_cu_inflight < c->fine_wg_per_cu)
         p.fine_grid = std::max(1u, std::min(p.fine_grid, static_cast<uint32_t>(c->n_cus) * c->fine_wg_per_cu_inflight));
+    // (the waves a frame's dense / not dense verdict is judged against: the GENERAL kernel's grid for this kind of frame, whichever
+    //  instantiation runs it -- round-5 advisor: judged against its own, larger grid the one-wave kernel called a scene "not dense"
+    //  that the general kernel called dense, and such a scene changed kernels every other frame)
+    p.verdict_waves = p.fine_grid * 4u;
     ChooseTileKernel(c, &p);
     const uint32_t n_striprows = BandRows(c) * c->strips_x;
     PM_TRY(ResetTileState(c, s, q));
@@ -1289,7 +1363,9 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     //  tile kernel's first tiles no longer share the chip with 2 025 clearing workgroups)
     if (c->fold_clear_mode == 3 && p.handout_static) p.clear_in_bin = 1u;
     const bool fold = p.clear_in_bin == 0u && (c->fold_clear_mode == 1 || (c->fold_clear_mode >= 2 && (!p.handout_static || BandTiles(c) < 16384u)));
+    g_submit_profile.mark(3);
     pm::LaunchBin(p, q, t[0], t[1]);
+    g_submit_profile.mark(4);
     if (!fold && p.clear_in_bin == 0u) pm::LaunchClear(p, n_striprows, q, t[2], t[3]);  // (needs tile_state)
     if (!c->fused) pm::LaunchCoarse(p, CoarseGrid(c), false, q, t[4], t[5]);
     pm::LaunchFine(p, fold ? n_striprows : 0u, c->fused, q, t[6], t[7]);
@@ -1297,6 +1373,8 @@ int Enqueue(pm_ctx *c, uint8_t *fb, size_t stride, hipStream_t user_stream, hipE
     Submitted(c, si, p, q);
     s->user_stream = user_stream != nullptr && std::find(c->streams.begin(), c->streams.end(), q) == c->streams.end();
     if (s->user_stream) PM_TRY(hipEventRecord(s->ev_done, q));  // the only handle kept on a caller's stream
+    g_submit_profile.mark(5);
+    g_submit_profile.n += 1;
     return PM_OK;
 }
 
@@ -1585,6 +1663,8 @@ extern "C" {
 
 const char *pm_last_error(void) { return g_last_error.c_str(); }
 
+uint32_t pm_abi_version(void) { return PM_ABI_VERSION; }
+
 pm_ctx *pm_create(int device, int *err) {
     int dummy;
     if (!err) err = &dummy;
@@ -1648,6 +1728,7 @@ pm_ctx *pm_create(int device, int *err) {
     c->bin_waves_env = static_cast<uint32_t>(EnvInt("PM_BIN_WAVES", 0, 0, 4));
     c->bin_waves_inflight = c->bin_waves_env ? c->bin_waves_env : static_cast<uint32_t>(EnvInt("PM_BIN_WAVES_INFLIGHT", 1, 1, 4));
     c->bin_prio_slots = static_cast<uint32_t>(EnvInt("PM_BIN_PRIO_SLOTS", 320, 0, 1 << 30));
+    c->query_every = static_cast<uint32_t>(EnvInt("PM_QUERY_EVERY", 8, 1, 1 << 20));
     c->bin_split_mode = EnvInt("PM_BIN_SPLIT", 1, 0, 2);
     c->bin_wt_mode = EnvInt("PM_BIN_WT", 2, 0, 2);
     c->bin_split_cands = static_cast<uint32_t>(EnvInt("PM_BIN_SPLIT_CANDS", 1 << 30, 1, 1 << 30));
@@ -1710,8 +1791,27 @@ pm_ctx *pm_create(int device, int *err) {
         if (e == hipSuccess) e = hipMalloc(&c->d_band_bbox, 65536 * sizeof(uint2));
         if (e == hipSuccess) e = hipMalloc(&c->d_band_item, 65536 * sizeof(uint32_t));
         if (e == hipSuccess) c->band_cap = 65536;
-        const uint32_t arena0 = 48u << 20;  // dwords (192 MB)
-        const uint32_t tile0 = ((1u << 22) * pm::kCmdQuadsNum) / pm::kCmdQuadsDen;  // quads: what EnsureArena asks for at least
+        {   // ... and frame slot 0's viewport buffers for anything up to 8192 x 8192 (BASELINE config 5: 256 MB of pixels, 42 MB of
+            // queues and per-tile tables -- a thousandth of the HBM): a resize within that allocates nothing
+            const size_t px = static_cast<size_t>(EnvInt("PM_PREALLOC_MPIXELS", 64, 0, 4096)) << 20;
+            const size_t tables = std::max<size_t>(px / (pm::kTileW * pm::kTileH), 4);
+            if (e == hipSuccess && px != 0) e = hipMalloc(&c->slot[0].d_fb, px * 4);
+            if (e == hipSuccess && px != 0) e = hipMalloc(&c->slot[0].d_queue, pm::kClasses * tables * sizeof(uint4) + 3 * tables * sizeof(uint32_t));
+            if (e == hipSuccess && px != 0) {
+                c->slot[0].fb_cap = px * 4;
+                c->slot[0].tables_cap = tables;
+            }
+        }
+        // (round 6: sized for BASELINE config 5 -- 2.2 GB of worst-case binning regions, 1.7 GB of tile arena, 1.4 % of the HBM -- whose
+        //  first frame used to spend 0.8 ms releasing slot 0's 192 MB arenas and allocating these; PM_PREALLOC_ARENA_MB / _TILE_MB)
+#ifdef PM_EMU
+        const int arena_mb = 192, tile_mb = 96;  // (the CPU emulation's "HBM" is the host's memory)
+#else
+        const int arena_mb = 2304, tile_mb = 1792;
+#endif
+        const uint32_t arena0 = static_cast<uint32_t>(EnvInt("PM_PREALLOC_ARENA_MB", arena_mb, 1, 12288)) << 18;  // dwords
+        const uint32_t tile0 = std::max<uint32_t>(static_cast<uint32_t>(EnvInt("PM_PREALLOC_TILE_MB", tile_mb, 1, 16384)) << 16,  // quads
+                                                  ((1u << 22) * pm::kCmdQuadsNum) / pm::kCmdQuadsDen);  // (what EnsureArena asks for at least)
         if (e == hipSuccess) e = hipMalloc(&c->slot[0].d_arena, static_cast<size_t>(arena0) * sizeof(uint32_t));
         if (e == hipSuccess) c->slot[0].arena_cap = arena0;
         if (e == hipSuccess && !std::getenv("PM_PTCL_INITIAL_CMDS")) {
@@ -1744,9 +1844,15 @@ pm_ctx *pm_create(int device, int *err) {
             pm_destroy(c);
             return nullptr;
         }
-        // back to a context without scene and viewport
+        // back to a context without scene and viewport (the slots KEEP their buffers: the first real viewport that fits them -- slot
+        // 0's are reserved for anything up to 8192 x 8192 -- allocates nothing, AllocSlotViewport)
         InvalidateScene(c);
-        FreeViewport(c);
+        c->vp_epoch += 1;
+        for (auto &s : c->slot) {
+            s.in_flight = false;
+            s.needs_check = false;
+        }
+        c->last_slot = -1;
         c->flatten_cache.resident = false;
         c->flatten_cache.meta_bytes = 0;
         c->width = c->height = c->tiles_x = c->tiles_y = c->strips_x = c->row0 = c->row1 = 0;
@@ -1807,9 +1913,12 @@ void pm_destroy(pm_ctx *c) {
 
 int pm_resize(pm_ctx *c, uint32_t width, uint32_t height) {
     if (!c || width == 0 || height == 0 || width > 65535 || height > 65535) return PM_ERR_INVALID;
+    const WallTimer tm;
     PM_TRY(hipSetDevice(c->device));
+    const float t_a = tm.ms();
     int r = SyncAll(c);
     if (r != PM_OK) return r;
+    if (std::getenv("PM_HOST_TIMING")) std::fprintf(stderr, "pm_resize: setdevice %.3f syncall %.3f ms\n", t_a, tm.ms() - t_a);
     c->width = width;
     c->height = height;
     c->tiles_x = (width + pm::kTileW - 1) / pm::kTileW;   // PietRenderer.m:63-64
@@ -1817,7 +1926,10 @@ int pm_resize(pm_ctx *c, uint32_t width, uint32_t height) {
     c->strips_x = (c->tiles_x + pm::kStripTiles - 1) / pm::kStripTiles;
     c->row0 = 0;
     c->row1 = c->tiles_y;
-    return AllocViewport(c);
+    const float t_b = tm.ms();
+    r = AllocViewport(c);
+    if (std::getenv("PM_HOST_TIMING")) std::fprintf(stderr, "pm_resize: viewport buffers %.3f ms\n", tm.ms() - t_b);
+    return r;
 }
 
 int pm_set_band(pm_ctx *c, uint32_t tile_row0, uint32_t tile_row1) {
@@ -2014,17 +2126,26 @@ int pm_sync(pm_ctx *c) {
         std::vector<pm::FrameParams> redo;
         uint64_t want = 0;
         bool gave_up = false;
+        // A one-launch frame gave up waiting inside its launch (its workgroups were not all resident, or somebody else's work
+        // held the device): the frame has holes, and its slot's hand-over state -- FIFO entries that were pushed and never
+        // popped, counters -- is no longer all zero.  EVERY slot whose frame gave up is put back to all zero, also a slot whose
+        // frame has since been superseded on its target and needs no second rendering (round-5 advisor: left alone, the next
+        // one-launch frame of that slot could pop a stale entry); every frame from now on takes two launches.
+        {
+            bool repaired = false;
+            for (auto &t : c->slot) {
+                if (!t.h_overflow || static_cast<volatile uint32_t *>(t.h_overflow)[1] == 0u) continue;
+                c->one_launch_broken = true;
+                if (t.d_fifo) PM_TRY(hipMemset(t.d_fifo, 0, static_cast<size_t>(pm::kFifos) * t.fifo_cap * sizeof(uint4)));
+                if (t.d_ctr) PM_TRY(hipMemset(t.d_ctr, 0, 2 * sizeof(pm::Counters)));
+                repaired = true;
+            }
+            if (repaired) PM_TRY(hipDeviceSynchronize());  // (the frame streams do not wait for the null stream's memsets)
+        }
         for (int si : latest) {
             FrameSlot &s = c->slot[si];
-            if (static_cast<volatile uint32_t *>(s.h_overflow)[1] != 0u) {
-                // A one-launch frame gave up waiting inside its launch (its workgroups were not all resident, or somebody
-                // else's work held the device): the frame has holes.  Its hand-over state goes back to all zero, the frame is
-                // rendered again with two launches, and so is every frame from now on.
+            if (static_cast<volatile uint32_t *>(s.h_overflow)[1] != 0u) {  // ... and the frame is rendered again with two launches
                 gave_up = true;
-                c->one_launch_broken = true;
-                if (s.d_fifo) PM_TRY(hipMemset(s.d_fifo, 0, static_cast<size_t>(pm::kFifos) * s.fifo_cap * sizeof(uint4)));
-                PM_TRY(hipMemset(s.d_ctr, 0, 2 * sizeof(pm::Counters)));
-                PM_TRY(hipDeviceSynchronize());  // (the frame streams do not wait for the null stream's memsets)
                 redo.push_back(s.params);
                 continue;
             }

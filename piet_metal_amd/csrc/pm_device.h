@@ -173,6 +173,8 @@ struct FrameParams {
     uint32_t split_mode;           // fine kernel: 0 = one wave per tile always, 1 = a workgroup per tile with a long list
     uint32_t fine_dense;           // 1: this frame's tile kernel is the one-wave-per-tile instantiation (six workgroups per CU)
     uint32_t *host_dense;          // pinned host word: the tile kernel says whether ITS frame was dense (1 no, 2 yes): the next frame's choice
+    uint32_t verdict_waves;        // ... judged against THIS many waves whichever instantiation runs (the general kernel's lone grid: a verdict that
+                                   // depended on the judging kernel's own grid flipped kernels every other frame for scenes between the two thresholds)
     uint32_t dense_factor;         // ... unless the long lists, at this many waves each, would occupy every wave of the grid (4: what a workgroup is)
     uint32_t class_thr[kClasses - 1];  // descending: a tile with more stream elements than class_thr[c] is in class <= c
     uint32_t n_heavy_classes;          // classes 0 .. n-1 are rendered by a whole workgroup per tile (long lists)

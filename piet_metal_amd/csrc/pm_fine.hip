@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kThreads, kDense ? 6 : 5) void pm_fine_kernel(Frame
     //  kernel's too -- nothing in it would get a workgroup, and six workgroups per CU take its many short lists faster than five:
     //  held-out 3, 20 k glyph-like paths over every tile of a 4K frame, 114 -> 106 us alone, -6 % per frame in flight)
     if (blockIdx.x == 0 && threadIdx.x == 0 && P.host_dense != nullptr)
-        *P.host_dense = (static_cast<uint64_t>(n_heavy) * P.dense_factor >= n_waves || P.split_mode == 0 || n_heavy == 0u) ? 2u : 1u;
+        *P.host_dense = (static_cast<uint64_t>(n_heavy) * P.dense_factor >= P.verdict_waves || P.split_mode == 0 || n_heavy == 0u) ? 2u : 1u;
     const uint32_t sh = dense ? 0u : 2u;
     const uint32_t s_h = n_heavy << sh;  // slots of the tiles with long lists: a workgroup (4 slots) each
     const uint32_t n_slots = s_h + (n_tiles - n_heavy);

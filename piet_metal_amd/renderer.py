@@ -21,6 +21,19 @@ from . import _lib
 from .encoder import PathSet
 
 
+_warned_default_stream = False
+
+
+def _warn_default_stream() -> None:
+    global _warned_default_stream
+    if not _warned_default_stream:
+        _warned_default_stream = True
+        import warnings
+
+        warnings.warn("piet_metal_amd: torch's default stream (handle 0) cannot be named through the C ABI -- the frame ran on the context's "
+                      "own stream and was waited for; pass a torch.cuda.Stream() to keep the submission asynchronous", RuntimeWarning, stacklevel=3)
+
+
 class Renderer:
     def __init__(self, device: int = 0):
         self._lib = _lib.load()
@@ -125,6 +138,12 @@ class Renderer:
             raise ValueError("tensor does not match the viewport band")
         s = stream.cuda_stream if stream is not None else None
         _lib.check(self._lib.pm_render_to(self._h, tensor.data_ptr(), tensor.stride(0), s), "pm_render_to")
+        if stream is not None and not s:
+            # torch's legacy default stream has handle 0, which the C ABI reads as "the context's own stream": the frame would run
+            # BESIDE the torch work queued on that tensor, not behind it (round-5 advisor).  Not silently: the frame is waited for
+            # here, so that whatever the caller queues next on any stream sees it complete, and the caller is told once.
+            _warn_default_stream()
+            self.sync()
 
     def sync(self) -> None:
         _lib.check(self._lib.pm_sync(self._h), "pm_sync")
@@ -272,6 +291,9 @@ class Comm:
             ),
             "pm_gather",
         )
+        if stream is not None and not stream.cuda_stream:  # (torch's default stream: see Renderer.render_to)
+            _warn_default_stream()
+            (renderer or self._r).sync()
 
     @staticmethod
     def library_path() -> str:

@@ -37,6 +37,10 @@ int main(int argc, char **argv) {
     const uint32_t w = argc > 1 ? (uint32_t)atoi(argv[1]) : 1024u;
     const uint32_t h = argc > 2 ? (uint32_t)atoi(argv[2]) : 768u;
     int err = PM_OK;
+    if (pm_abi_version() != PM_ABI_VERSION) { /* the struct layouts this file was compiled against */
+        fprintf(stderr, "library ABI %u, header %u\n", pm_abi_version(), PM_ABI_VERSION);
+        return 1;
+    }
     pm_ctx *c = pm_create(0, &err);
     if (!c) {
         fprintf(stderr, "pm_create -> %d: %s\n", err, pm_last_error());

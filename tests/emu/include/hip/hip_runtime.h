@@ -141,6 +141,9 @@ template <typename T> static inline T atomicMax(T *p, T v) { const T o = *p; *p 
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #endif
+#ifndef __HIP_MEMORY_SCOPE_WORKGROUP
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#endif
 // (__hip_atomic_* are clang builtins on every target)
 
 // ---- runtime API (host memory stands in for HBM; everything is synchronous) ----------------------

@@ -40,6 +40,7 @@ inline uint4 LoadCoherent16(const void *p) { return *static_cast<const uint4 *>(
 inline void DrainStores() {}
 // (a lane that waits for another wave of its workgroup lets the scheduler run that wave: tests/emu/emu_runtime.cpp)
 inline void SleepPoll() { pm_emu::Sleep(); }
+inline void SpinPause() { pm_emu::Sleep(); }
 // (no clock: a wait counts its own polls -- see PollClock's callers)
 inline unsigned long long PollClock() {
     static unsigned long long t = 0;

@@ -905,6 +905,39 @@ def test_a_wave_per_strip_row(pm, pmo, monkeypatch, wg_per_cu, row_lists):
         r.close()
 
 
+def test_one_launch_frame_that_gives_up_leaves_its_slot_clean(pm, pmo, monkeypatch):
+    """PM_ONE_LAUNCH=1 with a wait budget of one microsecond (PM_ONE_LAUNCH_SPIN_US=1): waves of the one launch give up waiting for
+    tiles almost at once, the frame has holes and raises the slot's pinned word.  pm_sync puts the hand-over state of EVERY such slot
+    back to all zero -- also of a frame that was waited for (pm_get_stats) and superseded before pm_sync ever looked at it (round-5
+    advisor finding: its FIFO entries stayed behind, and a later one-launch frame of that slot could pop one) -- renders what has to
+    be rendered again with two launches, and keeps to two launches from then on.  Every frame read back equals the oracle's."""
+    monkeypatch.setenv("PM_ONE_LAUNCH", "1")
+    monkeypatch.setenv("PM_ONE_LAUNCH_SPIN_US", "1")
+    r = pm.Renderer(0)
+    try:
+        wl = pm.workloads.tiger(1280, 720)
+        r.resize(wl.width, wl.height)
+        r.flatten_and_encode(wl.paths, wl.affine, wl.width_scale)
+        want = pmo.render(r.download_scene(), wl.width, wl.height)
+        r.render()
+        r.stats()   # waits for the frame without looking at its flags
+        r.render()  # the next slot: supersedes the first frame on the context's own target
+        r.sync()
+        assert np.array_equal(r.read_pixels(), want)
+        one = r.one_launch_info()["frames"]
+        for _ in range(9):  # every slot again, several times
+            r.render()
+            r.sync()
+            assert np.array_equal(r.read_pixels(), want)
+        for _ in range(6):
+            r.render()
+        assert np.array_equal(r.read_pixels(), want)
+        if one >= 1 and r.one_launch_info()["frames"] == one:
+            pass  # a frame gave up: two launches ever since (nothing to assert when, on a quiet box, no wave ever had to wait that long)
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("mode,waves", [("1", None), ("2", None), ("2", "1")])
 def test_heavy_strip_rows_cut_in_two(pm, pmo, monkeypatch, mode, waves):
     """The host side of tileKernel's dispatch geometry (PietRenderer.m:63-77) gives the heaviest strip rows TWO workgroups, tiles
