@@ -145,44 +145,31 @@ class Job:
 
     # ---- the product's own collective (pm_comm_* / pm_gather): id from rank 0 through the torch store ----
     def _setup_cabi(self):
-        self.comm, self.gather_impl = None, self.args.gather_impl
-        if self.gather_impl not in ("auto", "cabi"):
-            return
-        ok, why = 1, ""
-        # ncclCommInitRank is a collective: a rank that cannot even load RCCL must be found BEFORE the others
-        # enter it and wait for that rank (every rank makes an id -- which loads the library -- and they agree)
-        try:
-            self.pm.Comm.unique_id()
-        except Exception as e:  # noqa: BLE001
-            ok, why = 0, repr(e)
-        t = self.torch.tensor([ok], dtype=self.torch.int32, device=self.band.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        if int(t.item()) != 1:
-            if self.args.gather_impl == "cabi":
-                raise RuntimeError(f"--gather-impl cabi: RCCL cannot be loaded on some rank ({why or 'another rank'})")
-            if self.rank == 0:
-                print(f"bench.py: RCCL not loadable through the C ABI ({why or 'on another rank'}): falling back to torch.distributed send/recv", file=sys.stderr)
-            self.comm, self.gather_impl = None, "sendrecv"
-            return
-        try:
-            box = [self.pm.Comm.unique_id() if self.rank == 0 else None]
-            self.dist.broadcast_object_list(box, src=0)
-            self.comm = self.pm.Comm(self.r, box[0], self.rank, self.world)
+        """(the agreement itself: piet_metal_amd.dist.agree_on_c_abi_gather -- every rank ends with one answer, and the line is
+        printed either way; tests/test_dist_cpu.py runs it across three processes with a RCCL whose ncclCommInitRank fails)"""
+        torch, dist = self.torch, self.dist
+
+        def all_min(v):
+            t = torch.tensor([v], dtype=torch.int32, device=self.band.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t.item())
+
+        def broadcast_id(make_id):
+            box = [make_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        def try_exchange(comm):
             self.r.render_to(self.band, self.stream)
-            self.comm.gather(self.layout, root=0, full=self.full, band=self.band, stream=self.stream)  # one exchange: it works or it does not
-            self.torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001 -- any failure means: not on this stack
-            ok, why = 0, repr(e)
-        t = self.torch.tensor([ok], dtype=self.torch.int32, device=self.band.device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        if int(t.item()) == 1:
-            self.gather_impl = "cabi"
-            return
-        if self.args.gather_impl == "cabi":
-            raise RuntimeError(f"--gather-impl cabi: pm_comm_create / pm_gather failed on some rank ({why or 'another rank'})")
-        if self.rank == 0:
-            print(f"bench.py: pm_gather not usable here ({why or 'another rank failed'}): falling back to torch.distributed send/recv", file=sys.stderr)
-        self.comm, self.gather_impl = None, "sendrecv"
+            comm.gather(self.layout, root=0, full=self.full, band=self.band, stream=self.stream)  # one exchange: it works or it does not
+            torch.cuda.synchronize()
+
+        self.gather_impl, self.comm, why = self.pmd.agree_on_c_abi_gather(
+            self.args.gather_impl, self.world, self.pm.Comm.unique_id, broadcast_id,
+            lambda uid: self.pm.Comm(self.r, uid, self.rank, self.world), try_exchange, all_min)
+        self.gather_fallback = why
+        if why and self.rank == 0:
+            print(f"bench.py: pm_gather not usable here ({why}): falling back to torch.distributed send/recv", file=sys.stderr)
 
     # ---- the gather pipelined under the render (--gather-chunks K) ---------------------------
     def _setup_chunks(self):
@@ -197,13 +184,27 @@ class Job:
         torch = self.torch
         self.xstream = torch.cuda.Stream(device=self.band.device)
         r0 = self.layout[self.rank][0]
+        scene_bytes = None
         for lay in self.pmd.sub_band_layouts(self.layout, self.wl.height, k_req):
             s0, s1, srows = lay[self.rank]
             q = None
             if s1 > s0:
-                q = self.pm.Renderer(self.local)
+                # A sub-band's context is LEAN: nothing reserved up front (a context's reservations are for a whole frame: 4.4 GB;
+                # K of them would multiply a rank's memory by K -- these allocate what their band needs when it is first
+                # rendered), and it takes the scene the rank's own context flattened instead of flattening it again.
+                keep = os.environ.get("PM_PREALLOC")
+                os.environ["PM_PREALLOC"] = "0"
+                try:
+                    q = self.pm.Renderer(self.local)
+                finally:
+                    if keep is None:
+                        os.environ.pop("PM_PREALLOC", None)
+                    else:
+                        os.environ["PM_PREALLOC"] = keep
                 q.resize(self.wl.width, self.wl.height)
-                q.flatten_and_encode(self.wl.paths, self.wl.affine, self.wl.width_scale)
+                if scene_bytes is None:
+                    scene_bytes = self.r.download_scene()
+                q.set_scene_bytes(scene_bytes)
                 q.set_band(s0, s1)
             view = self.full[s0 * 16 : s0 * 16 + srows] if self.rank == 0 else self.band[(s0 - r0) * 16 : (s0 - r0) * 16 + srows]
             self.chunks.append((q, lay, view, torch.cuda.Event()))
@@ -564,6 +565,9 @@ def main() -> int:
                 "rccl_lib": rccl.get("rccl_lib"), "rccl_ranks": rccl.get("rccl_ranks"), **({"rccl_error": rccl["rccl_error"]} if "rccl_error" in rccl else {}),
                 "band_cuts": job.cuts, "balance": job.balance_log or None,
                 "t_render_ms": round(t_render, 5), "t_gather_ms": round(t_gather, 5), "t_frame_e2e_ms": round(t_frame_host, 5),
+                # (what t_gather cannot beat: the largest non-root band over one xGMI link at ~153 GB/s; launch latency comes on top)
+                "t_gather_wire_floor_ms": None if world == 1 else round(pmd.gather_wire_floor_ms(job.layout, W, world), 5),
+                **({"gather_fallback": job.gather_fallback} if world > 1 and getattr(job, "gather_fallback", "") else {}),
                 "queued_tiles_rank0": st["queued_tiles"], "precondition_steps": precondition,
             },
             "scene": {
@@ -658,6 +662,7 @@ def config5_block(pm, pmd, torch, dist, r, rank, world, local, args):
         "items": job.n_items, "scene_bytes": job.scene_bytes, "band_cuts": job.cuts,
         "value": round(px / (t_frame * 1e-3) / 1e6, 1), "t_frame_ms": round(t_frame, 4),
         "t_render_ms": round(t_render, 4), "t_gather_ms": round(t_gather, 4), "t_frame_e2e_ms": round(t_e2e, 4),
+        "t_gather_wire_floor_ms": None if world == 1 else round(pmd.gather_wire_floor_ms(job.layout, job.wl.width, world), 4),
         "sustained_mpix_s": round(px / (elapsed / steps) / 1e6, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
         "frac_frame": round(b_alg / world / (t_render * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         "gather_GBs_into_root": None if world == 1 or t_gather <= 0 else round(4 * px * (world - 1) / world / (t_gather * 1e-3) / 1e9, 1),

@@ -169,3 +169,49 @@ def gather_framebuffer(band, height: int, dst: int = 0, full=None):
 
     world = dist.get_world_size() if dist.is_initialized() else 1
     return gather_bands(band, band_layout(height, world), height, dst=dst, full=full)
+
+
+def agree_on_c_abi_gather(requested: str, world: int, make_id, broadcast_id, make_comm, try_exchange, all_min):
+    """Which exchange every rank of a job uses for the band gather: the product's own collective behind the C ABI
+    (pm_comm_create / pm_gather, "cabi") or torch.distributed's grouped send/recv ("sendrecv") -- decided so that a job ALWAYS ends
+    with one answer on every rank, whatever fails where (bench.py prints its line either way):
+
+      1. every rank loads RCCL (make_id() makes an id, which binds the library); the ranks agree (all_min) that all could --
+         ncclCommInitRank is a collective, a rank that cannot even load the library must be found before the others enter it;
+      2. rank 0's id travels (broadcast_id), every rank creates its communicator (make_comm(id)) and runs ONE exchange
+         (try_exchange(comm)); the ranks agree that all of that worked everywhere.
+
+    requested: "auto" (fall back to "sendrecv" when a step fails anywhere), "cabi" (raise instead), anything else is returned as is.
+    Returns (impl, comm or None, why) -- why: the first failure this rank saw, "" if none."""
+    if requested not in ("auto", "cabi"):
+        return requested, None, ""
+    ok, why, comm = 1, "", None
+    try:
+        make_id()
+    except Exception as e:  # noqa: BLE001
+        ok, why = 0, repr(e)
+    if all_min(ok) != 1:
+        if requested == "cabi":
+            raise RuntimeError(f"--gather-impl cabi: RCCL cannot be loaded on some rank ({why or 'another rank'})")
+        return "sendrecv", None, why or "RCCL not loadable on another rank"
+    try:
+        uid = broadcast_id(make_id)
+        comm = make_comm(uid)
+        try_exchange(comm)
+    except Exception as e:  # noqa: BLE001 -- any failure means: not on this stack
+        ok, why = 0, repr(e)
+    if all_min(ok) == 1:
+        return "cabi", comm, ""
+    if requested == "cabi":
+        raise RuntimeError(f"--gather-impl cabi: pm_comm_create / pm_gather failed on some rank ({why or 'another rank'})")
+    return "sendrecv", None, why or "pm_comm_create / pm_gather failed on another rank"
+
+
+def gather_wire_floor_ms(layout, width: int, world: int, link_gbs: float = 153.0) -> float:
+    """What the band gather cannot beat on one MI355X node: every non-root band travels into the root over its own xGMI link
+    (point to point, ~153 GB/s each, seven links per GPU), so the exchange takes at least the LARGEST non-root band's bytes over one
+    link -- launch and protocol latencies (tens of microseconds) come on top."""
+    if world <= 1:
+        return 0.0
+    worst = max((rows for k, (_r0, _r1, rows) in enumerate(layout) if k != 0), default=0)
+    return worst * width * 4 / (link_gbs * 1e9) * 1e3

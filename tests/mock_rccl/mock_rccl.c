@@ -42,6 +42,12 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id) {
 
 ncclResult_t ncclCommInitRank(ncclComm_t *comm, int world, ncclUniqueId id, int rank) {
     if (world < 1 || world > 64 || rank < 0 || rank >= world) return 4;
+    /* fault injection (tests/test_dist_cpu.py): PM_MOCK_RCCL_FAIL_INIT = "all", or one rank -- the id has travelled, the library is
+     * loaded, and the communicator cannot be made (ncclSystemError): what a job must survive with ONE answer on every rank */
+    {
+        const char *f = getenv("PM_MOCK_RCCL_FAIL_INIT");
+        if (f && *f && (strcmp(f, "all") == 0 || atoi(f) == rank)) return 2;
+    }
     struct mock_comm *c = (struct mock_comm *)calloc(1, sizeof(*c));
     if (!c) return 2;
     c->rank = rank;

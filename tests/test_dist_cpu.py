@@ -136,3 +136,50 @@ def test_c_abi_gather_across_processes_with_a_mock_rccl(built, tmp_path, world, 
     assert np.array_equal(np.load(box / "full_b.npy"), want)
     assert np.array_equal(np.load(box / "full_c.npy"), want), "four sub-bands per rank, one communicator (bench.py --gather-chunks)"
     assert not [f for f in os.listdir(box) if f.startswith("msg_")], "every message was consumed"
+
+
+@pytest.mark.parametrize("fail,requested", [("all", "auto"), ("1", "auto"), ("", "auto"), ("all", "cabi")])
+def test_a_job_agrees_on_one_gather_when_rccl_cannot_make_a_communicator(built, tmp_path, fail, requested):
+    """bench.py --gpus N must print a complete line whatever the node's RCCL does (the first real N > 1 run is the driver's): the ranks
+    exchange rank 0's id, and THEN ncclCommInitRank fails -- everywhere, or on one rank of three -- in the mock RCCL
+    (PM_MOCK_RCCL_FAIL_INIT).  Every rank ends with the same answer (piet_metal_amd.dist.agree_on_c_abi_gather, the function bench.py
+    calls): "sendrecv" and the reason with --gather-impl auto, an error that names the cause with --gather-impl cabi, "cabi" and a
+    gathered frame equal to the oracle's when nothing fails.  Three processes over gloo, the CPU emulation as the library."""
+    import json
+    import socket
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the real RCCL is bound there")
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "tests", "emu")])
+    shim = str(tmp_path / "libmock_rccl.so")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-shared", "-fPIC", "-Wall", "-Wextra", "-o", shim, os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.c")])
+    box = tmp_path / "box"
+    box.mkdir()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    world = 3
+    env = dict(os.environ, PM_RCCL_LIB=shim, PM_MOCK_RCCL_DIR=str(box), PM_WARMUP="0", PM_MOCK_RCCL_FAIL_INIT=fail)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "cabi_agree_worker.py"), str(k), str(world), port, requested],
+                              env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(world)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    lines = []
+    for k, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {k}: {outs[k][1][-2000:]}"
+        lines.append(json.loads(outs[k][0].strip().splitlines()[-1]))  # a valid JSON line from every rank
+    if requested == "cabi":
+        assert all("error" in ln and "pm_comm_create" in ln["error"] for ln in lines), lines
+        return
+    impls = {ln["config"]["gather_impl"] for ln in lines}
+    assert impls == ({"cabi"} if fail == "" else {"sendrecv"}), lines
+    if fail == "":
+        assert all(ln["gathered_frame_equals_oracle"] for ln in lines) and not any("gather_fallback" in ln["config"] for ln in lines)
+    else:
+        assert all(ln["config"]["gather_fallback"] for ln in lines), lines
+        failed = [ln for ln in lines if "ncclCommInitRank" in ln["config"]["gather_fallback"]]
+        assert len(failed) == (world if fail == "all" else 1), lines  # the ranks whose communicator failed say so; the others name their own
+        # failed exchange (a peer that never posted its send) or "another rank"
+    assert all(ln["config"]["t_gather_wire_floor_ms"] > 0 for ln in lines)
