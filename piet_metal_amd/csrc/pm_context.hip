@@ -869,15 +869,13 @@ int EnsureArena(pm_ctx *c) {
         // the strip rows without a workgroup: the binning launch (clear_in_bin) or a one-launch frame writes their (background) pixels from this list
         std::vector<uint32_t> &idle = c->stage_idle;
         idle.clear();
-        size_t k = 0;
-        for (size_t i = 0; i < need.size() && (c->one_grid_rows != 0 || c->fold_clear_mode >= 3); ++i) {
-            const uint32_t key = static_cast<uint32_t>(i % c->strips_x) | (static_cast<uint32_t>(i / c->strips_x) << 16);
-            if (k < desc.size() && (desc[k].x & 0xffff00ffu) == key) {  // (the empty list's one workgroup "has" strip row 0)
-                while (k < desc.size() && (desc[k].x & 0xffff00ffu) == key) ++k;  // (a strip row cut in two: both entries)
-                continue;
-            }
-            idle.push_back(static_cast<uint32_t>(i));
+        std::vector<uint8_t> listed(need.size(), 0);  // (the empty list's one workgroup "has" strip row 0; a strip row cut in two is listed twice)
+        for (const uint4 &d : desc) {
+            const size_t i = static_cast<size_t>(d.x >> 16) * c->strips_x + (d.x & 0xffu);
+            if (i < listed.size()) listed[i] = 1;
         }
+        for (size_t i = 0; i < need.size() && (c->one_grid_rows != 0 || c->fold_clear_mode >= 3); ++i)
+            if (!listed[i]) idle.push_back(static_cast<uint32_t>(i));
         c->n_idle_sr = static_cast<uint32_t>(idle.size());
         if (idle.size() > c->idle_sr_cap || !c->d_idle_sr) {
             if (c->d_idle_sr) (void)hipFree(c->d_idle_sr);
