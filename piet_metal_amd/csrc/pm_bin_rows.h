@@ -254,6 +254,7 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
     auto uniform_f = [](int v) { return __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__float_as_uint(static_cast<float>(v)))))); };
     // (the x extent of this entry's run of tiles: what boxes are culled against; the reference's own predicates keep the strip's sx0)
     const float fsx0 = uniform_f(sx0 + static_cast<int>(t_beg * kTileW)), fsx1 = uniform_f(sx0 + static_cast<int>((t_beg + t_cnt) * kTileW));
+    const float fstrip0 = uniform_f(sx0), fstrip1 = uniform_f(sx0 + static_cast<int>(kGroupW));  // (the whole strip's: the reference's votes)
     const float fy0 = uniform_f(y0), fy1 = uniform_f(y0 + static_cast<int>(kTileH));
     const float fsy0 = uniform_f(sy0), fsy1 = uniform_f(sy0 + static_cast<int>(kGroupH));
 
@@ -600,8 +601,9 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
                 WriteLane<t>(hub, static_cast<uint32_t>(__popcll(__ballot((cm >> t) & 1u))));
             });
             if (lane < kStripTiles) {
-                L.s_whub[wave][lane] = hub;
-                L.s_wcnt[wave][lane] = 0;
+                const uint32_t ol = Opaque(lane);  // (an address made here: hoisted out of the strip-row loop it is spilled)
+                L.s_whub[wave][ol] = hub;
+                L.s_wcnt[wave][ol] = 0;
             }
         }
         uint32_t total_sup;
@@ -812,12 +814,14 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
                     }
                     if (exists) {
                         seg = make_float4(a.x, a.y, b.x, b.y);
-                        vote = VoteFill(seg, y0, sx0);
+                        vote = VoteFillF(seg, fy0, fy1, fstrip0, fstrip1);
                     }
                 } else if (ctag_f == kItemPoly) {
                     seg = make_float4(a.x, a.y, b.x, b.y);
-                    const int y_test = sy0 + static_cast<int>(((k & 31u) >> 4) * kTileH);
-                    vote = VotePoly(seg, HalfWidthOf(L.s_caux0[vc]), y_test, sx0, sy0);
+                    // (the row of the lane that votes for this segment in the reference: lane = segment index & 31, row = lane >> 4, quirk Q4)
+                    const bool second_row = ((k & 31u) >> 4) != 0u;
+                    const float fyt0 = second_row ? fsy0 + static_cast<float>(kTileH) : fsy0;
+                    vote = VotePolyF(seg, HalfWidthOf(L.s_caux0[vc]), fyt0, fyt0 + static_cast<float>(kTileH), fstrip0, fstrip1, fsy0, fsy1);
                 } else if (ctag_f == kItemLine) {
                     seg = make_float4(a.x, a.y, b.x, b.y);
                     vote = true;
@@ -1022,9 +1026,10 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
                     v_lk = lane == j ? lk_q[j] : v_lk;
                     v_ls = lane == j ? ls_q[j] : v_ls;
                 }
-                L.s_wh[t0 + lane] = v_h;
-                L.s_wlk[t0 + lane] = v_lk;
-                L.s_wls[t0 + lane] = v_ls;
+                const uint32_t ol = t0 + Opaque(lane);
+                L.s_wh[ol] = v_h;
+                L.s_wlk[ol] = v_lk;
+                L.s_wls[ol] = v_ls;
             }
         }
         // the tail wave: where the pieces went

@@ -264,6 +264,52 @@ __device__ __forceinline__ bool VoteFill(float4 s, int y0, int sx0) {
     return hit;
 }
 
+// The same two votes with the strip row's edges handed in as FLOATS (wave-uniform, in SGPRs -- pm_bin_rows.h makes them once per strip
+// row): the int -> float conversions of VoteFill / VotePoly are vector instructions, the compiler hoists their results out of the
+// vote loop into VGPRs that live through the whole kernel, and under pressure it spills them -- a scratch reload (and its
+// `s_waitcnt vmcnt(0)`, which also waits for the next round's points and this round's stores) in the middle of every vote.
+// fsx0 / fsx1: the STRIP's x extent (sx0, sx0 + kGroupW), fy0 / fy1: the tile row's y extent.  Same expressions, same values.
+__device__ __forceinline__ bool VoteFillF(float4 s, float fy0, float fy1, float fsx0, float fsx1) {
+    const float xmin = fminf(s.x, s.z), ymin = fminf(s.y, s.w);
+    const float xmax = fmaxf(s.x, s.z), ymax = fmaxf(s.y, s.w);
+    if (!(ymax >= fy0 && ymin < fy1 && xmin < fsx1)) return false;
+    const float a = s.w - s.y;
+    const float b = s.x - s.z;
+    const float c = -(a * s.x + b * s.y);
+    const float left = a * fsx0;
+    const float right = a * fsx1;
+    const float ytop = fmaxf(fy0, ymin);
+    const float ybot = fminf(fy1, ymax);
+    const float top = b * ytop;
+    const float bot = b * ybot;
+    const float s_top_left = Sgn(right - a * static_cast<float>(kTileW) + fy0 * b + c);
+    const float s00 = Sgn(top + left + c);
+    const float s01 = Sgn(top + right + c);
+    const float s10 = Sgn(bot + left + c);
+    const float s11 = Sgn(bot + right + c);
+    bool hit = (s_top_left == Sgn(a)) && (ymin <= fy0);
+    if (Straddles(s00, s01, s10, s11) && xmax > fsx0) hit = true;
+    return hit;
+}
+// fyt0 / fyt1: y extent of the row the voting lane tests with (y_test, y_test + kTileH: quirk Q4), fsy0 / fsy1: the group's (sy0, sy0 + kGroupH)
+__device__ __forceinline__ bool VotePolyF(float4 s, float hw, float fyt0, float fyt1, float fsx0, float fsx1, float fsy0, float fsy1) {
+    const float xmin = fminf(s.x, s.z), ymin = fminf(s.y, s.w);
+    const float xmax = fmaxf(s.x, s.z), ymax = fmaxf(s.y, s.w);
+    if (!(ymax > fsy0 - hw && ymin < fsy1 + hw && xmax > fsx0 - hw && xmin < fsx1 + hw)) return false;
+    const float a = s.w - s.y;
+    const float b = s.x - s.z;
+    const float c = -(a * s.x + b * s.y);
+    const float left = a * (fsx0 - hw);
+    const float right = a * (fsx1 + hw);
+    const float top = b * (fyt0 - hw);
+    const float bot = b * (fyt1 + hw);
+    const float s00 = Sgn(top + left + c);
+    const float s01 = Sgn(top + right + c);
+    const float s10 = Sgn(bot + left + c);
+    const float s11 = Sgn(bot + right + c);
+    return Straddles(s00, s01, s10, s11);
+}
+
 // End points of segment k of a Fill item (pts = its point array, npt entries).  Plain (the
 // reference, PietRender.metal:262-263): point k to point k + 1, the last one back to point 0.
 // Compound (extension D11, pm_layout.h): NaN entries separate sub-paths and start no segment

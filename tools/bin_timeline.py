@@ -52,6 +52,7 @@ for lo, hi in [(0, 8), (8, 12), (12, 20), (20, 30), (30, 45), (45, 1000)]:
     print(f"  WGs with {lo}-{hi} us: {m2.sum()} -> {dur[m2].sum():.0f} us total")
 print("round 0 of the segment stream (WGs with >= 512 elements in it):")
 big = (t[:, 6] >= 512) & (t[:, 10] > 0)
+if not big.any(): big = (t[:, 6] >= 192) & (t[:, 10] > 0)
 for nm, a, b in [("headers done -> round start", 2, 8), ("chunk tests + scan (round 0)", 8, 9), ("other rounds + survivor list + barrier", 9, 10), ("votes (all rounds)", 10, 3)]:
     d = (t[big, b] - t[big, a]) * us
     print(f"   {nm:28s} mean {d.mean():.2f} p90 {np.percentile(d, 90):.2f} max {d.max():.2f}")
@@ -70,3 +71,13 @@ sl = t[:, 6]
 for lo, hi in [(0, 64), (64, 128), (128, 256), (256, 512), (512, 1024), (1024, 2048), (2048, 1 << 30)]:
     m2 = (sl >= lo) & (sl < hi)
     if m2.any(): print(f"  rows with {lo}-{hi} slots: {m2.sum()}, dur mean {dur[m2].mean():.2f} max {dur[m2].max():.2f}; stream {((t[m2,3]-t[m2,2])*us).mean():.2f} finalise {((t[m2,4]-t[m2,3])*us).mean():.2f}")
+
+# the slowest rows' segment stream taken apart (first record): super-chunk tests, chunk tests + survivor list, votes
+slow = np.argsort(-dur)[:12]
+for i in slow:
+    if t[i, 10] > 0 and t[i, 8] > 0:
+        print(f"  slow WG {i}: slots {t[i,6]} dur {dur[i]:.1f} | to round 0 {(t[i,8]-t[i,2])*us:.2f} sup tests {(t[i,9]-t[i,8])*us:.2f} chunk rounds+list {(t[i,10]-t[i,9])*us:.2f} votes {(t[i,3]-t[i,10])*us:.2f} | cand pass {(t[i,12]-t[i,3])*us:.2f} entries {(t[i,13]-t[i,12])*us:.2f} scatter {(t[i,4]-t[i,13])*us:.2f} tail after {(end[i]-t[i,4])*us:.2f}")
+m2 = (t[:, 10] > 0) & (t[:, 8] > 0)
+for nm, a, b in (("to round 0", 2, 8), ("sup tests", 8, 9), ("chunk rounds + list", 9, 10), ("votes", 10, 3)):
+    d = (t[m2, b] - t[m2, a]) * us
+    print(f"  all rows: {nm:20s} mean {d.mean():.2f} p90 {np.percentile(d,90):.2f} max {d.max():.2f}")
