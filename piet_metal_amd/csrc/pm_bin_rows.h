@@ -770,7 +770,10 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
                     const uint32_t six = f / kChunkSegs;
                     // (two plain accesses, not a select of two pointers: that becomes a FLAT load, which waits on both counters)
                     uint32_t spk = Opaque(L.s_surv[min(six, kSurvLds - 1u)]);
-                    if (six >= kSurvLds) spk = PM_META(six * kChunkSegs);
+                    if (sbase > kSurvLds) {  // (uniform: only a record whose list went beyond LDS pays for the load's wait -- a vmcnt(0) that
+                                             //  would also wait for the previous round's stores)
+                        if (six >= kSurvLds) spk = PM_META(six * kChunkSegs);
+                    }
                     vc = spk >> 24;
                     k = (spk & 0xffffffu) * kChunkSegs + (f % kChunkSegs);
                     const uint32_t vtag = L.s_cmask[vc] >> 16;

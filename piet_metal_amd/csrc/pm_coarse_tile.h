@@ -533,8 +533,9 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
     }
     if (solid_color != 0) {
         // the tile is one opaque colour, bytes as stored: 64 lanes x 16 B = the whole tile
-        const uint32_t pxi = static_cast<uint32_t>(x0) + (lane & 3u) * 4u;
-        const uint32_t prow = lane >> 2;
+        const uint32_t ol = Opaque(lane);  // (made here: hoisted out of the tile loop these were spilled)
+        const uint32_t pxi = static_cast<uint32_t>(x0) + (ol & 3u) * 4u;
+        const uint32_t prow = ol >> 2;
         const uint32_t pyi = static_cast<uint32_t>(y0) + prow;
         if (pyi < P.height && pxi < P.width) {
             uint8_t *dst = P.fb + static_cast<size_t>(ty_rel * kTileH + prow) * P.fb_stride + static_cast<size_t>(pxi) * 4;

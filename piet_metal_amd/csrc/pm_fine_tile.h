@@ -347,7 +347,8 @@ template <typename Lds>
 __device__ __forceinline__ void InterpretSparse(Lds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t n, uint32_t x0, uint32_t y0,
                                                 PixelStateS &st) {
     const uint32_t lane = LaneId();
-    const uint32_t row = lane >> 2, g = lane & 3u;
+    const uint32_t ol = Opaque(lane);  // (row and column made from a lane number the compiler cannot see through: hoisted out of the tile loop they are spilled)
+    const uint32_t row = ol >> 2, g = ol & 3u;
     const float px0 = static_cast<float>(x0 + 4u * g), py = static_cast<float>(y0 + row);
     // Lane i keeps command i of the chunk in registers; the loop below picks the command's words out with v_readlane
     // into SCALAR registers.  (Read from LDS command by command, every command began with a round trip to the LDS --
@@ -493,7 +494,8 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const C
                                                 uint32_t x0, uint32_t y0, half2_t &sa01, half2_t &sa23, float (&df)[4]) {
     if (s >= e) return;
     const uint32_t lane = LaneId();
-    const uint32_t row = lane >> 2, g = lane & 3u;
+    const uint32_t ol = Opaque(lane);  // (row and column made from a lane number the compiler cannot see through: hoisted out of the tile loop they are spilled)
+    const uint32_t row = ol >> 2, g = ol & 3u;
     const float px0 = static_cast<float>(x0 + 4u * g), py = static_cast<float>(y0 + row);
     uint32_t fo = static_cast<uint32_t>(__popcll(fm & ((1ull << s) - 1ull)));
     const uint32_t flimit = static_cast<uint32_t>(__popcll(fm & (e >= 64u ? ~0ull : ((1ull << e) - 1ull))));
@@ -570,7 +572,7 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
         }
     }
     WaveSync();
-    const uint32_t r4 = lane >> 2, g = lane & 3u;
+    const uint32_t r4 = Opaque(lane) >> 2, g = Opaque(lane) & 3u;
     uint32_t k0 = 0;
     do {  // rounds of kAlphaSlots items
         const uint32_t kend = min(k0 + kAlphaSlots, nitems);
@@ -774,8 +776,11 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &
         }
         if (!as_workgroup) {
             // lane -> 4 pixels: x = x0 + 4 * (lane & 3) + k, row = lane / 4
-            const uint32_t pxi = x0 + (lane & 3u) * 4u;
-            const uint32_t prow = lane >> 2;
+            // (from a lane number the compiler cannot see through: `(lane & 3) * 4` hoisted out of the tile loop was SPILLED, and its
+            //  reload -- scratch_load + s_waitcnt vmcnt(0) -- made every tile begin by waiting for the previous tile's pixel stores)
+            const uint32_t ol = Opaque(lane);
+            const uint32_t pxi = x0 + (ol & 3u) * 4u;
+            const uint32_t prow = ol >> 2;
             const uint32_t pyi = y0 + prow;
             Cmd *const cmds = S.w[wave].cmds;
             PixelStateS st;

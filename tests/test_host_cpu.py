@@ -995,7 +995,7 @@ def test_profile_stamp_digest_ignores_comments_but_not_code(tmp_path):
     assert stamp["_kernel_sources_sha16"] == mt.kernel_sources_sha16(), "profiles/hbm_traffic.json is older than the kernel sources: re-run tools/prof_round.sh"
 
 
-def test_the_binning_kernels_do_not_spill(tmp_path):
+def test_the_frame_path_kernels_do_not_spill(tmp_path):
     """pm_bin_kernel<false, 4> -- the frame path's binning kernel -- must fit its 96 VGPRs without scratch: a spilled value is reloaded
     with `s_waitcnt vmcnt(0)`, which also waits for the loads the vote loop keeps in flight for its next round and for its stores
     (round 6: three spills crept in with new code and cost every strip row's votes their software pipelining -- unnoticed for
@@ -1010,16 +1010,23 @@ def test_the_binning_kernels_do_not_spill(tmp_path):
     src = os.path.join(ROOT, "piet_metal_amd", "csrc")
     mk = open(os.path.join(src, "Makefile")).read()
     flags = re.search(r"^HIPFLAGS := (.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").replace("$(HERE)", src + "/").replace("$(EXTRA)", "").split()
-    out = str(tmp_path / "pm_bin.s")
-    subprocess.check_call([hipcc, *flags, "-S", "--cuda-device-only", os.path.join(src, "pm_bin.hip"), "-o", out], stderr=subprocess.DEVNULL)
-    text = open(out).read()
-    found = 0
-    for m in re.finditer(r"^\s*\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.M | re.S):
-        name, body = m.group(1), m.group(2)
-        if "pm_bin_kernelILb0ELi4E" not in name and "pm_bin_kernelILb1ELi4E" not in name:
-            continue
-        found += 1
-        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
-        vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
-        assert scratch == 0 and vgpr <= 96, (name, scratch, vgpr)
-    assert found == 2
+    # (kernel name fragment -> VGPR budget: five workgroups per CU, six for the one-wave tile kernel)
+    want = {"pm_bin.hip": {"pm_bin_kernelILb0ELi4E": 96, "pm_bin_kernelILb1ELi4E": 96},
+            # ... and the tile kernels of the frame path (general, one-wave, profiled): a reload at the top of a tile waits for the previous
+            # tile's pixel stores -- the frame path's general kernel carried three such spills for two rounds
+            "pm_fine.hip": {"pm_fine_kernelILb1ELb0ELb0ELb0E": 96, "pm_fine_kernelILb1ELb0ELb0ELb1E": 80, "pm_fine_kernelILb1ELb1ELb0ELb0E": 96}}
+    for unit, kernels in want.items():
+        out = str(tmp_path / (unit + ".s"))
+        subprocess.check_call([hipcc, *flags, "-S", "--cuda-device-only", os.path.join(src, unit), "-o", out], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+        found = 0
+        for m in re.finditer(r"^\s*\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.M | re.S):
+            name, body = m.group(1), m.group(2)
+            budget = next((v for k, v in kernels.items() if k in name), None)
+            if budget is None:
+                continue
+            found += 1
+            scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body).group(1))
+            vgpr = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", body).group(1))
+            assert scratch == 0 and vgpr <= budget, (name, scratch, vgpr)
+        assert found == len(kernels), unit
