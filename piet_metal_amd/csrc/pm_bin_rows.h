@@ -747,7 +747,11 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
         //      later places follows slot = paint order); each lane votes one segment (phase 1), writes
         //      its slot's meta word (0 = no vote) and, if voted, the segment -------------------------------
         const uint32_t q_share = ((n_slots + kBinWaves * 64u - 1u) / (kBinWaves * 64u)) * 64u;  // slots per wave, a multiple of 64 (equal shares of whole chunks: measured no better)
-        const uint32_t w_lo = min(n_slots, wave * q_share), w_hi = min(n_slots, w_lo + q_share);
+        // (as scalars: `wave` is tid >> 6 to the compiler, not provably uniform -- the vote loop's control was vector compares and exec
+        //  masks, and the wait for the next round's points sat in front of the loop's exit test: also behind the LAST round, where it
+        //  only waits for that round's stores)
+        const uint32_t wave_s = kW == 1 ? 0u : WaveId();
+        const uint32_t w_lo = __builtin_amdgcn_readfirstlane(min(n_slots, wave_s * q_share)), w_hi = __builtin_amdgcn_readfirstlane(min(n_slots, w_lo + q_share));
         // A wave's FIRST 64 slots never leave its registers (round 6): nine strip rows in ten of a 4K Tiger frame have at most 64
         // slots per wave, and their segments used to go to the binning arena and straight back -- two stores per lane in the vote
         // round, and in front of the scatter a read-back that waited for those stores' acknowledgements (vector memory completes
@@ -799,7 +803,7 @@ __device__ __forceinline__ void BinStripRows(const FrameParams &P, BinLds<kW, kP
                 const uint32_t f = f0 + lane;
                 const uint32_t vc = vc_n, k = k_n, ctag_f = ctag_n;
                 float2 a = a_n, b = b_n;
-                fetch(f + 64u, vc_n, k_n, ctag_n, a_n, b_n);
+                if (f0 + 64u < w_hi) fetch(f + 64u, vc_n, k_n, ctag_n, a_n, b_n);  // (uniform: the last round requests nothing and waits for nothing)
                 // (survivors beyond the LDS list are read from the first meta word of their chunk: every lane
                 //  has done so before the chunk's first lane overwrites it below -- in lockstep on the GPU
                 //  anyway; the statement keeps a lane-by-lane execution of this source honest)
