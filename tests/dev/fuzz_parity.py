@@ -29,7 +29,8 @@ def main():
         scene = encode_ops(pm, ops, cap=8 << 20)
         r.resize(w, h)
         r.set_scene_bytes(scene)
-        for _ in range(int(rng.integers(1, 4))):
+        frames = int(rng.integers(1, 4))
+        for _ in range(int(os.environ.get("PM_FUZZ_FRAMES", "0")) or frames):  # (PM_FUZZ_FRAMES=5: past the frame at which a plan is remade from the frames' report)
             r.render()
         got = r.read_pixels()
         want = pmo.render(scene, w, h)

@@ -32,6 +32,9 @@ fuzz)
     echo "== product build, one launch per frame on a quarter grid (chains of strip rows), extensions"; PM_ONE_LAUNCH=1 PM_FRAME_WG_PER_CU=1 timeout 3000 python tests/dev/fuzz_parity.py $((S+60000)) $N --ext 2>&1 | tail -1
     echo "== product build, a wave per strip row, one workgroup per CU"; PM_BIN_WAVES=1 PM_BIN_WG_PER_CU=1 timeout 3000 python tests/dev/fuzz_parity.py $((S+70000)) $N --ext 2>&1 | tail -1
     echo "== product build, row lists in parts of 13 items, every frame behind a scene's first on the one-wave tile kernel, extensions"; PM_ROW_LIST_MIN_ITEMS=1 PM_ROW_LIST_PART_ITEMS=13 PM_DENSE_FACTOR=100000 timeout 3000 python tests/dev/fuzz_parity.py $((S+90000)) $N --ext 2>&1 | tail -1
+    echo "== product build, every strip row cut in two, clearing inside the binning launch, extensions"; PM_BIN_SPLIT=2 PM_FOLD_CLEAR=4 timeout 3000 python tests/dev/fuzz_parity.py $((S+110000)) $N --ext 2>&1 | tail -1
+    echo "== strict build, every strip row cut in two, a wave per strip row, clearing inside the binning launch"; PM_BIN_SPLIT=2 PM_BIN_WAVES=1 PM_FOLD_CLEAR=4 PM_LIB_VARIANT=strict timeout 3000 python tests/dev/fuzz_parity.py $((S+120000)) $N 2>&1 | tail -1
+    echo "== product build, five frames per scene, strip rows of 24 slots and more cut by the frames' own report"; PM_FUZZ_FRAMES=5 PM_BIN_SPLIT_SLOTS=24 timeout 3000 python tests/dev/fuzz_parity.py $((S+130000)) $N --ext 2>&1 | tail -1
     echo "== product build, flatten, block-parallel sums above 64 elements"; PM_SCAN_SPLIT=64 timeout 1200 python tests/dev/fuzz_flatten.py $((S+100000)) 300 2>&1 | tail -1
     echo "== product build, flatten"; timeout 1200 python tests/dev/fuzz_flatten.py $((S+80000)) 300 2>&1 | tail -1
   } > gpurun_out/fuzz.log 2>&1; cat gpurun_out/fuzz.log ;;
