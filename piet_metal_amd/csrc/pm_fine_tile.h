@@ -305,18 +305,20 @@ __device__ __forceinline__ void AddFillRun(const WaveFineLds &W, const Cmd *cmds
         uint32_t hdr[4];  // row mask | first fragment << 16 (pass 1)
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) hdr[k] = (r + k < run) ? cmds[i + r + k].body[0] : 0u;
+        // (no branch on the row's bit: every lane reads a slot -- its own row's if it has one, some slot of the region if not --
+        //  and the sums are SELECTED.  A divergent branch anywhere in the command loop makes the compiler route the whole
+        //  dispatch through flow blocks that copy the pixel state, see InterpretSparse)
         uint2 v[4];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            v[k] = make_uint2(0u, 0u);
-            if ((hdr[k] >> row) & 1u) v[k] = W.contrib[(hdr[k] >> 16) + static_cast<uint32_t>(__popc(hdr[k] & below))][g];
-        }
-#pragma unroll
         for (uint32_t k = 0; k < 4u; ++k)
-            if ((hdr[k] >> row) & 1u) {
-                sa01 = sa01 + Half2FromBits(v[k].x);
-                sa23 = sa23 + Half2FromBits(v[k].y);
-            }
+            v[k] = W.contrib[((hdr[k] >> 16) + static_cast<uint32_t>(__popc(hdr[k] & below))) & (kMaxFrag - 1u)][g];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const bool on = ((hdr[k] >> row) & 1u) != 0u;
+            const half2_t n01 = sa01 + Half2FromBits(v[k].x), n23 = sa23 + Half2FromBits(v[k].y);
+            sa01 = on ? n01 : sa01;
+            sa23 = on ? n23 : sa23;
+        }
     }
 }
 
@@ -363,10 +365,20 @@ __device__ __forceinline__ void InterpretSparse(Lds &S, Cmd *cmds, const uint8_t
     if (isf) const_cast<uint8_t *>(fill_ix)[RankBelow(fm)] = static_cast<uint8_t>(lane);
     const uint32_t nfill = static_cast<uint32_t>(__popcll(fm));
     WaveSync();
-    uint32_t fo = 0, prepared = 0;
     // the chunk's Solid commands: runs of them (a tile inside several translucent shapes) are blended without the dispatch
     const uint64_t sm = __ballot(mine.tag == kCmdSolid);
-    for (uint32_t i = 0; i < n; ++i) {
+    // The command loop proper has NO divergent branch in it: with one anywhere inside, the compiler structurizes the whole
+    // dispatch -- every node of the switch becomes a flow block that copies the pixel state (a dozen v_mov per command
+    // and a vmcnt(0) wait in the dense kernel's listing).  So the fragments of the chunk's Fills (divergent code) are
+    // made OUTSIDE it, for as many Fills as the fragment region takes, and the loop runs up to the first Fill they do not cover.
+    uint32_t fo = 0, i = 0;
+    while (i < n) {
+    uint32_t stop = n;
+    if (fo < nfill) {
+        const uint32_t prepared = PrepareFills(S, cmds, fill_ix, nfill, fo, x0, y0);  // > fo, uniform
+        if (prepared < nfill) stop = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(fill_ix[prepared])));
+    }
+    for (; i < stop; ++i) {
         auto word = [&](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(i))); };
         switch (word(mine.tag)) {
             case kCmdCircle: {
@@ -420,8 +432,7 @@ __device__ __forceinline__ void InterpretSparse(Lds &S, Cmd *cmds, const uint8_t
                 break;
             }
             case kCmdFill: {
-                if (fo >= prepared) prepared = PrepareFills(S, cmds, fill_ix, nfill, fo, x0, y0);  // uniform
-                const uint32_t run = min(FillRunLength(fm, i), prepared - fo);  // >= 1
+                const uint32_t run = min(FillRunLength(fm, i), stop - i);  // >= 1, all of them prepared
                 AddFillRun(S.w[WaveId()].f, cmds, i, run, row, g, st.sa01, st.sa23);
                 fo += run;
                 i += run - 1u;
@@ -464,6 +475,7 @@ __device__ __forceinline__ void InterpretSparse(Lds &S, Cmd *cmds, const uint8_t
             default:
                 break;
         }
+    }
     }
 }
 
