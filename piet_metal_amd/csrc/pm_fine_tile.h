@@ -511,14 +511,20 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const C
     const float px0 = static_cast<float>(x0 + 4u * g), py = static_cast<float>(y0 + row);
     uint32_t fo = static_cast<uint32_t>(__popcll(fm & ((1ull << s) - 1ull)));
     const uint32_t flimit = static_cast<uint32_t>(__popcll(fm & (e >= 64u ? ~0ull : ((1ull << e) - 1ull))));
-    uint32_t prepared = fo;
+    // (as in InterpretSparse: the fragments are made outside the command loop, which has no divergent branch in it)
+    uint32_t i = s;
+    while (i < e) {
+    uint32_t stop = e;
+    if (fo < flimit) {
+        const uint32_t prepared = PrepareFills(S, cmds, fill_ix, flimit, fo, x0, y0);  // > fo, uniform
+        if (prepared < flimit) stop = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(fill_ix[prepared])));
+    }
 #pragma unroll 1
-    for (uint32_t i = s; i < e; ++i) {
+    for (; i < stop; ++i) {
         auto word = [&](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(i))); };
         const uint32_t tag = word(mine.tag);
         if (tag == kCmdFill) {
-            if (fo >= prepared) prepared = PrepareFills(S, cmds, fill_ix, flimit, fo, x0, y0);  // uniform
-            const uint32_t run = min(min(FillRunLength(fm, i), e - i), prepared - fo);  // >= 1
+            const uint32_t run = min(FillRunLength(fm, i), stop - i);  // >= 1, all of them prepared
             AddFillRun(S.w[WaveId()].f, cmds, i, run, row, g, sa01, sa23);
             fo += run;
             i += run - 1u;
@@ -544,6 +550,7 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const C
                 df[k] = fminf(df[k], fx * fx + fy * fy);  // (squared: see FarAway)
             }
         }
+    }
     }
 }
 
