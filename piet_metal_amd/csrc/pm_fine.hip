@@ -140,7 +140,9 @@ __global__ __launch_bounds__(kThreads, kDense ? 6 : 5) void pm_fine_kernel(Frame
         PhaseTicks prof;
         CoarseTicks ct;
         if (kProf) t_begin = wall_clock64();
-        const uint32_t n_cmd = RenderQueuedTile<kFused, kProf, kCapture, false>(P, S, cur, wg_mode, cur_slot, pass, lane, wave, lanes_below, next_card, prof, ct);
+        // (a wave for every queued tile: the workgroup tiles make their chunks' fragments together, RenderChunkWG)
+        const uint32_t n_cmd = RenderQueuedTile<kFused, kProf, kCapture, false>(P, S, cur, wg_mode, cur_slot, pass, lane, wave, lanes_below, next_card, prof, ct,
+                                                                                n_slots <= n_waves);
         if (kProf && lane == 0) {
             unsigned long long *d = P.dbg_time + 12ull * cur_slot;
             d[0] = t_begin;

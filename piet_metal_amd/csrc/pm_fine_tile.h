@@ -134,6 +134,7 @@ struct SparseLds {
     uint2 carry_sa[2][64];                // signedArea / distance state of an item cut by the chunk boundary
     float4 carry_df[2][64];               //   (two copies, alternating per chunk)
     uint32_t wg_ncmd[2];                  // fused kernel: list length found by wave 0 (alternating per pass)
+    uint32_t prep_over[2];                // per chunk (alternating): a wave's share of the chunk's Fill commands did not fit its fragment region
     CoarseShared coarse_shared;           // fused kernel: what the four waves exchange while they build a long list together
     uint32_t next_item;                   // next item of the round nobody has taken yet
     uint16_t item_se[kSpChunk + 1];       // per item: first command | blend command << 8 (last entry: the open tail)
@@ -170,8 +171,10 @@ __device__ __forceinline__ _Float16 FillContribution(float fsx, float fex, float
 // One step of pass 1: the Fill commands [pos, pos + 4) of the chunk's Fill list (those below
 // `limit`) x 16 rows.  Live pairs get the next fragment slots of this wave's region; returns
 // false (and writes nothing) if the region cannot take them.
+// slot_base: what the staged commands call this region's first fragment slot (workgroup tiles number the four waves' regions through:
+// a command's fragments may have been made by another wave than the one that adds them up, see PrepareFillsShared).
 __device__ __forceinline__ bool FillStep(WaveFineLds &W, Cmd *cmds, const uint8_t *fill_ix, uint32_t limit, uint32_t pos,
-                                         uint32_t &nfrag, uint32_t y0) {
+                                         uint32_t &nfrag, uint32_t y0, uint32_t slot_base = 0) {
     const uint32_t lane = LaneId();
     const uint32_t q = lane >> 4, row = lane & 15u;
     const uint32_t fi = pos + q;
@@ -193,7 +196,7 @@ __device__ __forceinline__ bool FillStep(WaveFineLds &W, Cmd *cmds, const uint8_
     if (row == 0 && valid) {
         const uint32_t gm = static_cast<uint32_t>(mask >> (16u * q)) & 0xffffu;
         const uint32_t gb = nfrag + static_cast<uint32_t>(__popcll(mask & ((1ull << (16u * q)) - 1ull)));
-        cmds[ci].body[0] = gm | (gb << 16);
+        cmds[ci].body[0] = gm | ((slot_base + gb) << 16);
     }
     nfrag += static_cast<uint32_t>(__popcll(mask));
     return true;
@@ -278,13 +281,13 @@ __device__ __forceinline__ void FillPass2(WaveFineLds &W, const Cmd *cmds, uint3
 // as the wave's fragment region takes.  Returns the ordinal of the first Fill NOT covered.
 template <typename Lds>
 __device__ __forceinline__ uint32_t PrepareFills(Lds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t nfill, uint32_t from,
-                                                 uint32_t x0, uint32_t y0) {
+                                                 uint32_t x0, uint32_t y0, uint32_t slot_base = 0) {
     WaveFineLds &W = S.w[WaveId()].f;
     uint32_t nfrag = 0;
     uint32_t pos = from;
 #pragma unroll 1
     while (pos < nfill) {  // (the first step always fits: it adds at most 64)
-        if (!FillStep(W, cmds, fill_ix, nfill, pos, nfrag, y0)) break;
+        if (!FillStep(W, cmds, fill_ix, nfill, pos, nfrag, y0, slot_base)) break;
         pos += 4u;
     }
     WaveSync();
@@ -297,6 +300,8 @@ __device__ __forceinline__ uint32_t PrepareFills(Lds &S, Cmd *cmds, const uint8_
 // done): pass 3 for the run.  The row masks of four commands are fetched together, then their
 // contributions, so that the LDS latencies overlap and no tag is dispatched inside the run; the
 // adds keep list order (binary16 addition is not associative).
+// kShared (workgroup tiles): W is wave 0's region and a slot number names the region too -- slot >> 6, sizeof(WaveLds) bytes apart.
+template <bool kShared = false>
 __device__ __forceinline__ void AddFillRun(const WaveFineLds &W, const Cmd *cmds, uint32_t i, uint32_t run, uint32_t row, uint32_t g,
                                            half2_t &sa01, half2_t &sa23) {
     const uint32_t below = (1u << row) - 1u;
@@ -310,8 +315,15 @@ __device__ __forceinline__ void AddFillRun(const WaveFineLds &W, const Cmd *cmds
         //  dispatch through flow blocks that copy the pixel state, see InterpretSparse)
         uint2 v[4];
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k)
-            v[k] = W.contrib[((hdr[k] >> 16) + static_cast<uint32_t>(__popc(hdr[k] & below))) & (kMaxFrag - 1u)][g];
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t slot = (hdr[k] >> 16) + static_cast<uint32_t>(__popc(hdr[k] & below));
+            if constexpr (kShared) {
+                const uint8_t *region = reinterpret_cast<const uint8_t *>(&W) + ((slot >> 6) & static_cast<uint32_t>(kWaves - 1)) * static_cast<uint32_t>(sizeof(WaveLds));
+                v[k] = reinterpret_cast<const WaveFineLds *>(region)->contrib[slot & (kMaxFrag - 1u)][g];
+            } else {
+                v[k] = W.contrib[slot & (kMaxFrag - 1u)][g];
+            }
+        }
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) {
             const bool on = ((hdr[k] >> row) & 1u) != 0u;
@@ -502,8 +514,10 @@ struct PixelRGB {
 // Commands [s, e) of one item, whole tile per wave (lane -> row lane / 4, 4 pixels): Fill,
 // FillEdge and Line exactly as in InterpretSparse(); fm = the chunk's Fill commands.
 // mine = the chunk's commands, lane i holding command i (their words reach the loop through v_readlane).
+// shared: the fragments of all the chunk's Fill commands are there already (PrepareFillsShared); otherwise this wave makes those of
+// its item's, in its own region.
 __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const Cmd &mine, const uint8_t *fill_ix, uint64_t fm, uint32_t s, uint32_t e,
-                                                uint32_t x0, uint32_t y0, half2_t &sa01, half2_t &sa23, float (&df)[4]) {
+                                                uint32_t x0, uint32_t y0, half2_t &sa01, half2_t &sa23, float (&df)[4], const bool shared) {
     if (s >= e) return;
     const uint32_t lane = LaneId();
     const uint32_t ol = Opaque(lane);  // (row and column made from a lane number the compiler cannot see through: hoisted out of the tile loop they are spilled)
@@ -515,8 +529,8 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const C
     uint32_t i = s;
     while (i < e) {
     uint32_t stop = e;
-    if (fo < flimit) {
-        const uint32_t prepared = PrepareFills(S, cmds, fill_ix, flimit, fo, x0, y0);  // > fo, uniform
+    if (!shared && fo < flimit) {
+        const uint32_t prepared = PrepareFills(S, cmds, fill_ix, flimit, fo, x0, y0, WaveId() * kMaxFrag);  // > fo, uniform
         if (prepared < flimit) stop = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(fill_ix[prepared])));
     }
 #pragma unroll 1
@@ -525,7 +539,7 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const C
         const uint32_t tag = word(mine.tag);
         if (tag == kCmdFill) {
             const uint32_t run = min(FillRunLength(fm, i), stop - i);  // >= 1, all of them prepared
-            AddFillRun(S.w[WaveId()].f, cmds, i, run, row, g, sa01, sa23);
+            AddFillRun<true>(S.w[0].f, cmds, i, run, row, g, sa01, sa23);
             fo += run;
             i += run - 1u;
         } else if (tag == kCmdFillEdge) {
@@ -554,6 +568,30 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const C
     }
 }
 
+// Workgroup tiles: passes 1 and 2 for ALL the chunk's Fill commands, a quarter of them per wave (in steps of four commands), each wave
+// into its own fragment region, BEFORE the items are handed out.  An item is then pass 3 and its closing command only: the expensive
+// half of a Fill no longer depends on which wave happens to take which item (the 4K Tiger's longest list is 13 items of 10-18 commands:
+// four waves took 4, 3, 3 and 3 of them, and the launch waited for the four).  Returns false if this wave's share does not fit its
+// region (a chunk of near-vertical segments: 16 fragments per command) -- the workgroup then falls back to fragments per item.
+__device__ __forceinline__ bool PrepareFillsShared(SparseLds &S, Cmd *cmds, const uint8_t *fill_ix, uint32_t nfill, uint32_t x0, uint32_t y0) {
+    const uint32_t wave = WaveId();
+    WaveFineLds &W = S.w[wave].f;
+    const uint32_t per = ((nfill + 15u) >> 4) << 2;
+    const uint32_t from = min(wave * per, nfill), to = min(from + per, nfill);
+    uint32_t nfrag = 0;
+    bool fits = true;
+#pragma unroll 1
+    for (uint32_t pos = from; pos < to; pos += 4u) {
+        if (!FillStep(W, cmds, fill_ix, to, pos, nfrag, y0, wave * kMaxFrag)) {
+            fits = false;
+            break;
+        }
+    }
+    WaveSync();
+    if (nfrag != 0u) FillPass2(W, cmds, nfrag, x0);  // uniform
+    return fits;
+}
+
 struct PhaseTicks {
     unsigned long long a = 0, b = 0, c = 0, busy = 0;
 };
@@ -562,7 +600,7 @@ struct PhaseTicks {
 // pix = this lane's pixel in phase B (row * 16 + x).
 template <bool kProf>
 __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *fill_ix, uint32_t n, uint32_t parity, uint32_t x0,
-                                              uint32_t y0, uint32_t pix, PixelRGB &st, PhaseTicks &prof) {
+                                              uint32_t y0, uint32_t pix, PixelRGB &st, PhaseTicks &prof, const bool share_fills) {
     const uint32_t lane = LaneId(), wave = WaveId();
     Cmd mine;  // lane i: command i of the chunk
     mine.tag = 0;
@@ -591,6 +629,40 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
         }
     }
     WaveSync();
+    const uint32_t nfill = static_cast<uint32_t>(__popcll(fm));  // (the same in every wave)
+    // (only for a chunk without Line commands: a stroke's item is the longest thing in a chunk, the other waves made their items' fragments
+    //  behind it anyway -- a separate pass in front of the items then only adds to the wave that takes the stroke: 4K Tiger +0.6 us with it,
+    //  the fills-only Tiger -1.6 us)
+    // share_fills: the launch has a wave for every queued tile (pm_fine.hip).  On a full machine the pass's barrier waits for the slowest of
+    // four waves that share their SIMDs with sixteen others: measured +0.5 us on the 4K Tiger's frame, where the fills-only 1080p Tiger
+    // (2 655 tiles on 5 120 waves) is 1.3 us faster with it.
+    bool try_shared = share_fills && nfill >= 16u && __ballot(tag == kCmdLine) == 0ull;
+    if (try_shared) {
+        // ... and only if every wave's share will fit its region: the rows a Fill's segment can touch bound its fragments (a share that
+        // overflows costs the pass AND the fall-back: the Tiger's longest list, whiskers crossing all 16 rows, was slower with than without)
+        uint32_t rows = 0;
+        if (lane < nfill) {
+            const uint32_t ci = fill_ix[lane];
+            const float fy0 = static_cast<float>(y0);
+            const float ya = __uint_as_float(cmds[ci].body[2]) - fy0, yb = __uint_as_float(cmds[ci].body[4]) - fy0;
+            const float lo = fminf(fmaxf(floorf(fminf(ya, yb)), 0.0f), 16.0f), hi = fminf(fmaxf(floorf(fmaxf(ya, yb)) + 1.0f, 0.0f), 16.0f);
+            rows = (ya == ya && yb == yb) ? static_cast<uint32_t>(fmaxf(hi - lo, 0.0f)) : 16u;
+        }
+        const uint32_t incl = WaveInclusiveScan(rows);
+        const uint32_t per = ((nfill + 15u) >> 4) << 2;  // (PrepareFillsShared's shares)
+        uint32_t before = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < static_cast<uint32_t>(kWaves); ++q) {
+            const uint32_t end = min((q + 1u) * per, nfill);
+            const uint32_t upto = end ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), static_cast<int>(end - 1u))) : 0u;
+            if (upto - before > kMaxFrag) try_shared = false;
+            before = upto;
+        }
+    }
+    if (try_shared) {
+        const bool fits = PrepareFillsShared(S, cmds, fill_ix, nfill, x0, y0);
+        if (!fits && lane == 0) S.prep_over[parity] = 1u;  // (zeroed during the previous chunk, or before the tile's first barrier)
+    }
     const uint32_t r4 = Opaque(lane) >> 2, g = Opaque(lane) & 3u;
     uint32_t k0 = 0;
     do {  // rounds of kAlphaSlots items
@@ -599,7 +671,9 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
         const uint32_t limit = last_round ? nitems + 1u : kend;  // (the open tail goes with the last round)
         unsigned long long t_a = 0;
         if (kProf) t_a = wall_clock64();
-        __syncthreads();  // phase B of the previous round (or chunk) is done with the alpha images
+        __syncthreads();  // phase B of the previous round (or chunk) is done with the alpha images; every wave's fragments are in place
+        const bool shared = try_shared && S.prep_over[parity] == 0u;
+        if (k0 == 0 && wave == 0 && lane == 0) S.prep_over[parity ^ 1u] = 0u;  // the next chunk's (nobody touches it before this chunk's last barrier)
         // ---- phase A: every wave takes the next item nobody has taken --------------------------
 #pragma unroll 1
         for (;;) {
@@ -620,7 +694,7 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
                 sa01 = Half2FromBits(cs.x); sa23 = Half2FromBits(cs.y);
                 df[0] = cd.x; df[1] = cd.y; df[2] = cd.z; df[3] = cd.w;
             }
-            RunItemCommands(S, cmds, mine, fill_ix, fm, s0, e0, x0, y0, sa01, sa23, df);
+            RunItemCommands(S, cmds, mine, fill_ix, fm, s0, e0, x0, y0, sa01, sa23, df, shared);
             if (is_tail) {  // (also when the tail is empty: the next chunk starts from a clean state)
                 uint2 cs;
                 cs.x = __builtin_bit_cast(uint32_t, sa01); cs.y = __builtin_bit_cast(uint32_t, sa23);
@@ -699,7 +773,7 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
 template <bool kFused, bool kProf, bool kCapture, bool kCoh, typename Next, typename Lds>
 __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &S, const uint4 cur, const bool wg_mode_in, const uint32_t quarter,
                                                      const uint32_t parity, const uint32_t lane, const uint32_t wave, const uint64_t lanes_below,
-                                                     Next &&next_card, PhaseTicks &prof, CoarseTicks &ct) {
+                                                     Next &&next_card, PhaseTicks &prof, CoarseTicks &ct, const bool share_fills = false) {
     constexpr bool kWg = std::is_same<Lds, SparseLds>::value;
     const bool wg_mode = kWg && wg_mode_in;
     // linear -> sRGB + unorm8 (:563-565): the 65,536-entry table of decision D2.  (A compact
@@ -731,7 +805,10 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &
                                                   lds_stride, lds_n, shared);
         if constexpr (kWg) {
             if (wg_mode) {
-                if (wave == 0 && lane == 0) S.wg_ncmd[parity & 1u] = n_cmd;
+                if (wave == 0 && lane == 0) {
+                    S.wg_ncmd[parity & 1u] = n_cmd;
+                    S.prep_over[0] = 0u;  // (the first chunk's "a share of the Fills did not fit" flag)
+                }
                 __syncthreads();  // (workgroup-scope release/acquire: the list wave 0 wrote is visible)
                 n_cmd = S.wg_ncmd[parity & 1u];
             }
@@ -764,6 +841,7 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &
             if (wave == 0) {  // no item is open when a list starts
                 S.carry_sa[0][lane] = make_uint2(OpaqueZero(), OpaqueZero());
                 S.carry_df[0][lane] = make_float4(FarAway(), FarAway(), FarAway(), FarAway());
+                if (!kFused && lane == 0) S.prep_over[0] = 0u;  // (fused: zeroed before the barrier behind the list building)
             }
             uint32_t parity = 0;
             for (uint32_t c0 = 0; c0 < n_cmd; c0 += kSpChunk, parity ^= 1u) {
@@ -778,7 +856,7 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &
                     for (uint32_t w = threadIdx.x; w < 3u * m; w += kThreads) l[w] = g[w];
                     __syncthreads();
                 }
-                RenderChunkWG<kProf>(S, chunk, S.w[wave].f.fill_ix, m, parity, x0, y0, pix, s1, prof);
+                RenderChunkWG<kProf>(S, chunk, S.w[wave].f.fill_ix, m, parity, x0, y0, pix, s1, prof, share_fills);
             }
             __syncthreads();  // the other waves may still read this wave's alpha images
             __builtin_amdgcn_s_setprio(0);
