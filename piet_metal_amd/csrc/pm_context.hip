@@ -1796,32 +1796,38 @@ pm_ctx *pm_create(int device, int *err) {
         if (e == hipSuccess) e = hipMalloc(&c->d_band_bbox, 65536 * sizeof(uint2));
         if (e == hipSuccess) e = hipMalloc(&c->d_band_item, 65536 * sizeof(uint32_t));
         if (e == hipSuccess) c->band_cap = 65536;
-        {   // ... and frame slot 0's viewport buffers for anything up to 8192 x 8192 (BASELINE config 5: 256 MB of pixels, 42 MB of
-            // queues and per-tile tables -- a thousandth of the HBM): a resize within that allocates nothing
-            const size_t px = static_cast<size_t>(EnvInt("PM_PREALLOC_MPIXELS", 64, 0, 4096)) << 20;
-            const size_t tables = std::max<size_t>(px / (pm::kTileW * pm::kTileH), 4);
-            if (e == hipSuccess && px != 0) e = hipMalloc(&c->slot[0].d_fb, px * 4);
-            if (e == hipSuccess && px != 0) e = hipMalloc(&c->slot[0].d_queue, pm::kClasses * tables * sizeof(uint4) + 3 * tables * sizeof(uint32_t));
-            if (e == hipSuccess && px != 0) {
-                c->slot[0].fb_cap = px * 4;
-                c->slot[0].tables_cap = tables;
-            }
-        }
-        // (round 6: sized for BASELINE config 5 -- 2.2 GB of worst-case binning regions, 1.7 GB of tile arena, 1.4 % of the HBM -- whose
-        //  first frame used to spend 0.8 ms releasing slot 0's 192 MB arenas and allocating these; PM_PREALLOC_ARENA_MB / _TILE_MB)
+        // ... and every frame slot's viewport buffers for anything up to 8192 x 8192 (BASELINE config 5: 256 MB of pixels, 42 MB of queues
+        // and per-tile tables) and its arenas, sized for config 5 (2.2 GB of worst-case binning regions, 1.7 GB of tile arena): four slots are
+        // 16 GB, 6 % of the HBM, and ~0.4 s of pm_create.  A resize within that allocates nothing, whichever slot the next frame lands on
+        // (round 6 first reserved slot 0 only: config 5's first frame was 1.2 ms when it landed there and 85-115 ms -- one hipMalloc of
+        // 3.8 GB -- when the frame counter stood elsewhere; PM_PREALLOC_SLOTS / _MPIXELS / _ARENA_MB / _TILE_MB).
 #ifdef PM_EMU
-        const int arena_mb = 192, tile_mb = 96;  // (the CPU emulation's "HBM" is the host's memory)
+        const int arena_mb = 192, tile_mb = 96, slots_dflt = 1;  // (the CPU emulation's "HBM" is the host's memory)
 #else
-        const int arena_mb = 2304, tile_mb = 1792;
+        const int arena_mb = 2304, tile_mb = 1792, slots_dflt = static_cast<int>(kMaxSlots);
 #endif
+        const size_t n_pre = std::min<size_t>(c->slot.size(), static_cast<size_t>(EnvInt("PM_PREALLOC_SLOTS", slots_dflt, 1, static_cast<int>(kMaxSlots))));
+        const size_t px = static_cast<size_t>(EnvInt("PM_PREALLOC_MPIXELS", 64, 0, 4096)) << 20;
+        const size_t tables = std::max<size_t>(px / (pm::kTileW * pm::kTileH), 4);
         const uint32_t arena0 = static_cast<uint32_t>(EnvInt("PM_PREALLOC_ARENA_MB", arena_mb, 1, 12288)) << 18;  // dwords
         const uint32_t tile0 = std::max<uint32_t>(static_cast<uint32_t>(EnvInt("PM_PREALLOC_TILE_MB", tile_mb, 1, 16384)) << 16,  // quads
                                                   ((1u << 22) * pm::kCmdQuadsNum) / pm::kCmdQuadsDen);  // (what EnsureArena asks for at least)
-        if (e == hipSuccess) e = hipMalloc(&c->slot[0].d_arena, static_cast<size_t>(arena0) * sizeof(uint32_t));
-        if (e == hipSuccess) c->slot[0].arena_cap = arena0;
-        if (e == hipSuccess && !std::getenv("PM_PTCL_INITIAL_CMDS")) {
-            e = hipMalloc(&c->slot[0].d_ptcl, static_cast<size_t>(tile0) * sizeof(uint4));
-            if (e == hipSuccess) c->slot[0].ptcl_cap = tile0;
+        for (size_t si = 0; si < n_pre && e == hipSuccess; ++si) {
+            FrameSlot &fs = c->slot[si];
+            if (px != 0) {
+                e = hipMalloc(&fs.d_fb, px * 4);
+                if (e == hipSuccess) e = hipMalloc(&fs.d_queue, pm::kClasses * tables * sizeof(uint4) + 3 * tables * sizeof(uint32_t));
+                if (e == hipSuccess) {
+                    fs.fb_cap = px * 4;
+                    fs.tables_cap = tables;
+                }
+            }
+            if (e == hipSuccess) e = hipMalloc(&fs.d_arena, static_cast<size_t>(arena0) * sizeof(uint32_t));
+            if (e == hipSuccess) fs.arena_cap = arena0;
+            if (e == hipSuccess && !std::getenv("PM_PTCL_INITIAL_CMDS")) {
+                e = hipMalloc(&fs.d_ptcl, static_cast<size_t>(tile0) * sizeof(uint4));
+                if (e == hipSuccess) fs.ptcl_cap = tile0;
+            }
         }
         if (e != hipSuccess) return fail(e, "working-set reservation");
     }
