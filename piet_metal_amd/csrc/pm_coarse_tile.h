@@ -420,7 +420,7 @@ __device__ __forceinline__ uint32_t CoarseTile(const FrameParams &P, CoarseLds &
                 // ---- wave-wide slots (ballots + popcounts, no scan network) ---------------------
                 const uint64_t m0 = __ballot((lane_total & 1u) != 0);
                 const uint64_t m1 = __ballot((lane_total & 2u) != 0);
-                uint32_t pos = static_cast<uint32_t>(__popcll(m0 & lanes_below)) + 2u * static_cast<uint32_t>(__popcll(m1 & lanes_below));
+                uint32_t pos = RankBelow(m0) + 2u * RankBelow(m1);  // (mbcnt: no 64-bit mask of the lanes below kept in registers across the tile loop)
                 uint32_t round_total = static_cast<uint32_t>(__popcll(m0)) + 2u * static_cast<uint32_t>(__popcll(m1));
                 if (!par && round_total == 0) continue;  // uniform
                 const uint64_t ms = __ballot(opaque_solid);

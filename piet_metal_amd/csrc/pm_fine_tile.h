@@ -202,6 +202,87 @@ __device__ __forceinline__ bool FillStep(WaveFineLds &W, Cmd *cmds, const uint8_
     return true;
 }
 
+// Pass 1, dense: the Fill commands [from, limit) of the chunk's Fill list (at most 64 of them: a chunk has 64 commands), a lane per
+// (command, row) PAIR of the rows the command's segment can touch -- floor(min y) .. floor(max y), clipped to the tile: a superset of the
+// rows FillStep finds live (live means Sat(sy) != Sat(ey): some of the segment lies strictly between py and py + 1) --, 64 pairs per step.
+// FillStep spends a lane on each of the 16 rows of four commands, and 3.4 of them are live at the 4K Tiger (2.9 at config 4): a chunk's 25
+// Fills are two steps here and seven there.  The same fragments in the same slots, the same words in the staged commands (a command
+// without a live row keeps the 0 it was staged with).  Returns the ordinal of the first Fill NOT covered (the fragment region is full).
+constexpr uint32_t kFillPairsMin = 9;  // fewer commands than this: FillStep (two steps cost what the set-up and one step cost here)
+__device__ __forceinline__ uint32_t FillPairs(WaveFineLds &W, Cmd *cmds, const uint8_t *fill_ix, uint32_t limit, uint32_t from, uint32_t &nfrag,
+                                              uint32_t y0, uint32_t slot_base) {
+    const uint32_t lane = LaneId();
+    const bool valid = from + lane < limit;
+    const uint32_t ci = fill_ix[valid ? from + lane : from];
+    const uint32_t wa = cmds[ci].body[2], wb = cmds[ci].body[4];
+    uint32_t lo = 0, cnt = 0;
+    if (valid) {
+        const float ya = __uint_as_float(wa), yb = __uint_as_float(wb), fy0 = static_cast<float>(y0);
+        // (floors of the absolute coordinates: integers, and so is y0 -- the differences are exact)
+        const float flo = fminf(fmaxf(floorf(fminf(ya, yb)) - fy0, 0.0f), 16.0f), fhi = fminf(fmaxf(floorf(fmaxf(ya, yb)) - fy0 + 1.0f, 0.0f), 16.0f);
+        const bool num = ya == ya && yb == yb;  // (a NaN takes part in FillStep's test as 0: every row is a candidate)
+        lo = num ? static_cast<uint32_t>(flo) : 0u;
+        cnt = num ? static_cast<uint32_t>(fmaxf(fhi - flo, 0.0f)) : 16u;
+    }
+    const uint32_t incl = WaveInclusiveScan(cnt);
+    const uint32_t off = incl - cnt, total = WaveLast(incl);
+    uint32_t covered = min(64u, limit - from);
+    uint32_t own_carry = 0;
+#pragma unroll 1
+    for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
+        // the command every pair of the step belongs to: each command marks where its pairs begin, a prefix maximum spreads the marks
+        W.hot_own[lane] = 0;
+        WaveSync();
+        if (cnt != 0u && off - e0 < 64u) W.hot_own[off - e0] = static_cast<uint8_t>(lane);
+        WaveSync();
+        const uint32_t owner = max(WaveInclusiveMax(W.hot_own[lane]), own_carry);
+        own_carry = WaveLast(owner);
+        const uint32_t e = e0 + lane;
+        const bool pv = e < total;
+        const uint32_t o_lo = static_cast<uint32_t>(__shfl(static_cast<int>(lo), static_cast<int>(owner)));
+        const uint32_t o_off = static_cast<uint32_t>(__shfl(static_cast<int>(off), static_cast<int>(owner)));
+        const uint32_t o_ci = static_cast<uint32_t>(__shfl(static_cast<int>(ci), static_cast<int>(owner)));
+        const uint32_t o_wa = static_cast<uint32_t>(__shfl(static_cast<int>(wa), static_cast<int>(owner)));
+        const uint32_t o_wb = static_cast<uint32_t>(__shfl(static_cast<int>(wb), static_cast<int>(owner)));
+        const uint32_t row = (o_lo + (e - o_off)) & 15u;
+        // ... and FillStep's body for the pair
+        const float py = static_cast<float>(y0 + row);
+        const float sy = __uint_as_float(o_wa) - py;
+        const float ey = __uint_as_float(o_wb) - py;
+        const float wx = Sat(sy), wy = Sat(ey);
+        const bool live = pv && wx != wy;
+        const uint64_t mask = __ballot(live);
+        if (mask == 0) continue;
+        const uint32_t nlive = static_cast<uint32_t>(__popcll(mask));
+        if (nfrag + nlive > kMaxFrag) {
+            // The region is full: this step's commands are not covered; one whose pairs began in an earlier step is taken back (the
+            // slots it has are lost until the next call).  Never the call's first command: 64 pairs are at least four commands.
+            const uint32_t first_owner = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(owner)));
+            const uint32_t first_off = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(o_off)));
+            if (lane == 0 && first_off < e0) cmds[o_ci].body[0] = 0;
+            covered = first_owner;
+            break;
+        }
+        const uint32_t rank = RankBelow(mask);
+        const uint32_t before = cmds[o_ci].body[0];  // (read in front of this step's atomics: a wave's LDS operations complete in order)
+        // live pairs in front of the command's first pair of this step = the rank the lane its pairs begin at computed (0: they began earlier)
+        const int a = static_cast<int>(o_off) - static_cast<int>(e0);
+        const uint32_t rank_a = static_cast<uint32_t>(__shfl(static_cast<int>(rank), a > 0 ? a : 0));
+        if (live) {
+            const float tx = (wx - sy) / (ey - sy);
+            const float ty = (wy - sy) / (ey - sy);
+            W.fparam[nfrag + rank] = make_float4(tx, ty, wx - wy, __uint_as_float(o_ci));
+            // row mask | first fragment << 16: the step in which a command has its first live pair brings the slot (every live pair of
+            // the command in that step ORs the same number in)
+            uint32_t bits = 1u << row;
+            if ((before & 0xffffu) == 0u) bits |= (slot_base + nfrag + (a > 0 ? rank_a : 0u)) << 16;
+            atomicOr(&cmds[o_ci].body[0], bits);
+        }
+        nfrag += nlive;
+    }
+    return from + covered;
+}
+
 // Pass 2 over this wave's fragments [0, nfrag) (nfrag <= kMaxFrag = one lane each).
 //
 // Of a fragment's 16 pixels only those the segment's piece of the pixel row passes over need the area integral:
@@ -285,10 +366,14 @@ __device__ __forceinline__ uint32_t PrepareFills(Lds &S, Cmd *cmds, const uint8_
     WaveFineLds &W = S.w[WaveId()].f;
     uint32_t nfrag = 0;
     uint32_t pos = from;
+    if (nfill - from >= kFillPairsMin) {  // uniform
+        pos = FillPairs(W, cmds, fill_ix, nfill, from, nfrag, y0, slot_base);
+    } else {
 #pragma unroll 1
-    while (pos < nfill) {  // (the first step always fits: it adds at most 64)
-        if (!FillStep(W, cmds, fill_ix, nfill, pos, nfrag, y0, slot_base)) break;
-        pos += 4u;
+        while (pos < nfill) {  // (the first step always fits: it adds at most 64)
+            if (!FillStep(W, cmds, fill_ix, nfill, pos, nfrag, y0, slot_base)) break;
+            pos += 4u;
+        }
     }
     WaveSync();
     FillPass2(W, cmds, nfrag, x0);
@@ -580,11 +665,15 @@ __device__ __forceinline__ bool PrepareFillsShared(SparseLds &S, Cmd *cmds, cons
     const uint32_t from = min(wave * per, nfill), to = min(from + per, nfill);
     uint32_t nfrag = 0;
     bool fits = true;
+    if (to - from >= kFillPairsMin) {  // uniform over the wave
+        fits = FillPairs(W, cmds, fill_ix, to, from, nfrag, y0, wave * kMaxFrag) == to;
+    } else {
 #pragma unroll 1
-    for (uint32_t pos = from; pos < to; pos += 4u) {
-        if (!FillStep(W, cmds, fill_ix, to, pos, nfrag, y0, wave * kMaxFrag)) {
-            fits = false;
-            break;
+        for (uint32_t pos = from; pos < to; pos += 4u) {
+            if (!FillStep(W, cmds, fill_ix, to, pos, nfrag, y0, wave * kMaxFrag)) {
+                fits = false;
+                break;
+            }
         }
     }
     WaveSync();
@@ -673,6 +762,10 @@ __device__ __forceinline__ void RenderChunkWG(SparseLds &S, Cmd *cmds, uint8_t *
         if (kProf) t_a = wall_clock64();
         __syncthreads();  // phase B of the previous round (or chunk) is done with the alpha images; every wave's fragments are in place
         const bool shared = try_shared && S.prep_over[parity] == 0u;
+        if (k0 == 0 && try_shared && !shared) {  // (cannot happen while the bound above holds: the words the pass left are taken back, FillPairs adds to them)
+            if (wave == 0 && lane < n && tag == kCmdFill) cmds[lane].body[0] = 0;
+            __syncthreads();
+        }
         if (k0 == 0 && wave == 0 && lane == 0) S.prep_over[parity ^ 1u] = 0u;  // the next chunk's (nobody touches it before this chunk's last barrier)
         // ---- phase A: every wave takes the next item nobody has taken --------------------------
 #pragma unroll 1
@@ -853,7 +946,7 @@ __device__ __forceinline__ uint32_t RenderQueuedTile(const FrameParams &P, Lds &
                 } else {
                     const uint2 *g = reinterpret_cast<const uint2 *>(src + 6u * c0);
                     uint2 *l = reinterpret_cast<uint2 *>(S.w[0].cmds);
-                    for (uint32_t w = threadIdx.x; w < 3u * m; w += kThreads) l[w] = g[w];
+                    for (uint32_t w = Opaque(threadIdx.x); w < 3u * m; w += kThreads) l[w] = g[w];  // (Opaque: no hoisted address to spill)
                     __syncthreads();
                 }
                 RenderChunkWG<kProf>(S, chunk, S.w[wave].f.fill_ix, m, parity, x0, y0, pix, s1, prof, share_fills);

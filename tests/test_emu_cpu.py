@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUBSET = ("random_scenes or many_items or longer_than or empty_scene or even_odd_fills_and_nested_groups and 31 or compound_fills "
           "or ellipses or bgra8 or plain_c or not_hidden or overflow_grows or reference_scenes and not 1536 and not 1501 "
           "or fuzz_regressions and 20206 or both_fine or failed_scene or malformed or pointer_survives or block_parallel or one_wave_kernel_lists or per_row_item_lists "
-          "or heavy_strip_rows and 1-None or workgroup_tile_fills")
+          "or heavy_strip_rows and 1-None or workgroup_tile_fills or dense_fill_pairs")
 
 
 def _run(k, extra_env=None, workers="4"):

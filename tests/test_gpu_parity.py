@@ -175,6 +175,27 @@ def test_workgroup_tile_fills_shared_fragments_and_their_fallback(pm, pmo, rende
         assert P.total_cmds()[1] > 190, (kind, P.total_cmds())  # longer than the single-wave limit: a workgroup tile, three chunks and more
 
 
+def test_dense_fill_pairs_fill_the_fragment_region(pm, pmo, renderer):
+    """Pass 1 of the row-sparse Fill evaluation takes nine and more Fill commands as (command, row) pairs, 64 per step (FillPairs).  Tall
+    translucent triangles through one tile: every long edge is live in 10-12 rows, so the second step finds the wave's 64 fragment slots
+    full in the middle of a command -- that command is taken back, the pass stops in front of it and the command loop comes back for the
+    rest.  Lists of 24-36 stream elements: a single wave's tiles (and with more triangles a workgroup's items of nine Fills and more)."""
+    rng = np.random.default_rng(31)
+    for n_tri, rows in ((8, 11.0), (9, 12.5), (7, 15.5), (14, 11.0)):
+        ops = []
+        for i in range(n_tri):
+            x = 65.0 + float(rng.uniform(0, 11))
+            y = 64.05 + float(rng.uniform(0, 15.9 - rows))
+            pts = np.array([(x, y), (x + float(rng.uniform(0.6, 3.0)), y + float(rng.uniform(0, 0.8))), (x + float(rng.uniform(-2.0, 2.0)), y + rows)])
+            ops.append(("fill", pts, (int(rng.integers(0, 1 << 24)) << 8) | int(rng.integers(0x20, 0x90))))
+        scene = encode_ops(pm, ops, cap=1 << 20)
+        got = gpu_render(renderer, scene, 192, 160)
+        P = pmo.Ptcl(scene, 192, 160)
+        assert np.array_equal(got, P.render()), (n_tri, rows)
+        assert_ptcl_equal(renderer, pmo, scene, 192, 160, maxc=4096)
+        assert P.total_cmds()[1] >= 3 * n_tri, (n_tri, P.total_cmds())
+
+
 def test_one_wave_kernel_lists_around_its_lds_chunks(pm, pmo, monkeypatch):
     """The tile kernel's one-wave-per-tile instantiation keeps the first TWO chunks of 64 commands of a wave's list in LDS and reads only
     what lies beyond back from the tile's list in HBM: lists that end just below, at and beyond both boundaries (three commands per
