@@ -381,41 +381,35 @@ __device__ __forceinline__ uint32_t PrepareFills(Lds &S, Cmd *cmds, const uint8_
     return min(pos, nfill);
 }
 
-// A run of `run` consecutive Fill commands from command i on, all of them prepared (passes 1 and 2
-// done): pass 3 for the run.  The row masks of four commands are fetched together, then their
-// contributions, so that the LDS latencies overlap and no tag is dispatched inside the run; the
-// adds keep list order (binary16 addition is not associative).
+// A run of `run` consecutive Fill commands from command i on, all of them prepared (passes 1 and 2 done): pass 3 for the run, in
+// list order (binary16 addition is not associative).  b0 = word 0 of the chunk's commands, lane k holding command k's AS PASS 1 LEFT IT
+// (row mask | first fragment << 16: read back from the staged commands after the fragments were made) -- a command's word reaches the
+// scalar unit with v_readlane, so a Fill is ONE dependent LDS access (its row's contribution), not two.
+// One command per step: a step of four -- row masks fetched together, then the contributions -- cost the same for one command as for
+// four, and config 4's runs are two or three Fills between a FillEdge and the DrawFill (its tile kernel 0.379 -> 0.349 ms, config 5 -3 %).
+// No branch on the row's bit: every lane reads a slot -- its own row's if it has one, some slot of the region if not -- and the sums are
+// SELECTED (a divergent branch anywhere in the command loop makes the compiler route the whole dispatch through flow blocks that copy the
+// pixel state, see InterpretSparse).
 // kShared (workgroup tiles): W is wave 0's region and a slot number names the region too -- slot >> 6, sizeof(WaveLds) bytes apart.
 template <bool kShared = false>
-__device__ __forceinline__ void AddFillRun(const WaveFineLds &W, const Cmd *cmds, uint32_t i, uint32_t run, uint32_t row, uint32_t g,
+__device__ __forceinline__ void AddFillRun(const WaveFineLds &W, const uint32_t b0, uint32_t i, uint32_t run, uint32_t row, uint32_t g,
                                            half2_t &sa01, half2_t &sa23) {
     const uint32_t below = (1u << row) - 1u;
 #pragma unroll 1
-    for (uint32_t r = 0; r < run; r += 4u) {
-        uint32_t hdr[4];  // row mask | first fragment << 16 (pass 1)
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) hdr[k] = (r + k < run) ? cmds[i + r + k].body[0] : 0u;
-        // (no branch on the row's bit: every lane reads a slot -- its own row's if it has one, some slot of the region if not --
-        //  and the sums are SELECTED.  A divergent branch anywhere in the command loop makes the compiler route the whole
-        //  dispatch through flow blocks that copy the pixel state, see InterpretSparse)
-        uint2 v[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const uint32_t slot = (hdr[k] >> 16) + static_cast<uint32_t>(__popc(hdr[k] & below));
-            if constexpr (kShared) {
-                const uint8_t *region = reinterpret_cast<const uint8_t *>(&W) + ((slot >> 6) & static_cast<uint32_t>(kWaves - 1)) * static_cast<uint32_t>(sizeof(WaveLds));
-                v[k] = reinterpret_cast<const WaveFineLds *>(region)->contrib[slot & (kMaxFrag - 1u)][g];
-            } else {
-                v[k] = W.contrib[slot & (kMaxFrag - 1u)][g];
-            }
+    for (uint32_t r = 0; r < run; ++r) {
+        const uint32_t hdr = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(b0), static_cast<int>(i + r)));
+        const uint32_t slot = (hdr >> 16) + static_cast<uint32_t>(__popc(hdr & below));
+        uint2 v;
+        if constexpr (kShared) {
+            const uint8_t *region = reinterpret_cast<const uint8_t *>(&W) + ((slot >> 6) & static_cast<uint32_t>(kWaves - 1)) * static_cast<uint32_t>(sizeof(WaveLds));
+            v = reinterpret_cast<const WaveFineLds *>(region)->contrib[slot & (kMaxFrag - 1u)][g];
+        } else {
+            v = W.contrib[slot & (kMaxFrag - 1u)][g];
         }
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k) {
-            const bool on = ((hdr[k] >> row) & 1u) != 0u;
-            const half2_t n01 = sa01 + Half2FromBits(v[k].x), n23 = sa23 + Half2FromBits(v[k].y);
-            sa01 = on ? n01 : sa01;
-            sa23 = on ? n23 : sa23;
-        }
+        const bool on = ((hdr >> row) & 1u) != 0u;
+        const half2_t n01 = sa01 + Half2FromBits(v.x), n23 = sa23 + Half2FromBits(v.y);
+        sa01 = on ? n01 : sa01;
+        sa23 = on ? n23 : sa23;
     }
 }
 
@@ -474,6 +468,7 @@ __device__ __forceinline__ void InterpretSparse(Lds &S, Cmd *cmds, const uint8_t
     if (fo < nfill) {
         const uint32_t prepared = PrepareFills(S, cmds, fill_ix, nfill, fo, x0, y0);  // > fo, uniform
         if (prepared < nfill) stop = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(fill_ix[prepared])));
+        mine.body[0] = cmds[lane].body[0];  // (pass 1 left the Fills' row masks and fragment slots there; lanes >= n: never looked at)
     }
     for (; i < stop; ++i) {
         auto word = [&](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(i))); };
@@ -530,7 +525,7 @@ __device__ __forceinline__ void InterpretSparse(Lds &S, Cmd *cmds, const uint8_t
             }
             case kCmdFill: {
                 const uint32_t run = min(FillRunLength(fm, i), stop - i);  // >= 1, all of them prepared
-                AddFillRun(S.w[WaveId()].f, cmds, i, run, row, g, st.sa01, st.sa23);
+                AddFillRun(S.w[WaveId()].f, mine.body[0], i, run, row, g, st.sa01, st.sa23);
                 fo += run;
                 i += run - 1u;
                 break;
@@ -611,12 +606,14 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const C
     uint32_t fo = static_cast<uint32_t>(__popcll(fm & ((1ull << s) - 1ull)));
     const uint32_t flimit = static_cast<uint32_t>(__popcll(fm & (e >= 64u ? ~0ull : ((1ull << e) - 1ull))));
     // (as in InterpretSparse: the fragments are made outside the command loop, which has no divergent branch in it)
+    uint32_t b0 = cmds[lane].body[0];  // word 0 of the chunk's commands as pass 1 left it (shared: the pass is behind us; else read again below)
     uint32_t i = s;
     while (i < e) {
     uint32_t stop = e;
     if (!shared && fo < flimit) {
         const uint32_t prepared = PrepareFills(S, cmds, fill_ix, flimit, fo, x0, y0, WaveId() * kMaxFrag);  // > fo, uniform
         if (prepared < flimit) stop = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(fill_ix[prepared])));
+        b0 = cmds[lane].body[0];
     }
 #pragma unroll 1
     for (; i < stop; ++i) {
@@ -624,7 +621,7 @@ __device__ __forceinline__ void RunItemCommands(SparseLds &S, Cmd *cmds, const C
         const uint32_t tag = word(mine.tag);
         if (tag == kCmdFill) {
             const uint32_t run = min(FillRunLength(fm, i), stop - i);  // >= 1, all of them prepared
-            AddFillRun<true>(S.w[0].f, cmds, i, run, row, g, sa01, sa23);
+            AddFillRun<true>(S.w[0].f, b0, i, run, row, g, sa01, sa23);
             fo += run;
             i += run - 1u;
         } else if (tag == kCmdFillEdge) {
