@@ -1,3 +1,7 @@
+#!/bin/bash
+# Developer probe (round 6): rocprofv3 PC sampling of the tile kernel.  NOT SUPPORTED on this stack: rocprofv3 answers "Given PC sampling
+# configuration is not supported on any of the agents" (host_trap as well as stochastic; `rocprofv3-avail info --pc-sampling` lists no agent).
+# Kept as the record of the attempt; the leave-one-part-out timings (tools/probes/skipab.sh) did the job instead.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 { echo "== tile timeline config4"; PM_TL_WORKLOAD=config4 timeout 200 python tools/tile_timeline.py 2>&1 | grep -v "amdgpu.ids\|^  slot [0-9]* tile" | head -80; } > gpurun_out/tl4.log 2>&1
 export ROCPROFILER_PC_SAMPLING_BETA_ENABLED=1
